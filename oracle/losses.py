@@ -1,0 +1,176 @@
+"""CPU fp32 oracle of the depth losses — TEST INFRASTRUCTURE ONLY.
+
+Functional restatements of reference criteria.py.  Each function cites the lines it
+follows; latent defects of the reference that change the numbers are reproduced on
+purpose and flagged, because parity is with the reference as it runs.
+"""
+import torch
+
+
+# ---------------------------------------------------------------- B1  criteria.py:724-732
+def silog(est, gt, variance_focus=0.85):
+    """10*sqrt(mean(d^2) - lambda*mean(d)^2), d = log est - log gt over gt > 1e-2.
+    Global over the whole batch; no guard for an empty mask (NaN, like the reference)."""
+    m = gt > 1e-2
+    d = torch.log(est[m]) - torch.log(gt[m])
+    return 10.0 * torch.sqrt((d * d).mean() - variance_focus * d.mean() ** 2)
+
+
+# ---------------------------------------------------------------- B6  criteria.py:17-64
+def masked_depth(pred, target):
+    """Eigen linear-space scale-invariant term + masked forward-difference gradient MSE."""
+    n = target.shape[0]
+    mask = (target > 0).to(torch.float32)
+    d = ((pred - target) * mask).reshape(n, -1)
+    nv = mask.reshape(n, -1).sum(1)
+    data = ((nv * (d * d).sum(1)).sum() - 0.5 * (d.sum(1) ** 2).sum()) / (nv * nv).sum()
+    if pred.ndim == 4:
+        pred, target, mask = pred[:, 0], target[:, 0], mask[:, 0]
+    gi = (pred[:, 1:] - pred[:, :-1]) - (target[:, 1:] - target[:, :-1])
+    gj = (pred[:, :, 1:] - pred[:, :, :-1]) - (target[:, :, 1:] - target[:, :, :-1])
+    mi = (mask[:, 1:] * mask[:, :-1])
+    mj = (mask[:, :, 1:] * mask[:, :, :-1])
+    return data + (mi * gi * gi).sum() / mi.sum() + (mj * gj * gj).sum() / mj.sum()
+
+
+# ---------------------------------------------------------------- B9  criteria.py:67-133
+def masked_mse(pred, target):
+    v = target > 0
+    return ((target - pred)[v] ** 2).mean()
+
+
+def masked_l1(pred, target):
+    v = target > 0
+    return (target - pred)[v].abs().mean()
+
+
+def berhu(pred, target):
+    """Reverse Huber as the reference writes it: c = 0.2*max(pred-target) over ALL
+    pixels (valid or not), loss = mean(cat(|d|, |d|[|d|>c]^2)) (criteria.py:118-131)."""
+    c = 0.2 * (pred - target).max()
+    d = (target - pred)[target > 0].abs()
+    return torch.cat((d, d[d > c] ** 2)).mean()
+
+
+# ---------------------------------------------------------------- B4  criteria.py:154-176
+def scale_and_shift(pred, target, mask):
+    """Per-image closed-form least squares for (scale, shift); zero where det == 0."""
+    a00 = (mask * pred * pred).sum((1, 2))
+    a01 = (mask * pred).sum((1, 2))
+    a11 = mask.sum((1, 2))
+    b0 = (mask * pred * target).sum((1, 2))
+    b1 = (mask * target).sum((1, 2))
+    det = a00 * a11 - a01 * a01
+    ok = det != 0
+    safe = torch.where(ok, det, torch.ones_like(det))
+    scale = torch.where(ok, (a11 * b0 - a01 * b1) / safe, torch.zeros_like(det))
+    shift = torch.where(ok, (-a01 * b0 + a00 * b1) / safe, torch.zeros_like(det))
+    return scale, shift
+
+
+# ---------------------------------------------------------------- criteria.py:179-199
+def _reduce(image_loss, M, batch_based):
+    if batch_based:
+        div = M.sum()
+        return image_loss.sum() / div if div != 0 else image_loss.sum() * 0
+    ok = M != 0
+    per = torch.where(ok, image_loss / torch.where(ok, M, torch.ones_like(M)), image_loss)
+    return per.mean()
+
+
+# ---------------------------------------------------------------- criteria.py:201-224
+def data_mse(pred, target, mask, batch_based=True):
+    """NB reference quirk: the per-pixel map (not per-image sums) is handed to the
+    reduction together with 2*M, so 'image-based' would index a 3-D map with a 1-D mask
+    (shape error in the reference); only batch-based is defined and is what the modules
+    use (midas.py:29-37)."""
+    if not batch_based:
+        raise NotImplementedError("reference mse_loss is only well-formed with batch-based reduction")
+    M = mask.sum((1, 2))
+    r = pred - target
+    return _reduce(mask * r * r, 2 * M, True)
+
+
+def data_l1(pred, target, mask):
+    M = mask.sum((1, 2))
+    return _reduce((target - pred)[mask.bool()].abs(), 2 * M, True)
+
+
+def data_trimmed_mae(pred, target, mask, trim=0.2):
+    """Reference defect reproduced (criteria.py:214-216): ``torch.sort(...)[:k]`` slices the
+    (values, indices) TUPLE, not the values -> nothing is trimmed; result == L1/(2M)."""
+    M = mask.sum((1, 2))
+    res = (pred - target)[mask.bool()].abs()
+    vals, _ = torch.sort(res.view(-1))
+    return _reduce(vals, 2 * M, True)
+
+
+# ---------------------------------------------------------------- B3  criteria.py:227-244,283-303
+def gradient_term(pred, target, mask, batch_based=True):
+    M = mask.sum((1, 2))
+    diff = mask * (pred - target)
+    gx = (diff[:, :, 1:] - diff[:, :, :-1]).abs() * (mask[:, :, 1:] * mask[:, :, :-1])
+    gy = (diff[:, 1:, :] - diff[:, :-1, :]).abs() * (mask[:, 1:, :] * mask[:, :-1, :])
+    return _reduce(gx.sum((1, 2)) + gy.sum((1, 2)), M, batch_based)
+
+
+def gradient_multiscale(pred, target, mask, scales=4, batch_based=True):
+    total = 0
+    for s in range(scales):
+        k = 2 ** s
+        total = total + gradient_term(pred[:, ::k, ::k], target[:, ::k, ::k], mask[:, ::k, ::k], batch_based)
+    return total
+
+
+# ---------------------------------------------------------------- criteria.py:306-332
+def midas_loss(pred, target, alpha=0.5, scales=4, loss="ssimse", batch_based=True):
+    if pred.ndim == 4:
+        pred = pred.squeeze(1)
+    if target.ndim == 4:
+        target = target.squeeze(1)
+    mask = (target > 0).to(torch.float32)
+    if "ssi" in loss:
+        s, t = scale_and_shift(pred, target, mask)
+        pred = s.view(-1, 1, 1) * pred + t.view(-1, 1, 1)
+    if "trim" in loss:
+        total = data_trimmed_mae(pred, target, mask)
+    elif "mse" in loss:
+        total = data_mse(pred, target, mask, batch_based)
+    elif "l1" in loss:
+        total = data_l1(pred, target, mask)
+    else:
+        raise ValueError(loss)
+    if alpha > 0:
+        total = total + alpha * gradient_multiscale(pred, target, mask, scales, batch_based)
+    return total
+
+
+# ---------------------------------------------------------------- B5  criteria.py:135-152,335-363
+def normalize_robust(x, mask):
+    """Per-image: subtract the median of (mask*x) (torch.median = lower median, zeros of
+    masked-out pixels included, as in the reference), divide by mean |.| over valid."""
+    n = x.shape[0]
+    cnt = mask.sum((1, 2))
+    ok = cnt > 0
+    med = torch.zeros_like(cnt)
+    if ok.any():
+        med[ok] = torch.median((mask[ok] * x[ok]).view(int(ok.sum()), -1), dim=1).values
+    x = x - med.view(n, 1, 1)
+    sq = (mask * x.abs()).sum((1, 2))
+    s = torch.ones_like(cnt)
+    s[ok] = torch.clamp(sq[ok] / cnt[ok], min=1e-6)
+    return x / s.view(n, 1, 1)
+
+
+def trimmed_procrustes(pred, target, alpha=0.5, scales=4, batch_based=True):
+    if pred.ndim == 4:
+        pred = pred.squeeze(1)
+    if target.ndim == 4:
+        target = target.squeeze(1)
+    mask = (target > 0).to(torch.float32)
+    p = normalize_robust(pred, mask)
+    t = normalize_robust(target, mask)
+    total = data_trimmed_mae(p, t, mask)
+    if alpha > 0:
+        total = total + alpha * gradient_multiscale(p, t, mask, scales, batch_based)
+    return total

@@ -1,0 +1,89 @@
+"""Deterministic, torch-RNG-free tensor generator — TEST INFRASTRUCTURE ONLY.
+
+Identical weights / inputs must be reproducible in the build container (where
+the goldens are minted from the reference) and on the GPU box (where neither the
+reference nor 254 MB of weights travel).  Every tensor is a pure function of
+(seed, tensor name): a Philox counter stream keyed by crc32(name).
+"""
+import zlib
+
+import numpy as np
+import torch
+
+
+def _gen(seed, name):
+    key = np.array([seed & 0xFFFFFFFFFFFFFFFF, zlib.crc32(name.encode())], dtype=np.uint64)
+    return np.random.Generator(np.random.Philox(key=key))
+
+
+def normal(seed, name, shape, std=1.0, mean=0.0):
+    a = _gen(seed, name).standard_normal(size=tuple(shape), dtype=np.float32)
+    return torch.from_numpy(a * np.float32(std) + np.float32(mean))
+
+
+def uniform(seed, name, shape, lo=0.0, hi=1.0):
+    a = _gen(seed, name).random(size=tuple(shape), dtype=np.float32)
+    return torch.from_numpy(a * np.float32(hi - lo) + np.float32(lo))
+
+
+def fill_state_dict(module, seed, perturb_bn=True):
+    """Overwrite every entry of ``module.state_dict()`` with a deterministic value.
+
+    conv / linear weights: N(0, sqrt(2 / fan_out)) (the He rule both the reference's
+    weights_init (FCRN.py:14-28) and torchvision's default use);  BN gamma ~ 1 +- 0.1,
+    beta ~ +-0.1, running_mean ~ +-0.1, running_var ~ U(0.5, 1.5) so that no BN term
+    is trivially the identity.  Returns the dict that was loaded.
+    """
+    sd = module.state_dict()
+    out = {}
+    for k, v in sd.items():
+        if k.endswith("num_batches_tracked"):
+            out[k] = torch.zeros_like(v)
+        elif v.ndim == 4:
+            co, _, kh, kw = v.shape
+            out[k] = normal(seed, k, v.shape, std=(2.0 / (kh * kw * co)) ** 0.5)
+        elif v.ndim == 2:
+            out[k] = normal(seed, k, v.shape, std=(2.0 / v.shape[0]) ** 0.5)
+        elif k.endswith("running_var"):
+            out[k] = uniform(seed, k, v.shape, 0.5, 1.5) if perturb_bn else torch.ones_like(v)
+        elif k.endswith("running_mean"):
+            out[k] = normal(seed, k, v.shape, 0.1) if perturb_bn else torch.zeros_like(v)
+        elif k.endswith("weight"):
+            out[k] = normal(seed, k, v.shape, 0.1, 1.0) if perturb_bn else torch.ones_like(v)
+        else:
+            out[k] = normal(seed, k, v.shape, 0.1) if perturb_bn else torch.zeros_like(v)
+    module.load_state_dict(out)
+    return out
+
+
+def synthetic_batch(seed, n, h, w, channels=1):
+    """The benchmark's synthetic data: RGB ~ U[0,1); target depth
+    ~ U(0.05, 1) with a fixed 10 % of pixels zeroed (invalid)."""
+    rgb = uniform(seed, "rgb", (n, 3, h, w))
+    depth = uniform(seed, "depth", (n, channels, h, w), 0.05, 1.0)
+    hole = uniform(seed, "hole", (n, channels, h, w)) < 0.10
+    return rgb, depth.masked_fill(hole, 0.0)
+
+
+def fcrn_fixture_state(model, seed):
+    """Deterministic weights for the G5 fixture.  conv3 is scaled by 0.05: the reference's
+    own init rule (fan = 3*3*out_channels = 9 -> std 0.47, FCRN.py:17-18) saturates the
+    sigmoid at out_channels=1 and would leave nothing to compare."""
+    sd = fill_state_dict(model, seed)
+    sd["conv3.weight"] = sd["conv3.weight"] * 0.05
+    model.load_state_dict(sd)
+    return sd
+
+
+def calibrate_running_stats(model, x):
+    """One train-mode forward with BN momentum 1.0 so running stats == batch stats of x
+    (otherwise eval-mode activations explode through 16 residual blocks)."""
+    bns = [m for m in model.modules() if isinstance(m, torch.nn.BatchNorm2d)]
+    old = [m.momentum for m in bns]
+    for m in bns:
+        m.momentum = 1.0
+    model.train()
+    with torch.no_grad():
+        model(x)
+    for m, o in zip(bns, old):
+        m.momentum = o

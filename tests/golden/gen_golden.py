@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""Mint golden vectors by running the REFERENCE's own code (build container only).
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/gen_golden.py
+
+Imports /root/reference/{criteria,stdepth_utils,metrics}.py and network/FCRN.py and
+records their outputs on deterministic inputs (oracle/weights.py) as small .npz files
+next to this script.  The reference never travels to the GPU box; these vectors do.
+
+What is the reference's own arithmetic here, and what is not:
+  * criteria.py, metrics.py pure functions, FCRN.py (Unpool / UpProj / weights_init /
+    ResNet.forward)                                       -> reference code, run as is.
+  * torchvision (absent from the image and from /root/reference; unpinned in the
+    reference's requirements.txt): FCRN.py:305 only takes conv1/bn1/relu/maxpool/
+    layer1..4 from ``torchvision.models.resnetNN``.  A module object exposing our
+    restated trunk (oracle/fcrn.py:ResNetTrunk, public v1.5 definition) is placed in
+    sys.modules so the reference file imports; the trunk's arithmetic is torch.nn.
+  * torchmetrics (absent): metrics.py:116-123 merely *references* four torchmetrics
+    functions in a dict; a namespace with those names lets the file import.  None of
+    them is called.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.dont_write_bytecode = True
+
+from oracle import fcrn as ofcrn  # noqa: E402
+from oracle import weights as W  # noqa: E402
+
+REF = "/root/reference"
+
+
+def _import_reference():
+    tv = types.ModuleType("torchvision")
+    tvm = types.ModuleType("torchvision.models")
+    for n in (18, 34, 50, 101, 152):
+        tvm.__dict__["resnet%d" % n] = (lambda n: (lambda pretrained=False: ofcrn.ResNetTrunk(n)))(n)
+    tv.models = tvm
+    sys.modules.setdefault("torchvision", tv)
+    sys.modules.setdefault("torchvision.models", tvm)
+    tm = types.ModuleType("torchmetrics")
+    fn = types.SimpleNamespace(
+        regression=types.SimpleNamespace(mean_absolute_error=None, mean_squared_log_error=None,
+                                         mean_squared_error=None),
+        structural_similarity_index_measure=None)
+    tm.functional = fn
+    sys.modules.setdefault("torchmetrics", tm)
+    sys.path.insert(0, REF)
+    import criteria  # noqa
+    import metrics  # noqa
+    from network import FCRN  # noqa
+    return criteria, metrics, FCRN
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def _loss_and_grad(fn, pred, *rest):
+    p = pred.clone().requires_grad_(True)
+    out = fn(p, *rest)
+    out.backward()
+    return _np(out), _np(p.grad)
+
+
+def depth_pair(seed, shape, hole=0.1):
+    pred = W.uniform(seed, "pred", shape, 0.05, 1.2)
+    tgt = W.uniform(seed, "tgt", shape, 0.02, 1.0)
+    tgt = tgt.masked_fill(W.uniform(seed, "hole", shape) < hole, 0.0)
+    return pred, tgt
+
+
+def gen_losses(criteria):
+    out = {}
+    # G1 silog
+    est, gt = depth_pair(11, (4, 1, 64, 64))
+    out["g1_est"], out["g1_gt"] = _np(est), _np(gt)
+    for lam in (0.85, 0.5):
+        l, g = _loss_and_grad(criteria.silog_loss(lam), est, gt)
+        out["g1_silog_%g" % lam], out["g1_silog_%g_grad" % lam] = l, g
+    # G2 family on 4x1x64x96
+    pred, tgt = depth_pair(12, (4, 1, 64, 96))
+    out["g2_pred"], out["g2_tgt"] = _np(pred), _np(tgt)
+    l, g = _loss_and_grad(criteria.MaskedDepthLoss(), pred, tgt)
+    out["g2_masked_depth"], out["g2_masked_depth_grad"] = l, g
+    for name, mod in (("masked_mse", criteria.MaskedMSELoss()), ("masked_l1", criteria.MaskedL1Loss()),
+                      ("berhu", criteria.berHuLoss())):
+        l, g = _loss_and_grad(mod, pred, tgt)
+        out["g2_" + name], out["g2_%s_grad" % name] = l, g
+    p3, t3 = pred[:, 0], tgt[:, 0]
+    m3 = (t3 > 0).float()
+    s, t = criteria.compute_scale_and_shift(p3, t3, m3)
+    out["g2_scale"], out["g2_shift"] = _np(s), _np(t)
+    for red in ("batch-based", "image-based"):
+        gl = criteria.GradientLoss(scales=4, reduction=red)
+        l, g = _loss_and_grad(lambda p: gl(p, t3, m3), p3)
+        out["g2_gradient_%s" % red[:5]], out["g2_gradient_%s_grad" % red[:5]] = l, g
+    for kind in ("ssimse", "ssil1", "mse", "l1", "trim", "ssitrim"):
+        l, g = _loss_and_grad(criteria.MidasLoss(alpha=0.5, loss=kind), pred, tgt)
+        out["g2_midas_" + kind], out["g2_midas_%s_grad" % kind] = l, g
+    l, g = _loss_and_grad(criteria.TrimmedProcrustesLoss(alpha=0.5), pred, tgt)
+    out["g2_procrustes"], out["g2_procrustes_grad"] = l, g
+    np.savez_compressed(os.path.join(HERE, "losses.npz"), **out)
+    print("losses.npz", len(out), "arrays")
+
+
+def gen_metrics(metrics):
+    pred, tgt = depth_pair(13, (4, 1, 48, 64))
+    mc = metrics.MetricComputation(["absrel", "rmse", "delta1", "delta2", "delta3", "log10"])
+    vals = mc.compute(pred, tgt)
+    out = {"pred": _np(pred), "tgt": _np(tgt)}
+    for n, v in zip(mc.names, vals):
+        out[n] = _np(v)
+    np.savez_compressed(os.path.join(HERE, "metrics.npz"), **out)
+    print("metrics.npz", {k: float(out[k]) for k in mc.names})
+
+
+def gen_upproj(FCRN):
+    """G4: reference Unpool and UpProjModule(16), fwd + input/weight grads, train-mode BN."""
+    torch.manual_seed(0)
+    x = W.normal(14, "x", (2, 16, 6, 8))
+    out = {"x": _np(x), "unpool": _np(FCRN.Unpool(16)(x))}
+    m = FCRN.UpProj.UpProjModule(16)
+    sd = W.fill_state_dict(m, 14)
+    m.train()
+    xi = x.clone().requires_grad_(True)
+    y = m(xi)
+    gy = W.normal(14, "gy", tuple(y.shape))
+    y.backward(gy)
+    out["y"], out["gy"], out["gx"] = _np(y), _np(gy), _np(xi.grad)
+    for k, p in m.named_parameters():
+        out["grad." + k] = _np(p.grad)
+    for k, v in m.state_dict().items():  # running stats after one train step
+        if "running" in k:
+            out["after." + k] = _np(v)
+    for k, v in sd.items():
+        out["sd." + k] = _np(v)
+    np.savez_compressed(os.path.join(HERE, "upproj.npz"), **out)
+    print("upproj.npz y", tuple(y.shape))
+
+
+def gen_fcrn(criteria, metrics, FCRN):
+    """G5: reference FCRN.ResNet(50) on 2x3x96x128, out_channels 1, eval + train BN;
+    silog + metrics against a seeded target; backward pinned by per-parameter grad stats."""
+    size = (96, 128)
+    ref = FCRN.ResNet(layers=50, decoder="upproj", output_size=size, in_channels=3,
+                      out_channels=1, pretrained=False)
+    W.fcrn_fixture_state(ref, 5)
+    rgb, tgt = W.synthetic_batch(5, 2, *size)
+    W.calibrate_running_stats(ref, rgb)
+    out = {}
+    ref.eval()
+    with torch.no_grad():
+        y = ref(rgb)
+    out["eval_out"] = _np(y)
+    out["eval_silog"] = _np(criteria.silog_loss(0.85)(y, tgt))
+    mc = metrics.MetricComputation(["absrel", "rmse", "delta1"])
+    for n, v in zip(mc.names, mc.compute(y, tgt)):
+        out["eval_" + n] = _np(v)
+    ref.train()
+    y = ref(rgb)
+    loss = criteria.silog_loss(0.85)(y, tgt)
+    loss.backward()
+    out["train_out"], out["train_silog"] = _np(y), _np(loss)
+    names, gnorm, gsum = [], [], []
+    for k, p in ref.named_parameters():
+        names.append(k)
+        gnorm.append(float(p.grad.double().norm()))
+        gsum.append(float(p.grad.double().sum()))
+    out["grad_names"] = np.array(names)
+    out["grad_norm"], out["grad_sum"] = np.array(gnorm), np.array(gsum)
+    out["grad_conv3"] = _np(ref.conv3.weight.grad)
+    out["grad_conv1_slice"] = _np(ref.conv1.weight.grad[:8])
+    out["after_bn1_running_mean"] = _np(ref.bn1.running_mean)
+    out["after_bn1_running_var"] = _np(ref.bn1.running_var)
+    out["eval_out_minmax"] = np.array([float(out["eval_out"].min()), float(out["eval_out"].max())])
+    out["n_state_keys"] = np.array(len(ref.state_dict()))
+    out["n_params"] = np.array(sum(p.numel() for p in ref.parameters()))
+    np.savez_compressed(os.path.join(HERE, "fcrn50.npz"), **out)
+    print("fcrn50.npz eval_silog", float(out["eval_silog"]), "train_silog", float(out["train_silog"]),
+          "keys", int(out["n_state_keys"]), "params", int(out["n_params"]))
+
+
+def main():
+    torch.set_num_threads(8)
+    criteria, metrics, FCRN = _import_reference()
+    gen_losses(criteria)
+    gen_metrics(metrics)
+    gen_upproj(FCRN)
+    gen_fcrn(criteria, metrics, FCRN)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,148 @@
+"""Pin the CPU oracle against vectors minted from the reference's own code
+(tests/golden/gen_golden.py).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import fcrn as ofcrn
+from oracle import losses as L
+from oracle import metrics as M
+from oracle import weights as W
+
+
+def _t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def _lg(fn, pred, *rest):
+    p = pred.clone().requires_grad_(True)
+    out = fn(p, *rest)
+    out.backward()
+    return out.detach(), p.grad
+
+
+def _close(a, b, rtol=2e-5, atol=1e-6):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    assert np.allclose(a, b, rtol=rtol, atol=atol), float(np.abs(a - b).max())
+
+
+@pytest.mark.parametrize("lam", [0.85, 0.5])
+def test_silog(golden, lam):
+    g = golden("losses")
+    l, gr = _lg(lambda e: L.silog(e, _t(g["g1_gt"]), lam), _t(g["g1_est"]))
+    _close(l, g["g1_silog_%g" % lam])
+    _close(gr, g["g1_silog_%g_grad" % lam], atol=1e-8)
+
+
+@pytest.mark.parametrize("name,fn", [
+    ("masked_depth", L.masked_depth), ("masked_mse", L.masked_mse),
+    ("masked_l1", L.masked_l1), ("berhu", L.berhu),
+    ("procrustes", L.trimmed_procrustes),
+])
+def test_pointwise_losses(golden, name, fn):
+    g = golden("losses")
+    l, gr = _lg(fn, _t(g["g2_pred"]), _t(g["g2_tgt"]))
+    _close(l, g["g2_" + name])
+    _close(gr, g["g2_%s_grad" % name], atol=1e-8)
+
+
+@pytest.mark.parametrize("kind", ["ssimse", "ssil1", "mse", "l1", "trim", "ssitrim"])
+def test_midas(golden, kind):
+    g = golden("losses")
+    l, gr = _lg(lambda p, t: L.midas_loss(p, t, 0.5, 4, kind), _t(g["g2_pred"]), _t(g["g2_tgt"]))
+    _close(l, g["g2_midas_" + kind])
+    _close(gr, g["g2_midas_%s_grad" % kind], rtol=1e-4, atol=1e-8)
+
+
+def test_trim_defect_is_reproduced(golden):
+    """the reference's trimmed MAE never trims -> equals L1/(2M)."""
+    g = golden("losses")
+    assert float(g["g2_midas_trim"]) == pytest.approx(float(g["g2_midas_l1"]), rel=1e-6)
+
+
+def test_scale_shift_and_gradient(golden):
+    g = golden("losses")
+    p, t = _t(g["g2_pred"])[:, 0], _t(g["g2_tgt"])[:, 0]
+    m = (t > 0).float()
+    s, sh = L.scale_and_shift(p, t, m)
+    _close(s, g["g2_scale"], rtol=1e-4)
+    _close(sh, g["g2_shift"], rtol=1e-4)
+    for tag, bb in (("batch", True), ("image", False)):
+        l, gr = _lg(lambda q: L.gradient_multiscale(q, t, m, 4, bb), p)
+        _close(l, g["g2_gradient_" + tag])
+        _close(gr, g["g2_gradient_%s_grad" % tag], atol=1e-8)
+
+
+def test_metrics(golden):
+    g = golden("metrics")
+    got = M.compute(_t(g["pred"]), _t(g["tgt"]))
+    for k in M.NAMES:
+        _close(got[k], g[k])
+
+
+def test_unpool_and_upproj(golden):
+    g = golden("upproj")
+    x = _t(g["x"])
+    assert np.array_equal(ofcrn.unpool2x(x).numpy(), g["unpool"])
+    m = ofcrn.UpProjModule(16)
+    m.load_state_dict({k[3:]: _t(g[k]) for k in g.files if k.startswith("sd.")})
+    m.train()
+    xi = x.clone().requires_grad_(True)
+    y = m(xi)
+    y.backward(_t(g["gy"]))
+    _close(y.detach(), g["y"], rtol=1e-4, atol=1e-5)
+    _close(xi.grad, g["gx"], rtol=1e-4, atol=1e-5)
+    for k, p in m.named_parameters():
+        _close(p.grad, g["grad." + k], rtol=1e-3, atol=1e-4)
+    for k, v in m.state_dict().items():
+        if "running" in k:
+            _close(v, g["after." + k], rtol=1e-5)
+
+
+@pytest.fixture(scope="module")
+def fcrn_oracle():
+    torch.set_num_threads(8)
+    net = ofcrn.FCRNOracle(layers=50, output_size=(96, 128), out_channels=1)
+    W.fcrn_fixture_state(net, 5)
+    rgb, tgt = W.synthetic_batch(5, 2, 96, 128)
+    W.calibrate_running_stats(net, rgb)
+    return net, rgb, tgt
+
+
+def test_fcrn50_keys_and_params(golden, fcrn_oracle):
+    g = golden("fcrn50")
+    net = fcrn_oracle[0]
+    assert len(net.state_dict()) == int(g["n_state_keys"]) == 397
+    assert sum(p.numel() for p in net.parameters()) == int(g["n_params"]) == 63563008
+    assert [k for k, _ in net.named_parameters()] == list(g["grad_names"])
+
+
+def test_fcrn50_eval(golden, fcrn_oracle):
+    g = golden("fcrn50")
+    net, rgb, tgt = fcrn_oracle
+    net.eval()
+    with torch.no_grad():
+        y = net(rgb)
+    _close(y, g["eval_out"], rtol=1e-4, atol=2e-5)
+    _close(L.silog(y, tgt), g["eval_silog"], rtol=1e-4)
+    got = M.compute(y, tgt)
+    for k in ("absrel", "rmse", "delta1"):
+        _close(got[k], g["eval_" + k], rtol=1e-4)
+
+
+def test_fcrn50_train_fwd_bwd(golden, fcrn_oracle):
+    g = golden("fcrn50")
+    net, rgb, tgt = fcrn_oracle
+    saved = {k: v.clone() for k, v in net.state_dict().items()}  # running stats move in train mode
+    net.train()
+    net.zero_grad()
+    y = net(rgb)
+    loss = L.silog(y, tgt)
+    loss.backward()
+    net.load_state_dict(saved)
+    _close(y.detach(), g["train_out"], rtol=1e-4, atol=2e-5)
+    _close(loss.detach(), g["train_silog"], rtol=1e-4)
+    gn = np.array([float(p.grad.double().norm()) for _, p in net.named_parameters()])
+    assert np.allclose(gn, g["grad_norm"], rtol=2e-3, atol=1e-6), np.abs(gn / g["grad_norm"] - 1).max()
+    _close(net.conv3.weight.grad, g["grad_conv3"], rtol=1e-3, atol=1e-5)
+    _close(net.conv1.weight.grad[:8], g["grad_conv1_slice"], rtol=2e-3, atol=1e-3)
