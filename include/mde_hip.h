@@ -1,0 +1,207 @@
+/* libmde_hip.so — C ABI of the MI355X (gfx950) monocular-depth training hot path.
+ *
+ * Drop-in boundary for xeTaiz/mono-depth-estimation's FCRN path.  The
+ * reference has no native layer: every op below replaces an ATen/cuDNN call that the
+ * reference reaches through torch.nn (file:line of the call site is cited per entry).
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative MDE_E* code; the message is in
+ *     mde_last_error() (thread-local).  No C++ exception crosses this boundary.
+ *   - the CALLER owns every buffer (activations, workspaces, outputs).  Nothing here
+ *     allocates or frees device memory, and nothing synchronises: kernels are enqueued
+ *     on `stream` (a hipStream_t passed as void*; NULL = the null stream).
+ *   - activations are NHWC ("pixel-major") bf16 unless stated; `ld` arguments are the
+ *     element distance between consecutive pixels so channel slices of a wider tensor can
+ *     be passed without copies.  Master weights / statistics / gradients are fp32.
+ *   - thread-safe: no global mutable state besides the thread-local error string.
+ */
+#ifndef MDE_HIP_H
+#define MDE_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MDE_OK 0
+#define MDE_EINVAL (-1)    /* bad argument (shape, alignment, null pointer)           */
+#define MDE_EHIP (-2)      /* a HIP runtime call / kernel launch failed               */
+#define MDE_ENOTSUP (-3)   /* valid request this build has no kernel for              */
+
+#define MDE_MAX_TAPS 32
+
+const char* mde_last_error(void);
+/* ABI version of this header (checked by the Python loader). */
+int mde_abi_version(void);
+/* Number of CUs of the current device (used by hosts to size split-K). */
+int mde_device_cu_count(int* out);
+
+/* ------------------------------------------------------------------------------------
+ * Implicit-GEMM convolution on MFMA (bf16 in, fp32 accumulate).
+ * Replaces every nn.Conv2d on the FCRN path: torchvision Bottleneck convs (called at
+ * reference network/FCRN.py:305,318-323), conv2 (FCRN.py:334), the UpProj 5x5/3x3 convs
+ * (FCRN.py:180-188) incl. the zero-insertion Unpool (FCRN.py:31-44) folded in as four
+ * output phases, and their autograd backward (dgrad / wgrad).
+ *
+ * One descriptor covers forward, stride-1 dgrad, strided dgrad (as output phases) and the
+ * phase-decomposed up-projection, because all are "for every pixel of an output grid,
+ * sum over taps t and channels c of   in[(gy*sy+dy[t], gx*sx+dx[t]), c] * w[col][wtap[t]][c]".
+ * ---------------------------------------------------------------------------------- */
+typedef struct mde_conv_desc {
+    /* gathered operand: bf16 [N][H][W][ld_in], C contracted channels per tap (C % 64 == 0) */
+    int32_t N, H, W, ld_in, C;
+    uint32_t in_bytes;          /* bytes addressable from `in` (bounds for zero-fill)       */
+    /* output pixel grid of this launch: M = N*GH*GW rows */
+    int32_t GH, GW;
+    int32_t sy, sx;             /* input step per grid step                                */
+    int32_t ntaps;              /* 1..MDE_MAX_TAPS                                         */
+    int16_t dy[MDE_MAX_TAPS];   /* input row  = gy*sy + dy[t]  (out of range -> zero)      */
+    int16_t dx[MDE_MAX_TAPS];   /* input col  = gx*sx + dx[t]                              */
+    int16_t wtap[MDE_MAX_TAPS]; /* tap slot of t inside the packed weight row              */
+    int32_t wtaps_total;        /* weight row = [wtaps_total][C] bf16                       */
+    /* output tensor: bf16 [N][OH][OW][ld_out]; grid pixel -> (gy*osy+ooy, gx*osx+oox)     */
+    int32_t OH, OW, ld_out;
+    int32_t osy, osx, ooy, oox;
+    int32_t ncols;              /* output channels (GEMM columns); weight rows             */
+    int32_t accumulate;         /* !=0: out += result (bf16 read-modify-write)             */
+} mde_conv_desc;
+
+/* out[pix][col] (+)= sum_t sum_c in[src(pix,t)][c] * w[col][wtap[t]][c]
+ * w: bf16 [ncols][wtaps_total][C].  stats (optional, may be NULL): fp32
+ * [mde_conv_gemm_stat_rows(d)][2][ncols] partial per-column sums and sums of squares of the
+ * fp32 results, one row per pixel tile (plain stores, deterministic) — fuses the BatchNorm
+ * batch-statistics pass into the conv epilogue; feed it to mde_bn_finalize as `part`. */
+int mde_conv_gemm(const mde_conv_desc* d, const void* in, const void* w, void* out,
+                  float* stats, void* stream);
+/* Rows of the `stats` partial buffer mde_conv_gemm writes for this descriptor. */
+int mde_conv_gemm_stat_rows(const mde_conv_desc* d);
+
+/* Weight gradient ("TN" GEMM over pixels), fp32 output accumulated with atomics:
+ *   dw[r][otap[t]][c] += sum_{pix in grid} direct[pix][.] x gathered[src(pix,t)][.]
+ * rows index the channels of `rows_from` (0: direct tensor, 1: gathered tensor), columns the
+ * other one.  The caller zeroes dw.  ksplit >= 1 splits the pixel range over workgroups. */
+typedef struct mde_wgrad_desc {
+    int32_t N, GH, GW;          /* pixel grid (of the direct tensor)                        */
+    int32_t ld_d, Cd;           /* direct tensor bf16 [N][GH][GW][ld_d], Cd channels used   */
+    int32_t H, W, ld_g, Cg;     /* gathered tensor bf16 [N][H][W][ld_g], Cg channels used   */
+    uint32_t d_bytes, g_bytes;
+    int32_t sy, sx, ntaps;
+    int16_t dy[MDE_MAX_TAPS], dx[MDE_MAX_TAPS];
+    int16_t otap[MDE_MAX_TAPS]; /* tap slot in the output                                   */
+    int32_t otaps_total;        /* dw is fp32 [rows][otaps_total][cols]                      */
+    int32_t rows_from_gathered; /* 0: rows = direct channels, cols = gathered channels       */
+    int32_t ksplit;
+} mde_wgrad_desc;
+
+int mde_conv_wgrad(const mde_wgrad_desc* d, const void* direct, const void* gathered,
+                   float* dw, void* stream);
+
+/* Stem 7x7/2 convolution on the raw image (torchvision conv1, used at FCRN.py:308,353).
+ * x: fp32 NCHW [N][3][H][W] (the tensor the LightningModule hands to model(x), laina.py:18)
+ * w: fp32 [64][7][7][3] (OHWI).  out: bf16 NHWC [N][H/2][W/2][64].  H, W even. */
+int mde_stem_conv_fwd(const float* x, const float* w, void* out, int N, int H, int W, void* stream);
+/* dw (fp32 [64][7][7][3], caller-zeroed) += wgrad from dout bf16 [N][H/2][W/2][64]. */
+int mde_stem_conv_wgrad(const float* x, const void* dout, float* dw, int N, int H, int W, void* stream);
+
+/* Head conv3 3x3, Cin -> Cout (Cout <= 32), fp32 output (FCRN.py:340,368).
+ * x: bf16 [N][H][W][Cin]; w: fp32 [Cout][3][3][Cin]; out: fp32 [N][H][W][Cout]. */
+int mde_head_conv_fwd(const void* x, const float* w, float* out, int N, int H, int W, int Cin,
+                      int Cout, void* stream);
+/* dx: bf16 [N][H][W][Cin];  dw: fp32 [Cout][3][3][Cin] caller-zeroed, atomically added. */
+int mde_head_conv_bwd(const void* x, const float* w, const float* dout, void* dx, float* dw,
+                      int N, int H, int W, int Cin, int Cout, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * BatchNorm2d, training and eval mode (nn.BatchNorm2d everywhere in FCRN.py / torchvision).
+ * Statistics are fp32; a "BN site" normalises C channels of a [M = N*H*W][ld] bf16 tensor.
+ * ---------------------------------------------------------------------------------- */
+/* Partial sums: part[blk][2][C] (fp32). nblk = mde_bn_stats_blocks(M, C). */
+int mde_bn_stats_blocks(int64_t M, int C);
+int mde_bn_stats(const void* x, int64_t M, int C, int ld, float* part, void* stream);
+/* Reduce partials (or conv-epilogue stats with nblk == 1) to scale/shift:
+ *   mean, var (biased) -> scale = gamma*rstd, shift = beta - mean*scale;
+ *   save_mean/save_rstd kept for backward; running stats updated with `momentum`
+ *   (unbiased variance), exactly as nn.BatchNorm2d in train mode.  */
+int mde_bn_finalize(const float* part, int nblk, int64_t M, int C, const float* gamma,
+                    const float* beta, float* running_mean, float* running_var, float momentum,
+                    float eps, float* scale, float* shift, float* save_mean, float* save_rstd,
+                    void* stream);
+/* Eval mode: scale/shift from running statistics. */
+int mde_bn_eval_scale_shift(const float* gamma, const float* beta, const float* running_mean,
+                            const float* running_var, float eps, int C, float* scale, float* shift,
+                            void* stream);
+/* out = act( x*scale + shift  [+ r  |  + r*rscale + rshift] );  relu != 0 applies ReLU.
+ * r may be NULL; rscale/rshift may be NULL (plain residual add).  All bf16, own ld each. */
+int mde_bn_apply(const void* x, int ldx, const float* scale, const float* shift, const void* r,
+                 int ldr, const float* rscale, const float* rshift, void* out, int ldo, int64_t M,
+                 int C, int relu, void* stream);
+/* Backward of  out = act(bn(x) [+ ...]):  g = dout * (relu ? out > 0 : 1).
+ * pass 1 (reduce): part[blk][2][C] = (sum g, sum g*xhat).  nblk as mde_bn_stats_blocks. */
+int mde_bn_bwd_reduce(const void* dout, int ldd, const void* out, int ldo, const void* x, int ldx,
+                      const float* save_mean, const float* save_rstd, int64_t M, int C, int relu,
+                      float* part, void* stream);
+/* pass 2: dgamma = sum g*xhat, dbeta = sum g (added into the fp32 grads);
+ *   dx = gamma*rstd*(g - mean(g) - xhat*mean(g*xhat)) (bf16, ld ldxo).
+ *   dres (optional): receives g (the masked upstream gradient) for the residual branch;
+ *   accumulate_dx != 0 adds into dx instead of overwriting. */
+int mde_bn_bwd_apply(const void* dout, int ldd, const void* out, int ldo, const void* x, int ldx,
+                     const float* save_mean, const float* save_rstd, const float* gamma,
+                     const float* part, int nblk, int64_t M, int C, int relu, float* dgamma,
+                     float* dbeta, void* dx, int ldxo, int accumulate_dx, void* dres, int ldres,
+                     void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Pooling / resize / pointwise.
+ * ---------------------------------------------------------------------------------- */
+/* MaxPool 3x3 stride 2 pad 1 (torchvision maxpool, FCRN.py:319,356). idx: uint8 argmax
+ * (first maximum in window scan order, as ATen) kept for backward. */
+int mde_maxpool_fwd(const void* x, void* out, uint8_t* idx, int N, int H, int W, int C, void* stream);
+int mde_maxpool_bwd(const void* dout, const uint8_t* idx, void* dx, int N, int H, int W, int C,
+                    void* stream);
+/* Bilinear resize align_corners=True followed by sigmoid (FCRN.py:341,369-371).
+ * x: fp32 [N][H][W][C] -> out fp32 NCHW [N][C][OH][OW] (the module's return tensor). */
+int mde_upsample_sigmoid_fwd(const float* x, float* out, int N, int H, int W, int C, int OH, int OW,
+                             void* stream);
+/* dx fp32 [N][H][W][C] = d(loss)/dx given dout = d(loss)/d(out) and out (both NCHW fp32). */
+int mde_upsample_sigmoid_bwd(const float* dout, const float* out, float* dx, int N, int H, int W,
+                             int C, int OH, int OW, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Losses and metrics (criteria.py / metrics.py), fp32 in, fp32/fp64 accumulation.
+ * ---------------------------------------------------------------------------------- */
+/* SILog (criteria.py:724-732).  ws: >= mde_silog_ws_bytes() bytes, zeroed by the call.
+ * loss: 1 float.  grad (optional): d loss / d est, same shape as est, scaled by *gscale
+ * (device pointer to 1 float = upstream gradient; NULL -> 1). */
+size_t mde_silog_ws_bytes(void);
+int mde_silog_fwd(const float* est, const float* gt, int64_t n, float variance_focus, void* ws,
+                  float* loss, void* stream);
+int mde_silog_bwd(const float* est, const float* gt, int64_t n, float variance_focus, const void* ws,
+                  const float* gscale, float* grad, void* stream);
+/* Depth metrics (metrics.py:58-109): out[6] = absrel, 'rmse' (= mean sqrt((p-t)^2/t), sic),
+ * delta1, delta2, delta3, log10.  ws >= mde_metrics_ws_bytes(). */
+size_t mde_metrics_ws_bytes(void);
+int mde_depth_metrics(const float* pred, const float* target, int64_t n, void* ws, float* out,
+                      void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Optimiser / parameter plumbing (torch.optim.Adam as configured at modules/laina.py:51-57).
+ * ---------------------------------------------------------------------------------- */
+/* One Adam step over a flat fp32 range; also refreshes the bf16 shadow copy used by the convs.
+ * step >= 1.  weight_decay is L2 (added to grad) like torch.optim.Adam.  grad_scale multiplies
+ * the gradient first (1/world_size after a sum all-reduce). */
+int mde_adam_step(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, float lr,
+                  float beta1, float beta2, float eps, float weight_decay, float grad_scale, int step,
+                  void* stream);
+/* bf16 cast of a flat fp32 range (weight shadow refresh after load_state_dict). */
+int mde_cast_bf16(const float* src, void* dst, int64_t n, void* stream);
+/* dst[i][t][o] = bf16(src[o][t][i])  — the dgrad ("transposed") weight packing. */
+int mde_pack_wt(const float* src, void* dst, int O, int T, int I, void* stream);
+/* fp32 NCHW -> bf16 NHWC (and back) layout changes at the module boundary. */
+int mde_nchw_to_nhwc_bf16(const float* src, void* dst, int N, int C, int H, int W, void* stream);
+int mde_nhwc_bf16_to_nchw(const void* src, float* dst, int N, int C, int H, int W, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MDE_HIP_H */

@@ -1,0 +1,117 @@
+"""ctypes binding of libmde_hip.so (include/mde_hip.h).
+
+The product path has no CPU fallback: if the shared library is missing or an entry point
+is absent this module raises at import/first use, loudly.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmde_hip.so")
+ABI_VERSION = 1
+MAX_TAPS = 32
+
+
+class MdeError(RuntimeError):
+    pass
+
+
+class ConvDesc(C.Structure):
+    """mde_conv_desc (include/mde_hip.h)."""
+    _fields_ = [
+        ("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("ld_in", C.c_int32), ("C", C.c_int32),
+        ("in_bytes", C.c_uint32),
+        ("GH", C.c_int32), ("GW", C.c_int32), ("sy", C.c_int32), ("sx", C.c_int32), ("ntaps", C.c_int32),
+        ("dy", C.c_int16 * MAX_TAPS), ("dx", C.c_int16 * MAX_TAPS), ("wtap", C.c_int16 * MAX_TAPS),
+        ("wtaps_total", C.c_int32),
+        ("OH", C.c_int32), ("OW", C.c_int32), ("ld_out", C.c_int32),
+        ("osy", C.c_int32), ("osx", C.c_int32), ("ooy", C.c_int32), ("oox", C.c_int32),
+        ("ncols", C.c_int32), ("accumulate", C.c_int32),
+    ]
+
+
+class WgradDesc(C.Structure):
+    """mde_wgrad_desc (include/mde_hip.h)."""
+    _fields_ = [
+        ("N", C.c_int32), ("GH", C.c_int32), ("GW", C.c_int32),
+        ("ld_d", C.c_int32), ("Cd", C.c_int32),
+        ("H", C.c_int32), ("W", C.c_int32), ("ld_g", C.c_int32), ("Cg", C.c_int32),
+        ("d_bytes", C.c_uint32), ("g_bytes", C.c_uint32),
+        ("sy", C.c_int32), ("sx", C.c_int32), ("ntaps", C.c_int32),
+        ("dy", C.c_int16 * MAX_TAPS), ("dx", C.c_int16 * MAX_TAPS), ("otap", C.c_int16 * MAX_TAPS),
+        ("otaps_total", C.c_int32), ("rows_from_gathered", C.c_int32), ("ksplit", C.c_int32),
+    ]
+
+
+_P, _I, _L, _F, _Z = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
+
+# name -> (restype, argtypes); every symbol include/mde_hip.h declares
+SIGNATURES = {
+    "mde_last_error": (C.c_char_p, []),
+    "mde_abi_version": (_I, []),
+    "mde_device_cu_count": (_I, [C.POINTER(_I)]),
+    "mde_conv_gemm": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P]),
+    "mde_conv_gemm_stat_rows": (_I, [C.POINTER(ConvDesc)]),
+    "mde_conv_wgrad": (_I, [C.POINTER(WgradDesc), _P, _P, _P, _P]),
+    "mde_stem_conv_fwd": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "mde_stem_conv_wgrad": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "mde_head_conv_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "mde_head_conv_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "mde_bn_stats_blocks": (_I, [_L, _I]),
+    "mde_bn_stats": (_I, [_P, _L, _I, _I, _P, _P]),
+    "mde_bn_finalize": (_I, [_P, _I, _L, _I, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P]),
+    "mde_bn_eval_scale_shift": (_I, [_P, _P, _P, _P, _F, _I, _P, _P, _P]),
+    "mde_bn_apply": (_I, [_P, _I, _P, _P, _P, _I, _P, _P, _P, _I, _L, _I, _I, _P]),
+    "mde_bn_bwd_reduce": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _L, _I, _I, _P, _P]),
+    "mde_bn_bwd_apply": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _P, _I, _L, _I, _I, _P, _P, _P, _I, _I,
+                              _P, _I, _P]),
+    "mde_maxpool_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    "mde_maxpool_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    "mde_upsample_sigmoid_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "mde_upsample_sigmoid_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "mde_silog_ws_bytes": (_Z, []),
+    "mde_silog_fwd": (_I, [_P, _P, _L, _F, _P, _P, _P]),
+    "mde_silog_bwd": (_I, [_P, _P, _L, _F, _P, _P, _P, _P]),
+    "mde_metrics_ws_bytes": (_Z, []),
+    "mde_depth_metrics": (_I, [_P, _P, _L, _P, _P, _P]),
+    "mde_adam_step": (_I, [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _F, _I, _P]),
+    "mde_cast_bf16": (_I, [_P, _P, _L, _P]),
+    "mde_pack_wt": (_I, [_P, _P, _I, _I, _I, _P]),
+    "mde_nchw_to_nhwc_bf16": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "mde_nhwc_bf16_to_nchw": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libmde_hip.so once and bind every declared symbol. Raises MdeError if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MdeError(
+            "libmde_hip.so not found at %s — build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` (or mono_depth_estimation_amd/csrc/build.sh). There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    missing = []
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            missing.append(name)
+            continue
+        fn.restype = res
+        fn.argtypes = args
+    if missing:
+        raise MdeError("libmde_hip.so lacks symbols declared in include/mde_hip.h: %s" % ", ".join(missing))
+    if lib.mde_abi_version() != ABI_VERSION:
+        raise MdeError("libmde_hip.so ABI %d != binding ABI %d" % (lib.mde_abi_version(), ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().mde_last_error()
+        raise MdeError("%s failed (%d): %s" % (what or "libmde_hip call", rc, (msg or b"").decode()))

@@ -1,0 +1,21 @@
+#!/bin/bash
+# Build libmde_hip.so for gfx950 (MI355X).  hipcc cross-compiles without a GPU.
+set -euo pipefail
+cd "$(dirname "$0")"
+OUT=../libmde_hip.so
+HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -ffp-contract=off"
+mkdir -p build
+objs=()
+pids=()
+for src in *.hip; do
+    obj=build/${src%.hip}.o
+    objs+=("$obj")
+    if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ mde_common.h -nt "$obj" ] || [ ../../include/mde_hip.h -nt "$obj" ]; then
+        $HIPCC $FLAGS -c "$src" -o "$obj" &
+        pids+=($!)
+    fi
+done
+for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o $OUT "${objs[@]}"
+echo "built $(readlink -f $OUT)"

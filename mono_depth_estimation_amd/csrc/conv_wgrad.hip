@@ -1,0 +1,261 @@
+// Weight-gradient GEMM on MFMA for gfx950 — the "TN" form: both operands are pixel-major
+// (NHWC bf16) and the contraction runs over PIXELS, so each MFMA fragment needs 8
+// consecutive pixels of one channel: a transposed read.  The tiles are staged row-major
+// ([pixel][channel], full 128/256-byte lines from HBM) and consumed with
+// ds_read_b64_tr_b16 (hardware transpose), XOR-swizzled so both the 16-byte staging writes
+// and the transposed reads are bank-conflict-free.
+//
+//   dw[r][otap[t]][c] += sum_{pix} A[pix or src(pix,t)][r] * B[src(pix,t) or pix][c]
+//
+// One workgroup (256 threads, 2x2 waves) owns a BA x BB tile of one tap and one slice of
+// the pixel range (split-K); partial tiles are added with fp32 global atomics.
+// Replaces the autograd weight-gradient of every nn.Conv2d on the FCRN path (reference
+// network/FCRN.py:180-188,334 and the torchvision Bottleneck convs) including the
+// up-projection 5x5, whose zero-stuffed input (FCRN.py:31-44) becomes a stride-2 gather on
+// the dY side.
+#include "mde_common.h"
+
+namespace {
+
+constexpr int BKP = 64;   // pixels per K-step
+constexpr int NT = 256;
+
+struct KArgs {
+    mde_wgrad_desc d;
+    const void* direct;
+    const void* gathered;
+    float* dw;
+    int32_t M;            // N*GH*GW
+    int32_t kchunk;       // pixels per split-K slice (multiple of 64)
+    int32_t nA, nB;       // tiles along rows / cols
+    int32_t Crows, Ccols;
+    uint32_t inv_gw, inv_ghw;
+};
+
+// byte offset of 16-byte chunk `ch` of row `row` in a [64][CH] bf16 tile, CH = 128 or 64
+template <int CH>
+__device__ __forceinline__ int tile_off(int row, int ch) {
+    if constexpr (CH == 128) {
+        return row * 256 + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
+    } else {
+        return row * 128 + 16 * (ch ^ ((((row >> 1) & 1) | (((row >> 3) & 1) << 1)) << 1));
+    }
+}
+
+// One 16(channel) x 32(pixel) MFMA operand fragment out of a row-major [pixel][channel] tile:
+// two transposed reads of 4 pixel-rows x 16 channels each (guide T10).
+template <int CH>
+__device__ __forceinline__ bf16x8_t read_frag_tr(const char* tile, int k0, int c0, int lane) {
+    const int i = lane & 15, g = lane >> 4;
+    const int q = i >> 2, p = i & 3;
+    const int row = k0 + 8 * g + q;
+    const int ch = (c0 >> 3) + (p >> 1);
+    const int sub = (p & 1) * 8;
+    typedef __attribute__((address_space(3))) s16x4_t* lds_ptr;
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (lds_ptr)(uintptr_t)(uint32_t)(uintptr_t)(tile + tile_off<CH>(row, ch) + sub));
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (lds_ptr)(uintptr_t)(uint32_t)(uintptr_t)(tile + tile_off<CH>(row + 4, ch) + sub));
+    union { struct { s16x4_t a, b; } s; bf16x8_t v; } u;
+    u.s.a = lo;
+    u.s.b = hi;
+    return u.v;
+}
+
+// GA: the gathered tensor supplies the A operand (rows of dw); otherwise the direct one does.
+template <int BA, int BB, bool GA>
+__global__ __launch_bounds__(NT, 2) void conv_wgrad_tn(const KArgs a) {
+    constexpr int FA = BA / 32, FB = BB / 32;      // 16-wide fragments per wave along rows / cols
+    constexpr int AT_BYTES = BKP * BA * 2, BT_BYTES = BKP * BB * 2;
+    constexpr int BUF_BYTES = AT_BYTES + BT_BYTES;
+    constexpr int CPR_A = BA / 8, CPR_B = BB / 8;  // 16-byte chunks per tile row
+    constexpr int RPP_A = NT / CPR_A, RPP_B = NT / CPR_B;
+    constexpr int PA = BKP / RPP_A, PB = BKP / RPP_B;  // loads per thread per step
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const mde_wgrad_desc& d = a.d;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wa = wave >> 1, wb = wave & 1;
+
+    // block -> (tap, tileB, tileA, kslice), tap fastest so neighbours share operand tiles in L2
+    uint32_t b = blockIdx.x;
+    const int tap = b % d.ntaps; b /= d.ntaps;
+    const int tb = b % a.nB; b /= a.nB;
+    const int ta = b % a.nA; b /= a.nA;
+    const int ks = b;
+    const int row0 = ta * BA, col0 = tb * BB;
+    const int kbeg = ks * a.kchunk;
+    const int kend = min(a.M, kbeg + a.kchunk);
+    if (kbeg >= kend) return;
+    const int nsteps = (kend - kbeg + BKP - 1) / BKP;
+
+    const int tdy = d.dy[tap], tdx = d.dx[tap];
+    const __amdgpu_buffer_rsrc_t rs_d = mde_rsrc(a.direct, d.d_bytes);
+    const __amdgpu_buffer_rsrc_t rs_g = mde_rsrc(a.gathered, d.g_bytes);
+
+    const int a_chunk = tid % CPR_A, a_row = tid / CPR_A;
+    const int b_chunk = tid % CPR_B, b_row = tid / CPR_B;
+    // channel offsets inside the source tensors
+    const int a_c = row0 + a_chunk * 8, b_c = col0 + b_chunk * 8;
+
+    int a_st[PA], b_st[PB];
+#pragma unroll
+    for (int p = 0; p < PA; ++p) a_st[p] = tile_off<BA>(a_row + p * RPP_A, a_chunk);
+#pragma unroll
+    for (int p = 0; p < PB; ++p) b_st[p] = tile_off<BB>(b_row + p * RPP_B, b_chunk);
+
+    auto direct_off = [&](int m, int c) -> uint32_t {
+        return m < kend ? (uint32_t)(m * d.ld_d + c) * 2u : MDE_OOB_OFFSET;
+    };
+    auto gathered_off = [&](int m, int c) -> uint32_t {
+        if (m >= kend) return MDE_OOB_OFFSET;
+        const uint32_t n = mde_fastdiv((uint32_t)m, (uint32_t)(d.GH * d.GW), a.inv_ghw);
+        const uint32_t rem = (uint32_t)m - n * (uint32_t)(d.GH * d.GW);
+        const uint32_t gy = mde_fastdiv(rem, (uint32_t)d.GW, a.inv_gw);
+        const uint32_t gx = rem - gy * (uint32_t)d.GW;
+        const int iy = (int)gy * d.sy + tdy, ix = (int)gx * d.sx + tdx;
+        const bool ok = ((uint32_t)iy < (uint32_t)d.H) & ((uint32_t)ix < (uint32_t)d.W);
+        return ok ? (uint32_t)((((int)n * d.H + iy) * d.W + ix) * d.ld_g + c) * 2u : MDE_OOB_OFFSET;
+    };
+
+    i32x4_t ar[PA], br[PB];
+    auto issue_loads = [&](int s) {
+        const int mb = kbeg + s * BKP;
+#pragma unroll
+        for (int p = 0; p < PA; ++p) {
+            const int m = mb + a_row + p * RPP_A;
+            ar[p] = GA ? __builtin_amdgcn_raw_buffer_load_b128(rs_g, gathered_off(m, a_c), 0, 0)
+                       : __builtin_amdgcn_raw_buffer_load_b128(rs_d, direct_off(m, a_c), 0, 0);
+        }
+#pragma unroll
+        for (int p = 0; p < PB; ++p) {
+            const int m = mb + b_row + p * RPP_B;
+            br[p] = GA ? __builtin_amdgcn_raw_buffer_load_b128(rs_d, direct_off(m, b_c), 0, 0)
+                       : __builtin_amdgcn_raw_buffer_load_b128(rs_g, gathered_off(m, b_c), 0, 0);
+        }
+    };
+    auto stage_write = [&](int buf) {
+        char* at = smem + buf * BUF_BYTES;
+        char* bt = at + AT_BYTES;
+#pragma unroll
+        for (int p = 0; p < PA; ++p) *reinterpret_cast<i32x4_t*>(at + a_st[p]) = ar[p];
+#pragma unroll
+        for (int p = 0; p < PB; ++p) *reinterpret_cast<i32x4_t*>(bt + b_st[p]) = br[p];
+    };
+
+    f32x4_t acc[FA][FB];
+#pragma unroll
+    for (int i = 0; i < FA; ++i)
+#pragma unroll
+        for (int j = 0; j < FB; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    issue_loads(0);
+    stage_write(0);
+    __syncthreads();
+
+    for (int s = 0; s < nsteps; ++s) {
+        const int buf = s & 1;
+        const bool more = s + 1 < nsteps;
+        if (more) issue_loads(s + 1);
+        const char* at = smem + buf * BUF_BYTES;
+        const char* bt = at + AT_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < BKP; kk += 32) {
+            bf16x8_t fa[FA], fb[FB];
+#pragma unroll
+            for (int i = 0; i < FA; ++i) fa[i] = read_frag_tr<BA>(at, kk, wa * (BA / 2) + i * 16, lane);
+#pragma unroll
+            for (int j = 0; j < FB; ++j) fb[j] = read_frag_tr<BB>(bt, kk, wb * (BB / 2) + j * 16, lane);
+#pragma unroll
+            for (int i = 0; i < FA; ++i)
+#pragma unroll
+                for (int j = 0; j < FB; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) stage_write(buf ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: fp32 atomic accumulation into dw[row][otap][col]
+    const int otap = d.otap[tap];
+    const size_t rstride = (size_t)d.otaps_total * a.Ccols;
+#pragma unroll
+    for (int i = 0; i < FA; ++i)
+#pragma unroll
+        for (int j = 0; j < FB; ++j) {
+            const int col = col0 + wb * (BB / 2) + j * 16 + (lane & 15);
+            const int rbase = row0 + wa * (BA / 2) + i * 16 + (lane >> 4) * 4;
+            if (col < a.Ccols) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = rbase + r;
+                    if (row < a.Crows)
+                        atomicAdd(a.dw + (size_t)row * rstride + (size_t)otap * a.Ccols + col, acc[i][j][r]);
+                }
+            }
+        }
+}
+
+template <int BA, int BB, bool GA>
+int launch(const KArgs& ka, int nblk, hipStream_t st) {
+    constexpr size_t smem = 2 * (size_t)BKP * (BA + BB) * 2;
+    conv_wgrad_tn<BA, BB, GA><<<dim3(nblk), dim3(NT), smem, st>>>(ka);
+    MDE_LAUNCH_CHECK("conv_wgrad_tn");
+    return MDE_OK;
+}
+
+template <bool GA>
+int dispatch(const KArgs& ka, int ba, int bb, int nblk, hipStream_t st) {
+    if (ba == 128 && bb == 128) return launch<128, 128, GA>(ka, nblk, st);
+    if (ba == 128 && bb == 64) return launch<128, 64, GA>(ka, nblk, st);
+    if (ba == 64 && bb == 128) return launch<64, 128, GA>(ka, nblk, st);
+    return launch<64, 64, GA>(ka, nblk, st);
+}
+
+inline uint32_t inv32(uint32_t dv) { return dv <= 1 ? 0xFFFFFFFFu : (uint32_t)((1ull << 32) / dv); }
+
+}  // namespace
+
+extern "C" int mde_conv_wgrad(const mde_wgrad_desc* d, const void* direct, const void* gathered,
+                              float* dw, void* stream) {
+    MDE_REQUIRE(d && direct && gathered && dw, "mde_conv_wgrad: null argument");
+    MDE_REQUIRE(d->Cd > 0 && d->Cg > 0 && d->Cd % 64 == 0 && d->Cg % 64 == 0,
+                "mde_conv_wgrad: channel counts (%d, %d) must be positive multiples of 64", d->Cd, d->Cg);
+    MDE_REQUIRE(d->ntaps >= 1 && d->ntaps <= MDE_MAX_TAPS, "mde_conv_wgrad: ntaps=%d out of range", d->ntaps);
+    MDE_REQUIRE(d->N > 0 && d->GH > 0 && d->GW > 0 && d->H > 0 && d->W > 0, "mde_conv_wgrad: non-positive dimension");
+    MDE_REQUIRE(d->ld_d % 8 == 0 && d->ld_g % 8 == 0 && ((uintptr_t)direct % 16) == 0 && ((uintptr_t)gathered % 16) == 0,
+                "mde_conv_wgrad: operands must be 16-byte aligned with ld %% 8 == 0");
+    MDE_REQUIRE(d->d_bytes > 0 && d->d_bytes < MDE_OOB_OFFSET && d->g_bytes > 0 && d->g_bytes < MDE_OOB_OFFSET,
+                "mde_conv_wgrad: operand sizes must be < 2 GiB");
+    MDE_REQUIRE(d->ksplit >= 1, "mde_conv_wgrad: ksplit must be >= 1");
+    for (int t = 0; t < d->ntaps; ++t)
+        MDE_REQUIRE(d->otap[t] >= 0 && d->otap[t] < d->otaps_total, "mde_conv_wgrad: otap[%d] out of range", t);
+    const int64_t M = (int64_t)d->N * d->GH * d->GW;
+    MDE_REQUIRE(M < (1ll << 31) && M * d->ld_d < (1ll << 30) && (int64_t)d->N * d->H * d->W * d->ld_g < (1ll << 30),
+                "mde_conv_wgrad: tensor too large for 32-bit indexing");
+
+    KArgs ka;
+    ka.d = *d;
+    ka.direct = direct;
+    ka.gathered = gathered;
+    ka.dw = dw;
+    ka.M = (int32_t)M;
+    const bool ga = d->rows_from_gathered != 0;
+    ka.Crows = ga ? d->Cg : d->Cd;
+    ka.Ccols = ga ? d->Cd : d->Cg;
+    const int ba = ka.Crows % 128 == 0 ? 128 : 64;
+    const int bb = ka.Ccols % 128 == 0 ? 128 : 64;
+    ka.nA = ka.Crows / ba;
+    ka.nB = ka.Ccols / bb;
+    int64_t chunk = (M + d->ksplit - 1) / d->ksplit;
+    chunk = (chunk + BKP - 1) / BKP * BKP;
+    ka.kchunk = (int32_t)chunk;
+    const int kslices = mde_cdiv(M, chunk);
+    ka.inv_gw = inv32((uint32_t)d->GW);
+    ka.inv_ghw = inv32((uint32_t)(d->GH * d->GW));
+    const int64_t nblk = (int64_t)d->ntaps * ka.nA * ka.nB * kslices;
+    MDE_REQUIRE(nblk < (1ll << 31), "mde_conv_wgrad: grid too large");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    return ga ? dispatch<true>(ka, ba, bb, (int)nblk, st) : dispatch<false>(ka, ba, bb, (int)nblk, st);
+}

@@ -1,0 +1,90 @@
+// Shared device/host helpers for libmde_hip.so (gfx950 / MI355X only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/mde_hip.h"
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) int i32x4_t;
+typedef __attribute__((ext_vector_type(2))) int i32x2_t;
+
+#define MDE_WAVE 64
+#define MDE_OOB_OFFSET 0x80000000u  // any voffset >= num_records reads as zero through a raw buffer
+
+// ---------------------------------------------------------------- error plumbing (host)
+void mde_set_error(const char* fmt, ...);
+int mde_check_hip(hipError_t e, const char* what);
+
+#define MDE_REQUIRE(cond, ...)            \
+    do {                                  \
+        if (!(cond)) {                    \
+            mde_set_error(__VA_ARGS__);   \
+            return MDE_EINVAL;            \
+        }                                 \
+    } while (0)
+
+#define MDE_LAUNCH_CHECK(what)                                     \
+    do {                                                           \
+        int _rc = mde_check_hip(hipGetLastError(), what);          \
+        if (_rc) return _rc;                                       \
+    } while (0)
+
+static inline int mde_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// ---------------------------------------------------------------- device helpers
+#ifdef __HIPCC__
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t mde_rsrc(const void* p, uint32_t bytes) {
+    // raw buffer, stride 0: loads whose byte offset is >= bytes return 0
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+
+__device__ __forceinline__ float mde_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ double mde_wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// Block-wide sum of `v`; result valid in thread 0.  `scratch` >= blockDim/64 floats of LDS.
+__device__ __forceinline__ float mde_block_sum(float v, float* scratch) {
+    v = mde_wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) scratch[w] = v;
+    __syncthreads();
+    float r = 0.f;
+    if (threadIdx.x == 0)
+        for (int i = 0; i < (int)(blockDim.x >> 6); ++i) r += scratch[i];
+    __syncthreads();
+    return r;
+}
+
+// floor(m / d) for m < 2^32 with inv = floor(2^32 / d) (one correction step; d >= 2).
+// For d == 1 pass inv = 0xFFFFFFFF.
+__device__ __forceinline__ uint32_t mde_fastdiv(uint32_t m, uint32_t d, uint32_t inv) {
+    uint32_t q = __umulhi(m, inv);
+    uint32_t r = m - q * d;
+    return q + (r >= d ? 1u : 0u);
+}
+
+// XCD-aware block remap (bijective for any grid size): blocks b, b+8, ... share an XCD under
+// round-robin dispatch, so give each of the 8 groups a contiguous run of the tile order.
+// Speed only, never correctness (guide T1).
+__device__ __forceinline__ uint32_t mde_xcd_remap(uint32_t bid, uint32_t nblk) {
+    const uint32_t q = nblk >> 3, r = nblk & 7u, x = bid & 7u, i = bid >> 3;
+    const uint32_t start = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+    return start + i;
+}
+#endif

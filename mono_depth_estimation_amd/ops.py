@@ -1,0 +1,149 @@
+"""Host-side wrappers over the C ABI (include/mde_hip.h): descriptor builders and launchers.
+
+Tensors are torch CUDA tensors used purely as device-memory handles (data_ptr + current
+stream); all arithmetic happens in libmde_hip.so.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, WgradDesc, check
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _nbytes_from(t):
+    """Bytes addressable from t.data_ptr() inside its storage."""
+    return t.untyped_storage().nbytes() - t.storage_offset() * t.element_size()
+
+
+# ------------------------------------------------------------------------------ conv descriptors
+def _fill_taps(d, taps, field3):
+    assert 1 <= len(taps) <= _lib.MAX_TAPS, len(taps)
+    d.ntaps = len(taps)
+    third = getattr(d, field3)
+    for i, (dy, dx, wt) in enumerate(taps):
+        d.dy[i], d.dx[i], third[i] = dy, dx, wt
+
+
+def conv_desc(N, H, W, ld_in, Cc, in_bytes, GH, GW, sy, sx, taps, wtaps_total, OH, OW, ld_out,
+              osy=1, osx=1, ooy=0, oox=0, ncols=0, accumulate=False):
+    d = ConvDesc()
+    d.N, d.H, d.W, d.ld_in, d.C, d.in_bytes = N, H, W, ld_in, Cc, in_bytes
+    d.GH, d.GW, d.sy, d.sx = GH, GW, sy, sx
+    _fill_taps(d, taps, "wtap")
+    d.wtaps_total = wtaps_total
+    d.OH, d.OW, d.ld_out = OH, OW, ld_out
+    d.osy, d.osx, d.ooy, d.oox = osy, osx, ooy, oox
+    d.ncols, d.accumulate = ncols, int(accumulate)
+    return d
+
+
+def out_size(n, k, s, p, dil=1):
+    return (n + 2 * p - dil * (k - 1) - 1) // s + 1
+
+
+def fwd_desc(N, H, W, ld_in, Cin, in_bytes, k, stride, pad, Cout, ld_out, dil=1):
+    """Plain Conv2d forward, square kernel k, weights [Cout][k*k][Cin]."""
+    OH, OW = out_size(H, k, stride, pad, dil), out_size(W, k, stride, pad, dil)
+    taps = [(i * dil - pad, j * dil - pad, i * k + j) for i in range(k) for j in range(k)]
+    return conv_desc(N, H, W, ld_in, Cin, in_bytes, OH, OW, stride, stride, taps, k * k, OH, OW, ld_out,
+                     ncols=Cout)
+
+
+def dgrad_descs(N, H, W, ld_dx, Cin, OH, OW, ld_dy, Cout, dy_bytes, k, stride, pad, dil=1, accumulate=False):
+    """Conv2d input gradient as 1 (stride 1) or stride^2 output-phase launches over
+    dY [N][OH][OW][ld_dy] with the transposed weights [Cin][k*k][Cout].
+    Returns (descs, needs_zero_fill): phases without any tap are not launched."""
+    s = stride
+    descs, covered = [], 0
+    for a in range(s):
+        for b in range(s):
+            ti = [(i, (a + pad - i * dil) // s) for i in range(k) if (a + pad - i * dil) % s == 0]
+            tj = [(j, (b + pad - j * dil) // s) for j in range(k) if (b + pad - j * dil) % s == 0]
+            gh, gw = (H - a + s - 1) // s, (W - b + s - 1) // s
+            if not ti or not tj or gh <= 0 or gw <= 0:
+                continue
+            taps = [(dy, dx, i * k + j) for (i, dy) in ti for (j, dx) in tj]
+            descs.append(conv_desc(N, OH, OW, ld_dy, Cout, dy_bytes, gh, gw, 1, 1, taps, k * k, H, W, ld_dx,
+                                   osy=s, osx=s, ooy=a, oox=b, ncols=Cin, accumulate=accumulate))
+            covered += 1
+    return descs, covered != s * s
+
+
+def upproj_fwd_descs(N, h, w, ld_in, Cin, in_bytes, ncols, ld_out):
+    """5x5/pad-2 conv over the zero-stuffed 2x upsampling of x [N][h][w][Cin], as four
+    output phases over x itself (FCRN.py:31-44 + 180,187).  Weights [ncols][25][Cin]."""
+    descs = []
+    for a in range(2):
+        for b in range(2):
+            taps = [((a + i - 2) // 2, (b + j - 2) // 2, i * 5 + j)
+                    for i in range(5) if (a + i) % 2 == 0 for j in range(5) if (b + j) % 2 == 0]
+            descs.append(conv_desc(N, h, w, ld_in, Cin, in_bytes, h, w, 1, 1, taps, 25, 2 * h, 2 * w, ld_out,
+                                   osy=2, osx=2, ooy=a, oox=b, ncols=ncols))
+    return descs
+
+
+def upproj_dgrad_desc(N, h, w, ld_dx, Cin, ld_dy, Cdy, dy_bytes, accumulate=False):
+    """dx[gy,gx] = sum_{i,j} dY[2gy+2-i, 2gx+2-j] * W[.,i,j,.]: a stride-2 5x5 gather over
+    dY [N][2h][2w][ld_dy] with transposed weights [Cin][25][Cdy]."""
+    taps = [(2 - i, 2 - j, i * 5 + j) for i in range(5) for j in range(5)]
+    return conv_desc(N, 2 * h, 2 * w, ld_dy, Cdy, dy_bytes, h, w, 2, 2, taps, 25, h, w, ld_dx, ncols=Cin,
+                     accumulate=accumulate)
+
+
+def conv_gemm(desc, x, w, out, stats=None):
+    check(_lib.load().mde_conv_gemm(C.byref(desc), _p(x), _p(w), _p(out), _p(stats), _stream()), "mde_conv_gemm")
+
+
+def conv_gemm_stat_rows(desc):
+    n = _lib.load().mde_conv_gemm_stat_rows(C.byref(desc))
+    if n < 0:
+        raise _lib.MdeError("mde_conv_gemm_stat_rows failed")
+    return n
+
+
+# ------------------------------------------------------------------------------ wgrad descriptors
+def wgrad_desc(N, GH, GW, ld_d, Cd, d_bytes, H, W, ld_g, Cg, g_bytes, sy, sx, taps, otaps_total,
+               rows_from_gathered, ksplit):
+    d = WgradDesc()
+    d.N, d.GH, d.GW, d.ld_d, d.Cd = N, GH, GW, ld_d, Cd
+    d.H, d.W, d.ld_g, d.Cg = H, W, ld_g, Cg
+    d.d_bytes, d.g_bytes = d_bytes, g_bytes
+    d.sy, d.sx = sy, sx
+    _fill_taps(d, taps, "otap")
+    d.otaps_total, d.rows_from_gathered, d.ksplit = otaps_total, int(rows_from_gathered), ksplit
+    return d
+
+
+def conv_wgrad_desc(N, H, W, ld_x, Cin, x_bytes, OH, OW, ld_dy, Cout, dy_bytes, k, stride, pad, ksplit, dil=1):
+    """dW[Cout][k*k][Cin] of a plain Conv2d: direct = dY, gathered = x."""
+    taps = [(i * dil - pad, j * dil - pad, i * k + j) for i in range(k) for j in range(k)]
+    return wgrad_desc(N, OH, OW, ld_dy, Cout, dy_bytes, H, W, ld_x, Cin, x_bytes, stride, stride, taps, k * k,
+                      False, ksplit)
+
+
+def upproj_wgrad_desc(N, h, w, ld_x, Cin, x_bytes, ld_dy, Cdy, dy_bytes, ksplit):
+    """dW[Cdy][25][Cin] of the up-projection 5x5: direct = x (grid h x w), gathered = dY."""
+    taps = [(2 - i, 2 - j, i * 5 + j) for i in range(5) for j in range(5)]
+    return wgrad_desc(N, h, w, ld_x, Cin, x_bytes, 2 * h, 2 * w, ld_dy, Cdy, dy_bytes, 2, 2, taps, 25, True, ksplit)
+
+
+def conv_wgrad(desc, direct, gathered, dw):
+    check(_lib.load().mde_conv_wgrad(C.byref(desc), _p(direct), _p(gathered), _p(dw), _stream()), "mde_conv_wgrad")
+
+
+def choose_ksplit(pixels, row_tiles, col_tiles, ntaps, cus=256, min_steps=8):
+    """Split the pixel (K) range so the grid reaches ~3 workgroups per CU, each keeping at
+    least `min_steps` 64-pixel K-steps."""
+    base = max(1, row_tiles * col_tiles * ntaps)
+    want = max(1, (3 * cus + base - 1) // base)
+    cap = max(1, pixels // (64 * min_steps))
+    return max(1, min(want, cap))

@@ -1,0 +1,146 @@
+"""GPU parity of the implicit-GEMM conv kernel (mde_conv_gemm) against plain torch fp32
+ops on the same bf16-rounded operands.  Tolerance: the kernel accumulates in fp32 and
+rounds once to bf16, so |hip - ref| <= 2^-8 * |ref| + 2^-8 * rms(ref) (stated here)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import weights as W
+
+pytestmark = pytest.mark.gpu
+
+
+def _bf(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def _nhwc(t):  # NCHW fp32 cpu -> NHWC bf16 cuda
+    return t.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).cuda()
+
+
+def _nchw(t):  # NHWC bf16 cuda -> NCHW fp32 cpu
+    return t.float().cpu().permute(0, 3, 1, 2).contiguous()
+
+
+def _pack_fwd(w):  # OIHW fp32 -> [O][kh*kw][I] bf16 cuda
+    o, i, kh, kw = w.shape
+    return w.permute(0, 2, 3, 1).reshape(o, kh * kw, i).contiguous().to(torch.bfloat16).cuda()
+
+
+def _pack_dgrad(w):  # OIHW -> [I][kh*kw][O]
+    o, i, kh, kw = w.shape
+    return w.permute(1, 2, 3, 0).reshape(i, kh * kw, o).contiguous().to(torch.bfloat16).cuda()
+
+
+def _assert_close(got, ref, what, tol=2.0 ** -8):
+    err = (got - ref).abs()
+    bound = tol * ref.abs() + tol * ref.pow(2).mean().sqrt()
+    bad = (err > bound).sum().item()
+    assert bad == 0, "%s: %d/%d outside tolerance, max err %.4g (ref rms %.4g)" % (
+        what, bad, ref.numel(), err.max().item(), ref.pow(2).mean().sqrt().item())
+
+
+@pytest.mark.parametrize("N,H,Wd,Cin,Cout,k,s,p", [
+    (2, 12, 20, 64, 128, 3, 1, 1),     # one full column tile
+    (2, 12, 20, 128, 64, 1, 1, 0),     # 64-column variant, ragged pixel tile (480 rows)
+    (1, 13, 17, 64, 192, 3, 2, 1),     # stride 2, odd sizes, ragged column tile
+    (2, 9, 11, 192, 320, 1, 2, 0),     # 1x1 stride 2 (downsample)
+    (1, 10, 10, 64, 72, 5, 1, 2),      # 25 taps, columns not a multiple of the tile
+])
+def test_conv_forward(N, H, Wd, Cin, Cout, k, s, p):
+    from mono_depth_estimation_amd import ops
+    x = _bf(W.normal(1, "x", (N, Cin, H, Wd)))
+    w = _bf(W.normal(1, "w", (Cout, Cin, k, k), std=(2.0 / (k * k * Cin)) ** 0.5))
+    ref = F.conv2d(x, w, stride=s, padding=p)
+    xd, wd = _nhwc(x), _pack_fwd(w)
+    OH, OW = ref.shape[2:]
+    ld_out = Cout + 8                                    # channel-sliced output view
+    out = torch.full((N, OH, OW, ld_out), 7.0, dtype=torch.bfloat16, device="cuda")
+    d = ops.fwd_desc(N, H, Wd, Cin, Cin, xd.numel() * 2, k, s, p, Cout, ld_out)
+    rows = ops.conv_gemm_stat_rows(d)
+    stats = torch.zeros(rows, 2, Cout, device="cuda")
+    ops.conv_gemm(d, xd, wd, out, stats)
+    torch.cuda.synchronize()
+    _assert_close(_nchw(out[..., :Cout]), ref, "conv fwd")
+    assert (out[..., Cout:].float() == 7.0).all(), "wrote outside its channel slice"
+    st = stats.sum(0).cpu()
+    ref_s1, ref_s2 = ref.sum((0, 2, 3)), (ref * ref).sum((0, 2, 3))
+    assert torch.allclose(st[0], ref_s1, rtol=1e-3, atol=1e-2 * ref_s2.max().sqrt().item())
+    assert torch.allclose(st[1], ref_s2, rtol=1e-3, atol=1e-3 * ref_s2.max().item())
+
+
+@pytest.mark.parametrize("N,H,Wd,Cin,Cout,k,s,p", [
+    (2, 12, 20, 64, 128, 3, 1, 1),
+    (1, 14, 18, 128, 64, 3, 2, 1),     # strided: four output phases
+    (1, 13, 17, 128, 64, 3, 2, 1),     # odd input size
+    (2, 10, 12, 64, 128, 1, 2, 0),     # 1x1 stride 2: three empty phases -> zero fill
+    (2, 8, 8, 192, 64, 1, 1, 0),
+])
+def test_conv_dgrad(N, H, Wd, Cin, Cout, k, s, p):
+    from mono_depth_estimation_amd import ops
+    w = _bf(W.normal(2, "w", (Cout, Cin, k, k), std=(2.0 / (k * k * Cout)) ** 0.5))
+    OH, OW = ops.out_size(H, k, s, p), ops.out_size(Wd, k, s, p)
+    dy = _bf(W.normal(2, "dy", (N, Cout, OH, OW)))
+    x = torch.zeros(N, Cin, H, Wd, requires_grad=True)
+    F.conv2d(x, w, stride=s, padding=p).backward(dy)
+    ref = x.grad
+    dyd, wd = _nhwc(dy), _pack_dgrad(w)
+    dx = torch.full((N, H, Wd, Cin), 3.0, dtype=torch.bfloat16, device="cuda")
+    descs, zero = ops.dgrad_descs(N, H, Wd, Cin, Cin, OH, OW, Cout, Cout, dyd.numel() * 2, k, s, p)
+    if zero:
+        dx.zero_()
+    for d in descs:
+        ops.conv_gemm(d, dyd, wd, dx)
+    torch.cuda.synchronize()
+    _assert_close(_nchw(dx), ref, "conv dgrad")
+    # accumulate: a second pass adds onto the first
+    for d in descs:
+        d.accumulate = 1
+        ops.conv_gemm(d, dyd, wd, dx)
+    torch.cuda.synchronize()
+    _assert_close(_nchw(dx), 2 * ref, "conv dgrad accumulate", tol=2.0 ** -7)
+
+
+def _unpool(x):
+    n, c, h, w = x.shape
+    u = x.new_zeros(n, c, 2 * h, 2 * w)
+    u[:, :, ::2, ::2] = x
+    return u
+
+
+@pytest.mark.parametrize("N,h,w,Cin", [(2, 6, 8, 64), (1, 5, 7, 128)])
+def test_upproj_phases_fwd_and_dgrad(N, h, w, Cin):
+    """Four-phase 5x5 over x == 5x5/pad2 over the zero-stuffed map (FCRN.py:31-44,180,187),
+    both 5x5 branches fused along the output channels."""
+    from mono_depth_estimation_amd import ops
+    Cout = Cin // 2
+    x = _bf(W.normal(3, "x", (N, Cin, h, w)))
+    wu = _bf(W.normal(3, "wu", (Cout, Cin, 5, 5), std=(2.0 / (25 * Cout)) ** 0.5))
+    wb = _bf(W.normal(3, "wb", (Cout, Cin, 5, 5), std=(2.0 / (25 * Cout)) ** 0.5))
+    wcat = torch.cat([wu, wb], 0)
+    xi = x.clone().requires_grad_(True)
+    ref = F.conv2d(_unpool(xi), wcat, padding=2)
+    xd = _nhwc(x)
+    out = torch.empty(N, 2 * h, 2 * w, 2 * Cout, dtype=torch.bfloat16, device="cuda")
+    for d in ops.upproj_fwd_descs(N, h, w, Cin, Cin, xd.numel() * 2, 2 * Cout, 2 * Cout):
+        ops.conv_gemm(d, xd, _pack_fwd(wcat), out)
+    torch.cuda.synchronize()
+    _assert_close(_nchw(out), ref.detach(), "upproj fwd")
+    dy = _bf(W.normal(3, "dy", tuple(ref.shape)))
+    ref.backward(dy)
+    dyd = _nhwc(dy)
+    dx = torch.empty(N, h, w, Cin, dtype=torch.bfloat16, device="cuda")
+    d = ops.upproj_dgrad_desc(N, h, w, Cin, Cin, 2 * Cout, 2 * Cout, dyd.numel() * 2)
+    ops.conv_gemm(d, dyd, _pack_dgrad(wcat), dx)
+    torch.cuda.synchronize()
+    _assert_close(_nchw(dx), xi.grad, "upproj dgrad")
+
+
+def test_conv_rejects_bad_args():
+    from mono_depth_estimation_amd import _lib, ops
+    x = torch.zeros(1, 4, 4, 48, dtype=torch.bfloat16, device="cuda")
+    w = torch.zeros(64, 1, 48, dtype=torch.bfloat16, device="cuda")
+    out = torch.zeros(1, 4, 4, 64, dtype=torch.bfloat16, device="cuda")
+    d = ops.fwd_desc(1, 4, 4, 48, 48, x.numel() * 2, 1, 1, 0, 64, 64)
+    with pytest.raises(_lib.MdeError, match="multiple of 64"):
+        ops.conv_gemm(d, x, w, out)
