@@ -2,7 +2,6 @@
 // Each returns MDE_ENOTSUP loudly; this file shrinks to nothing as kernels land.
 #include "mde_common.h"
 #define STUB(name, ...) extern "C" int name(__VA_ARGS__) { mde_set_error(#name ": not implemented in this build"); return MDE_ENOTSUP; }
-STUB(mde_conv_wgrad, const mde_wgrad_desc*, const void*, const void*, float*, void*)
 STUB(mde_stem_conv_fwd, const float*, const float*, void*, int, int, int, void*)
 STUB(mde_stem_conv_wgrad, const float*, const void*, float*, int, int, int, void*)
 STUB(mde_head_conv_fwd, const void*, const float*, float*, int, int, int, int, int, void*)

@@ -1,0 +1,76 @@
+"""GPU parity of the weight-gradient kernel (mde_conv_wgrad) against torch autograd on
+the same bf16-rounded operands.  fp32 accumulation (MFMA + fp32 atomics): tolerance
+|hip - ref| <= 1e-3*|ref| + 1e-3*rms(ref)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import weights as W
+
+pytestmark = pytest.mark.gpu
+
+
+def _bf(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def _nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).cuda()
+
+
+def _assert_close(got, ref, what, tol=1e-3):
+    err = (got - ref).abs()
+    bound = tol * ref.abs() + tol * ref.pow(2).mean().sqrt()
+    bad = (err > bound).sum().item()
+    assert bad == 0, "%s: %d/%d outside tolerance, max err %.4g (ref rms %.4g)" % (
+        what, bad, ref.numel(), err.max().item(), ref.pow(2).mean().sqrt().item())
+
+
+@pytest.mark.parametrize("N,H,Wd,Cin,Cout,k,s,p,ksplit", [
+    (2, 12, 20, 64, 128, 3, 1, 1, 1),
+    (2, 12, 20, 64, 128, 3, 1, 1, 3),     # split-K with a ragged last slice
+    (3, 9, 11, 128, 64, 1, 1, 0, 2),      # 64-row tile, pixel count not a multiple of 64
+    (1, 14, 18, 128, 192, 3, 2, 1, 2),    # stride 2; 192 rows -> 64-wide tiles
+    (2, 10, 12, 256, 128, 1, 2, 0, 1),    # 1x1 stride 2
+    (1, 30, 40, 64, 64, 3, 1, 1, 4),
+])
+def test_conv_wgrad(N, H, Wd, Cin, Cout, k, s, p, ksplit):
+    from mono_depth_estimation_amd import ops
+    x = _bf(W.normal(4, "x", (N, Cin, H, Wd)))
+    w = torch.zeros(Cout, Cin, k, k, requires_grad=True)
+    y = F.conv2d(x, w, stride=s, padding=p)
+    dy = _bf(W.normal(4, "dy", tuple(y.shape)))
+    y.backward(dy)
+    ref = w.grad.permute(0, 2, 3, 1).reshape(Cout, k * k, Cin)
+    xd, dyd = _nhwc(x), _nhwc(dy)
+    OH, OW = y.shape[2:]
+    d = ops.conv_wgrad_desc(N, H, Wd, Cin, Cin, xd.numel() * 2, OH, OW, Cout, Cout, dyd.numel() * 2, k, s, p, ksplit)
+    dw = torch.zeros(Cout, k * k, Cin, device="cuda")
+    ops.conv_wgrad(d, dyd, xd, dw)
+    torch.cuda.synchronize()
+    _assert_close(dw.cpu(), ref, "wgrad")
+
+
+def _unpool(x):
+    n, c, h, w = x.shape
+    u = x.new_zeros(n, c, 2 * h, 2 * w)
+    u[:, :, ::2, ::2] = x
+    return u
+
+
+@pytest.mark.parametrize("N,h,w,Cin,ksplit", [(2, 6, 8, 64, 1), (2, 9, 7, 128, 2)])
+def test_upproj_wgrad(N, h, w, Cin, ksplit):
+    from mono_depth_estimation_amd import ops
+    Cout2 = Cin  # both 5x5 branches fused: 2 * (Cin/2)
+    x = _bf(W.normal(5, "x", (N, Cin, h, w)))
+    wcat = torch.zeros(Cout2, Cin, 5, 5, requires_grad=True)
+    y = F.conv2d(_unpool(x), wcat, padding=2)
+    dy = _bf(W.normal(5, "dy", tuple(y.shape)))
+    y.backward(dy)
+    ref = wcat.grad.permute(0, 2, 3, 1).reshape(Cout2, 25, Cin)
+    xd, dyd = _nhwc(x), _nhwc(dy)
+    d = ops.upproj_wgrad_desc(N, h, w, Cin, Cin, xd.numel() * 2, Cout2, Cout2, dyd.numel() * 2, ksplit)
+    dw = torch.zeros(Cout2, 25, Cin, device="cuda")
+    ops.conv_wgrad(d, xd, dyd, dw)
+    torch.cuda.synchronize()
+    _assert_close(dw.cpu(), ref, "upproj wgrad")
