@@ -68,14 +68,12 @@ typedef struct mde_conv_desc {
 } mde_conv_desc;
 
 /* out[pix][col] (+)= sum_t sum_c in[src(pix,t)][c] * w[col][wtap[t]][c]
- * w: bf16 [ncols][wtaps_total][C].  stats (optional, may be NULL): fp32
- * [mde_conv_gemm_stat_rows(d)][2][ncols] partial per-column sums and sums of squares of the
- * fp32 results, one row per pixel tile (plain stores, deterministic) — fuses the BatchNorm
- * batch-statistics pass into the conv epilogue; feed it to mde_bn_finalize as `part`. */
+ * w: bf16 [ncols][wtaps_total][C].  stats (optional, may be NULL): a BatchNorm partial-sum
+ * buffer fp32 [mde_stat_slots()][2][ncols] (see the BatchNorm section) that receives the
+ * per-column sum and sum of squares of the fp32 results — fuses the BN batch-statistics pass
+ * into the conv epilogue; feed it to mde_bn_finalize as `part`. */
 int mde_conv_gemm(const mde_conv_desc* d, const void* in, const void* w, void* out,
                   float* stats, void* stream);
-/* Rows of the `stats` partial buffer mde_conv_gemm writes for this descriptor. */
-int mde_conv_gemm_stat_rows(const mde_conv_desc* d);
 
 /* Weight gradient ("TN" GEMM over pixels), fp32 output accumulated with atomics:
  *   dw[r][otap[t]][c] += sum_{pix in grid} direct[pix][.] x gathered[src(pix,t)][.]
@@ -114,19 +112,22 @@ int mde_head_conv_bwd(const void* x, const float* w, const float* dout, void* dx
 
 /* ------------------------------------------------------------------------------------
  * BatchNorm2d, training and eval mode (nn.BatchNorm2d everywhere in FCRN.py / torchvision).
- * Statistics are fp32; a "BN site" normalises C channels of a [M = N*H*W][ld] bf16 tensor.
+ * Statistics are fp32; a "BN site" normalises C channels (C % 8 == 0, C <= 2048) of a
+ * [M = N*H*W][ld] bf16 tensor.
+ *
+ * Partial-sum buffers ("part"): fp32 [mde_stat_slots()][2][C].  Producers (mde_bn_stats,
+ * mde_conv_gemm's epilogue, mde_bn_bwd_reduce) ADD into slot (workgroup % slots) with fp32
+ * atomics; the finalize kernels consume the buffer and leave it ZEROED, so a buffer that
+ * starts zeroed (caller's job, once) can be reused every step without a memset.
  * ---------------------------------------------------------------------------------- */
-/* Partial sums: part[blk][2][C] (fp32). nblk = mde_bn_stats_blocks(M, C). */
-int mde_bn_stats_blocks(int64_t M, int C);
+int mde_stat_slots(void);
 int mde_bn_stats(const void* x, int64_t M, int C, int ld, float* part, void* stream);
-/* Reduce partials (or conv-epilogue stats with nblk == 1) to scale/shift:
- *   mean, var (biased) -> scale = gamma*rstd, shift = beta - mean*scale;
+/* part -> mean, biased var -> scale = gamma*rstd, shift = beta - mean*scale;
  *   save_mean/save_rstd kept for backward; running stats updated with `momentum`
- *   (unbiased variance), exactly as nn.BatchNorm2d in train mode.  */
-int mde_bn_finalize(const float* part, int nblk, int64_t M, int C, const float* gamma,
-                    const float* beta, float* running_mean, float* running_var, float momentum,
-                    float eps, float* scale, float* shift, float* save_mean, float* save_rstd,
-                    void* stream);
+ *   (unbiased variance), exactly as nn.BatchNorm2d in train mode.  part is zeroed. */
+int mde_bn_finalize(float* part, int64_t M, int C, const float* gamma, const float* beta,
+                    float* running_mean, float* running_var, float momentum, float eps, float* scale,
+                    float* shift, float* save_mean, float* save_rstd, void* stream);
 /* Eval mode: scale/shift from running statistics. */
 int mde_bn_eval_scale_shift(const float* gamma, const float* beta, const float* running_mean,
                             const float* running_var, float eps, int C, float* scale, float* shift,
@@ -137,18 +138,19 @@ int mde_bn_apply(const void* x, int ldx, const float* scale, const float* shift,
                  int ldr, const float* rscale, const float* rshift, void* out, int ldo, int64_t M,
                  int C, int relu, void* stream);
 /* Backward of  out = act(bn(x) [+ ...]):  g = dout * (relu ? out > 0 : 1).
- * pass 1 (reduce): part[blk][2][C] = (sum g, sum g*xhat).  nblk as mde_bn_stats_blocks. */
+ * pass 1: part += (sum g, sum g*xhat) per channel, xhat = (x - save_mean)*save_rstd. */
 int mde_bn_bwd_reduce(const void* dout, int ldd, const void* out, int ldo, const void* x, int ldx,
                       const float* save_mean, const float* save_rstd, int64_t M, int C, int relu,
                       float* part, void* stream);
-/* pass 2: dgamma = sum g*xhat, dbeta = sum g (added into the fp32 grads);
- *   dx = gamma*rstd*(g - mean(g) - xhat*mean(g*xhat)) (bf16, ld ldxo).
- *   dres (optional): receives g (the masked upstream gradient) for the residual branch;
- *   accumulate_dx != 0 adds into dx instead of overwriting. */
+/* pass 2 (tiny): dgamma += sum g*xhat, dbeta += sum g; coef[3][C] = (gamma*rstd, mean g,
+ * mean g*xhat); part is zeroed. */
+int mde_bn_bwd_finalize(float* part, int64_t M, int C, const float* gamma, const float* save_rstd,
+                        float* dgamma, float* dbeta, float* coef, void* stream);
+/* pass 3: dx = coef0*(g - coef1 - xhat*coef2) (bf16, ld ldxo; accumulate_dx != 0 adds into dx);
+ *   dres (optional) receives g, the masked upstream gradient, for the residual branch. */
 int mde_bn_bwd_apply(const void* dout, int ldd, const void* out, int ldo, const void* x, int ldx,
-                     const float* save_mean, const float* save_rstd, const float* gamma,
-                     const float* part, int nblk, int64_t M, int C, int relu, float* dgamma,
-                     float* dbeta, void* dx, int ldxo, int accumulate_dx, void* dres, int ldres,
+                     const float* save_mean, const float* save_rstd, const float* coef, int64_t M,
+                     int C, int relu, void* dx, int ldxo, int accumulate_dx, void* dres, int ldres,
                      void* stream);
 
 /* ------------------------------------------------------------------------------------

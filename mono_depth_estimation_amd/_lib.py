@@ -51,20 +51,19 @@ SIGNATURES = {
     "mde_abi_version": (_I, []),
     "mde_device_cu_count": (_I, [C.POINTER(_I)]),
     "mde_conv_gemm": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P]),
-    "mde_conv_gemm_stat_rows": (_I, [C.POINTER(ConvDesc)]),
     "mde_conv_wgrad": (_I, [C.POINTER(WgradDesc), _P, _P, _P, _P]),
     "mde_stem_conv_fwd": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "mde_stem_conv_wgrad": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "mde_head_conv_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "mde_head_conv_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
-    "mde_bn_stats_blocks": (_I, [_L, _I]),
+    "mde_stat_slots": (_I, []),
     "mde_bn_stats": (_I, [_P, _L, _I, _I, _P, _P]),
-    "mde_bn_finalize": (_I, [_P, _I, _L, _I, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P]),
+    "mde_bn_finalize": (_I, [_P, _L, _I, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P]),
     "mde_bn_eval_scale_shift": (_I, [_P, _P, _P, _P, _F, _I, _P, _P, _P]),
     "mde_bn_apply": (_I, [_P, _I, _P, _P, _P, _I, _P, _P, _P, _I, _L, _I, _I, _P]),
     "mde_bn_bwd_reduce": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _L, _I, _I, _P, _P]),
-    "mde_bn_bwd_apply": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _P, _I, _L, _I, _I, _P, _P, _P, _I, _I,
-                              _P, _I, _P]),
+    "mde_bn_bwd_finalize": (_I, [_P, _L, _I, _P, _P, _P, _P, _P, _P]),
+    "mde_bn_bwd_apply": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _L, _I, _I, _P, _I, _I, _P, _I, _P]),
     "mde_maxpool_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "mde_maxpool_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "mde_upsample_sigmoid_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),

@@ -1,0 +1,326 @@
+// BatchNorm2d (train + eval) forward/backward for NHWC bf16 activations on gfx950.
+// Replaces nn.BatchNorm2d (+ the ReLU / residual add that follows it) everywhere on the
+// FCRN path (reference network/FCRN.py:181-188,335,354 and the torchvision Bottlenecks).
+//
+// All kernels are HBM-bound streaming passes: 16-byte (8 x bf16) accesses per lane, every
+// thread owns one fixed 8-channel column so per-channel parameters sit in registers and
+// per-channel sums need no cross-lane traffic until the end of the workgroup.
+// Statistics: fp32 per-thread partials over <= ~64 rows, combined with LDS atomics per
+// workgroup, then fp32 global atomics into one of MDE_STAT_SLOTS rows; the single-wave
+// finalize kernels sum the slots in double and re-zero them.
+#include "mde_common.h"
+
+namespace {
+
+constexpr int NT = 256;
+constexpr int MAXC = 2048;
+
+__device__ __forceinline__ void ld8(const bf16_t* p, float (&v)[8]) {
+    const bf16x8_t t = *reinterpret_cast<const bf16x8_t*>(p);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (float)t[e];
+}
+__device__ __forceinline__ void st8(bf16_t* p, const float (&v)[8]) {
+    bf16x8_t t;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) t[e] = (bf16_t)v[e];
+    *reinterpret_cast<bf16x8_t*>(p) = t;
+}
+__device__ __forceinline__ void ldf8(const float* p, float (&v)[8]) {
+    const f32x4_t a = *reinterpret_cast<const f32x4_t*>(p), b = *reinterpret_cast<const f32x4_t*>(p + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[e] = a[e]; v[4 + e] = b[e]; }
+}
+
+// Workgroup-level combine of per-thread column sums into part[slot][2][C].
+__device__ __forceinline__ void flush_sums(const float (&s1)[8], const float (&s2)[8], int col, int C,
+                                           float* part, float* sh) {
+    for (int i = threadIdx.x; i < 2 * C; i += NT) sh[i] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        atomicAdd(&sh[col * 8 + e], s1[e]);
+        atomicAdd(&sh[C + col * 8 + e], s2[e]);
+    }
+    __syncthreads();
+    float* dst = part + (size_t)(blockIdx.x % MDE_STAT_SLOTS) * 2 * C;
+    for (int i = threadIdx.x; i < 2 * C; i += NT) atomicAdd(dst + i, sh[i]);
+}
+
+__global__ __launch_bounds__(NT) void bn_stats_k(const bf16_t* __restrict__ x, int64_t M, int C, int ld,
+                                                 float* part, int rows_per_blk) {
+    __shared__ float sh[2 * MAXC];
+    const int cpr = C >> 3, rpb = NT / cpr, col = threadIdx.x % cpr, rl = threadIdx.x / cpr;
+    float s1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_blk;
+    const int64_t r1 = min(M, r0 + rows_per_blk);
+    for (int64_t r = r0 + rl; r < r1; r += rpb) {
+        float v[8];
+        ld8(x + r * ld + col * 8, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s1[e] += v[e]; s2[e] += v[e] * v[e]; }
+    }
+    flush_sums(s1, s2, col, C, part, sh);
+}
+
+__global__ void bn_finalize_k(float* part, int64_t M, int C, const float* gamma, const float* beta,
+                              float* rmean, float* rvar, float momentum, float eps, float* scale,
+                              float* shift, float* smean, float* srstd) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int s = 0; s < MDE_STAT_SLOTS; ++s) {
+        float* p = part + (size_t)s * 2 * C;
+        s1 += (double)p[c];
+        s2 += (double)p[C + c];
+        p[c] = 0.f;
+        p[C + c] = 0.f;
+    }
+    const double mean = s1 / (double)M;
+    double var = s2 / (double)M - mean * mean;
+    var = var > 0.0 ? var : 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float sc = gamma[c] * rstd;
+    scale[c] = sc;
+    shift[c] = beta[c] - (float)mean * sc;
+    smean[c] = (float)mean;
+    srstd[c] = rstd;
+    if (rmean) {
+        const double unb = M > 1 ? var * (double)M / (double)(M - 1) : var;
+        rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)mean;
+        rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
+    }
+}
+
+__global__ void bn_eval_k(const float* gamma, const float* beta, const float* rmean, const float* rvar,
+                          float eps, int C, float* scale, float* shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float sc = gamma[c] / sqrtf(rvar[c] + eps);
+    scale[c] = sc;
+    shift[c] = beta[c] - rmean[c] * sc;
+}
+
+// RES: 0 none, 1 plain residual add, 2 residual with its own scale/shift (second BN site)
+template <int RES>
+__global__ __launch_bounds__(NT) void bn_apply_k(const bf16_t* __restrict__ x, int ldx, const float* __restrict__ scale,
+                                                 const float* __restrict__ shift, const bf16_t* __restrict__ r, int ldr,
+                                                 const float* __restrict__ rscale, const float* __restrict__ rshift,
+                                                 bf16_t* __restrict__ out, int ldo, int64_t M, int C, int relu) {
+    const int cpr = C >> 3, rpb = NT / cpr, col = threadIdx.x % cpr, rl = threadIdx.x / cpr;
+    float sc[8], sh[8], rsc[8], rsh[8];
+    ldf8(scale + col * 8, sc);
+    ldf8(shift + col * 8, sh);
+    if (RES == 2) {
+        ldf8(rscale + col * 8, rsc);
+        ldf8(rshift + col * 8, rsh);
+    }
+    for (int64_t row = (int64_t)blockIdx.x * rpb + rl; row < M; row += (int64_t)gridDim.x * rpb) {
+        float v[8], q[8];
+        ld8(x + row * ldx + col * 8, v);
+        if (RES) ld8(r + row * ldr + col * 8, q);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float y = v[e] * sc[e] + sh[e];
+            if (RES == 1) y += q[e];
+            if (RES == 2) y += q[e] * rsc[e] + rsh[e];
+            v[e] = relu ? fmaxf(y, 0.f) : y;
+        }
+        st8(out + row * ldo + col * 8, v);
+    }
+}
+
+__global__ __launch_bounds__(NT) void bn_bwd_reduce_k(const bf16_t* __restrict__ dout, int ldd,
+                                                      const bf16_t* __restrict__ out, int ldo,
+                                                      const bf16_t* __restrict__ x, int ldx,
+                                                      const float* __restrict__ smean, const float* __restrict__ srstd,
+                                                      int64_t M, int C, int relu, float* part, int rows_per_blk) {
+    __shared__ float sh[2 * MAXC];
+    const int cpr = C >> 3, rpb = NT / cpr, col = threadIdx.x % cpr, rl = threadIdx.x / cpr;
+    float mu[8], rs[8];
+    ldf8(smean + col * 8, mu);
+    ldf8(srstd + col * 8, rs);
+    float s1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_blk;
+    const int64_t r1 = min(M, r0 + rows_per_blk);
+    for (int64_t r = r0 + rl; r < r1; r += rpb) {
+        float g[8], v[8], o[8];
+        ld8(dout + r * ldd + col * 8, g);
+        ld8(x + r * ldx + col * 8, v);
+        if (relu) ld8(out + r * ldo + col * 8, o);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float ge = (relu && !(o[e] > 0.f)) ? 0.f : g[e];
+            s1[e] += ge;
+            s2[e] += ge * ((v[e] - mu[e]) * rs[e]);
+        }
+    }
+    flush_sums(s1, s2, col, C, part, sh);
+}
+
+__global__ void bn_bwd_finalize_k(float* part, int64_t M, int C, const float* gamma, const float* srstd,
+                                  float* dgamma, float* dbeta, float* coef) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int s = 0; s < MDE_STAT_SLOTS; ++s) {
+        float* p = part + (size_t)s * 2 * C;
+        s1 += (double)p[c];
+        s2 += (double)p[C + c];
+        p[c] = 0.f;
+        p[C + c] = 0.f;
+    }
+    if (dgamma) dgamma[c] += (float)s2;
+    if (dbeta) dbeta[c] += (float)s1;
+    coef[c] = gamma[c] * srstd[c];
+    coef[C + c] = (float)(s1 / (double)M);
+    coef[2 * C + c] = (float)(s2 / (double)M);
+}
+
+__global__ __launch_bounds__(NT) void bn_bwd_apply_k(const bf16_t* __restrict__ dout, int ldd,
+                                                     const bf16_t* __restrict__ out, int ldo,
+                                                     const bf16_t* __restrict__ x, int ldx,
+                                                     const float* __restrict__ smean, const float* __restrict__ srstd,
+                                                     const float* __restrict__ coef, int64_t M, int C, int relu,
+                                                     bf16_t* dx, int ldxo, int accumulate, bf16_t* dres, int ldres) {
+    const int cpr = C >> 3, rpb = NT / cpr, col = threadIdx.x % cpr, rl = threadIdx.x / cpr;
+    float mu[8], rs[8], c0[8], c1[8], c2[8];
+    ldf8(smean + col * 8, mu);
+    ldf8(srstd + col * 8, rs);
+    ldf8(coef + col * 8, c0);
+    ldf8(coef + C + col * 8, c1);
+    ldf8(coef + 2 * C + col * 8, c2);
+    for (int64_t row = (int64_t)blockIdx.x * rpb + rl; row < M; row += (int64_t)gridDim.x * rpb) {
+        float g[8], v[8], o[8], d[8];
+        ld8(dout + row * ldd + col * 8, g);
+        ld8(x + row * ldx + col * 8, v);
+        if (relu) ld8(out + row * ldo + col * 8, o);
+        if (accumulate) ld8(dx + row * ldxo + col * 8, d);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            if (relu && !(o[e] > 0.f)) g[e] = 0.f;
+            const float xh = (v[e] - mu[e]) * rs[e];
+            const float r = c0[e] * (g[e] - c1[e] - xh * c2[e]);
+            d[e] = accumulate ? d[e] + r : r;
+        }
+        st8(dx + row * ldxo + col * 8, d);
+        if (dres) st8(dres + row * ldres + col * 8, g);
+    }
+}
+
+int check_site(const char* who, int64_t M, int C) {
+    MDE_REQUIRE(M > 0 && C > 0, "%s: non-positive size", who);
+    MDE_REQUIRE(C % 8 == 0 && C <= MAXC && NT % (C / 8) == 0,
+                "%s: C=%d unsupported (need C %% 8 == 0, C <= %d, C/8 dividing %d)", who, C, MAXC, NT);
+    return MDE_OK;
+}
+bool al16(const void* p, int ld) { return ((uintptr_t)p % 16) == 0 && ld % 8 == 0; }
+
+void reduce_geometry(int64_t M, int C, int* nblk, int* rows_per_blk) {
+    const int rpb = NT / (C / 8);
+    int64_t nb = (M + (int64_t)rpb * 32 - 1) / ((int64_t)rpb * 32);
+    nb = nb < 1 ? 1 : (nb > 2048 ? 2048 : nb);
+    int64_t rows = (M + nb - 1) / nb;
+    rows = (rows + rpb - 1) / rpb * rpb;
+    *nblk = (int)((M + rows - 1) / rows);
+    *rows_per_blk = (int)rows;
+}
+int stream_grid(int64_t M, int C) {
+    const int rpb = NT / (C / 8);
+    int64_t nb = (M + rpb - 1) / rpb;
+    return (int)(nb > 256 * 8 ? 256 * 8 : nb);
+}
+
+}  // namespace
+
+extern "C" int mde_stat_slots(void) { return MDE_STAT_SLOTS; }
+
+extern "C" int mde_bn_stats(const void* x, int64_t M, int C, int ld, float* part, void* stream) {
+    MDE_REQUIRE(x && part, "mde_bn_stats: null argument");
+    if (int rc = check_site("mde_bn_stats", M, C)) return rc;
+    MDE_REQUIRE(al16(x, ld), "mde_bn_stats: x must be 16-byte aligned with ld %% 8 == 0");
+    int nblk, rows;
+    reduce_geometry(M, C, &nblk, &rows);
+    bn_stats_k<<<nblk, NT, 0, (hipStream_t)stream>>>((const bf16_t*)x, M, C, ld, part, rows);
+    MDE_LAUNCH_CHECK("bn_stats_k");
+    return MDE_OK;
+}
+
+extern "C" int mde_bn_finalize(float* part, int64_t M, int C, const float* gamma, const float* beta,
+                               float* running_mean, float* running_var, float momentum, float eps,
+                               float* scale, float* shift, float* save_mean, float* save_rstd, void* stream) {
+    MDE_REQUIRE(part && gamma && beta && scale && shift && save_mean && save_rstd, "mde_bn_finalize: null argument");
+    MDE_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "mde_bn_finalize: running stats must come in pairs");
+    MDE_REQUIRE(M > 0 && C > 0, "mde_bn_finalize: non-positive size");
+    bn_finalize_k<<<mde_cdiv(C, 64), 64, 0, (hipStream_t)stream>>>(part, M, C, gamma, beta, running_mean, running_var,
+                                                                 momentum, eps, scale, shift, save_mean, save_rstd);
+    MDE_LAUNCH_CHECK("bn_finalize_k");
+    return MDE_OK;
+}
+
+extern "C" int mde_bn_eval_scale_shift(const float* gamma, const float* beta, const float* running_mean,
+                                       const float* running_var, float eps, int C, float* scale, float* shift,
+                                       void* stream) {
+    MDE_REQUIRE(gamma && beta && running_mean && running_var && scale && shift && C > 0,
+                "mde_bn_eval_scale_shift: bad argument");
+    bn_eval_k<<<mde_cdiv(C, 64), 64, 0, (hipStream_t)stream>>>(gamma, beta, running_mean, running_var, eps, C, scale, shift);
+    MDE_LAUNCH_CHECK("bn_eval_k");
+    return MDE_OK;
+}
+
+extern "C" int mde_bn_apply(const void* x, int ldx, const float* scale, const float* shift, const void* r,
+                            int ldr, const float* rscale, const float* rshift, void* out, int ldo, int64_t M,
+                            int C, int relu, void* stream) {
+    MDE_REQUIRE(x && scale && shift && out, "mde_bn_apply: null argument");
+    if (int rc = check_site("mde_bn_apply", M, C)) return rc;
+    MDE_REQUIRE(al16(x, ldx) && al16(out, ldo) && (!r || al16(r, ldr)), "mde_bn_apply: tensors must be 16-byte aligned, ld %% 8 == 0");
+    MDE_REQUIRE((rscale == nullptr) == (rshift == nullptr) && (!rscale || r), "mde_bn_apply: rscale/rshift need r and each other");
+    const int grid = stream_grid(M, C);
+    hipStream_t st = (hipStream_t)stream;
+    const bf16_t *xp = (const bf16_t*)x, *rp = (const bf16_t*)r;
+    if (!r)
+        bn_apply_k<0><<<grid, NT, 0, st>>>(xp, ldx, scale, shift, nullptr, 0, nullptr, nullptr, (bf16_t*)out, ldo, M, C, relu);
+    else if (!rscale)
+        bn_apply_k<1><<<grid, NT, 0, st>>>(xp, ldx, scale, shift, rp, ldr, nullptr, nullptr, (bf16_t*)out, ldo, M, C, relu);
+    else
+        bn_apply_k<2><<<grid, NT, 0, st>>>(xp, ldx, scale, shift, rp, ldr, rscale, rshift, (bf16_t*)out, ldo, M, C, relu);
+    MDE_LAUNCH_CHECK("bn_apply_k");
+    return MDE_OK;
+}
+
+extern "C" int mde_bn_bwd_reduce(const void* dout, int ldd, const void* out, int ldo, const void* x, int ldx,
+                                 const float* save_mean, const float* save_rstd, int64_t M, int C, int relu,
+                                 float* part, void* stream) {
+    MDE_REQUIRE(dout && x && save_mean && save_rstd && part && (!relu || out), "mde_bn_bwd_reduce: null argument");
+    if (int rc = check_site("mde_bn_bwd_reduce", M, C)) return rc;
+    MDE_REQUIRE(al16(dout, ldd) && al16(x, ldx) && (!relu || al16(out, ldo)), "mde_bn_bwd_reduce: alignment");
+    int nblk, rows;
+    reduce_geometry(M, C, &nblk, &rows);
+    bn_bwd_reduce_k<<<nblk, NT, 0, (hipStream_t)stream>>>((const bf16_t*)dout, ldd, (const bf16_t*)out, ldo,
+                                                         (const bf16_t*)x, ldx, save_mean, save_rstd, M, C, relu, part, rows);
+    MDE_LAUNCH_CHECK("bn_bwd_reduce_k");
+    return MDE_OK;
+}
+
+extern "C" int mde_bn_bwd_finalize(float* part, int64_t M, int C, const float* gamma, const float* save_rstd,
+                                   float* dgamma, float* dbeta, float* coef, void* stream) {
+    MDE_REQUIRE(part && gamma && save_rstd && coef && M > 0 && C > 0, "mde_bn_bwd_finalize: bad argument");
+    bn_bwd_finalize_k<<<mde_cdiv(C, 64), 64, 0, (hipStream_t)stream>>>(part, M, C, gamma, save_rstd, dgamma, dbeta, coef);
+    MDE_LAUNCH_CHECK("bn_bwd_finalize_k");
+    return MDE_OK;
+}
+
+extern "C" int mde_bn_bwd_apply(const void* dout, int ldd, const void* out, int ldo, const void* x, int ldx,
+                                const float* save_mean, const float* save_rstd, const float* coef, int64_t M,
+                                int C, int relu, void* dx, int ldxo, int accumulate_dx, void* dres, int ldres,
+                                void* stream) {
+    MDE_REQUIRE(dout && x && save_mean && save_rstd && coef && dx && (!relu || out), "mde_bn_bwd_apply: null argument");
+    if (int rc = check_site("mde_bn_bwd_apply", M, C)) return rc;
+    MDE_REQUIRE(al16(dout, ldd) && al16(x, ldx) && al16(dx, ldxo) && (!relu || al16(out, ldo)) && (!dres || al16(dres, ldres)),
+                "mde_bn_bwd_apply: alignment");
+    bn_bwd_apply_k<<<stream_grid(M, C), NT, 0, (hipStream_t)stream>>>(
+        (const bf16_t*)dout, ldd, (const bf16_t*)out, ldo, (const bf16_t*)x, ldx, save_mean, save_rstd, coef, M, C,
+        relu, (bf16_t*)dx, ldxo, accumulate_dx, (bf16_t*)dres, ldres);
+    MDE_LAUNCH_CHECK("bn_bwd_apply_k");
+    return MDE_OK;
+}

@@ -22,9 +22,9 @@
 // Two LDS buffers, one barrier per K-step, next step's loads in flight under the MFMAs.
 //
 // Epilogue: fp32 accumulators -> bf16 -> LDS [pixel][channel] -> full-line 16-byte stores
-// (optionally read-modify-write for dgrad accumulation), plus optional per-workgroup
-// BatchNorm partial sums (sum, sum of squares per channel) so the BN statistics pass over
-// the conv output is not needed.
+// (optionally read-modify-write for dgrad accumulation), plus optional BatchNorm partial
+// sums (sum, sum of squares per channel, reduced per workgroup then added with fp32 atomics
+// to one of MDE_STAT_SLOTS rows) so the BN statistics pass over the conv output is not needed.
 #include "mde_common.h"
 
 namespace {
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(NT, 2) void conv_gemm_nt(const KArgs a) {
                 float s = 0.f;
 #pragma unroll
                 for (int q = 0; q < WAVES_P; ++q) s += s_stat[(q * 2 + which) * BC + ch];
-                a.stats[((size_t)pi * 2 + which) * d.ncols + n0 + ch] = s;
+                atomicAdd(a.stats + ((size_t)(pi % MDE_STAT_SLOTS) * 2 + which) * d.ncols + n0 + ch, s);
             }
         }
     }
@@ -305,15 +305,7 @@ int launch(const KArgs& ka, hipStream_t st) {
     return MDE_OK;
 }
 
-inline int tile_bp(int /*ncols*/) { return 128; }
-
 }  // namespace
-
-extern "C" int mde_conv_gemm_stat_rows(const mde_conv_desc* d) {
-    if (!d) return MDE_EINVAL;
-    const int64_t M = (int64_t)d->N * d->GH * d->GW;
-    return mde_cdiv(M, tile_bp(d->ncols));
-}
 
 extern "C" int mde_conv_gemm(const mde_conv_desc* d, const void* in, const void* w, void* out,
                              float* stats, void* stream) {

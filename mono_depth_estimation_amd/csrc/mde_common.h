@@ -17,6 +17,7 @@ typedef __attribute__((ext_vector_type(4))) int i32x4_t;
 typedef __attribute__((ext_vector_type(2))) int i32x2_t;
 
 #define MDE_WAVE 64
+#define MDE_STAT_SLOTS 32       // rows of a BatchNorm partial-sum buffer (mde_stat_slots())
 #define MDE_OOB_OFFSET 0x80000000u  // any voffset >= num_records reads as zero through a raw buffer
 
 // ---------------------------------------------------------------- error plumbing (host)

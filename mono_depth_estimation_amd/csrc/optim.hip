@@ -1,0 +1,115 @@
+// Optimiser step and parameter plumbing on flat fp32 ranges (gfx950).
+//   Adam as torch.optim.Adam computes it (reference modules/laina.py:51-57); the same pass
+//   refreshes the bf16 shadow copy the conv kernels read, so no separate cast pass per step.
+//   mde_pack_wt builds the transposed ("dgrad") bf16 weight packing [I][T][O] from the
+//   fp32 master [O][T][I] through a 32x32 LDS tile (coalesced on both sides).
+#include "mde_common.h"
+
+namespace {
+
+constexpr int NT = 256;
+
+__global__ __launch_bounds__(NT) void adam_k(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                             float* __restrict__ v, bf16_t* __restrict__ pb, int64_t n, float lr,
+                                             float b1, float b2, float eps, float wd, float gs, float bc1, float bc2s) {
+    // bc1 = 1 - b1^t ; bc2s = sqrt(1 - b2^t)
+    const float step = lr / bc1;
+    for (int64_t i = ((int64_t)blockIdx.x * NT + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * NT * 4) {
+        if (i + 4 <= n) {
+            f32x4_t pp = *reinterpret_cast<f32x4_t*>(p + i);
+            const f32x4_t gg = *reinterpret_cast<const f32x4_t*>(g + i);
+            f32x4_t mm = *reinterpret_cast<f32x4_t*>(m + i), vv = *reinterpret_cast<f32x4_t*>(v + i);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float ge = gg[e] * gs + wd * pp[e];
+                mm[e] = b1 * mm[e] + (1.f - b1) * ge;
+                vv[e] = b2 * vv[e] + (1.f - b2) * ge * ge;
+                pp[e] -= step * mm[e] / (sqrtf(vv[e]) / bc2s + eps);
+            }
+            *reinterpret_cast<f32x4_t*>(p + i) = pp;
+            *reinterpret_cast<f32x4_t*>(m + i) = mm;
+            *reinterpret_cast<f32x4_t*>(v + i) = vv;
+            if (pb) {
+                bf16x4_t o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (bf16_t)pp[e];
+                *reinterpret_cast<bf16x4_t*>(pb + i) = o;
+            }
+        } else {
+            for (int64_t j = i; j < n; ++j) {
+                const float ge = g[j] * gs + wd * p[j];
+                m[j] = b1 * m[j] + (1.f - b1) * ge;
+                v[j] = b2 * v[j] + (1.f - b2) * ge * ge;
+                p[j] -= step * m[j] / (sqrtf(v[j]) / bc2s + eps);
+                if (pb) pb[j] = (bf16_t)p[j];
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(NT) void cast_k(const float* __restrict__ src, bf16_t* __restrict__ dst, int64_t n) {
+    for (int64_t i = ((int64_t)blockIdx.x * NT + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * NT * 4) {
+        if (i + 4 <= n) {
+            const f32x4_t s = *reinterpret_cast<const f32x4_t*>(src + i);
+            bf16x4_t o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (bf16_t)s[e];
+            *reinterpret_cast<bf16x4_t*>(dst + i) = o;
+        } else {
+            for (int64_t j = i; j < n; ++j) dst[j] = (bf16_t)src[j];
+        }
+    }
+}
+
+// dst[i][t][o] = bf16(src[o][t][i]); grid (ceil(I/32), ceil(O/32), T), block (32, 8)
+__global__ void pack_wt_k(const float* __restrict__ src, bf16_t* __restrict__ dst, int O, int T, int I) {
+    __shared__ float tile[32][33];
+    const int t = blockIdx.z;
+    const int i0 = blockIdx.x * 32, o0 = blockIdx.y * 32;
+    for (int r = threadIdx.y; r < 32; r += 8) {
+        const int o = o0 + r, i = i0 + threadIdx.x;
+        tile[r][threadIdx.x] = (o < O && i < I) ? src[((size_t)o * T + t) * I + i] : 0.f;
+    }
+    __syncthreads();
+    for (int r = threadIdx.y; r < 32; r += 8) {
+        const int i = i0 + r, o = o0 + threadIdx.x;
+        if (i < I && o < O) dst[((size_t)i * T + t) * O + o] = (bf16_t)tile[threadIdx.x][r];
+    }
+}
+
+int grid_for4(int64_t n) {
+    int64_t nb = (n / 4 + NT - 1) / NT + 1;
+    return (int)(nb > 256 * 8 ? 256 * 8 : nb);
+}
+
+}  // namespace
+
+extern "C" int mde_adam_step(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, float lr,
+                             float beta1, float beta2, float eps, float weight_decay, float grad_scale, int step,
+                             void* stream) {
+    MDE_REQUIRE(p && g && m && v && n > 0 && step >= 1, "mde_adam_step: bad argument");
+    MDE_REQUIRE(((uintptr_t)p % 16) == 0 && ((uintptr_t)g % 16) == 0 && ((uintptr_t)m % 16) == 0 &&
+                    ((uintptr_t)v % 16) == 0 && (!p_bf16 || ((uintptr_t)p_bf16 % 8) == 0),
+                "mde_adam_step: ranges must be 16-byte aligned");
+    const float bc1 = 1.f - powf(beta1, (float)step);
+    const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
+    adam_k<<<grid_for4(n), NT, 0, (hipStream_t)stream>>>(p, g, m, v, (bf16_t*)p_bf16, n, lr, beta1, beta2, eps,
+                                                        weight_decay, grad_scale, bc1, bc2s);
+    MDE_LAUNCH_CHECK("adam_k");
+    return MDE_OK;
+}
+
+extern "C" int mde_cast_bf16(const float* src, void* dst, int64_t n, void* stream) {
+    MDE_REQUIRE(src && dst && n > 0, "mde_cast_bf16: bad argument");
+    MDE_REQUIRE(((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 8) == 0, "mde_cast_bf16: alignment");
+    cast_k<<<grid_for4(n), NT, 0, (hipStream_t)stream>>>(src, (bf16_t*)dst, n);
+    MDE_LAUNCH_CHECK("cast_k");
+    return MDE_OK;
+}
+
+extern "C" int mde_pack_wt(const float* src, void* dst, int O, int T, int I, void* stream) {
+    MDE_REQUIRE(src && dst && O > 0 && T > 0 && I > 0 && T <= 65535, "mde_pack_wt: bad argument");
+    pack_wt_k<<<dim3(mde_cdiv(I, 32), mde_cdiv(O, 32), T), dim3(32, 8), 0, (hipStream_t)stream>>>(src, (bf16_t*)dst, O, T, I);
+    MDE_LAUNCH_CHECK("pack_wt_k");
+    return MDE_OK;
+}

@@ -1,0 +1,250 @@
+// MaxPool 3x3/2 (torchvision stem, used at reference network/FCRN.py:319,356), the
+// bilinear(align_corners=True)+sigmoid head (FCRN.py:341,369-371) and the NCHW<->NHWC
+// boundary layout changes.  HBM-bound streaming kernels, 16-byte accesses where the layout
+// allows.
+#include "mde_common.h"
+
+namespace {
+
+constexpr int NT = 256;
+
+// ------------------------------------------------------------------ maxpool 3x3 s2 p1
+// one thread = one output pixel x 8 channels.  idx = kh*3+kw of the FIRST maximum in scan
+// order (ATen: `val > max || isnan(val)`), kept for the backward routing of ties (post-ReLU
+// inputs tie at 0 all the time).
+__global__ __launch_bounds__(NT) void maxpool_fwd_k(const bf16_t* __restrict__ x, bf16_t* __restrict__ out,
+                                                    uint8_t* __restrict__ idx, int N, int H, int W, int C,
+                                                    int OH, int OW) {
+    const int cpr = C >> 3;
+    const int64_t total = (int64_t)N * OH * OW * cpr;
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
+        const int col = (int)(i % cpr);
+        int64_t p = i / cpr;
+        const int ow = (int)(p % OW); p /= OW;
+        const int oh = (int)(p % OH);
+        const int n = (int)(p / OH);
+        float best[8];
+        int bi[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { best[e] = -INFINITY; bi[e] = -1; }
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int ih = oh * 2 - 1 + kh;
+            if ((unsigned)ih >= (unsigned)H) continue;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int iw = ow * 2 - 1 + kw;
+                if ((unsigned)iw >= (unsigned)W) continue;
+                const bf16x8_t t = *reinterpret_cast<const bf16x8_t*>(x + (((int64_t)n * H + ih) * W + iw) * C + col * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float v = (float)t[e];
+                    if (bi[e] < 0 || v > best[e] || v != v) { best[e] = v; bi[e] = kh * 3 + kw; }
+                }
+            }
+        }
+        bf16x8_t o;
+        uint64_t packed = 0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            o[e] = (bf16_t)best[e];
+            packed |= (uint64_t)(uint8_t)bi[e] << (8 * e);
+        }
+        const int64_t ob = (((int64_t)n * OH + oh) * OW + ow) * C + col * 8;
+        *reinterpret_cast<bf16x8_t*>(out + ob) = o;
+        *reinterpret_cast<uint64_t*>(idx + ob) = packed;
+    }
+}
+
+// gather form (no atomics): an input pixel sums dout of the <= 4 windows whose argmax is it.
+__global__ __launch_bounds__(NT) void maxpool_bwd_k(const bf16_t* __restrict__ dout, const uint8_t* __restrict__ idx,
+                                                    bf16_t* __restrict__ dx, int N, int H, int W, int C, int OH, int OW) {
+    const int cpr = C >> 3;
+    const int64_t total = (int64_t)N * H * W * cpr;
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
+        const int col = (int)(i % cpr);
+        int64_t p = i / cpr;
+        const int iw = (int)(p % W); p /= W;
+        const int ih = (int)(p % H);
+        const int n = (int)(p / H);
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        // windows oh with oh*2-1 <= ih <= oh*2+1
+        const int oh0 = ih >> 1, oh1 = (ih + 1) >> 1;
+        const int ow0 = iw >> 1, ow1 = (iw + 1) >> 1;
+        for (int oh = oh0; oh <= oh1; ++oh) {
+            if (oh >= OH) continue;
+            const int kh = ih - (oh * 2 - 1);
+            for (int ow = ow0; ow <= ow1; ++ow) {
+                if (ow >= OW) continue;
+                const int k = kh * 3 + (iw - (ow * 2 - 1));
+                const int64_t ob = (((int64_t)n * OH + oh) * OW + ow) * C + col * 8;
+                const uint64_t packed = *reinterpret_cast<const uint64_t*>(idx + ob);
+                const bf16x8_t g = *reinterpret_cast<const bf16x8_t*>(dout + ob);
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if ((int)((packed >> (8 * e)) & 0xFF) == k) acc[e] += (float)g[e];
+            }
+        }
+        bf16x8_t o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (bf16_t)acc[e];
+        *reinterpret_cast<bf16x8_t*>(dx + (((int64_t)n * H + ih) * W + iw) * C + col * 8) = o;
+    }
+}
+
+// ------------------------------------------------------------------ bilinear (align_corners) + sigmoid
+// source coordinate exactly as ATen computes it in float: src = dst * ((in-1)/(out-1)).
+struct Lerp { int i0, i1; float l0, l1; };
+__device__ __forceinline__ Lerp lerp_of(int dst, float scale, int in_size) {
+    const float src = scale * (float)dst;
+    Lerp r;
+    r.i0 = min((int)src, in_size - 1);
+    r.i1 = r.i0 + (r.i0 < in_size - 1 ? 1 : 0);
+    r.l1 = fminf(fmaxf(src - (float)r.i0, 0.f), 1.f);
+    r.l0 = 1.f - r.l1;
+    return r;
+}
+
+__global__ __launch_bounds__(NT) void upsig_fwd_k(const float* __restrict__ x, float* __restrict__ out, int N, int H,
+                                                  int W, int C, int OH, int OW, float sh, float sw) {
+    const int64_t total = (int64_t)N * C * OH * OW;
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
+        const int ow = (int)(i % OW);
+        int64_t p = i / OW;
+        const int oh = (int)(p % OH); p /= OH;
+        const int c = (int)(p % C);
+        const int n = (int)(p / C);
+        const Lerp ly = lerp_of(oh, sh, H), lx = lerp_of(ow, sw, W);
+        const float* b = x + (int64_t)n * H * W * C + c;
+        const float v00 = b[((int64_t)ly.i0 * W + lx.i0) * C], v01 = b[((int64_t)ly.i0 * W + lx.i1) * C];
+        const float v10 = b[((int64_t)ly.i1 * W + lx.i0) * C], v11 = b[((int64_t)ly.i1 * W + lx.i1) * C];
+        const float v = ly.l0 * (lx.l0 * v00 + lx.l1 * v01) + ly.l1 * (lx.l0 * v10 + lx.l1 * v11);
+        out[i] = 1.f / (1.f + expf(-v));
+    }
+}
+
+// gather form of the transposed interpolation: source pixel (h,w) collects every destination
+// pixel whose stencil touches it (deterministic, no atomics); sigmoid' = out*(1-out).
+__global__ __launch_bounds__(NT) void upsig_bwd_k(const float* __restrict__ dout, const float* __restrict__ out,
+                                                  float* __restrict__ dx, int N, int H, int W, int C, int OH, int OW,
+                                                  float sh, float sw, float ish, float isw) {
+    const int64_t total = (int64_t)N * H * W * C;
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
+        const int c = (int)(i % C);
+        int64_t p = i / C;
+        const int w = (int)(p % W); p /= W;
+        const int h = (int)(p % H);
+        const int n = (int)(p / H);
+        // destination rows whose i0 is h-1 or h lie in [(h-1)/s, (h+1)/s]; widen by one and test exactly
+        const int oh_lo = max(0, (int)floorf((float)(h - 1) * ish) - 1), oh_hi = min(OH - 1, (int)ceilf((float)(h + 1) * ish) + 1);
+        const int ow_lo = max(0, (int)floorf((float)(w - 1) * isw) - 1), ow_hi = min(OW - 1, (int)ceilf((float)(w + 1) * isw) + 1);
+        const float* go = dout + ((int64_t)n * C + c) * OH * OW;
+        const float* oo = out + ((int64_t)n * C + c) * OH * OW;
+        float acc = 0.f;
+        for (int oh = oh_lo; oh <= oh_hi; ++oh) {
+            const Lerp ly = lerp_of(oh, sh, H);
+            float wy = 0.f;
+            if (ly.i0 == h) wy += ly.l0;
+            if (ly.i1 == h) wy += ly.l1;
+            if (wy == 0.f) continue;
+            for (int ow = ow_lo; ow <= ow_hi; ++ow) {
+                const Lerp lx = lerp_of(ow, sw, W);
+                float wx = 0.f;
+                if (lx.i0 == w) wx += lx.l0;
+                if (lx.i1 == w) wx += lx.l1;
+                if (wx == 0.f) continue;
+                const float o = oo[(int64_t)oh * OW + ow];
+                acc += wy * wx * (go[(int64_t)oh * OW + ow] * o * (1.f - o));
+            }
+        }
+        dx[i] = acc;
+    }
+}
+
+// ------------------------------------------------------------------ layout changes
+__global__ __launch_bounds__(NT) void nchw2nhwc_k(const float* __restrict__ src, bf16_t* __restrict__ dst, int N, int C,
+                                                  int H, int W) {
+    const int64_t total = (int64_t)N * H * W * C;
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
+        const int c = (int)(i % C);
+        const int64_t p = i / C;
+        const int64_t hw = p % ((int64_t)H * W);
+        const int64_t n = p / ((int64_t)H * W);
+        dst[i] = (bf16_t)src[(n * C + c) * (int64_t)H * W + hw];
+    }
+}
+__global__ __launch_bounds__(NT) void nhwc2nchw_k(const bf16_t* __restrict__ src, float* __restrict__ dst, int N, int C,
+                                                  int H, int W) {
+    const int64_t total = (int64_t)N * H * W * C;
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
+        const int64_t hw = i % ((int64_t)H * W);
+        const int64_t q = i / ((int64_t)H * W);
+        const int c = (int)(q % C);
+        const int64_t n = q / C;
+        dst[i] = (float)src[(n * (int64_t)H * W + hw) * C + c];
+    }
+}
+
+int grid_for(int64_t total) {
+    int64_t nb = (total + NT - 1) / NT;
+    return (int)(nb > 256 * 16 ? 256 * 16 : (nb < 1 ? 1 : nb));
+}
+
+}  // namespace
+
+extern "C" int mde_maxpool_fwd(const void* x, void* out, uint8_t* idx, int N, int H, int W, int C, void* stream) {
+    MDE_REQUIRE(x && out && idx && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "mde_maxpool_fwd: bad argument (C %% 8 == 0)");
+    MDE_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)out % 16) == 0 && ((uintptr_t)idx % 8) == 0, "mde_maxpool_fwd: alignment");
+    const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
+    maxpool_fwd_k<<<grid_for((int64_t)N * OH * OW * (C / 8)), NT, 0, (hipStream_t)stream>>>(
+        (const bf16_t*)x, (bf16_t*)out, idx, N, H, W, C, OH, OW);
+    MDE_LAUNCH_CHECK("maxpool_fwd_k");
+    return MDE_OK;
+}
+
+extern "C" int mde_maxpool_bwd(const void* dout, const uint8_t* idx, void* dx, int N, int H, int W, int C, void* stream) {
+    MDE_REQUIRE(dout && dx && idx && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "mde_maxpool_bwd: bad argument (C %% 8 == 0)");
+    MDE_REQUIRE(((uintptr_t)dout % 16) == 0 && ((uintptr_t)dx % 16) == 0 && ((uintptr_t)idx % 8) == 0, "mde_maxpool_bwd: alignment");
+    const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
+    maxpool_bwd_k<<<grid_for((int64_t)N * H * W * (C / 8)), NT, 0, (hipStream_t)stream>>>(
+        (const bf16_t*)dout, idx, (bf16_t*)dx, N, H, W, C, OH, OW);
+    MDE_LAUNCH_CHECK("maxpool_bwd_k");
+    return MDE_OK;
+}
+
+static inline float ac_scale(int in, int out) { return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f; }
+
+extern "C" int mde_upsample_sigmoid_fwd(const float* x, float* out, int N, int H, int W, int C, int OH, int OW,
+                                        void* stream) {
+    MDE_REQUIRE(x && out && N > 0 && H > 0 && W > 0 && C > 0 && OH > 0 && OW > 0, "mde_upsample_sigmoid_fwd: bad argument");
+    upsig_fwd_k<<<grid_for((int64_t)N * C * OH * OW), NT, 0, (hipStream_t)stream>>>(x, out, N, H, W, C, OH, OW,
+                                                                                  ac_scale(H, OH), ac_scale(W, OW));
+    MDE_LAUNCH_CHECK("upsig_fwd_k");
+    return MDE_OK;
+}
+
+extern "C" int mde_upsample_sigmoid_bwd(const float* dout, const float* out, float* dx, int N, int H, int W, int C,
+                                        int OH, int OW, void* stream) {
+    MDE_REQUIRE(dout && out && dx && N > 0 && H > 0 && W > 0 && C > 0 && OH > 0 && OW > 0, "mde_upsample_sigmoid_bwd: bad argument");
+    const float sh = ac_scale(H, OH), sw = ac_scale(W, OW);
+    // inverse scales only bound the candidate window; a degenerate scale (out size 1) scans everything
+    const float ish = sh > 0.f ? 1.f / sh : (float)OH, isw = sw > 0.f ? 1.f / sw : (float)OW;
+    upsig_bwd_k<<<grid_for((int64_t)N * H * W * C), NT, 0, (hipStream_t)stream>>>(dout, out, dx, N, H, W, C, OH, OW, sh,
+                                                                                sw, ish, isw);
+    MDE_LAUNCH_CHECK("upsig_bwd_k");
+    return MDE_OK;
+}
+
+extern "C" int mde_nchw_to_nhwc_bf16(const float* src, void* dst, int N, int C, int H, int W, void* stream) {
+    MDE_REQUIRE(src && dst && N > 0 && C > 0 && H > 0 && W > 0, "mde_nchw_to_nhwc_bf16: bad argument");
+    nchw2nhwc_k<<<grid_for((int64_t)N * C * H * W), NT, 0, (hipStream_t)stream>>>(src, (bf16_t*)dst, N, C, H, W);
+    MDE_LAUNCH_CHECK("nchw2nhwc_k");
+    return MDE_OK;
+}
+
+extern "C" int mde_nhwc_bf16_to_nchw(const void* src, float* dst, int N, int C, int H, int W, void* stream) {
+    MDE_REQUIRE(src && dst && N > 0 && C > 0 && H > 0 && W > 0, "mde_nhwc_bf16_to_nchw: bad argument");
+    nhwc2nchw_k<<<grid_for((int64_t)N * C * H * W), NT, 0, (hipStream_t)stream>>>((const bf16_t*)src, dst, N, C, H, W);
+    MDE_LAUNCH_CHECK("nhwc2nchw_k");
+    return MDE_OK;
+}

@@ -103,11 +103,13 @@ def conv_gemm(desc, x, w, out, stats=None):
     check(_lib.load().mde_conv_gemm(C.byref(desc), _p(x), _p(w), _p(out), _p(stats), _stream()), "mde_conv_gemm")
 
 
-def conv_gemm_stat_rows(desc):
-    n = _lib.load().mde_conv_gemm_stat_rows(C.byref(desc))
-    if n < 0:
-        raise _lib.MdeError("mde_conv_gemm_stat_rows failed")
-    return n
+def stat_slots():
+    return _lib.load().mde_stat_slots()
+
+
+def new_stat_buffer(C_, device="cuda"):
+    """A zeroed BatchNorm partial-sum buffer [slots][2][C] (finalize kernels re-zero it)."""
+    return torch.zeros(stat_slots(), 2, C_, dtype=torch.float32, device=device)
 
 
 # ------------------------------------------------------------------------------ wgrad descriptors
@@ -147,3 +149,126 @@ def choose_ksplit(pixels, row_tiles, col_tiles, ntaps, cus=256, min_steps=8):
     want = max(1, (3 * cus + base - 1) // base)
     cap = max(1, pixels // (64 * min_steps))
     return max(1, min(want, cap))
+
+
+# ------------------------------------------------------------------------------ small convs
+def stem_conv_fwd(x, w, out):
+    N, _, H, W = x.shape
+    check(_lib.load().mde_stem_conv_fwd(_p(x), _p(w), _p(out), N, H, W, _stream()), "mde_stem_conv_fwd")
+
+
+def stem_conv_wgrad(x, dout, dw):
+    N, _, H, W = x.shape
+    check(_lib.load().mde_stem_conv_wgrad(_p(x), _p(dout), _p(dw), N, H, W, _stream()), "mde_stem_conv_wgrad")
+
+
+def head_conv_fwd(x, w, out, N, H, W, Cin, Cout):
+    check(_lib.load().mde_head_conv_fwd(_p(x), _p(w), _p(out), N, H, W, Cin, Cout, _stream()), "mde_head_conv_fwd")
+
+
+def head_conv_bwd(x, w, dout, dx, dw, N, H, W, Cin, Cout):
+    check(_lib.load().mde_head_conv_bwd(_p(x), _p(w), _p(dout), _p(dx), _p(dw), N, H, W, Cin, Cout, _stream()),
+          "mde_head_conv_bwd")
+
+
+# ------------------------------------------------------------------------------ batch norm
+def bn_stats(x, M, C_, ld, part):
+    check(_lib.load().mde_bn_stats(_p(x), M, C_, ld, _p(part), _stream()), "mde_bn_stats")
+
+
+def bn_finalize(part, M, C_, gamma, beta, rmean, rvar, momentum, eps, scale, shift, smean, srstd):
+    check(_lib.load().mde_bn_finalize(_p(part), M, C_, _p(gamma), _p(beta), _p(rmean), _p(rvar), momentum, eps,
+                                      _p(scale), _p(shift), _p(smean), _p(srstd), _stream()), "mde_bn_finalize")
+
+
+def bn_eval_scale_shift(gamma, beta, rmean, rvar, eps, C_, scale, shift):
+    check(_lib.load().mde_bn_eval_scale_shift(_p(gamma), _p(beta), _p(rmean), _p(rvar), eps, C_, _p(scale), _p(shift),
+                                              _stream()), "mde_bn_eval_scale_shift")
+
+
+def bn_apply(x, ldx, scale, shift, out, ldo, M, C_, relu, r=None, ldr=0, rscale=None, rshift=None):
+    check(_lib.load().mde_bn_apply(_p(x), ldx, _p(scale), _p(shift), _p(r), ldr, _p(rscale), _p(rshift), _p(out), ldo,
+                                   M, C_, int(relu), _stream()), "mde_bn_apply")
+
+
+def bn_bwd_reduce(dout, ldd, out, ldo, x, ldx, smean, srstd, M, C_, relu, part):
+    check(_lib.load().mde_bn_bwd_reduce(_p(dout), ldd, _p(out), ldo, _p(x), ldx, _p(smean), _p(srstd), M, C_, int(relu),
+                                        _p(part), _stream()), "mde_bn_bwd_reduce")
+
+
+def bn_bwd_finalize(part, M, C_, gamma, srstd, dgamma, dbeta, coef):
+    check(_lib.load().mde_bn_bwd_finalize(_p(part), M, C_, _p(gamma), _p(srstd), _p(dgamma), _p(dbeta), _p(coef),
+                                          _stream()), "mde_bn_bwd_finalize")
+
+
+def bn_bwd_apply(dout, ldd, out, ldo, x, ldx, smean, srstd, coef, M, C_, relu, dx, ldxo, accumulate=False, dres=None,
+                 ldres=0):
+    check(_lib.load().mde_bn_bwd_apply(_p(dout), ldd, _p(out), ldo, _p(x), ldx, _p(smean), _p(srstd), _p(coef), M, C_,
+                                       int(relu), _p(dx), ldxo, int(accumulate), _p(dres), ldres, _stream()),
+          "mde_bn_bwd_apply")
+
+
+# ------------------------------------------------------------------------------ pool / resize
+def maxpool_fwd(x, out, idx, N, H, W, C_):
+    check(_lib.load().mde_maxpool_fwd(_p(x), _p(out), _p(idx), N, H, W, C_, _stream()), "mde_maxpool_fwd")
+
+
+def maxpool_bwd(dout, idx, dx, N, H, W, C_):
+    check(_lib.load().mde_maxpool_bwd(_p(dout), _p(idx), _p(dx), N, H, W, C_, _stream()), "mde_maxpool_bwd")
+
+
+def upsample_sigmoid_fwd(x, out, N, H, W, C_, OH, OW):
+    check(_lib.load().mde_upsample_sigmoid_fwd(_p(x), _p(out), N, H, W, C_, OH, OW, _stream()), "mde_upsample_sigmoid_fwd")
+
+
+def upsample_sigmoid_bwd(dout, out, dx, N, H, W, C_, OH, OW):
+    check(_lib.load().mde_upsample_sigmoid_bwd(_p(dout), _p(out), _p(dx), N, H, W, C_, OH, OW, _stream()),
+          "mde_upsample_sigmoid_bwd")
+
+
+def nchw_to_nhwc_bf16(src, dst):
+    N, C_, H, W = src.shape
+    check(_lib.load().mde_nchw_to_nhwc_bf16(_p(src), _p(dst), N, C_, H, W, _stream()), "mde_nchw_to_nhwc_bf16")
+
+
+def nhwc_bf16_to_nchw(src, dst):
+    N, C_, H, W = dst.shape
+    check(_lib.load().mde_nhwc_bf16_to_nchw(_p(src), _p(dst), N, C_, H, W, _stream()), "mde_nhwc_bf16_to_nchw")
+
+
+# ------------------------------------------------------------------------------ losses / metrics
+def silog_ws(device="cuda"):
+    return torch.zeros((_lib.load().mde_silog_ws_bytes() + 7) // 8, dtype=torch.float64, device=device)
+
+
+def silog_fwd(est, gt, variance_focus, ws, loss):
+    check(_lib.load().mde_silog_fwd(_p(est), _p(gt), est.numel(), variance_focus, _p(ws), _p(loss), _stream()),
+          "mde_silog_fwd")
+
+
+def silog_bwd(est, gt, variance_focus, ws, gscale, grad):
+    check(_lib.load().mde_silog_bwd(_p(est), _p(gt), est.numel(), variance_focus, _p(ws), _p(gscale), _p(grad),
+                                    _stream()), "mde_silog_bwd")
+
+
+def metrics_ws(device="cuda"):
+    return torch.zeros((_lib.load().mde_metrics_ws_bytes() + 7) // 8, dtype=torch.float64, device=device)
+
+
+def depth_metrics(pred, target, ws, out):
+    check(_lib.load().mde_depth_metrics(_p(pred), _p(target), pred.numel(), _p(ws), _p(out), _stream()),
+          "mde_depth_metrics")
+
+
+# ------------------------------------------------------------------------------ optimiser plumbing
+def adam_step(p, g, m, v, p_bf16, n, lr, beta1, beta2, eps, weight_decay, grad_scale, step):
+    check(_lib.load().mde_adam_step(_p(p), _p(g), _p(m), _p(v), _p(p_bf16), n, lr, beta1, beta2, eps, weight_decay,
+                                    grad_scale, step, _stream()), "mde_adam_step")
+
+
+def cast_bf16(src, dst, n=None):
+    check(_lib.load().mde_cast_bf16(_p(src), _p(dst), src.numel() if n is None else n, _stream()), "mde_cast_bf16")
+
+
+def pack_wt(src, dst, O, T, I):
+    check(_lib.load().mde_pack_wt(_p(src), _p(dst), O, T, I, _stream()), "mde_pack_wt")

@@ -57,8 +57,7 @@ def test_conv_forward(N, H, Wd, Cin, Cout, k, s, p):
     ld_out = Cout + 8                                    # channel-sliced output view
     out = torch.full((N, OH, OW, ld_out), 7.0, dtype=torch.bfloat16, device="cuda")
     d = ops.fwd_desc(N, H, Wd, Cin, Cin, xd.numel() * 2, k, s, p, Cout, ld_out)
-    rows = ops.conv_gemm_stat_rows(d)
-    stats = torch.zeros(rows, 2, Cout, device="cuda")
+    stats = ops.new_stat_buffer(Cout)
     ops.conv_gemm(d, xd, wd, out, stats)
     torch.cuda.synchronize()
     _assert_close(_nchw(out[..., :Cout]), ref, "conv fwd")

@@ -1,0 +1,298 @@
+"""GPU parity of the streaming kernels (BatchNorm, maxpool, bilinear+sigmoid, SILog, metrics,
+Adam, packing, stem/head convs) against the CPU oracle / plain torch fp32 ops.
+bf16-output kernels: |hip - ref| <= 2^-8|ref| + 2^-8 rms(ref); fp32 kernels: rtol 1e-4/1e-5."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import losses as OL
+from oracle import metrics as OM
+from oracle import weights as W
+
+pytestmark = pytest.mark.gpu
+
+
+def _bf(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def _nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).cuda()
+
+
+def _nchw(t):
+    return t.float().cpu().permute(0, 3, 1, 2).contiguous()
+
+
+def _close_bf16(got, ref, what, tol=2.0 ** -8):
+    err = (got - ref).abs()
+    bound = tol * ref.abs() + tol * ref.pow(2).mean().sqrt()
+    bad = (err > bound).sum().item()
+    assert bad == 0, "%s: %d/%d outside tolerance, max err %.4g" % (what, bad, ref.numel(), err.max().item())
+
+
+# ------------------------------------------------------------------------------------ BatchNorm
+@pytest.mark.parametrize("N,H,Wd,C,relu,res", [
+    (2, 9, 11, 64, True, 0), (3, 7, 5, 256, False, 0), (2, 6, 6, 128, True, 1), (2, 5, 9, 64, True, 2),
+    (1, 3, 4, 2048, True, 1),
+])
+def test_bn_train_forward_backward(N, H, Wd, C, relu, res):
+    """stats -> finalize -> apply and the three backward passes vs nn.BatchNorm2d autograd.
+    res: 0 none, 1 identity residual, 2 residual through a second BN (up-projection join)."""
+    from mono_depth_estimation_amd import ops
+    M = N * H * Wd
+    x = _bf(W.normal(7, "x", (N, C, H, Wd), 1.5, 0.3)).requires_grad_(True)
+    r = _bf(W.normal(7, "r", (N, C, H, Wd))).requires_grad_(True)
+    bn, bn2 = torch.nn.BatchNorm2d(C), torch.nn.BatchNorm2d(C)
+    for i, b in enumerate((bn, bn2)):
+        b.weight.data = W.normal(7, "g%d" % i, (C,), 0.2, 1.0)
+        b.bias.data = W.normal(7, "b%d" % i, (C,), 0.2)
+        b.running_mean.data = W.normal(7, "rm%d" % i, (C,), 0.2)
+        b.running_var.data = W.uniform(7, "rv%d" % i, (C,), 0.5, 1.5)
+    rm0, rv0 = bn.running_mean.clone(), bn.running_var.clone()
+    y = bn(x)
+    if res == 1:
+        y = y + r
+    elif res == 2:
+        y = y + bn2(r)
+    if relu:
+        y = F.relu(y)
+    dy = _bf(W.normal(7, "dy", tuple(y.shape)))
+    y.backward(dy)
+
+    dev = "cuda"
+    xd, rd, dyd = _nhwc(x.detach()), _nhwc(r.detach()), _nhwc(dy)
+    part = ops.new_stat_buffer(C)
+    f = lambda t: t.detach().clone().to(dev)
+    gamma, beta, rmean, rvar = f(bn.weight), f(bn.bias), rm0.to(dev), rv0.to(dev)
+    scale, shift, smean, srstd = (torch.empty(C, device=dev) for _ in range(4))
+    ops.bn_stats(xd, M, C, C, part)
+    ops.bn_finalize(part, M, C, gamma, beta, rmean, rvar, 0.1, 1e-5, scale, shift, smean, srstd)
+    assert float(part.abs().max()) == 0.0, "finalize must re-zero the partial buffer"
+    out = torch.empty_like(xd)
+    if res == 2:
+        part2 = ops.new_stat_buffer(C)
+        g2, b2 = f(bn2.weight), f(bn2.bias)
+        sc2, sh2, sm2, sr2 = (torch.empty(C, device=dev) for _ in range(4))
+        ops.bn_stats(rd, M, C, C, part2)
+        ops.bn_finalize(part2, M, C, g2, b2, None, None, 0.1, 1e-5, sc2, sh2, sm2, sr2)
+        ops.bn_apply(xd, C, scale, shift, out, C, M, C, relu, r=rd, ldr=C, rscale=sc2, rshift=sh2)
+    elif res == 1:
+        ops.bn_apply(xd, C, scale, shift, out, C, M, C, relu, r=rd, ldr=C)
+    else:
+        ops.bn_apply(xd, C, scale, shift, out, C, M, C, relu)
+    torch.cuda.synchronize()
+    _close_bf16(_nchw(out), y.detach(), "bn fwd")
+    assert torch.allclose(rmean.cpu(), bn.running_mean, rtol=1e-4, atol=1e-5)
+    assert torch.allclose(rvar.cpu(), bn.running_var, rtol=1e-4, atol=1e-5)
+
+    # backward
+    coef = torch.empty(3, C, device=dev)
+    dgamma, dbeta = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+    dx = torch.empty_like(xd)
+    dres = torch.empty_like(xd) if res == 1 else None
+    ops.bn_bwd_reduce(dyd, C, out, C, xd, C, smean, srstd, M, C, relu, part)
+    ops.bn_bwd_finalize(part, M, C, gamma, srstd, dgamma, dbeta, coef)
+    ops.bn_bwd_apply(dyd, C, out, C, xd, C, smean, srstd, coef, M, C, relu, dx, C, dres=dres, ldres=C)
+    torch.cuda.synchronize()
+    _close_bf16(_nchw(dx), x.grad, "bn dx", tol=2.0 ** -7)
+    tolp = dict(rtol=2e-2, atol=2e-2 * float(bn.weight.grad.abs().max()))
+    assert torch.allclose(dgamma.cpu(), bn.weight.grad, **tolp)
+    assert torch.allclose(dbeta.cpu(), bn.bias.grad, **tolp)
+    if res == 1:
+        _close_bf16(_nchw(dres), r.grad, "bn dres")
+    if res == 2:
+        dr = torch.empty_like(xd)
+        ops.bn_bwd_reduce(dyd, C, out, C, rd, C, sm2, sr2, M, C, relu, part2)
+        ops.bn_bwd_finalize(part2, M, C, g2, sr2, None, None, coef)
+        ops.bn_bwd_apply(dyd, C, out, C, rd, C, sm2, sr2, coef, M, C, relu, dr, C)
+        torch.cuda.synchronize()
+        _close_bf16(_nchw(dr), r.grad, "bn2 dx", tol=2.0 ** -7)
+
+
+def test_bn_eval_and_channel_slices():
+    """Eval-mode scale/shift, and a BN site living in a channel slice of a wider tensor."""
+    from mono_depth_estimation_amd import ops
+    N, H, Wd, C, LD = 2, 5, 7, 64, 128
+    M = N * H * Wd
+    x = _bf(W.normal(8, "x", (N, LD, H, Wd)))
+    bn = torch.nn.BatchNorm2d(C).eval()
+    bn.weight.data = W.normal(8, "g", (C,), 0.2, 1.0)
+    bn.bias.data = W.normal(8, "b", (C,), 0.2)
+    bn.running_mean.data = W.normal(8, "rm", (C,), 0.2)
+    bn.running_var.data = W.uniform(8, "rv", (C,), 0.5, 1.5)
+    ref = F.relu(bn(x[:, C:]))
+    xd = _nhwc(x)
+    scale, shift = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+    ops.bn_eval_scale_shift(bn.weight.cuda(), bn.bias.cuda(), bn.running_mean.cuda(), bn.running_var.cuda(), 1e-5, C,
+                            scale, shift)
+    out = torch.zeros(N, H, Wd, C, dtype=torch.bfloat16, device="cuda")
+    ops.bn_apply(xd[..., C:], LD, scale, shift, out, C, M, C, True)
+    torch.cuda.synchronize()
+    _close_bf16(_nchw(out), ref, "bn eval slice")
+
+
+# ------------------------------------------------------------------------------------ maxpool
+@pytest.mark.parametrize("N,H,Wd,C", [(2, 12, 16, 64), (1, 9, 11, 64)])
+def test_maxpool(N, H, Wd, C):
+    from mono_depth_estimation_amd import ops
+    x = F.relu(_bf(W.normal(9, "x", (N, C, H, Wd)))).requires_grad_(True)   # post-ReLU: many ties at 0
+    y = F.max_pool2d(x, 3, 2, 1)
+    dy = _bf(W.normal(9, "dy", tuple(y.shape)))
+    y.backward(dy)
+    OH, OW = y.shape[2:]
+    xd, dyd = _nhwc(x.detach()), _nhwc(dy)
+    out = torch.empty(N, OH, OW, C, dtype=torch.bfloat16, device="cuda")
+    idx = torch.empty(N, OH, OW, C, dtype=torch.uint8, device="cuda")
+    dx = torch.empty_like(xd)
+    ops.maxpool_fwd(xd, out, idx, N, H, Wd, C)
+    ops.maxpool_bwd(dyd, idx, dx, N, H, Wd, C)
+    torch.cuda.synchronize()
+    assert torch.equal(_nchw(out), y.detach())
+    _close_bf16(_nchw(dx), x.grad, "maxpool bwd")
+
+
+# ------------------------------------------------------------------------------------ bilinear + sigmoid
+@pytest.mark.parametrize("N,C,H,Wd,OH,OW", [(2, 1, 12, 16, 24, 32), (1, 3, 7, 9, 20, 13), (2, 1, 6, 8, 6, 8)])
+def test_upsample_sigmoid(N, C, H, Wd, OH, OW):
+    from mono_depth_estimation_amd import ops
+    x = W.normal(10, "x", (N, C, H, Wd)).requires_grad_(True)
+    y = torch.sigmoid(F.interpolate(x, size=(OH, OW), mode="bilinear", align_corners=True))
+    dy = W.normal(10, "dy", tuple(y.shape))
+    y.backward(dy)
+    xd = x.detach().permute(0, 2, 3, 1).contiguous().cuda()      # fp32 NHWC
+    out = torch.empty(N, C, OH, OW, device="cuda")
+    dx = torch.empty_like(xd)
+    ops.upsample_sigmoid_fwd(xd, out, N, H, Wd, C, OH, OW)
+    ops.upsample_sigmoid_bwd(dy.cuda(), out, dx, N, H, Wd, C, OH, OW)
+    torch.cuda.synchronize()
+    assert torch.allclose(out.cpu(), y.detach(), rtol=1e-5, atol=1e-6)
+    assert torch.allclose(dx.cpu().permute(0, 3, 1, 2), x.grad, rtol=1e-4, atol=1e-6)
+
+
+# ------------------------------------------------------------------------------------ SILog / metrics
+@pytest.mark.parametrize("lam", [0.85, 0.5])
+def test_silog_golden(golden, lam):
+    """HIP SILog vs the reference's own output (tests/golden/losses.npz) and the oracle."""
+    from mono_depth_estimation_amd import ops
+    g = golden("losses")
+    est, gt = torch.from_numpy(g["g1_est"]).cuda(), torch.from_numpy(g["g1_gt"]).cuda()
+    ws, loss, grad = ops.silog_ws(), torch.empty(1, device="cuda"), torch.empty_like(est)
+    ops.silog_fwd(est, gt, lam, ws, loss)
+    ops.silog_bwd(est, gt, lam, ws, None, grad)
+    torch.cuda.synchronize()
+    assert np.allclose(loss.item(), g["g1_silog_%g" % lam], rtol=1e-5)
+    assert np.allclose(grad.cpu().numpy(), g["g1_silog_%g_grad" % lam], rtol=1e-4, atol=1e-8)
+    gs = torch.full((1,), 0.25, device="cuda")
+    ops.silog_bwd(est, gt, lam, ws, gs, grad)
+    assert np.allclose(grad.cpu().numpy(), 0.25 * g["g1_silog_%g_grad" % lam], rtol=1e-4, atol=1e-8)
+
+
+def test_silog_large_matches_oracle():
+    from mono_depth_estimation_amd import ops
+    est = W.uniform(11, "est", (4, 1, 480, 640), 0.05, 1.0)
+    _, gt = W.synthetic_batch(11, 4, 480, 640)
+    e = est.clone().requires_grad_(True)
+    ref = OL.silog(e, gt, 0.85)
+    ref.backward()
+    ed, gd = est.cuda(), gt.cuda()
+    ws, loss, grad = ops.silog_ws(), torch.empty(1, device="cuda"), torch.empty_like(ed)
+    ops.silog_fwd(ed, gd, 0.85, ws, loss)
+    ops.silog_bwd(ed, gd, 0.85, ws, None, grad)
+    assert np.allclose(loss.item(), ref.item(), rtol=1e-5)
+    assert torch.allclose(grad.cpu(), e.grad, rtol=2e-3, atol=1e-9)
+
+
+def test_metrics_golden(golden):
+    from mono_depth_estimation_amd import ops
+    g = golden("metrics")
+    pred, tgt = torch.from_numpy(g["pred"]).cuda(), torch.from_numpy(g["tgt"]).cuda()
+    ws, out = ops.metrics_ws(), torch.empty(6, device="cuda")
+    ops.depth_metrics(pred, tgt, ws, out)
+    got = out.cpu().numpy()
+    for i, k in enumerate(OM.NAMES):
+        assert np.allclose(got[i], g[k], rtol=1e-5), k
+
+
+# ------------------------------------------------------------------------------------ optimiser plumbing
+def test_adam_matches_torch():
+    from mono_depth_estimation_amd import ops
+    n = 100003
+    p0, g1, g2 = W.normal(12, "p", (n,)), W.normal(12, "g1", (n,)), W.normal(12, "g2", (n,), 0.3)
+    p = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([p], lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
+    pd, m, v = p0.clone().cuda(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    pb = torch.empty(n, dtype=torch.bfloat16, device="cuda")
+    for step, g in enumerate((g1, g2), 1):
+        p.grad = g.clone()
+        opt.step()
+        ops.adam_step(pd, (2.0 * g).cuda(), m, v, pb, n, 1e-3, 0.9, 0.999, 1e-8, 0.01, 0.5, step)
+    torch.cuda.synchronize()
+    assert torch.allclose(pd.cpu(), p.detach(), rtol=1e-5, atol=1e-7)
+    assert torch.equal(pb.cpu(), pd.cpu().to(torch.bfloat16))
+
+
+def test_cast_and_pack():
+    from mono_depth_estimation_amd import ops
+    O, T, I = 70, 9, 130
+    w = W.normal(13, "w", (O, T, I))
+    wd = w.cuda()
+    c = torch.empty(O, T, I, dtype=torch.bfloat16, device="cuda")
+    t = torch.empty(I, T, O, dtype=torch.bfloat16, device="cuda")
+    ops.cast_bf16(wd, c)
+    ops.pack_wt(wd, t, O, T, I)
+    torch.cuda.synchronize()
+    assert torch.equal(c.cpu(), w.to(torch.bfloat16))
+    assert torch.equal(t.cpu(), w.permute(2, 1, 0).contiguous().to(torch.bfloat16))
+    x = W.normal(13, "x", (2, 5, 6, 7))
+    xd = torch.empty(2, 6, 7, 5, dtype=torch.bfloat16, device="cuda")
+    ops.nchw_to_nhwc_bf16(x.cuda(), xd)
+    back = torch.empty(2, 5, 6, 7, device="cuda")
+    ops.nhwc_bf16_to_nchw(xd, back)
+    assert torch.equal(back.cpu(), _bf(x))
+
+
+# ------------------------------------------------------------------------------------ stem / head convs
+@pytest.mark.parametrize("N,H,Wd", [(2, 32, 48), (1, 30, 200)])
+def test_stem_conv(N, H, Wd):
+    from mono_depth_estimation_amd import ops
+    x = W.uniform(14, "x", (N, 3, H, Wd))
+    w = W.normal(14, "w", (64, 3, 7, 7), (2.0 / (49 * 64)) ** 0.5).requires_grad_(True)
+    y = F.conv2d(x, w, stride=2, padding=3)
+    dy = _bf(W.normal(14, "dy", tuple(y.shape)))
+    y.backward(dy)
+    w_ohwi = w.detach().permute(0, 2, 3, 1).contiguous().cuda()
+    OH, OW = y.shape[2:]
+    out = torch.empty(N, OH, OW, 64, dtype=torch.bfloat16, device="cuda")
+    dw = torch.zeros(64, 7, 7, 3, device="cuda")
+    ops.stem_conv_fwd(x.cuda(), w_ohwi, out)
+    ops.stem_conv_wgrad(x.cuda(), _nhwc(dy), dw)
+    torch.cuda.synchronize()
+    _close_bf16(_nchw(out), y.detach(), "stem fwd")
+    ref = w.grad.permute(0, 2, 3, 1)
+    assert torch.allclose(dw.cpu(), ref, rtol=1e-3, atol=1e-3 * float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("N,H,Wd,Cout", [(2, 10, 12, 1), (1, 7, 9, 20), (1, 6, 6, 3)])
+def test_head_conv(N, H, Wd, Cout):
+    from mono_depth_estimation_amd import ops
+    Cin = 64
+    x = _bf(W.normal(15, "x", (N, Cin, H, Wd))).requires_grad_(True)
+    w = W.normal(15, "w", (Cout, Cin, 3, 3), 0.05).requires_grad_(True)
+    y = F.conv2d(x, w, padding=1)
+    dy = W.normal(15, "dy", tuple(y.shape))
+    y.backward(dy)
+    xd = _nhwc(x.detach())
+    w_ohwi = w.detach().permute(0, 2, 3, 1).contiguous().cuda()
+    out = torch.empty(N, H, Wd, Cout, device="cuda")
+    ops.head_conv_fwd(xd, w_ohwi, out, N, H, Wd, Cin, Cout)
+    dyd = dy.permute(0, 2, 3, 1).contiguous().cuda()
+    dx = torch.empty_like(xd)
+    dw = torch.zeros(Cout, 3, 3, Cin, device="cuda")
+    ops.head_conv_bwd(xd, w_ohwi, dyd, dx, dw, N, H, Wd, Cin, Cout)
+    torch.cuda.synchronize()
+    assert torch.allclose(out.cpu().permute(0, 3, 1, 2), y.detach(), rtol=1e-4, atol=1e-5)
+    _close_bf16(_nchw(dx), x.grad, "head dgrad")
+    ref = w.grad.permute(0, 2, 3, 1)
+    assert torch.allclose(dw.cpu(), ref, rtol=1e-3, atol=1e-4 * float(ref.abs().max()))
