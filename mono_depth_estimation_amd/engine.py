@@ -1,0 +1,543 @@
+"""Execution engine of the HIP FCRN path: flat parameter storage + a static plan of kernel
+launches for forward and backward of reference network/FCRN.py:351-371 (ResNet-50/101/152
+trunk, conv2/bn2, UpProj decoder, conv3, bilinear, sigmoid).
+
+Design:
+  * parameters, gradients, Adam moments and BN running statistics live in a few FLAT fp32
+    buffers; the nn.Module's Parameters are views into them (conv weights stored OHWI, i.e.
+    torch channels_last, so the bf16 shadow copy *is* the packed GEMM weight and the wgrad
+    kernel's output *is* the .grad tensor).  One Adam launch and one all-reduce cover
+    everything; encoder and decoder are two contiguous ranges (1x / 10x learning rates,
+    reference modules/laina.py:51-57).
+  * activations are NHWC bf16, allocated once per input shape; the plan is a list of
+    pre-built descriptors so a step is a fixed sequence of C-ABI calls on the current stream
+    (capturable in a HIP graph).
+  * BatchNorm batch statistics come out of the conv epilogue; ReLU and residual adds are
+    fused into the BN apply; the zero-insertion Unpool never materialises (four output
+    phases of the 5x5 convs); both 5x5 branches of an UpProj module run as one GEMM.
+"""
+import torch
+
+from . import ops
+
+_ALIGN = 64
+
+
+def _round_up(n, a=_ALIGN):
+    return (n + a - 1) // a * a
+
+
+class Act:
+    """NHWC bf16 activation (or a channel slice of one) with a lazily allocated gradient."""
+
+    def __init__(self, dev, N, H, W, C, parent=None, c0=0):
+        self.N, self.H, self.W, self.C = N, H, W, C
+        self.parent, self.c0 = parent, c0
+        if parent is None:
+            self.ld = C
+            self.t = torch.empty(N, H, W, C, dtype=torch.bfloat16, device=dev)
+        else:
+            self.ld = parent.ld
+            self.t = parent.t[..., c0:c0 + C]
+        self._g = None
+        self.gw = False          # gradient already written during the current backward
+
+    @property
+    def M(self):
+        return self.N * self.H * self.W
+
+    @property
+    def nbytes(self):            # bytes addressable from the first element
+        root = self if self.parent is None else self.parent
+        return (root.t.numel() - self.c0) * 2
+
+    def slice(self, c0, C):
+        return Act(None, self.N, self.H, self.W, C, parent=self, c0=self.c0 + c0)
+
+    @property
+    def g(self):
+        if self._g is None:
+            if self.parent is None:
+                self._g = torch.empty_like(self.t)
+            else:
+                self._g = self.parent.g[..., self.c0 - self.parent.c0:self.c0 - self.parent.c0 + self.C]
+        return self._g
+
+
+class BNSite:
+    """Per-BatchNorm device state: fp32 views into the flat stores + saved statistics."""
+
+    def __init__(self, eng, C, gamma, beta, dgamma, dbeta, rmean, rvar, bn, eps):
+        dev = eng.dev
+        self.C, self.bn, self.eps = C, bn, eps        # momentum is read from the module at run time
+        self.gamma, self.beta, self.dgamma, self.dbeta, self.rmean, self.rvar = gamma, beta, dgamma, dbeta, rmean, rvar
+        self.scale, self.shift, self.smean, self.srstd = (torch.empty(C, device=dev) for _ in range(4))
+        self.part = ops.new_stat_buffer(C, dev)
+        self.coef = torch.empty(3, C, device=dev)
+
+    def half(self, eng, i):
+        """View of channels [i*C/2, (i+1)*C/2) of a fused site (own partial buffer for backward)."""
+        h = self.C // 2
+        s = BNSite.__new__(BNSite)
+        s.C, s.bn, s.eps = h, self.bn, self.eps
+        for k in ("gamma", "beta", "dgamma", "dbeta", "rmean", "rvar", "scale", "shift", "smean", "srstd"):
+            setattr(s, k, getattr(self, k)[i * h:(i + 1) * h])
+        s.part = ops.new_stat_buffer(h, eng.dev)
+        s.coef = torch.empty(3, h, device=eng.dev)
+        return s
+
+    def finalize(self, M, train):
+        if train:
+            mom = self.bn.momentum if self.bn.momentum is not None else 0.1
+            ops.bn_finalize(self.part, M, self.C, self.gamma, self.beta, self.rmean, self.rvar, mom, self.eps,
+                            self.scale, self.shift, self.smean, self.srstd)
+        else:
+            ops.bn_eval_scale_shift(self.gamma, self.beta, self.rmean, self.rvar, self.eps, self.C, self.scale, self.shift)
+
+    def backward(self, dout, out, x, relu, dx, accumulate=False, dres=None):
+        """g = dout*(out>0 if relu); writes dgamma/dbeta (+=), dx (bf16) and optionally dres = g."""
+        M, C = x.M, self.C
+        ops.bn_bwd_reduce(dout, _ld(dout, out), out.t if out is not None else None, out.ld if out is not None else 0,
+                          x.t, x.ld, self.smean, self.srstd, M, C, relu, self.part)
+        ops.bn_bwd_finalize(self.part, M, C, self.gamma, self.srstd, self.dgamma, self.dbeta, self.coef)
+        ops.bn_bwd_apply(dout, _ld(dout, out), out.t if out is not None else None, out.ld if out is not None else 0,
+                         x.t, x.ld, self.smean, self.srstd, self.coef, M, C, relu, dx, _ld(dx, x), accumulate,
+                         dres, _ld(dres, x) if dres is not None else 0)
+
+
+def _ld(t, like):
+    """Pixel stride (elements) of a gradient/activation tensor view."""
+    return t.stride(2) if t is not None and t.dim() == 4 else like.ld
+
+
+class Conv:
+    """A conv parameter: fp32 master [O][T][I] slice of P, bf16 shadow slice, grad slice, and
+    (when its input gradient is needed) the transposed bf16 packing [I][T][O]."""
+
+    def __init__(self, store, off, O, T, I, need_dgrad=True):
+        n = O * T * I
+        self.O, self.T, self.I = O, T, I
+        self.w32 = store.P[off:off + n]
+        self.wf = store.Pb[off:off + n]
+        self.dw = store.G[off:off + n]
+        self.wd = torch.empty(n, dtype=torch.bfloat16, device=store.dev) if need_dgrad else None
+
+    def repack(self):
+        if self.wd is not None:
+            ops.pack_wt(self.w32, self.wd, self.O, self.T, self.I)
+
+
+class ParamStore:
+    """Flat fp32 parameter / gradient / BN-buffer storage of one FCRN module (created once;
+    every per-shape plan shares it).  Re-points the module's Parameters and buffers at views."""
+
+    def __init__(self, module, device):
+        self.m, self.dev = module, device
+        self.convs = {}           # id(first weight) -> Conv (shared packings)
+        self.packed_version = -1
+        self.adam_state = None
+        self.step_count = 0
+        self._flatten_parameters()
+
+    def _blocks(self):
+        for li in (1, 2, 3, 4):
+            for blk in getattr(self.m, "layer%d" % li):
+                yield li, blk
+
+    def _flatten_parameters(self):
+        m, dev = self.m, self.dev
+        plist, blist = [], []     # (key, [tensors])  -- a fused entry lists several tensors back to back
+
+        def conv_bn(conv, bn):
+            plist.append(("w", [conv.weight]))
+            plist.append(("g", [bn.weight]))
+            plist.append(("b", [bn.bias]))
+            blist.append([bn.running_mean])
+            blist.append([bn.running_var])
+
+        conv_bn(m.conv1, m.bn1)
+        for _, blk in self._blocks():
+            if not hasattr(blk, "conv3"):
+                raise NotImplementedError("HIP engine supports bottleneck trunks (layers 50/101/152) only")
+            conv_bn(blk.conv1, blk.bn1)
+            conv_bn(blk.conv2, blk.bn2)
+            conv_bn(blk.conv3, blk.bn3)
+            if blk.downsample is not None:
+                conv_bn(blk.downsample[0], blk.downsample[1])
+        self.n_encoder_entries = len(plist)
+        conv_bn(m.conv2, m.bn2)
+        for name in ("layer1", "layer2", "layer3", "layer4"):
+            up = getattr(m.upSample, name)
+            ub, bb = up.upper_branch, up.bottom_branch
+            plist.append(("w", [ub.conv1.weight, bb.conv.weight]))          # fused [2C][25][Cin]
+            plist.append(("g", [ub.batchnorm1.weight, bb.batchnorm.weight]))
+            plist.append(("b", [ub.batchnorm1.bias, bb.batchnorm.bias]))
+            blist.append([ub.batchnorm1.running_mean, bb.batchnorm.running_mean])
+            blist.append([ub.batchnorm1.running_var, bb.batchnorm.running_var])
+            conv_bn(ub.conv2, ub.batchnorm2)
+        plist.append(("w", [m.conv3.weight]))
+
+        offs, size = [], 0
+        for i, (_, ts) in enumerate(plist):
+            if i == self.n_encoder_entries:
+                self.encoder_numel = size
+            offs.append(size)
+            size = _round_up(size + sum(t.numel() for t in ts))
+        self.P = torch.zeros(size, dtype=torch.float32, device=dev)
+        self.G = torch.zeros(size, dtype=torch.float32, device=dev)
+        self.Pb = torch.zeros(size, dtype=torch.bfloat16, device=dev)
+        self.p_off = {}
+        for (kind, ts), off in zip(plist, offs):
+            o = off
+            for t in ts:
+                n = t.numel()
+                if t.dim() == 4:
+                    O, I, kh, kw = t.shape
+                    view = self.P[o:o + n].view(O, kh, kw, I).permute(0, 3, 1, 2)     # OIHW view of OHWI storage
+                    gview = self.G[o:o + n].view(O, kh, kw, I).permute(0, 3, 1, 2)
+                else:
+                    view, gview = self.P[o:o + n].view(t.shape), self.G[o:o + n].view(t.shape)
+                with torch.no_grad():
+                    view.copy_(t.detach().to(dev))
+                t.data = view
+                t._mde_grad = gview
+                self.p_off[id(t)] = o
+                o += n
+        bsize, boffs = 0, []
+        for ts in blist:
+            boffs.append(bsize)
+            bsize = _round_up(bsize + sum(t.numel() for t in ts))
+        self.B = torch.zeros(bsize, dtype=torch.float32, device=dev)
+        self.b_off = {}
+        for ts, off in zip(blist, boffs):
+            o = off
+            for t in ts:
+                n = t.numel()
+                view = self.B[o:o + n]
+                view.copy_(t.detach().to(dev))
+                t.data = view
+                self.b_off[id(t)] = o
+                o += n
+        # one shared int64 counter vector for every BN's num_batches_tracked
+        bns = [mod for mod in m.modules() if isinstance(mod, torch.nn.BatchNorm2d)]
+        self.nbt = torch.zeros(len(bns), dtype=torch.int64, device=dev)
+        for i, bn in enumerate(bns):
+            self.nbt[i] = int(bn.num_batches_tracked)
+            bn.num_batches_tracked.data = self.nbt[i]
+        self.params = [p for p in m.parameters()]
+
+    def attach_grads(self):
+        """Make every Parameter's .grad the matching view of the flat gradient buffer.
+        Returns True if the buffer had to be (re)attached and zeroed."""
+        fresh = False
+        for p in self.params:
+            if p.grad is None or p.grad.data_ptr() != p._mde_grad.data_ptr():
+                fresh = True
+                break
+        if fresh:
+            self.G.zero_()
+            for p in self.params:
+                p.grad = p._mde_grad
+        return fresh
+
+    def storage_is_current(self):
+        p = self.m.conv1.weight
+        return p.data_ptr() == self.P.data_ptr() + self.p_off[id(p)] * 4
+
+    def conv(self, weights, need_dgrad=True):
+        t0 = weights[0]
+        c = self.convs.get(id(t0))
+        if c is None:
+            O = sum(t.shape[0] for t in weights)
+            _, I, kh, kw = t0.shape
+            c = Conv(self, self.p_off[id(t0)], O, kh * kw, I, need_dgrad)
+            self.convs[id(t0)] = c
+        return c
+
+    def refresh_weights(self, force=False):
+        """bf16 shadow + transposed packings follow the fp32 masters (after any in-place update)."""
+        if force or self.P._version != self.packed_version:
+            ops.cast_bf16(self.P, self.Pb)
+            for c in self.convs.values():
+                c.repack()
+            self.packed_version = self.P._version
+
+    # fused Adam over the two flat ranges (encoder 1x LR, decoder 10x LR: modules/laina.py:51-57)
+    def adam_step(self, lr_encoder, lr_decoder, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, grad_scale=1.0):
+        if self.adam_state is None:
+            self.adam_state = (torch.zeros_like(self.P), torch.zeros_like(self.P))
+        mom, var = self.adam_state
+        self.step_count += 1
+        e, n = self.encoder_numel, self.P.numel()
+        ops.adam_step(self.P, self.G, mom, var, self.Pb, e, lr_encoder, betas[0], betas[1], eps, weight_decay, grad_scale,
+                      self.step_count)
+        ops.adam_step(self.P[e:], self.G[e:], mom[e:], var[e:], self.Pb[e:], n - e, lr_decoder, betas[0], betas[1], eps,
+                      weight_decay, grad_scale, self.step_count)
+        for c in self.convs.values():
+            c.repack()
+        self.packed_version = self.P._version   # shadow + packings are current (torch saw no in-place op on P)
+
+
+class FCRNEngine:
+    """Static launch plan for one (batch, height, width) input shape over a ParamStore."""
+
+    def __init__(self, module, store, N, H, W):
+        self.m, self.store, self.N, self.H, self.W, self.dev = module, store, N, H, W, store.dev
+        self.P, self.G, self.B, self.Pb = store.P, store.G, store.B, store.Pb
+        self.p_off, self.b_off, self.params = store.p_off, store.b_off, store.params
+        self.out_channels = module.conv3.out_channels
+        self.OH, self.OW = module.output_size
+        self.cus = torch.cuda.get_device_properties(self.dev).multi_processor_count
+        self._plan()
+
+    def _blocks(self):
+        return self.store._blocks()
+
+    def attach_grads(self):
+        return self.store.attach_grads()
+
+    # ------------------------------------------------------------------ plan helpers
+    def _conv(self, weights, need_dgrad=True):
+        return self.store.conv(weights, need_dgrad)
+
+    def _site(self, bns):
+        g0, b0, rm0, rv0 = bns[0].weight, bns[0].bias, bns[0].running_mean, bns[0].running_var
+        C = sum(b.num_features for b in bns)
+        po, pb = self.p_off[id(g0)], self.p_off[id(b0)]
+        bo, bv = self.b_off[id(rm0)], self.b_off[id(rv0)]
+        return BNSite(self, C, self.P[po:po + C], self.P[pb:pb + C], self.G[po:po + C], self.G[pb:pb + C],
+                      self.B[bo:bo + C], self.B[bv:bv + C], bns[0], bns[0].eps)
+
+    def _ksplit(self, pixels, rows, cols, ntaps):
+        rt = rows // (128 if rows % 128 == 0 else 64)
+        ct = cols // (128 if cols % 128 == 0 else 64)
+        return ops.choose_ksplit(pixels, rt, ct, ntaps, self.cus)
+
+    # ------------------------------------------------------------------ the plan
+    def _plan(self):
+        m, dev, N, H, W = self.m, self.dev, self.N, self.H, self.W
+        self.layers = []
+        # stem: conv1 (fp32 NCHW in) -> bn1 + relu -> maxpool
+        H2, W2 = ops.out_size(H, 7, 2, 3), ops.out_size(W, 7, 2, 3)
+        self.stem_w = self._conv([m.conv1.weight], need_dgrad=False)
+        self.stem_c = Act(dev, N, H2, W2, 64)
+        self.stem_a = Act(dev, N, H2, W2, 64)
+        self.stem_site = self._site([m.bn1])
+        H4, W4 = ops.out_size(H2, 3, 2, 1), ops.out_size(W2, 3, 2, 1)
+        self.pool = Act(dev, N, H4, W4, 64)
+        self.pool_idx = torch.empty(N, H4, W4, 64, dtype=torch.uint8, device=dev)
+        x = self.pool
+        for _, blk in self._blocks():
+            L = Bottleneck(self, x, blk)
+            self.layers.append(L)
+            x = L.out
+        L = ConvBN(self, x, self._conv([m.conv2.weight]), self._site([m.bn2]), 1, 1, 0, relu=False)
+        self.layers.append(L)
+        x = L.out
+        for name in ("layer1", "layer2", "layer3", "layer4"):
+            L = UpProjLayer(self, x, getattr(m.upSample, name))
+            self.layers.append(L)
+            x = L.out
+        self.feat = x                                   # [N][H/2][W/2][64] for the standard net
+        self.head_w = self._conv([m.conv3.weight], need_dgrad=False)
+        Co = self.out_channels
+        self.logits = torch.empty(N, x.H, x.W, Co, device=dev)
+        self.dlogits = torch.empty(N, x.H, x.W, Co, device=dev)
+        self.y = torch.empty(N, Co, self.OH, self.OW, device=dev)
+
+    # ------------------------------------------------------------------ execution
+    def forward(self, x, train):
+        assert x.shape == (self.N, 3, self.H, self.W) and x.dtype == torch.float32 and x.is_contiguous()
+        self.store.refresh_weights()
+        self.x = x
+        ops.stem_conv_fwd(x, self.stem_w.w32, self.stem_c.t)
+        s = self.stem_site
+        if train:
+            ops.bn_stats(self.stem_c.t, self.stem_c.M, 64, 64, s.part)
+        s.finalize(self.stem_c.M, train)
+        ops.bn_apply(self.stem_c.t, 64, s.scale, s.shift, self.stem_a.t, 64, self.stem_c.M, 64, True)
+        ops.maxpool_fwd(self.stem_a.t, self.pool.t, self.pool_idx, self.N, self.stem_a.H, self.stem_a.W, 64)
+        for L in self.layers:
+            L.fwd(train)
+        f = self.feat
+        ops.head_conv_fwd(f.t, self.head_w.w32, self.logits, f.N, f.H, f.W, f.C, self.out_channels)
+        ops.upsample_sigmoid_fwd(self.logits, self.y, f.N, f.H, f.W, self.out_channels, self.OH, self.OW)
+        if train:
+            self.store.nbt += 1
+        return self.y
+
+    def backward(self, dy):
+        """dy: fp32 NCHW gradient w.r.t. the output.  Adds parameter gradients into self.G."""
+        assert dy.shape == self.y.shape and dy.dtype == torch.float32 and dy.is_contiguous()
+        f = self.feat
+        for L in self.layers:
+            L.reset_grad_flags()
+        self.pool.gw = self.stem_a.gw = False
+        ops.upsample_sigmoid_bwd(dy, self.y, self.dlogits, f.N, f.H, f.W, self.out_channels, self.OH, self.OW)
+        ops.head_conv_bwd(f.t, self.head_w.w32, self.dlogits, f.g, self.head_w.dw, f.N, f.H, f.W, f.C, self.out_channels)
+        f.gw = True
+        for L in reversed(self.layers):
+            L.bwd()
+        ops.maxpool_bwd(self.pool.g, self.pool_idx, self.stem_a.g, self.N, self.stem_a.H, self.stem_a.W, 64)
+        s = self.stem_site
+        s.backward(self.stem_a.g, self.stem_a, self.stem_c, True, self.stem_c.g)
+        ops.stem_conv_wgrad(self.x, self.stem_c.g, self.stem_w.dw)
+
+
+class ConvBN:
+    """conv (implicit GEMM, BN statistics from its epilogue) -> BN -> [+ residual] -> [ReLU]."""
+
+    def __init__(self, eng, x, conv, site, k, stride, pad, relu, res=None, res_site=None, has_out=True):
+        self.eng, self.x, self.conv, self.site = eng, x, conv, site
+        self.k, self.stride, self.pad, self.relu, self.res, self.res_site = k, stride, pad, relu, res, res_site
+        Cout, dev = conv.O, eng.dev
+        OH, OW = ops.out_size(x.H, k, stride, pad), ops.out_size(x.W, k, stride, pad)
+        self.c = Act(dev, x.N, OH, OW, Cout)      # pre-BN
+        self.out = Act(dev, x.N, OH, OW, Cout) if has_out else None   # post BN / residual / ReLU
+        self.fdesc = ops.fwd_desc(x.N, x.H, x.W, x.ld, x.C, x.nbytes, k, stride, pad, Cout, Cout)
+        self.ddescs, self.dzero = ops.dgrad_descs(x.N, x.H, x.W, x.ld, x.C, OH, OW, Cout, Cout, self.c.nbytes, k, stride, pad)
+        ks = eng._ksplit(self.c.M, Cout, x.C, k * k)
+        self.wdesc = ops.conv_wgrad_desc(x.N, x.H, x.W, x.ld, x.C, x.nbytes, OH, OW, Cout, Cout, self.c.nbytes, k,
+                                         stride, pad, ks)
+
+    def reset_grad_flags(self):
+        self.c.gw = False
+        if self.out is not None:
+            self.out.gw = False
+
+    def conv_fwd(self, train):
+        ops.conv_gemm(self.fdesc, self.x.t, self.conv.wf, self.c.t, self.site.part if train else None)
+        self.site.finalize(self.c.M, train)
+
+    def fwd(self, train):
+        self.conv_fwd(train)
+        s, c, o = self.site, self.c, self.out
+        if self.res is None:
+            ops.bn_apply(c.t, c.ld, s.scale, s.shift, o.t, o.ld, c.M, c.C, self.relu)
+        elif self.res_site is None:
+            ops.bn_apply(c.t, c.ld, s.scale, s.shift, o.t, o.ld, c.M, c.C, self.relu, r=self.res.t, ldr=self.res.ld)
+        else:
+            rs = self.res_site
+            ops.bn_apply(c.t, c.ld, s.scale, s.shift, o.t, o.ld, c.M, c.C, self.relu, r=self.res.t, ldr=self.res.ld,
+                         rscale=rs.scale, rshift=rs.shift)
+
+    def bn_bwd(self, dres_to=None):
+        """d(out) -> d(c) (in self.c.g); optionally routes the masked gradient to an identity residual."""
+        dres = None
+        if dres_to is not None:
+            assert not dres_to.gw, "identity-residual gradient must be the first writer"
+            dres = dres_to.g
+            dres_to.gw = True
+        self.site.backward(self.out.g, self.out, self.c, self.relu, self.c.g, dres=dres)
+        self.c.gw = True
+
+    def conv_bwd(self):
+        x, eng = self.x, self.eng
+        ops.conv_wgrad(self.wdesc, self.c.g, x.t, self.conv.dw)
+        acc = x.gw
+        if self.dzero and not acc:
+            x.g.zero_()
+        for d in self.ddescs:
+            d.accumulate = int(acc)
+            ops.conv_gemm(d, self.c.g, self.conv.wd, x.g)
+        x.gw = True
+
+    def bwd(self):
+        self.bn_bwd()
+        self.conv_bwd()
+
+
+class Bottleneck:
+    """torchvision Bottleneck v1.5 (called from reference network/FCRN.py:320-323)."""
+
+    def __init__(self, eng, x, blk):
+        self.x = x
+        s = blk.conv2.stride[0]
+        self.a = ConvBN(eng, x, eng._conv([blk.conv1.weight]), eng._site([blk.bn1]), 1, 1, 0, True)
+        self.b = ConvBN(eng, self.a.out, eng._conv([blk.conv2.weight]), eng._site([blk.bn2]), 3, s, 1, True)
+        self.ds = None
+        if blk.downsample is not None:
+            self.ds = ConvBN(eng, x, eng._conv([blk.downsample[0].weight]), eng._site([blk.downsample[1]]), 1,
+                             blk.downsample[0].stride[0], 0, False, has_out=False)
+            self.c = ConvBN(eng, self.b.out, eng._conv([blk.conv3.weight]), eng._site([blk.bn3]), 1, 1, 0, True,
+                            res=self.ds.c, res_site=self.ds.site)
+        else:
+            self.c = ConvBN(eng, self.b.out, eng._conv([blk.conv3.weight]), eng._site([blk.bn3]), 1, 1, 0, True, res=x)
+        self.out = self.c.out
+
+    def reset_grad_flags(self):
+        for u in (self.a, self.b, self.c, self.ds):
+            if u is not None:
+                u.reset_grad_flags()
+
+    def fwd(self, train):
+        self.a.fwd(train)
+        self.b.fwd(train)
+        if self.ds is not None:
+            self.ds.conv_fwd(train)          # its BN apply is folded into c's join
+        self.c.fwd(train)
+
+    def bwd(self):
+        c, ds = self.c, self.ds
+        if ds is None:
+            c.bn_bwd(dres_to=self.x)         # identity shortcut: d(x) = masked d(out)
+        else:
+            c.bn_bwd()
+            # second BN site of the join: same masked gradient, statistics of the shortcut conv
+            ds.site.backward(c.out.g, c.out, ds.c, True, ds.c.g)
+            ds.c.gw = True
+            ds.conv_bwd()
+        c.conv_bwd()
+        self.b.bwd()
+        self.a.bwd()
+
+
+class UpProjLayer:
+    """reference network/FCRN.py:170-198 without the zero-stuffed tensor: both 5x5 branches as
+    one 4-phase GEMM into y55 [N][2h][2w][2C]; upper half -> BN -> ReLU -> 3x3 -> BN, joined
+    with BN(lower half) and ReLU."""
+
+    def __init__(self, eng, x, mod):
+        self.eng, self.x = eng, x
+        dev, N, h, w, Cin = eng.dev, x.N, x.H, x.W, x.C
+        C = Cin // 2
+        ub, bb = mod.upper_branch, mod.bottom_branch
+        self.w55 = eng._conv([ub.conv1.weight, bb.conv.weight])
+        self.site55 = eng._site([ub.batchnorm1, bb.batchnorm])
+        self.site_u, self.site_b = self.site55.half(eng, 0), self.site55.half(eng, 1)
+        self.y55 = Act(dev, N, 2 * h, 2 * w, 2 * C)
+        self.y_u, self.y_b = self.y55.slice(0, C), self.y55.slice(C, C)
+        self.a1 = Act(dev, N, 2 * h, 2 * w, C)
+        self.fdescs = ops.upproj_fwd_descs(N, h, w, x.ld, Cin, x.nbytes, 2 * C, 2 * C)
+        self.ddesc = ops.upproj_dgrad_desc(N, h, w, x.ld, Cin, 2 * C, 2 * C, self.y55.nbytes)
+        ks = eng._ksplit(x.M, 2 * C, Cin, 25)
+        self.wdesc = ops.upproj_wgrad_desc(N, h, w, x.ld, Cin, x.nbytes, 2 * C, 2 * C, self.y55.nbytes, ks)
+        self.c2 = ConvBN(eng, self.a1, eng._conv([ub.conv2.weight]), eng._site([ub.batchnorm2]), 3, 1, 1, True,
+                         res=self.y_b, res_site=self.site_b)
+        self.out = self.c2.out
+
+    def reset_grad_flags(self):
+        self.y55.gw = self.a1.gw = False
+        self.c2.reset_grad_flags()
+
+    def fwd(self, train):
+        x, y = self.x, self.y55
+        for d in self.fdescs:
+            ops.conv_gemm(d, x.t, self.w55.wf, y.t, self.site55.part if train else None)
+        self.site55.finalize(y.M, train)
+        su = self.site_u
+        ops.bn_apply(self.y_u.t, y.ld, su.scale, su.shift, self.a1.t, self.a1.ld, y.M, su.C, True)
+        self.c2.fwd(train)
+
+    def bwd(self):
+        x, y, c2 = self.x, self.y55, self.c2
+        yg = y.g
+        C = self.site_u.C
+        c2.bn_bwd()                                                         # d(out) -> d(c2.c)
+        self.site_b.backward(c2.out.g, c2.out, self.y_b, True, yg[..., C:])  # join's second site -> d(y55[:, C:])
+        c2.conv_bwd()                                                       # -> d(a1), dW(conv2)
+        self.site_u.backward(self.a1.g, self.a1, self.y_u, True, yg[..., :C])
+        ops.conv_wgrad(self.wdesc, x.t, yg, self.w55.dw)
+        self.ddesc.accumulate = int(x.gw)
+        ops.conv_gemm(self.ddesc, yg, self.w55.wd, x.g)
+        x.gw = True

@@ -1,0 +1,236 @@
+"""Drop-in for reference network/FCRN.py on MI355X.
+
+Same public surface as the reference file — ``ResNet(dataset, layers, decoder, output_size,
+in_channels, out_channels, pretrained)`` with ``forward``, ``get_1x_lr_params``,
+``get_10x_lr_params``, ``weights_init`` and byte-identical ``state_dict`` keys (397 for
+ResNet-50) — but ``forward``/``backward`` run on hand-written gfx950 HIP
+kernels through libmde_hip.so (mono_depth_estimation_amd/engine.py).  The submodules below
+are parameter containers only: they keep the reference's names so checkpoints load, and have
+no arithmetic of their own (there is no PyTorch fallback path).
+"""
+import collections
+import math
+import os
+import warnings
+
+import torch
+import torch.nn as nn
+
+from ..engine import FCRNEngine, ParamStore
+
+
+def weights_init(m):
+    """reference network/FCRN.py:14-28 — He-normal with fan = kh*kw*Cout; BN -> (1, 0)."""
+    if isinstance(m, nn.Conv2d):
+        n = m.kernel_size[0] * m.kernel_size[1] * m.out_channels
+        m.weight.data.normal_(0, math.sqrt(2. / n))
+        if m.bias is not None:
+            m.bias.data.zero_()
+    elif isinstance(m, nn.ConvTranspose2d):
+        n = m.kernel_size[0] * m.kernel_size[1] * m.in_channels
+        m.weight.data.normal_(0, math.sqrt(2. / n))
+        if m.bias is not None:
+            m.bias.data.zero_()
+    elif isinstance(m, nn.BatchNorm2d):
+        m.weight.data.fill_(1)
+        m.bias.data.zero_()
+
+
+class _Container(nn.Module):
+    """A module that only holds parameters; the HIP engine does the arithmetic."""
+
+    def forward(self, *a, **k):
+        raise RuntimeError("%s is a parameter container of the HIP FCRN path; call the parent "
+                           "mono_depth_estimation_amd.network.FCRN.ResNet instead" % type(self).__name__)
+
+
+class Bottleneck(_Container):
+    """torchvision Bottleneck (v1.5: stride on conv2) — names as torchvision's."""
+    expansion = 4
+
+    def __init__(self, cin, width, stride=1, project=False):
+        super().__init__()
+        cout = width * 4
+        self.conv1 = nn.Conv2d(cin, width, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(width)
+        self.conv2 = nn.Conv2d(width, width, 3, stride=stride, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(width)
+        self.conv3 = nn.Conv2d(width, cout, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(cout)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = None
+        if project:
+            self.downsample = nn.Sequential(nn.Conv2d(cin, cout, 1, stride=stride, bias=False), nn.BatchNorm2d(cout))
+
+
+_BLOCKS = {50: [3, 4, 6, 3], 101: [3, 4, 23, 3], 152: [3, 8, 36, 3]}
+
+
+def _stage(cin, width, n, stride):
+    mods = [Bottleneck(cin, width, stride, project=True)]
+    mods += [Bottleneck(width * 4, width) for _ in range(1, n)]
+    return nn.Sequential(*mods)
+
+
+class Unpool(_Container):
+    """reference FCRN.py:31-44.  Never materialised on the HIP path: the zero insertion is
+    folded into the following 5x5 convs as four output phases (csrc/conv_gemm.hip)."""
+
+    def __init__(self, num_channels, stride=2):
+        super().__init__()
+        self.num_channels, self.stride = num_channels, stride
+
+
+class Decoder(_Container):
+    names = ['deconv2', 'deconv3', 'upconv', 'upproj']
+
+
+class UpProj(Decoder):
+    """reference FCRN.py:167-205."""
+
+    class UpProjModule(_Container):
+        def __init__(self, in_channels):
+            super().__init__()
+            out_channels = in_channels // 2
+            self.unpool = Unpool(in_channels)
+            self.upper_branch = nn.Sequential(collections.OrderedDict([
+                ('conv1', nn.Conv2d(in_channels, out_channels, kernel_size=5, stride=1, padding=2, bias=False)),
+                ('batchnorm1', nn.BatchNorm2d(out_channels)),
+                ('relu', nn.ReLU()),
+                ('conv2', nn.Conv2d(out_channels, out_channels, kernel_size=3, stride=1, padding=1, bias=False)),
+                ('batchnorm2', nn.BatchNorm2d(out_channels)),
+            ]))
+            self.bottom_branch = nn.Sequential(collections.OrderedDict([
+                ('conv', nn.Conv2d(in_channels, out_channels, kernel_size=5, stride=1, padding=2, bias=False)),
+                ('batchnorm', nn.BatchNorm2d(out_channels)),
+            ]))
+            self.relu = nn.ReLU()
+
+    def __init__(self, in_channels):
+        super().__init__()
+        self.layer1 = self.UpProjModule(in_channels)
+        self.layer2 = self.UpProjModule(in_channels // 2)
+        self.layer3 = self.UpProjModule(in_channels // 4)
+        self.layer4 = self.UpProjModule(in_channels // 8)
+
+
+def choose_decoder(decoder, in_channels):
+    """reference FCRN.py:282-294.  Only the reference's default ('upproj', the one
+    modules/laina.py uses) has HIP kernels; the alternatives are SURVEY.md §8f row N4."""
+    if decoder == "upproj":
+        return UpProj(in_channels)
+    if decoder[:6] == 'deconv' or decoder in ("upconv", "fasterupproj"):
+        raise NotImplementedError("decoder '%s' has no HIP path yet (only 'upproj')" % decoder)
+    assert False, "invalid option for decoder: {}".format(decoder)
+
+
+class _FCRNFunction(torch.autograd.Function):
+    """One autograd node for the whole network: forward/backward are the engine's plans.
+    Parameter gradients are accumulated straight into the flat gradient buffer that every
+    Parameter's .grad views, so backward hands autograd no tensors to copy."""
+
+    @staticmethod
+    def forward(ctx, x, engine, train, *params):
+        ctx.engine = engine
+        y = engine.forward(x, train)
+        return y.clone()
+
+    @staticmethod
+    def backward(ctx, dy):
+        eng = ctx.engine
+        eng.attach_grads()
+        eng.backward(dy.contiguous())
+        return (None, None, None) + (None,) * len(eng.params)
+
+
+class ResNet(nn.Module):
+    def __init__(self, dataset='kitti', layers=50, decoder='upproj', output_size=(228, 304), in_channels=3,
+                 out_channels=20, pretrained=True):
+        if layers not in [18, 34, 50, 101, 152]:
+            raise RuntimeError('Only 18, 34, 50, 101, and 152 layer model are defined for ResNet. Got {}'.format(layers))
+        if layers not in _BLOCKS:
+            raise NotImplementedError("HIP FCRN path implements the bottleneck trunks (50/101/152); got %d" % layers)
+        if in_channels != 3:
+            raise NotImplementedError("HIP FCRN stem kernel takes 3-channel images (got in_channels=%d)" % in_channels)
+        super(ResNet, self).__init__()
+        n = _BLOCKS[layers]
+        self.conv1 = nn.Conv2d(3, 64, kernel_size=7, stride=2, padding=3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.output_size = tuple(output_size)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+        self.layer1 = _stage(64, 64, n[0], 1)
+        self.layer2 = _stage(256, 128, n[1], 2)
+        self.layer3 = _stage(512, 256, n[2], 2)
+        self.layer4 = _stage(1024, 512, n[3], 2)
+        # torchvision's default init of the trunk (pretrained=False): He fan-out normal, BN (1, 0)
+        for m in (self.conv1, self.layer1, self.layer2, self.layer3, self.layer4):
+            for mod in m.modules():
+                if isinstance(mod, nn.Conv2d):
+                    nn.init.kaiming_normal_(mod.weight, mode='fan_out', nonlinearity='relu')
+        num_channels = 2048
+        self.conv2 = nn.Conv2d(num_channels, num_channels // 2, kernel_size=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(num_channels // 2)
+        self.upSample = choose_decoder(decoder, num_channels // 2)
+        self.conv3 = nn.Conv2d(num_channels // 32, out_channels, kernel_size=3, stride=1, padding=1, bias=False)
+        self.bilinear = nn.Upsample(size=self.output_size, mode='bilinear', align_corners=True)
+        self.conv2.apply(weights_init)
+        self.bn2.apply(weights_init)
+        self.upSample.apply(weights_init)
+        self.conv3.apply(weights_init)
+        if pretrained:
+            self._load_pretrained_trunk(layers)
+        self._engines = {}
+        self._store = None
+
+    def _load_pretrained_trunk(self, layers):
+        """The reference downloads torchvision ImageNet weights (FCRN.py:305); there is no
+        network here, so they are read from $MDE_PRETRAINED_RESNET (a torchvision resnetNN
+        state_dict file) when set."""
+        path = os.environ.get("MDE_PRETRAINED_RESNET")
+        if not path:
+            warnings.warn("pretrained=True but $MDE_PRETRAINED_RESNET is not set: the ResNet-%d trunk keeps its "
+                          "random initialisation (the reference would download torchvision weights)" % layers)
+            return
+        sd = torch.load(path, map_location="cpu")
+        own = self.state_dict()
+        own.update({k: v for k, v in sd.items() if k in own and not k.startswith("fc.")})
+        self.load_state_dict(own)
+
+    def _engine(self, x):
+        if x.dim() != 4 or x.shape[1] != 3:
+            raise ValueError("expected an N x 3 x H x W image batch, got %s" % (tuple(x.shape),))
+        if not x.is_cuda:
+            raise RuntimeError("mono_depth_estimation_amd FCRN runs on MI355X only (input is on %s); there is no "
+                               "CPU fallback" % x.device)
+        st = self._store
+        if st is None or st.dev != x.device or not st.storage_is_current():
+            # first use, or the parameters were moved / replaced: (re)build the flat stores
+            self._store = st = ParamStore(self, x.device)
+            self._engines.clear()
+        key = tuple(x.shape)
+        eng = self._engines.get(key)
+        if eng is None:
+            eng = self._engines[key] = FCRNEngine(self, st, x.shape[0], x.shape[2], x.shape[3])
+        return eng
+
+    def forward(self, x):
+        eng = self._engine(x)
+        x = x.contiguous().float()
+        return _FCRNFunction.apply(x, eng, self.training, *eng.params)
+
+    def get_1x_lr_params(self):
+        """Encoder parameters (reference FCRN.py:373-381)."""
+        b = [self.conv1, self.bn1, self.relu, self.maxpool, self.layer1, self.layer2, self.layer3, self.layer4]
+        for i in range(len(b)):
+            for k in b[i].parameters():
+                if k.requires_grad:
+                    yield k
+
+    def get_10x_lr_params(self):
+        """conv2/bn2/decoder/conv3 parameters (reference FCRN.py:383-391)."""
+        b = [self.conv2, self.bn2, self.upSample, self.conv3, self.bilinear]
+        for j in range(len(b)):
+            for k in b[j].parameters():
+                if k.requires_grad:
+                    yield k

@@ -87,3 +87,26 @@ def calibrate_running_stats(model, x):
         model(x)
     for m, o in zip(bns, old):
         m.momentum = o
+
+
+def fcrn_conditioned_state(model, seed):
+    """A WELL-CONDITIONED deterministic state for end-to-end precision parity: the last BN of
+    every residual branch has gamma x0.05 (the "zero-init residual" regime) and the decoder's
+    joining BNs gamma x0.3.  With plain He-init (fcrn_fixture_state) the 50-layer net amplifies
+    a 1e-6 relative weight perturbation ~700x at the output, so bf16 rounding alone moves the
+    fp32 reference's own AbsRel by ~8e-3; here activation rounding moves it by ~3e-5.
+    Conv weights are made exactly bf16-representable: "identical weights" for a bf16 MFMA path
+    and the fp32 reference alike (bf16 *weight* quantisation alone shifts the fp32 oracle's
+    AbsRel by 0.5-2e-4 on this net, which is the bound itself; DESIGN.md, parity)."""
+    sd = fill_state_dict(model, seed)
+    for k in sd:
+        if sd[k].ndim == 4:
+            sd[k] = sd[k].to(torch.bfloat16).to(torch.float32)
+    for k in sd:
+        if k.endswith("bn3.weight"):
+            sd[k] = sd[k] * 0.05
+        elif "upper_branch.batchnorm2.weight" in k or "bottom_branch.batchnorm.weight" in k:
+            sd[k] = sd[k] * 0.3
+    sd["conv3.weight"] = (sd["conv3.weight"] * 0.05).to(torch.bfloat16).to(torch.float32)
+    model.load_state_dict(sd)
+    return sd

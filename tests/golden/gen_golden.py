@@ -188,6 +188,33 @@ def gen_fcrn(criteria, metrics, FCRN):
           "keys", int(out["n_state_keys"]), "params", int(out["n_params"]))
 
 
+def gen_fcrn_conditioned(criteria, metrics, FCRN):
+    """G5b: the same reference network on the well-conditioned state (oracle/weights.py:
+    fcrn_conditioned_state) — the fixture on which the 1e-4 AbsRel bound is asserted."""
+    size = (96, 128)
+    ref = FCRN.ResNet(layers=50, decoder="upproj", output_size=size, in_channels=3,
+                      out_channels=1, pretrained=False)
+    W.fcrn_conditioned_state(ref, 7)
+    rgb, tgt = W.synthetic_batch(7, 2, *size)
+    W.calibrate_running_stats(ref, rgb)
+    out = {}
+    ref.eval()
+    with torch.no_grad():
+        y = ref(rgb)
+    out["eval_out"] = _np(y)
+    out["eval_silog"] = _np(criteria.silog_loss(0.85)(y, tgt))
+    mc = metrics.MetricComputation(["absrel", "rmse", "delta1", "delta2", "delta3", "log10"])
+    for n, v in zip(mc.names, mc.compute(y, tgt)):
+        out["eval_" + n] = _np(v)
+    ref.train()
+    y = ref(rgb)
+    loss = criteria.silog_loss(0.85)(y, tgt)
+    out["train_out"], out["train_silog"] = _np(y), _np(loss)
+    np.savez_compressed(os.path.join(HERE, "fcrn50_cond.npz"), **out)
+    print("fcrn50_cond.npz eval_absrel", float(out["eval_absrel"]), "eval_silog", float(out["eval_silog"]),
+          "range", float(out["eval_out"].min()), float(out["eval_out"].max()))
+
+
 def main():
     torch.set_num_threads(8)
     criteria, metrics, FCRN = _import_reference()
@@ -195,6 +222,7 @@ def main():
     gen_metrics(metrics)
     gen_upproj(FCRN)
     gen_fcrn(criteria, metrics, FCRN)
+    gen_fcrn_conditioned(criteria, metrics, FCRN)
 
 
 if __name__ == "__main__":

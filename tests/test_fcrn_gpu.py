@@ -1,0 +1,268 @@
+"""End-to-end GPU parity of the HIP FCRN path (mono_depth_estimation_amd.network.FCRN.ResNet)
+against (a) the REFERENCE's own outputs (tests/golden/fcrn50.npz, minted from
+/root/reference/network/FCRN.py) and (b) the CPU oracle.
+
+Tolerances (bf16 tensor-core path vs fp32 reference), stated per check:
+  * eval mode, well-conditioned state: |dAbsRel| <= 1e-4 (the north-star bound), 'rmse' and log10
+    <= 1e-4, deltas <= 2e-3, output max |diff| <= 2e-2, SILog within 0.2 % — vs the reference's values.
+  * eval mode, He-init state: deviation <= 1.5x what bf16 rounding does to the fp32 oracle itself
+    (that net amplifies perturbations ~700x; see test docstring and DESIGN.md).
+  * train-mode SILog: within 1 % (He-init) / 0.2 % (conditioned) of the reference's value.
+  * layer-isolated (teacher-forced) checks against an oracle that rounds to bf16 where the
+    HIP path does: forward relL2 <= 1e-2; input/weight gradients relL2 <= 1e-1 on ReLU blocks
+    (ReLU-mask flips of near-zero activations between two slightly different forwards give
+    sqrt(flip rate) ~ 5 %), <= 1e-2 on the ReLU-free conv2/bn2 layer.
+Free-running deep comparisons in train mode are NOT asserted at this tiny size (2 x 96 x 128:
+layer4 sees 24 samples per channel, and batch-statistics BN amplifies rounding ~200x).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import fcrn as ofcrn
+from oracle import losses as OL
+from oracle import weights as W
+
+pytestmark = pytest.mark.gpu
+
+SIZE = (96, 128)
+
+
+def _rel(a, b):
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def _nchw(t):
+    return t.float().cpu().permute(0, 3, 1, 2)
+
+
+@pytest.fixture(scope="module")
+def setup():
+    from mono_depth_estimation_amd.network import FCRN
+    ora = ofcrn.FCRNOracle(50, SIZE, out_channels=1)
+    sd = W.fcrn_fixture_state(ora, 5)
+    rgb, tgt = W.synthetic_batch(5, 2, *SIZE)
+    hip = FCRN.ResNet(layers=50, output_size=SIZE, out_channels=1, pretrained=False)
+    hip.load_state_dict(sd)
+    hip = hip.cuda()
+    # running statistics calibrated exactly as the golden generator did, by the fp32 oracle
+    # (a train-mode pass; doing it on the bf16 path would fold tiny-batch BN chaos into eval)
+    W.calibrate_running_stats(ora, rgb)
+    cal = {k: v.clone() for k, v in ora.state_dict().items()}
+    ora.load_state_dict(sd)
+    return hip, ora, sd, rgb, tgt, cal
+
+
+def test_state_dict_surface(setup, golden):
+    hip, ora = setup[0], setup[1]
+    g = golden("fcrn50")
+    assert len(hip.state_dict()) == int(g["n_state_keys"]) == 397
+    assert list(hip.state_dict().keys()) == list(ora.state_dict().keys())
+    assert [k for k, _ in hip.named_parameters()] == list(g["grad_names"])
+    assert sum(p.numel() for p in hip.get_1x_lr_params()) + sum(p.numel() for p in hip.get_10x_lr_params()) == int(g["n_params"])
+
+
+def test_eval_absrel_parity_conditioned(golden):
+    """NORTH-STAR BOUND: |AbsRel_hip - AbsRel_reference| <= 1e-4 on identical weights/inputs,
+    asserted on the well-conditioned state (oracle/weights.py:fcrn_conditioned_state) against
+    the reference's own eval output (tests/golden/fcrn50_cond.npz)."""
+    from mono_depth_estimation_amd import criteria, metrics
+    from mono_depth_estimation_amd.network import FCRN
+    g = golden("fcrn50_cond")
+    ora = ofcrn.FCRNOracle(50, SIZE, out_channels=1)
+    W.fcrn_conditioned_state(ora, 7)
+    rgb, tgt = W.synthetic_batch(7, 2, *SIZE)
+    W.calibrate_running_stats(ora, rgb)        # running stats as the golden generator made them
+    hip = FCRN.ResNet(layers=50, output_size=SIZE, out_channels=1, pretrained=False)
+    hip.load_state_dict(ora.state_dict())
+    hip = hip.cuda().eval()
+    x, t = rgb.cuda(), tgt.cuda()
+    with torch.no_grad():
+        y = hip(x)
+    ref = torch.from_numpy(g["eval_out"])
+    diff = (y.cpu() - ref).abs()
+    mc = metrics.MetricComputation(list(metrics.NAMES))
+    vals = {k: float(v) for k, v in zip(mc.names, mc.compute(y, t))}
+    print("conditioned eval: max|diff| %.3e mean %.3e; " % (diff.max(), diff.mean()) +
+          ", ".join("d%s %.2e" % (k, vals[k] - float(g["eval_" + k])) for k in mc.names))
+    assert diff.max() <= 2e-2 and diff.mean() <= 3e-3
+    assert abs(vals["absrel"] - float(g["eval_absrel"])) <= 1e-4
+    assert abs(vals["rmse"] - float(g["eval_rmse"])) <= 1e-4
+    assert abs(vals["log10"] - float(g["eval_log10"])) <= 1e-4
+    for k in ("delta1", "delta2", "delta3"):
+        assert abs(vals[k] - float(g["eval_" + k])) <= 2e-3
+    loss = float(criteria.silog_loss(0.85)(y, t))
+    assert abs(loss - float(g["eval_silog"])) <= 2e-3 * float(g["eval_silog"])
+    # train mode on the same state: loss within 0.2 % of the reference's
+    hip.train()
+    lt = float(criteria.silog_loss(0.85)(hip(x), t))
+    print("conditioned train silog hip %.5f reference %.5f" % (lt, float(g["train_silog"])))
+    assert abs(lt - float(g["train_silog"])) <= 2e-3 * float(g["train_silog"])
+
+
+def _bf16_rounded_oracle_eval(state, rgb):
+    """The fp32 CPU oracle with weights and activations rounded to bf16 where the HIP path rounds."""
+    o = ofcrn.FCRNOracle(50, SIZE, out_channels=1)
+    o.load_state_dict(state)
+    _emulate_bf16(o)
+    o.eval()
+    with torch.no_grad():
+        return o(rgb)
+
+
+def test_eval_he_init_within_bf16_rounding_noise(setup, golden):
+    """He-init fixture (tests/golden/fcrn50.npz).  This 50-layer random net amplifies a 1e-6
+    relative weight perturbation ~700x, so the fp32 reference ITSELF moves by mean ~5e-2 when
+    its weights/activations are merely rounded to bf16 on the CPU.  Assert the HIP path
+    deviates from the reference no more than 1.5x what that rounding does to the oracle."""
+    from mono_depth_estimation_amd import metrics
+    hip, _, sd, rgb, tgt, cal = setup
+    g = golden("fcrn50")
+    hip.load_state_dict(cal)
+    hip.eval()
+    with torch.no_grad():
+        y = hip(rgb.cuda())
+    ref = torch.from_numpy(g["eval_out"])
+    noise = (_bf16_rounded_oracle_eval(cal, rgb) - ref).abs()
+    diff = (y.cpu() - ref).abs()
+    mc = metrics.MetricComputation(["absrel", "rmse", "delta1"])
+    vals = [float(v) for v in mc.compute(y, tgt.cuda())]
+    print("He-init eval: hip mean|diff| %.3e max %.3e | bf16-rounded oracle mean %.3e max %.3e | dAbsRel %.2e" % (
+        diff.mean(), diff.max(), noise.mean(), noise.max(), vals[0] - float(g["eval_absrel"])))
+    assert diff.mean() <= 1.5 * noise.mean() and diff.max() <= 1.5 * noise.max()
+    assert abs(vals[0] - float(g["eval_absrel"])) <= 3e-2
+
+
+def test_train_loss_and_running_stats(setup, golden):
+    from mono_depth_estimation_amd import criteria
+    hip, ora, sd, rgb, tgt, cal = setup
+    g = golden("fcrn50")
+    hip.load_state_dict(cal)
+    hip.train()
+    y = hip(rgb.cuda())
+    loss = criteria.silog_loss(0.85)(y, tgt.cuda())
+    loss.backward()
+    print("train silog hip %.5f reference %.5f" % (float(loss), float(g["train_silog"])))
+    assert abs(float(loss) - float(g["train_silog"])) <= 1e-2 * float(g["train_silog"])
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in hip.parameters())
+    # first BN sees only the (fp32) stem conv: running stats after one step match tightly
+    assert torch.allclose(hip.bn1.running_mean.cpu(), torch.from_numpy(g["after_bn1_running_mean"]), rtol=1e-3, atol=1e-5)
+    assert torch.allclose(hip.bn1.running_var.cpu(), torch.from_numpy(g["after_bn1_running_var"]), rtol=1e-3, atol=1e-6)
+    assert int(hip.bn1.num_batches_tracked) == int(cal["bn1.num_batches_tracked"]) + 1
+    assert int(hip.layer4[2].bn3.num_batches_tracked) == int(cal["layer4.2.bn3.num_batches_tracked"]) + 1
+
+
+def _emulate_bf16(ora):
+    rnd = lambda mod, inp, out: out.to(torch.bfloat16).float()
+    for name, mod in ora.named_modules():
+        if isinstance(mod, torch.nn.Conv2d):
+            if name not in ("conv1", "conv3"):
+                mod.weight.data = mod.weight.data.to(torch.bfloat16).float()
+            if name != "conv3":
+                mod.register_forward_hook(rnd)
+        elif isinstance(mod, (torch.nn.ReLU, ofcrn.UpProjModule)) or name == "bn2":
+            mod.register_forward_hook(rnd)
+
+
+def test_layers_teacher_forced(setup):
+    """Every engine layer, fed the oracle's input activation / output gradient."""
+    hip, _, sd, rgb, tgt, _ = setup
+    ora = ofcrn.FCRNOracle(50, SIZE, out_channels=1)
+    ora.load_state_dict(sd)
+    hip.load_state_dict(sd)
+    _emulate_bf16(ora)
+    ora.train()
+    hip.train()
+    names = ["layer%d.%d" % (li, bi) for li in (1, 2, 3, 4) for bi in range(len(getattr(ora, "layer%d" % li)))]
+    names += ["bn2", "up1", "up2", "up3", "up4"]
+    mods = {n: dict(ora.named_modules())[n] for n in names if n.startswith("layer")}
+    mods["bn2"] = None
+    for i in (1, 2, 3, 4):
+        mods["up%d" % i] = getattr(ora.upSample, "layer%d" % i)
+    ins, outs = {}, {}
+
+    def pre(n):
+        return lambda mod, inp: ins.__setitem__(n, inp[0])
+
+    def post(n):
+        def f(mod, inp, out):
+            out.retain_grad()
+            outs[n] = out
+        return f
+    for n in names:
+        if n == "bn2":
+            ora.conv2.register_forward_pre_hook(pre(n))
+            ora.bn2.register_forward_hook(post(n))
+        else:
+            mods[n].register_forward_pre_hook(pre(n))
+            mods[n].register_forward_hook(post(n))
+    y = ora(rgb)
+    for t in ins.values():
+        t.retain_grad()
+    OL.silog(y, tgt).backward()
+    with torch.no_grad():
+        hip(rgb.cuda())
+    eng = next(iter(hip._engines.values()))
+    hp = dict(hip.named_parameters())
+    dev = lambda t: t.detach().permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).cuda()
+    report = []
+    for n, L in zip(names, eng.layers):
+        L.x.t.copy_(dev(ins[n]))
+        L.fwd(True)
+        e_f = _rel(_nchw(L.out.t), outs[n].detach())
+        eng.store.G.zero_()
+        L.reset_grad_flags()
+        L.x.gw = False
+        L.out.g.copy_(dev(outs[n].grad))
+        L.bwd()
+        e_b = _rel(_nchw(L.x.g), ins[n].grad)
+        prefix = ("conv2.", "bn2.") if n == "bn2" else ((n + ".",) if n.startswith("layer") else ("upSample.layer%s." % n[2:],))
+        e_w = max(_rel(hp[k]._mde_grad.cpu(), q.grad) for k, q in ora.named_parameters() if k.startswith(prefix))
+        report.append((n, e_f, e_b, e_w))
+    torch.cuda.synchronize()
+    for r in report:
+        print("%-10s fwd %.3e  dx %.3e  dW %.3e" % r)
+    for n, e_f, e_b, e_w in report:
+        lim = 1e-2 if n == "bn2" else 1e-1
+        assert e_f <= 1e-2 and e_b <= lim and e_w <= lim, (n, e_f, e_b, e_w)
+
+
+def test_fused_adam_training_reduces_loss(setup):
+    """Three steps of the engine's own train path (forward, SILog, backward, fused Adam)."""
+    from mono_depth_estimation_amd import criteria
+    hip, _, sd, rgb, tgt, _ = setup
+    hip.load_state_dict(sd)
+    hip.train()
+    x, t = rgb.cuda(), tgt.cuda()
+    crit = criteria.silog_loss(0.85)
+    losses = []
+    for _ in range(4):
+        hip.zero_grad(set_to_none=True)
+        loss = crit(hip(x), t)
+        loss.backward()
+        losses.append(float(loss))
+        hip._store.adam_step(1e-4, 1e-3)
+    print("losses", losses)
+    assert np.isfinite(losses).all() and losses[-1] < losses[0]
+
+
+def test_torch_optimizer_drop_in(setup):
+    """torch.optim.Adam with the reference's two parameter groups (laina.py:51-57) trains the
+    HIP module: Parameters stay leaf tensors whose .grad the engine fills in place."""
+    from mono_depth_estimation_amd import criteria
+    hip, _, sd, rgb, tgt, _ = setup
+    hip.load_state_dict(sd)
+    hip.train()
+    opt = torch.optim.Adam([{"params": hip.get_1x_lr_params(), "lr": 1e-4},
+                            {"params": hip.get_10x_lr_params(), "lr": 1e-3}], lr=1e-4)
+    x, t = rgb.cuda(), tgt.cuda()
+    crit = criteria.silog_loss(0.85)
+    losses = []
+    for _ in range(3):
+        opt.zero_grad()
+        loss = crit(hip(x), t)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    print("losses", losses)
+    assert np.isfinite(losses).all() and losses[-1] < losses[0]

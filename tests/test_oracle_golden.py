@@ -146,3 +146,19 @@ def test_fcrn50_train_fwd_bwd(golden, fcrn_oracle):
     assert np.allclose(gn, g["grad_norm"], rtol=2e-3, atol=1e-6), np.abs(gn / g["grad_norm"] - 1).max()
     _close(net.conv3.weight.grad, g["grad_conv3"], rtol=1e-3, atol=1e-5)
     _close(net.conv1.weight.grad[:8], g["grad_conv1_slice"], rtol=2e-3, atol=1e-3)
+
+
+def test_fcrn50_conditioned_eval(golden):
+    """The well-conditioned fixture (the one the 1e-4 AbsRel bound is asserted on)."""
+    g = golden("fcrn50_cond")
+    net = ofcrn.FCRNOracle(layers=50, output_size=(96, 128), out_channels=1)
+    W.fcrn_conditioned_state(net, 7)
+    rgb, tgt = W.synthetic_batch(7, 2, 96, 128)
+    W.calibrate_running_stats(net, rgb)
+    net.eval()
+    with torch.no_grad():
+        y = net(rgb)
+    _close(y, g["eval_out"], rtol=1e-4, atol=2e-5)
+    got = M.compute(y, tgt)
+    for k in M.NAMES:
+        _close(got[k], g["eval_" + k], rtol=1e-4)
