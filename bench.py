@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""Headline benchmark: training images/sec, FCRN ResNet-50 (UpProj) 640x480 bf16 on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+One step = forward + SILog + backward + gradient all-reduce (N > 1) + Adam on one batch of
+synthetic 32 x 3 x 480 x 640 images per GPU (weak scaling), inputs resident in HBM.
+Rank 0 prints ONE JSON line with the throughput, the roofline of the dominant kernel
+(the MFMA implicit-GEMM convolution, timed per launch with HIP events on its own stream
+during the timed steps) and the CPU-oracle baseline timed on the host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+H, W, BATCH = 480, 640, 32
+PEAK_BF16_TFLOPS = 2500.0                 # dense MFMA bf16 (MI355X_MICROARCH.md)
+ALGO_GFLOP_PER_IMAGE = 410.9              # useful conv MACs x 2 x 3 (fwd+dgrad+wgrad)
+
+
+def synthetic(n, seed, device):
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    rgb = torch.rand(n, 3, H, W, generator=g, device=device)
+    depth = 0.05 + 0.95 * torch.rand(n, 1, H, W, generator=g, device=device)
+    hole = torch.rand(n, 1, H, W, generator=g, device=device) < 0.10
+    return rgb, depth.masked_fill(hole, 0.0)
+
+
+def host_cores():
+    """Cores this process may actually use: affinity mask capped by the cgroup CPU quota
+    (the GPU box shows 256 CPUs but grants a 16-core share)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def cpu_baseline(threads):
+    """The CPU oracle (a port of the reference's fp32 torch.nn path, pinned to the reference by
+    tests/golden) on the host cores: FCRN-50 480x640, batch 2, 1 warm-up + 2 timed steps of
+    forward + SILog + backward + Adam."""
+    from oracle import fcrn as ofcrn
+    from oracle import losses as OL
+    torch.set_num_threads(threads)
+    torch.manual_seed(0)
+    net = ofcrn.FCRNOracle(50, (H, W), out_channels=1)
+    net.conv3.weight.data.mul_(0.05)
+    opt = torch.optim.Adam([{"params": net.get_1x_lr_params(), "lr": 1e-4},
+                            {"params": net.get_10x_lr_params(), "lr": 1e-3}], lr=1e-4)
+    n = 2
+    rgb, tgt = synthetic(n, 1234, "cpu")
+    times = []
+    for i in range(3):
+        t0 = time.perf_counter()
+        opt.zero_grad()
+        loss = OL.silog(net(rgb), tgt)
+        loss.backward()
+        opt.step()
+        if i:
+            times.append(time.perf_counter() - t0)
+    return {"value": round(n / (sum(times) / len(times)), 4), "unit": "images/sec", "cores": threads, "kind": "port",
+            "sample": "oracle FCRN-50 fp32 480x640, batch %d, 1 warm-up + %d timed train steps (fwd+SILog+bwd+Adam)" % (n, len(times))}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=BATCH, help="images per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-launch-timing", action="store_true")
+    args = ap.parse_args()
+
+    t_start = time.perf_counter()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from mono_depth_estimation_amd import dp, ops
+    from mono_depth_estimation_amd.network import FCRN
+
+    torch.manual_seed(0)                                  # identical initial weights on every rank
+    net = FCRN.ResNet(layers=50, decoder="upproj", output_size=(H, W), out_channels=1, pretrained=False)
+    net.conv3.weight.data.mul_(0.05)                      # keep the sigmoid unsaturated at init (see tests/golden)
+    net = net.to(dev).train()
+    x, tgt = synthetic(args.batch, 1234 + rank, dev)
+    eng = net._engine(x)
+    store = net._store
+    if world > 1:
+        dist.broadcast(store.P, 0)
+        dist.broadcast(store.B, 0)
+    reducer = dp.FlatGradReducer(store.G, eng.grad_boundaries(), target_bytes=64 << 20)
+    ws, loss = ops.silog_ws(dev), torch.empty(1, device=dev)
+    dy = torch.empty(args.batch, 1, H, W, device=dev)
+    lr = 1e-4
+
+    def step():
+        y = eng.forward(x, True)
+        ops.silog_fwd(y, tgt, 0.85, ws, loss)
+        ops.silog_bwd(y, tgt, 0.85, ws, None, dy)
+        store.G.zero_()
+        eng.backward(dy, reducer.ready)
+        reducer.finish()
+        store.adam_step(lr, 10 * lr, grad_scale=1.0 / world)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def log(msg):
+        if rank == 0:
+            print("[bench %.1fs] %s" % (time.perf_counter() - t_start, msg), file=sys.stderr, flush=True)
+
+    log("plan built, starting warm-up")
+    for i in range(args.warmup):
+        step()
+        torch.cuda.synchronize()
+        log("warm-up step %d done" % i)
+    fence()
+    timer = None if args.no_launch_timing else ops.LaunchTimer()
+    ops.TIMER = timer
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    ops.TIMER = None
+    tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = float(tt)
+    final_loss = float(loss)
+    log("timed region done: %.1f ms/step" % (1e3 * dt / args.steps))
+
+    if rank == 0:
+        ips = args.batch * world * args.steps / dt
+        out = {
+            "metric": "training images/sec, FCRN 640x480 bf16", "value": round(ips, 2), "unit": "images/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "FCRN ResNet-50 + UpProj (reference network/FCRN.py), %dx3x480x640 per GPU -> 1x480x640 "
+                                   "depth, train step = fwd + SILog(0.85) + bwd + Adam(lr, 10*lr)%s" % (
+                                       args.batch, " + flat-gradient all-reduce (RCCL)" if world > 1 else ""),
+                       "global_batch": args.batch * world, "per_gpu_batch": args.batch, "parallelism": "dp%d" % world,
+                       "final_loss": round(final_loss, 5)},
+            "step_mfma_frac": round(ips * ALGO_GFLOP_PER_IMAGE / 1e3 / (world * PEAK_BF16_TFLOPS), 4),
+        }
+        if timer is not None:
+            summ = timer.summary()
+            n, fl, sec = summ.get("conv_gemm_nt", (0, 0.0, 1.0))
+            ach = fl / sec / 1e12 if n else 0.0
+            out["roofline"] = {
+                "bound": "mfma", "kernel": "conv_gemm_nt (implicit-GEMM conv fwd/dgrad/up-projection, bf16 MFMA)",
+                "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
+                "traffic": None, "launches": n, "avg_launch_us": round(1e6 * sec / max(n, 1), 2),
+                "avg_launch_gflop": round(fl / max(n, 1) / 1e9, 3),
+                "share_of_step_time": round(sec / dt, 4),
+            }
+            if "conv_wgrad_tn" in summ:
+                n2, fl2, sec2 = summ["conv_wgrad_tn"]
+                out["roofline"]["wgrad_kernel"] = {"achieved": round(fl2 / sec2 / 1e12, 2), "launches": n2,
+                                                   "avg_launch_us": round(1e6 * sec2 / n2, 2), "share_of_step_time": round(sec2 / dt, 4)}
+        if world == 1 and not args.no_cpu_baseline:
+            log("timing the CPU oracle baseline on %d host cores" % host_cores())
+            out["cpu_baseline"] = cpu_baseline(host_cores())
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

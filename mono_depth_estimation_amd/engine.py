@@ -332,6 +332,7 @@ class FCRNEngine:
             self.layers.append(L)
             x = L.out
         L = ConvBN(self, x, self._conv([m.conv2.weight]), self._site([m.bn2]), 1, 1, 0, relu=False)
+        L.conv_weight0 = m.conv2.weight
         self.layers.append(L)
         x = L.out
         for name in ("layer1", "layer2", "layer3", "layer4"):
@@ -366,8 +367,18 @@ class FCRNEngine:
             self.store.nbt += 1
         return self.y
 
-    def backward(self, dy):
-        """dy: fp32 NCHW gradient w.r.t. the output.  Adds parameter gradients into self.G."""
+    def grad_boundaries(self):
+        """Flat-gradient offsets at which each plan layer's parameters start (forward order)."""
+        offs = [self.store.p_off[id(self.m.conv1.weight)]]
+        for L in self.layers:
+            offs.append(L.first_param_offset())
+        offs.append(self.store.p_off[id(self.m.conv3.weight)])
+        return sorted(offs)
+
+    def backward(self, dy, on_progress=None):
+        """dy: fp32 NCHW gradient w.r.t. the output.  Adds parameter gradients into self.G.
+        on_progress(offset), if given, is called whenever every gradient element >= offset of
+        the flat buffer is final (backward walks the forward-ordered buffer from its tail)."""
         assert dy.shape == self.y.shape and dy.dtype == torch.float32 and dy.is_contiguous()
         f = self.feat
         for L in self.layers:
@@ -378,10 +389,14 @@ class FCRNEngine:
         f.gw = True
         for L in reversed(self.layers):
             L.bwd()
+            if on_progress is not None:
+                on_progress(L.first_param_offset())
         ops.maxpool_bwd(self.pool.g, self.pool_idx, self.stem_a.g, self.N, self.stem_a.H, self.stem_a.W, 64)
         s = self.stem_site
         s.backward(self.stem_a.g, self.stem_a, self.stem_c, True, self.stem_c.g)
         ops.stem_conv_wgrad(self.x, self.stem_c.g, self.stem_w.dw)
+        if on_progress is not None:
+            on_progress(0)
 
 
 class ConvBN:
@@ -389,6 +404,7 @@ class ConvBN:
 
     def __init__(self, eng, x, conv, site, k, stride, pad, relu, res=None, res_site=None, has_out=True):
         self.eng, self.x, self.conv, self.site = eng, x, conv, site
+        self.conv_weight0 = None      # set by the owner (first Parameter of this unit)
         self.k, self.stride, self.pad, self.relu, self.res, self.res_site = k, stride, pad, relu, res, res_site
         Cout, dev = conv.O, eng.dev
         OH, OW = ops.out_size(x.H, k, stride, pad), ops.out_size(x.W, k, stride, pad)
@@ -399,6 +415,9 @@ class ConvBN:
         ks = eng._ksplit(self.c.M, Cout, x.C, k * k)
         self.wdesc = ops.conv_wgrad_desc(x.N, x.H, x.W, x.ld, x.C, x.nbytes, OH, OW, Cout, Cout, self.c.nbytes, k,
                                          stride, pad, ks)
+
+    def first_param_offset(self):
+        return self.eng.store.p_off[id(self.conv_weight0)]
 
     def reset_grad_flags(self):
         self.c.gw = False
@@ -451,7 +470,7 @@ class Bottleneck:
     """torchvision Bottleneck v1.5 (called from reference network/FCRN.py:320-323)."""
 
     def __init__(self, eng, x, blk):
-        self.x = x
+        self.x, self.eng, self.blk = x, eng, blk
         s = blk.conv2.stride[0]
         self.a = ConvBN(eng, x, eng._conv([blk.conv1.weight]), eng._site([blk.bn1]), 1, 1, 0, True)
         self.b = ConvBN(eng, self.a.out, eng._conv([blk.conv2.weight]), eng._site([blk.bn2]), 3, s, 1, True)
@@ -464,6 +483,9 @@ class Bottleneck:
         else:
             self.c = ConvBN(eng, self.b.out, eng._conv([blk.conv3.weight]), eng._site([blk.bn3]), 1, 1, 0, True, res=x)
         self.out = self.c.out
+
+    def first_param_offset(self):
+        return self.eng.store.p_off[id(self.blk.conv1.weight)]
 
     def reset_grad_flags(self):
         for u in (self.a, self.b, self.c, self.ds):
@@ -498,7 +520,7 @@ class UpProjLayer:
     with BN(lower half) and ReLU."""
 
     def __init__(self, eng, x, mod):
-        self.eng, self.x = eng, x
+        self.eng, self.x, self.mod = eng, x, mod
         dev, N, h, w, Cin = eng.dev, x.N, x.H, x.W, x.C
         C = Cin // 2
         ub, bb = mod.upper_branch, mod.bottom_branch
@@ -515,6 +537,9 @@ class UpProjLayer:
         self.c2 = ConvBN(eng, self.a1, eng._conv([ub.conv2.weight]), eng._site([ub.batchnorm2]), 3, 1, 1, True,
                          res=self.y_b, res_site=self.site_b)
         self.out = self.c2.out
+
+    def first_param_offset(self):
+        return self.eng.store.p_off[id(self.mod.upper_branch.conv1.weight)]
 
     def reset_grad_flags(self):
         self.y55.gw = self.a1.gw = False

@@ -99,8 +99,43 @@ def upproj_dgrad_desc(N, h, w, ld_dx, Cin, ld_dy, Cdy, dy_bytes, accumulate=Fals
                      accumulate=accumulate)
 
 
+class LaunchTimer:
+    """Optional per-launch HIP-event timing of the GEMM kernels (bench.py's roofline leg).
+    Events are recorded on the stream the kernels run on (torch's current stream)."""
+
+    def __init__(self):
+        self.records = []          # (kind, flops, start_event, end_event)
+
+    def summary(self):
+        """kind -> (launches, total flops, total seconds); call after a device synchronize."""
+        out = {}
+        for kind, flops, e0, e1 in self.records:
+            n, f, t = out.get(kind, (0, 0.0, 0.0))
+            out[kind] = (n + 1, f + flops, t + e0.elapsed_time(e1) * 1e-3)
+        return out
+
+
+TIMER = None   # set to a LaunchTimer to time every conv_gemm / conv_wgrad launch
+
+
+def _timed(kind, flops, fn):
+    if TIMER is None:
+        return fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    fn()
+    e1.record()
+    TIMER.records.append((kind, flops, e0, e1))
+
+
 def conv_gemm(desc, x, w, out, stats=None):
-    check(_lib.load().mde_conv_gemm(C.byref(desc), _p(x), _p(w), _p(out), _p(stats), _stream()), "mde_conv_gemm")
+    lib = _lib.load()
+    if TIMER is None:
+        check(lib.mde_conv_gemm(C.byref(desc), _p(x), _p(w), _p(out), _p(stats), _stream()), "mde_conv_gemm")
+        return
+    flops = 2.0 * desc.N * desc.GH * desc.GW * desc.ncols * desc.ntaps * desc.C
+    _timed("conv_gemm_nt", flops, lambda: check(
+        lib.mde_conv_gemm(C.byref(desc), _p(x), _p(w), _p(out), _p(stats), _stream()), "mde_conv_gemm"))
 
 
 def stat_slots():
@@ -139,7 +174,13 @@ def upproj_wgrad_desc(N, h, w, ld_x, Cin, x_bytes, ld_dy, Cdy, dy_bytes, ksplit)
 
 
 def conv_wgrad(desc, direct, gathered, dw):
-    check(_lib.load().mde_conv_wgrad(C.byref(desc), _p(direct), _p(gathered), _p(dw), _stream()), "mde_conv_wgrad")
+    lib = _lib.load()
+    if TIMER is None:
+        check(lib.mde_conv_wgrad(C.byref(desc), _p(direct), _p(gathered), _p(dw), _stream()), "mde_conv_wgrad")
+        return
+    flops = 2.0 * desc.N * desc.GH * desc.GW * desc.Cd * desc.Cg * desc.ntaps
+    _timed("conv_wgrad_tn", flops, lambda: check(
+        lib.mde_conv_wgrad(C.byref(desc), _p(direct), _p(gathered), _p(dw), _stream()), "mde_conv_wgrad"))
 
 
 def choose_ksplit(pixels, row_tiles, col_tiles, ntaps, cus=256, min_steps=8):
