@@ -83,6 +83,7 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH, help="images per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-launch-timing", action="store_true")
+    ap.add_argument("--per-shape", action="store_true", help="print a per-shape table of the GEMM launches to stderr")
     args = ap.parse_args()
 
     t_start = time.perf_counter()
@@ -170,6 +171,14 @@ def main():
                        "final_loss": round(final_loss, 5)},
             "step_mfma_frac": round(ips * ALGO_GFLOP_PER_IMAGE / 1e3 / (world * PEAK_BF16_TFLOPS), 4),
         }
+        if timer is not None and args.per_shape:
+            tab = {}
+            for kind, flops, e0, e1, tag in timer.records:
+                n, t = tab.get((kind, tag, flops), (0, 0.0))
+                tab[(kind, tag, flops)] = (n + 1, t + e0.elapsed_time(e1) * 1e-3)
+            for (kind, tag, flops), (n, t) in sorted(tab.items(), key=lambda kv: -kv[1][1]):
+                print("%-14s %-46s x%-3d %8.1f us  %7.1f TF/s  %5.2f ms/step" % (
+                    kind, tag, n // args.steps, 1e6 * t / n, flops / (t / n) / 1e12, 1e3 * t / args.steps), file=sys.stderr)
         if timer is not None:
             summ = timer.summary()
             n, fl, sec = summ.get("conv_gemm_nt", (0, 0.0, 1.0))

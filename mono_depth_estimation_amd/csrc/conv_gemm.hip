@@ -19,19 +19,27 @@
 // as zero through the buffer bounds check, so padding costs no branches), written to a
 // fragment-linear XOR-swizzled image: fragment (16 rows x 32 k) = 1 KiB, lane l reads
 // 16 B at l*16 ^ swizzle -> conflict-free ds_read_b128 and conflict-free ds_write_b128.
-// Two LDS buffers, one barrier per K-step, next step's loads in flight under the MFMAs.
+// Two LDS buffers and two register staging sets, one barrier per K-step: every global load is
+// issued two K-steps before it is needed (the single-stage version was latency-bound: 41 % of
+// wave cycles parked in s_waitcnt, MFMA busy 28 %; profiles/r01_b_pmc_conv.txt).
 //
 // Epilogue: fp32 accumulators -> bf16 -> LDS [pixel][channel] -> full-line 16-byte stores
 // (optionally read-modify-write for dgrad accumulation), plus optional BatchNorm partial
 // sums (sum, sum of squares per channel, reduced per workgroup then added with fp32 atomics
 // to one of MDE_STAT_SLOTS rows) so the BN statistics pass over the conv output is not needed.
+#include <stdlib.h>
+
 #include "mde_common.h"
+
+// MDE_ABLATE (timing-only diagnostic builds, results are wrong): 1 = no global loads in the
+// K-loop, 2 = also no LDS staging writes, 3 = no MFMAs, 4 = no barriers in the K-loop.
+#ifndef MDE_ABLATE
+#define MDE_ABLATE 0
+#endif
 
 namespace {
 
 constexpr int BK = 64;
-constexpr int NT = 256;
-
 struct KArgs {
     mde_conv_desc d;
     const void* in;
@@ -50,25 +58,45 @@ __device__ __forceinline__ int chunk_off(int row, int kslot8) {
     return ((((row >> 4) * 2 + (kslot8 >> 2)) * 64) + (kslot8 & 3) * 16 + ((row & 15) ^ kslot8)) * 16;
 }
 
-template <int BP, int BC>
+// NT threads (4 or 8 waves).  Waves are laid out WAVES_P (pixels) x WAVES_C (columns); a wave
+// owns PF x CF fragments of 16 pixels x 16 columns.
+//
+// DMA = true: the tiles are filled by LDS-DMA (buffer_load ... lds, 1 KiB = 8 rows x 128 B per
+// wave-instruction, no VGPR staging, no ds_write) into a ring of NBUF LDS buffers, issued
+// NBUF-1 K-steps ahead; ordering is a counted s_waitcnt vmcnt(N) + one raw s_barrier per step.
+// The LDS destination of a DMA is lane-linear, so the bank swizzle lives in the SOURCE k-slot
+// each lane fetches and in the fragment read address (guide rule 21).  Out-of-image taps use
+// an out-of-range buffer offset: the DMA then writes zeros (tools/probes/lds_dma_probe.hip).
+template <int BP, int BC, int NT, bool DMA, int NBUF>
 __global__ __launch_bounds__(NT, 2) void conv_gemm_nt(const KArgs a) {
-    constexpr int XP = BP / 32;          // X chunks per thread per K-step
-    constexpr int WP = BC / 32;          // W chunks per thread per K-step
-    constexpr int WAVES_C = BC / 64;     // waves along columns
-    constexpr int WAVES_P = 4 / WAVES_C; // waves along pixels
-    constexpr int PF = BP / WAVES_P / 16;// 16-pixel fragments per wave
+    constexpr int NW = NT / 64;
+    constexpr int RPL = NT / 8;          // tile rows covered by one load pass (8 chunks per row)
+    constexpr int XP = BP / RPL;         // X chunks per thread per K-step
+    constexpr int WP = BC / RPL;         // W chunks per thread per K-step
+    constexpr int WAVES_C = BC >= 128 ? 2 : 1;   // waves along columns
+    constexpr int WAVES_P = NW / WAVES_C;        // waves along pixels
+    constexpr int PF = BP / WAVES_P / 16;        // 16-pixel fragments per wave
+    constexpr int CF = BC / WAVES_C / 16;        // 16-column fragments per wave
     constexpr int XT_BYTES = BP * BK * 2;
     constexpr int WT_BYTES = BC * BK * 2;
     constexpr int BUF_BYTES = XT_BYTES + WT_BYTES;
     constexpr int ROWB = BC * 2 + 16;    // epilogue tile row pitch (bytes)
-    static_assert(WAVES_P * WAVES_C == 4 && PF * 16 * WAVES_P == BP && (PF == 2 || PF == 4), "wave tiling");
-    static_assert(BP * ROWB <= 2 * BUF_BYTES, "epilogue tile fits in the staging buffers");
+    // the epilogue re-tiles through LDS; when the whole tile does not fit, in EPASS pixel slabs
+    constexpr int EPASS = (BP * ROWB <= 2 * BUF_BYTES) ? 1 : 2;
+    constexpr int EROWS = BP / EPASS;    // pixel rows per epilogue pass
+    static_assert(WAVES_P * WAVES_C == NW && PF * 16 * WAVES_P == BP && CF * 16 * WAVES_C == BC, "wave tiling");
+    static_assert(XP >= 1 && WP >= 1 && XP * RPL == BP && WP * RPL == BC, "load tiling");
+    static_assert(EROWS * ROWB <= 2 * BUF_BYTES && (WAVES_P % EPASS) == 0, "epilogue slab fits in the staging buffers");
+    static_assert(NBUF == 2 || (DMA && NBUF == 3), "register staging uses two LDS buffers");
+    constexpr int XR = BP / 8 / NW, WR = BC / 8 / NW;   // DMA regions (8 rows) per wave per K-step
+    static_assert(!DMA || (XR >= 1 && WR >= 1 && XR * NW * 8 == BP && WR * NW * 8 == BC && NW % 2 == 0), "DMA tiling");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    int* s_inbase = reinterpret_cast<int*>(smem + 2 * BUF_BYTES);
+    int* s_inbase = reinterpret_cast<int*>(smem + NBUF * BUF_BYTES);
     int* s_yx = s_inbase + BP;
     int* s_out = s_yx + BP;
     float* s_stat = reinterpret_cast<float*>(s_out + BP);  // [WAVES_P][2][BC]
+    int* s_tap = reinterpret_cast<int*>(s_stat + WAVES_P * 2 * BC);   // [3][MDE_MAX_TAPS]: x offset, w offset, dy|dx
 
     const mde_conv_desc& d = a.d;
     const int tid = threadIdx.x;
@@ -98,51 +126,68 @@ __global__ __launch_bounds__(NT, 2) void conv_gemm_nt(const KArgs a) {
         s_yx[r] = yx;
         s_out[r] = oo;
     }
+    // per-tap scalars into LDS: indexing the kernarg tables dynamically inside the K-loop makes
+    // hipcc fetch them with VECTOR global loads and wait vmcnt(0) for them, which drains every
+    // prefetched tile each step (seen in the .s; MFMA busy 28 % -> see profiles/).
+    if (tid < d.ntaps) {
+        const int tdy = d.dy[tid], tdx = d.dx[tid];
+        s_tap[tid] = (tdy * d.W + tdx) * d.ld_in;
+        s_tap[MDE_MAX_TAPS + tid] = d.wtap[tid] * d.C;
+        s_tap[2 * MDE_MAX_TAPS + tid] = (tdy << 16) | (tdx & 0xFFFF);
+    }
     __syncthreads();
 
     const int kslot8 = tid & 7;
-    const int lrow = tid >> 3;           // 0..31
+    const int lrow = tid >> 3;           // 0..RPL-1
     int x_base[XP], x_yx[XP];
 #pragma unroll
     for (int p = 0; p < XP; ++p) {
-        x_base[p] = s_inbase[p * 32 + lrow] + kslot8 * 8;
-        x_yx[p] = s_yx[p * 32 + lrow];
+        x_base[p] = s_inbase[p * RPL + lrow] + kslot8 * 8;
+        x_yx[p] = s_yx[p * RPL + lrow];
     }
     const int wrow_len = d.wtaps_total * d.C;
     int w_base[WP];
 #pragma unroll
-    for (int p = 0; p < WP; ++p) w_base[p] = (n0 + p * 32 + lrow) * wrow_len + kslot8 * 8;
+    for (int p = 0; p < WP; ++p) w_base[p] = (n0 + p * RPL + lrow) * wrow_len + kslot8 * 8;
 
     const __amdgpu_buffer_rsrc_t rs_in = mde_rsrc(a.in, d.in_bytes);
     const __amdgpu_buffer_rsrc_t rs_w = mde_rsrc(a.w, a.w_bytes);
 
     int st_off[XP > WP ? XP : WP];       // LDS chunk offsets of this thread's rows (same for X and W)
 #pragma unroll
-    for (int p = 0; p < (XP > WP ? XP : WP); ++p) st_off[p] = chunk_off(p * 32 + lrow, kslot8);
+    for (int p = 0; p < (XP > WP ? XP : WP); ++p) st_off[p] = chunk_off(p * RPL + lrow, kslot8);
 
     // fragment read offsets: lane l reads row (l&15), k-slot (l>>4) of fragment (rb, kb)
     int rd_off[2];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
         const int ks = lane >> 4, r = lane & 15;
-        rd_off[kb] = (kb * 64 + ks * 16 + (r ^ (kb * 4 + ks))) * 16;
+        if constexpr (DMA)   // region (r>>3) of 8 rows x 8 k-slots, k-slot XORed with (row>>1)&7
+            rd_off[kb] = (r >> 3) * 1024 + ((r & 7) * 8 + ((kb * 4 + ks) ^ ((r >> 1) & 7))) * 16;
+        else
+            rd_off[kb] = (kb * 64 + ks * 16 + (r ^ (kb * 4 + ks))) * 16;
     }
 
-    f32x4_t acc[4][PF];
+    f32x4_t acc[CF][PF];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < CF; ++i)
 #pragma unroll
         for (int j = 0; j < PF; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     const int csteps = d.C / BK;
     const int nsteps = d.ntaps * csteps;
-    i32x4_t xr[XP], wr[WP];
+    // two register staging sets: loads are issued TWO K-steps ahead of their use, so each has
+    // two full compute phases to land (the loop was global-latency-bound with one).
+    constexpr bool DEEP = (CF * PF <= 16);   // second staging set only when the accumulators leave room
+    i32x4_t xa[XP], wa[WP], xb[DEEP ? XP : 1], wb_[DEEP ? WP : 1];
+    int ltap = 0, lcs = 0;                // cursor of the next K-step to load
 
-    auto issue_loads = [&](int tap, int cs) {
-        const int tdy = d.dy[tap], tdx = d.dx[tap];
-        const int c0 = cs * BK;
-        const int tapoff = (tdy * d.W + tdx) * d.ld_in + c0;
-        const int woff = d.wtap[tap] * d.C + c0;
+    auto issue_loads = [&](i32x4_t (&xr)[XP], i32x4_t (&wr)[WP]) {
+        const int c0 = lcs * BK;
+        const int tapoff = s_tap[ltap] + c0;
+        const int woff = s_tap[MDE_MAX_TAPS + ltap] + c0;
+        const int dydx = s_tap[2 * MDE_MAX_TAPS + ltap];
+        const int tdy = dydx >> 16, tdx = (int)(short)(dydx & 0xFFFF);
 #pragma unroll
         for (int p = 0; p < XP; ++p) {
             const int iy = (int)((uint32_t)x_yx[p] >> 16) + tdy;
@@ -154,69 +199,157 @@ __global__ __launch_bounds__(NT, 2) void conv_gemm_nt(const KArgs a) {
 #pragma unroll
         for (int p = 0; p < WP; ++p)
             wr[p] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, (uint32_t)(w_base[p] + woff) * 2u, 0, 0);
+        if (++lcs == csteps) { lcs = 0; ++ltap; }
     };
-    auto stage_write = [&](int buf) {
-        char* xb = smem + buf * BUF_BYTES;
-        char* wb = xb + XT_BYTES;
+    auto stage_write = [&](int buf, const i32x4_t (&xr)[XP], const i32x4_t (&wr)[WP]) {
+        char* xbuf = smem + buf * BUF_BYTES;
+        char* wbuf = xbuf + XT_BYTES;
 #pragma unroll
-        for (int p = 0; p < XP; ++p) *reinterpret_cast<i32x4_t*>(xb + st_off[p]) = xr[p];
+        for (int p = 0; p < XP; ++p) *reinterpret_cast<i32x4_t*>(xbuf + st_off[p]) = xr[p];
 #pragma unroll
-        for (int p = 0; p < WP; ++p) *reinterpret_cast<i32x4_t*>(wb + st_off[p]) = wr[p];
+        for (int p = 0; p < WP; ++p) *reinterpret_cast<i32x4_t*>(wbuf + st_off[p]) = wr[p];
     };
-
-    issue_loads(0, 0);
-    stage_write(0);
-    __syncthreads();
-
-    int tap = 0, cs = 0;
-    for (int s = 0; s < nsteps; ++s) {
-        const int buf = s & 1;
-        if (++cs == csteps) { cs = 0; ++tap; }
-        const bool more = s + 1 < nsteps;
-        if (more) issue_loads(tap, cs);
-
-        const char* xb = smem + buf * BUF_BYTES + wp * (PF * 2048);
-        const char* wb = smem + buf * BUF_BYTES + XT_BYTES + wc * (4 * 2048);
+    auto compute = [&](int buf) {
+        const char* xbuf = smem + buf * BUF_BYTES + wp * (PF * 2048);
+        const char* wbuf = smem + buf * BUF_BYTES + XT_BYTES + wc * (CF * 2048);
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
-            bf16x8_t fa[4], fb[PF];
+            bf16x8_t fa[CF], fb[PF];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                fa[i] = *reinterpret_cast<const bf16x8_t*>(wb + i * 2048 + rd_off[kb]);
+            for (int i = 0; i < CF; ++i)
+                fa[i] = *reinterpret_cast<const bf16x8_t*>(wbuf + i * 2048 + rd_off[kb]);
 #pragma unroll
             for (int j = 0; j < PF; ++j)
-                fb[j] = *reinterpret_cast<const bf16x8_t*>(xb + j * 2048 + rd_off[kb]);
+                fb[j] = *reinterpret_cast<const bf16x8_t*>(xbuf + j * 2048 + rd_off[kb]);
+#if MDE_ABLATE == 3
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < CF; ++i) asm volatile("" ::"v"(fa[i]));
+#pragma unroll
+            for (int j = 0; j < PF; ++j) asm volatile("" ::"v"(fb[j]));
+#else
+#pragma unroll
+            for (int i = 0; i < CF; ++i)
 #pragma unroll
                 for (int j = 0; j < PF; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+#endif
         }
-        if (more) stage_write(buf ^ 1);
+    };
+
+#if MDE_ABLATE == 1 || MDE_ABLATE == 2
+#define LOOP_LOADS(...)
+#else
+#define LOOP_LOADS(...) issue_loads(__VA_ARGS__)
+#endif
+#if MDE_ABLATE == 2
+#define LOOP_WRITE(...)
+#else
+#define LOOP_WRITE(...) stage_write(__VA_ARGS__)
+#endif
+#if MDE_ABLATE == 4
+#define LOOP_SYNC()
+#else
+#define LOOP_SYNC() __syncthreads()
+#endif
+    if constexpr (DMA) {
+        const int wv = __builtin_amdgcn_readfirstlane(wave);
+        const int lr = lane >> 3;
+        const int k8 = (lane & 7) ^ ((((wv & 1) << 2) + (lr >> 1)) & 7);   // source k-slot of this lane
+        int dx_base[XR], dx_yx[XR], dw_base[WR];
+#pragma unroll
+        for (int q = 0; q < XR; ++q) {
+            const int row = (wv + q * NW) * 8 + lr;
+            dx_base[q] = s_inbase[row] + k8 * 8;
+            dx_yx[q] = s_yx[row];
+        }
+#pragma unroll
+        for (int q = 0; q < WR; ++q) dw_base[q] = (n0 + (wv + q * NW) * 8 + lr) * wrow_len + k8 * 8;
+        typedef __attribute__((address_space(3))) void* lds_ptr;
+        auto issue_dma = [&](int buf) {
+            const int c0 = lcs * BK;
+            const int tapoff = s_tap[ltap] + c0;
+            const int woff = s_tap[MDE_MAX_TAPS + ltap] + c0;
+            const int dydx = s_tap[2 * MDE_MAX_TAPS + ltap];
+            const int tdy = dydx >> 16, tdx = (int)(short)(dydx & 0xFFFF);
+            char* xbuf = smem + buf * BUF_BYTES + wv * 1024;
+#pragma unroll
+            for (int q = 0; q < XR; ++q) {
+                const int iy = (int)((uint32_t)dx_yx[q] >> 16) + tdy;
+                const int ix = (dx_yx[q] & 0xFFFF) + tdx;
+                const bool ok = ((uint32_t)iy < (uint32_t)d.H) & ((uint32_t)ix < (uint32_t)d.W);
+                const uint32_t off = ok ? (uint32_t)(dx_base[q] + tapoff) * 2u : MDE_OOB_OFFSET;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr)(xbuf + q * NW * 1024), 16, off, 0, 0, 0);
+            }
+#pragma unroll
+            for (int q = 0; q < WR; ++q)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr)(xbuf + XT_BYTES + q * NW * 1024), 16,
+                                                         (uint32_t)(dw_base[q] + woff) * 2u, 0, 0, 0);
+            if (++lcs == csteps) { lcs = 0; ++ltap; }
+        };
+        constexpr int IPS = XR + WR;          // DMA instructions per wave per K-step
+        constexpr int DIST = NBUF - 1;        // prefetch distance in K-steps
+        int lbuf = 0, cbuf = 0;
+#pragma unroll
+        for (int q = 0; q < DIST; ++q)
+            if (q < nsteps) { issue_dma(lbuf); lbuf = lbuf + 1 == NBUF ? 0 : lbuf + 1; }
+        for (int s = 0; s < nsteps; ++s) {
+            // step s landed once only the younger group(s) remain outstanding
+            if (DIST == 2 && s + 1 < nsteps)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IPS) : "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();     // every wave's DMA of step s is in; everyone left step s-1
+            __builtin_amdgcn_sched_barrier(0);
+            if (s + DIST < nsteps) { issue_dma(lbuf); lbuf = lbuf + 1 == NBUF ? 0 : lbuf + 1; }
+            compute(cbuf);
+            cbuf = cbuf + 1 == NBUF ? 0 : cbuf + 1;
+        }
+        __syncthreads();                      // staging ring is free for the epilogue
+    } else
+    if constexpr (DEEP) {
+        issue_loads(xa, wa);                              // step 0
+        if (nsteps > 1) issue_loads(xb, wb_);             // step 1
+        stage_write(0, xa, wa);
         __syncthreads();
+#if MDE_ABLATE == 1 || MDE_ABLATE == 2
+        stage_write(1, xb, wb_);
+        __syncthreads();
+#endif
+        for (int s = 0; s < nsteps; s += 2) {
+            // even step s: LDS buffer 0; set B holds step s+1 (in flight); set A is free
+            if (s + 2 < nsteps) LOOP_LOADS(xa, wa);
+            compute(0);
+            if (s + 1 < nsteps) LOOP_WRITE(1, xb, wb_);
+            LOOP_SYNC();
+            if (s + 1 >= nsteps) break;
+            // odd step s+1: LDS buffer 1; set A holds step s+2 (in flight); set B is free
+            if (s + 3 < nsteps) LOOP_LOADS(xb, wb_);
+            compute(1);
+            if (s + 2 < nsteps) LOOP_WRITE(0, xa, wa);
+            LOOP_SYNC();
+        }
+    } else {
+        issue_loads(xa, wa);
+        stage_write(0, xa, wa);
+        __syncthreads();
+        for (int s = 0; s < nsteps; ++s) {
+            const bool more = s + 1 < nsteps;
+            if (more) LOOP_LOADS(xa, wa);
+            compute(s & 1);
+            if (more) LOOP_WRITE((s & 1) ^ 1, xa, wa);
+            LOOP_SYNC();
+        }
     }
+#undef LOOP_LOADS
+#undef LOOP_WRITE
+#undef LOOP_SYNC
 
     // ---------------------------------------------------------------- epilogue
     // (the loop's last barrier guarantees every wave is done reading the staging tiles)
-    {
-        const int prow = wp * (PF * 16) + (lane & 15);
-        const int chb = wc * 64 + (lane >> 4) * 4;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < PF; ++j) {
-                bf16x4_t v;
-                v[0] = (bf16_t)acc[i][j][0];
-                v[1] = (bf16_t)acc[i][j][1];
-                v[2] = (bf16_t)acc[i][j][2];
-                v[3] = (bf16_t)acc[i][j][3];
-                *reinterpret_cast<bf16x4_t*>(smem + (prow + j * 16) * ROWB + (chb + i * 16) * 2) = v;
-            }
-    }
     if (a.stats) {
         // per-wave channel sums over its pixels (rows beyond M are exact zeros)
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < CF; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float s1 = 0.f, s2 = 0.f;
@@ -232,35 +365,53 @@ __global__ __launch_bounds__(NT, 2) void conv_gemm_nt(const KArgs a) {
                     s2 += __shfl_xor(s2, o, 64);
                 }
                 if ((lane & 15) == 0) {
-                    const int ch = wc * 64 + i * 16 + (lane >> 4) * 4 + r;
+                    const int ch = wc * (CF * 16) + i * 16 + (lane >> 4) * 4 + r;
                     s_stat[(wp * 2 + 0) * BC + ch] = s1;
                     s_stat[(wp * 2 + 1) * BC + ch] = s2;
                 }
             }
     }
-    __syncthreads();
-    if (a.stats) {
-        for (int e = tid; e < 2 * BC; e += NT) {
-            const int which = e / BC, ch = e - which * BC;
-            if (n0 + ch < d.ncols) {
-                float s = 0.f;
+    constexpr int CPR = BC / 8;          // 16-byte chunks per pixel row
+    constexpr int RPP = NT / CPR;        // rows per store pass
+    static_assert(RPP >= 1 && RPP * CPR == NT, "store tiling");
+    bf16_t* outp = reinterpret_cast<bf16_t*>(a.out);
 #pragma unroll
-                for (int q = 0; q < WAVES_P; ++q) s += s_stat[(q * 2 + which) * BC + ch];
-                atomicAdd(a.stats + ((size_t)(pi % MDE_STAT_SLOTS) * 2 + which) * d.ncols + n0 + ch, s);
+    for (int ep = 0; ep < EPASS; ++ep) {
+        if (ep) __syncthreads();         // previous slab fully stored before it is overwritten
+        if (wp / (WAVES_P / EPASS) == ep) {
+            const int prow = (wp % (WAVES_P / EPASS)) * (PF * 16) + (lane & 15);
+            const int chb = wc * (CF * 16) + (lane >> 4) * 4;
+#pragma unroll
+            for (int i = 0; i < CF; ++i)
+#pragma unroll
+                for (int j = 0; j < PF; ++j) {
+                    bf16x4_t v;
+                    v[0] = (bf16_t)acc[i][j][0];
+                    v[1] = (bf16_t)acc[i][j][1];
+                    v[2] = (bf16_t)acc[i][j][2];
+                    v[3] = (bf16_t)acc[i][j][3];
+                    *reinterpret_cast<bf16x4_t*>(smem + (prow + j * 16) * ROWB + (chb + i * 16) * 2) = v;
+                }
+        }
+        __syncthreads();
+        if (ep == 0 && a.stats) {
+            for (int e = tid; e < 2 * BC; e += NT) {
+                const int which = e / BC, ch = e - which * BC;
+                if (n0 + ch < d.ncols) {
+                    float sum = 0.f;
+#pragma unroll
+                    for (int q = 0; q < WAVES_P; ++q) sum += s_stat[(q * 2 + which) * BC + ch];
+                    atomicAdd(a.stats + ((size_t)(pi % MDE_STAT_SLOTS) * 2 + which) * d.ncols + n0 + ch, sum);
+                }
             }
         }
-    }
-    {
-        constexpr int CPR = BC / 8;          // 16-byte chunks per pixel row
-        constexpr int RPP = NT / CPR;        // rows per pass
         const int chunk = tid % CPR, r0 = tid / CPR;
         const int col = n0 + chunk * 8;
-        bf16_t* outp = reinterpret_cast<bf16_t*>(a.out);
         if (col < d.ncols) {
             const bool full = a.vec_ok && (col + 8 <= d.ncols);
 #pragma unroll 4
-            for (int r = r0; r < BP; r += RPP) {
-                const int oo = s_out[r];
+            for (int r = r0; r < EROWS; r += RPP) {
+                const int oo = s_out[ep * EROWS + r];
                 if (oo < 0) continue;
                 bf16x8_t v = *reinterpret_cast<const bf16x8_t*>(smem + r * ROWB + chunk * 16);
                 bf16_t* dst = outp + (size_t)oo + col;
@@ -284,25 +435,53 @@ __global__ __launch_bounds__(NT, 2) void conv_gemm_nt(const KArgs a) {
     }
 }
 
-template <int BP, int BC>
+template <int BP, int BC, int NT, int NBUF>
 constexpr size_t smem_bytes() {
-    return 2 * (size_t)(BP + BC) * BK * 2 + 3 * BP * sizeof(int) + (4 / (BC / 64)) * 2 * BC * sizeof(float);
+    return NBUF * (size_t)(BP + BC) * BK * 2 + 3 * BP * sizeof(int) +
+           ((NT / 64) / (BC >= 128 ? 2 : 1)) * 2 * BC * sizeof(float) + 3 * MDE_MAX_TAPS * sizeof(int);
 }
 
-template <int BP, int BC>
-int launch(const KArgs& ka, hipStream_t st) {
+template <int BP, int BC, int NT, bool DMA, int NBUF>
+int launch(KArgs& ka, int64_t M, hipStream_t st) {
     static bool attr_done = false;
-    constexpr size_t smem = smem_bytes<BP, BC>();
+    constexpr size_t smem = smem_bytes<BP, BC, NT, NBUF>();
+    static_assert(smem <= 160 * 1024, "LDS budget");
     if (!attr_done) {
-        int rc = mde_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_nt<BP, BC>),
+        int rc = mde_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_nt<BP, BC, NT, DMA, NBUF>),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem),
                                "hipFuncSetAttribute(conv_gemm_nt)");
         if (rc) return rc;
         attr_done = true;
     }
-    conv_gemm_nt<BP, BC><<<dim3(ka.nP * ka.nC), dim3(NT), smem, st>>>(ka);
+    ka.nP = mde_cdiv(M, BP);
+    ka.nC = mde_cdiv(ka.d.ncols, BC);
+    conv_gemm_nt<BP, BC, NT, DMA, NBUF><<<dim3(ka.nP * ka.nC), dim3(NT), smem, st>>>(ka);
     MDE_LAUNCH_CHECK("conv_gemm_nt");
     return MDE_OK;
+}
+
+// Tile choice: the biggest workgroup tile whose grid still fills the chip about twice over
+// (one 8-wave workgroup per CU for the 256-pixel tiles).  Diagnostics: MDE_CONV_TILE=<BP>x<BC>
+// forces a tile, MDE_CONV_PATH=reg selects the register-staged main loop instead of LDS-DMA.
+int pick_and_launch(KArgs& ka, int64_t M, hipStream_t st) {
+    static int forced = -1, reg = 0;
+    if (forced < 0) {
+        const char* e = getenv("MDE_CONV_TILE");
+        forced = !e ? 0 : !strcmp(e, "256x256") ? 1 : !strcmp(e, "256x128") ? 2 : !strcmp(e, "128x128") ? 3 : 0;
+        const char* q = getenv("MDE_CONV_PATH");
+        reg = q && !strcmp(q, "reg");
+    }
+    const int n = ka.d.ncols;
+    if (n <= 64) return reg ? launch<128, 64, 256, false, 2>(ka, M, st) : launch<128, 64, 256, true, 3>(ka, M, st);
+    const int64_t t256 = (int64_t)mde_cdiv(M, 256) * mde_cdiv(n, 256), t128 = (int64_t)mde_cdiv(M, 256) * mde_cdiv(n, 128);
+    // measured (tools/conv_microbench.py): two independent 4-wave 128x128 groups per CU beat one
+    // 8-wave 256x128 group; 256x256 pays only when its grid still covers the chip > 2x.
+    (void)t128;
+    if (forced == 1 || (forced == 0 && n >= 256 && t256 >= 560))
+        return reg ? launch<256, 256, 512, false, 2>(ka, M, st) : launch<256, 256, 512, true, 2>(ka, M, st);
+    if (forced == 2)
+        return reg ? launch<256, 128, 512, false, 2>(ka, M, st) : launch<256, 128, 512, true, 3>(ka, M, st);
+    return reg ? launch<128, 128, 256, false, 2>(ka, M, st) : launch<128, 128, 256, true, 2>(ka, M, st);
 }
 
 }  // namespace
@@ -339,12 +518,5 @@ extern "C" int mde_conv_gemm(const mde_conv_desc* d, const void* in, const void*
     ka.out_bytes = (uint32_t)(out_elems * 2);
     ka.M = (int32_t)M;
     ka.vec_ok = (d->ld_out % 8 == 0) && (((uintptr_t)out % 16) == 0);
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    ka.nP = mde_cdiv(M, 128);
-    if (d->ncols <= 64) {
-        ka.nC = 1;
-        return launch<128, 64>(ka, st);
-    }
-    ka.nC = mde_cdiv(d->ncols, 128);
-    return launch<128, 128>(ka, st);
+    return pick_and_launch(ka, M, reinterpret_cast<hipStream_t>(stream));
 }

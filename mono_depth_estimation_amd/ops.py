@@ -104,12 +104,12 @@ class LaunchTimer:
     Events are recorded on the stream the kernels run on (torch's current stream)."""
 
     def __init__(self):
-        self.records = []          # (kind, flops, start_event, end_event)
+        self.records = []          # (kind, flops, start_event, end_event, shape tag)
 
     def summary(self):
         """kind -> (launches, total flops, total seconds); call after a device synchronize."""
         out = {}
-        for kind, flops, e0, e1 in self.records:
+        for kind, flops, e0, e1, _ in self.records:
             n, f, t = out.get(kind, (0, 0.0, 0.0))
             out[kind] = (n + 1, f + flops, t + e0.elapsed_time(e1) * 1e-3)
         return out
@@ -118,14 +118,14 @@ class LaunchTimer:
 TIMER = None   # set to a LaunchTimer to time every conv_gemm / conv_wgrad launch
 
 
-def _timed(kind, flops, fn):
+def _timed(kind, flops, fn, tag=""):
     if TIMER is None:
         return fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     fn()
     e1.record()
-    TIMER.records.append((kind, flops, e0, e1))
+    TIMER.records.append((kind, flops, e0, e1, tag))
 
 
 def conv_gemm(desc, x, w, out, stats=None):
@@ -135,7 +135,9 @@ def conv_gemm(desc, x, w, out, stats=None):
         return
     flops = 2.0 * desc.N * desc.GH * desc.GW * desc.ncols * desc.ntaps * desc.C
     _timed("conv_gemm_nt", flops, lambda: check(
-        lib.mde_conv_gemm(C.byref(desc), _p(x), _p(w), _p(out), _p(stats), _stream()), "mde_conv_gemm"))
+        lib.mde_conv_gemm(C.byref(desc), _p(x), _p(w), _p(out), _p(stats), _stream()), "mde_conv_gemm"),
+        "M=%d N=%d taps=%d C=%d s=%d%s" % (desc.N * desc.GH * desc.GW, desc.ncols, desc.ntaps, desc.C, desc.sy,
+                                          " acc" if desc.accumulate else ""))
 
 
 def stat_slots():
@@ -180,7 +182,8 @@ def conv_wgrad(desc, direct, gathered, dw):
         return
     flops = 2.0 * desc.N * desc.GH * desc.GW * desc.Cd * desc.Cg * desc.ntaps
     _timed("conv_wgrad_tn", flops, lambda: check(
-        lib.mde_conv_wgrad(C.byref(desc), _p(direct), _p(gathered), _p(dw), _stream()), "mde_conv_wgrad"))
+        lib.mde_conv_wgrad(C.byref(desc), _p(direct), _p(gathered), _p(dw), _stream()), "mde_conv_wgrad"),
+        "K=%d Cd=%d Cg=%d taps=%d ks=%d" % (desc.N * desc.GH * desc.GW, desc.Cd, desc.Cg, desc.ntaps, desc.ksplit))
 
 
 def choose_ksplit(pixels, row_tiles, col_tiles, ntaps, cus=256, min_steps=8):
