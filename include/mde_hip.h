@@ -138,10 +138,13 @@ int mde_bn_apply(const void* x, int ldx, const float* scale, const float* shift,
                  int ldr, const float* rscale, const float* rshift, void* out, int ldo, int64_t M,
                  int C, int relu, void* stream);
 /* Backward of  out = act(bn(x) [+ ...]):  g = dout * (relu ? out > 0 : 1).
+ * If mask_scale/mask_shift are given (sites WITHOUT a residual), the ReLU mask is recomputed
+ * as (x*mask_scale + mask_shift > 0) from the tensor already being read and `out` is not
+ * touched (may be NULL): one full-tensor read less per pass.
  * pass 1: part += (sum g, sum g*xhat) per channel, xhat = (x - save_mean)*save_rstd. */
 int mde_bn_bwd_reduce(const void* dout, int ldd, const void* out, int ldo, const void* x, int ldx,
-                      const float* save_mean, const float* save_rstd, int64_t M, int C, int relu,
-                      float* part, void* stream);
+                      const float* save_mean, const float* save_rstd, const float* mask_scale,
+                      const float* mask_shift, int64_t M, int C, int relu, float* part, void* stream);
 /* pass 2 (tiny): dgamma += sum g*xhat, dbeta += sum g; coef[3][C] = (gamma*rstd, mean g,
  * mean g*xhat); part is zeroed. */
 int mde_bn_bwd_finalize(float* part, int64_t M, int C, const float* gamma, const float* save_rstd,
@@ -149,9 +152,9 @@ int mde_bn_bwd_finalize(float* part, int64_t M, int C, const float* gamma, const
 /* pass 3: dx = coef0*(g - coef1 - xhat*coef2) (bf16, ld ldxo; accumulate_dx != 0 adds into dx);
  *   dres (optional) receives g, the masked upstream gradient, for the residual branch. */
 int mde_bn_bwd_apply(const void* dout, int ldd, const void* out, int ldo, const void* x, int ldx,
-                     const float* save_mean, const float* save_rstd, const float* coef, int64_t M,
-                     int C, int relu, void* dx, int ldxo, int accumulate_dx, void* dres, int ldres,
-                     void* stream);
+                     const float* save_mean, const float* save_rstd, const float* mask_scale,
+                     const float* mask_shift, const float* coef, int64_t M, int C, int relu, void* dx,
+                     int ldxo, int accumulate_dx, void* dres, int ldres, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Pooling / resize / pointwise.

@@ -130,16 +130,23 @@ __global__ __launch_bounds__(NT) void bn_apply_k(const bf16_t* __restrict__ x, i
     }
 }
 
+// MASK: 0 no ReLU, 1 mask from `out` > 0, 2 mask recomputed from x*msc+msh > 0
+template <int MASK>
 __global__ __launch_bounds__(NT) void bn_bwd_reduce_k(const bf16_t* __restrict__ dout, int ldd,
                                                       const bf16_t* __restrict__ out, int ldo,
                                                       const bf16_t* __restrict__ x, int ldx,
                                                       const float* __restrict__ smean, const float* __restrict__ srstd,
-                                                      int64_t M, int C, int relu, float* part, int rows_per_blk) {
+                                                      const float* __restrict__ msc, const float* __restrict__ msh,
+                                                      int64_t M, int C, float* part, int rows_per_blk) {
     __shared__ float sh[2 * MAXC];
     const int cpr = C >> 3, rpb = NT / cpr, col = threadIdx.x % cpr, rl = threadIdx.x / cpr;
-    float mu[8], rs[8];
+    float mu[8], rs[8], ms[8], mh[8];
     ldf8(smean + col * 8, mu);
     ldf8(srstd + col * 8, rs);
+    if (MASK == 2) {
+        ldf8(msc + col * 8, ms);
+        ldf8(msh + col * 8, mh);
+    }
     float s1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_blk;
     const int64_t r1 = min(M, r0 + rows_per_blk);
@@ -147,10 +154,11 @@ __global__ __launch_bounds__(NT) void bn_bwd_reduce_k(const bf16_t* __restrict__
         float g[8], v[8], o[8];
         ld8(dout + r * ldd + col * 8, g);
         ld8(x + r * ldx + col * 8, v);
-        if (relu) ld8(out + r * ldo + col * 8, o);
+        if (MASK == 1) ld8(out + r * ldo + col * 8, o);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const float ge = (relu && !(o[e] > 0.f)) ? 0.f : g[e];
+            if (MASK == 2) o[e] = v[e] * ms[e] + mh[e];
+            const float ge = (MASK && !(o[e] > 0.f)) ? 0.f : g[e];
             s1[e] += ge;
             s2[e] += ge * ((v[e] - mu[e]) * rs[e]);
         }
@@ -177,14 +185,20 @@ __global__ void bn_bwd_finalize_k(float* part, int64_t M, int C, const float* ga
     coef[2 * C + c] = (float)(s2 / (double)M);
 }
 
+template <int MASK>
 __global__ __launch_bounds__(NT) void bn_bwd_apply_k(const bf16_t* __restrict__ dout, int ldd,
                                                      const bf16_t* __restrict__ out, int ldo,
                                                      const bf16_t* __restrict__ x, int ldx,
                                                      const float* __restrict__ smean, const float* __restrict__ srstd,
-                                                     const float* __restrict__ coef, int64_t M, int C, int relu,
+                                                     const float* __restrict__ msc, const float* __restrict__ msh,
+                                                     const float* __restrict__ coef, int64_t M, int C,
                                                      bf16_t* dx, int ldxo, int accumulate, bf16_t* dres, int ldres) {
     const int cpr = C >> 3, rpb = NT / cpr, col = threadIdx.x % cpr, rl = threadIdx.x / cpr;
-    float mu[8], rs[8], c0[8], c1[8], c2[8];
+    float mu[8], rs[8], c0[8], c1[8], c2[8], ms[8], mh[8];
+    if (MASK == 2) {
+        ldf8(msc + col * 8, ms);
+        ldf8(msh + col * 8, mh);
+    }
     ldf8(smean + col * 8, mu);
     ldf8(srstd + col * 8, rs);
     ldf8(coef + col * 8, c0);
@@ -194,11 +208,12 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_k(const bf16_t* __restrict__ 
         float g[8], v[8], o[8], d[8];
         ld8(dout + row * ldd + col * 8, g);
         ld8(x + row * ldx + col * 8, v);
-        if (relu) ld8(out + row * ldo + col * 8, o);
+        if (MASK == 1) ld8(out + row * ldo + col * 8, o);
         if (accumulate) ld8(dx + row * ldxo + col * 8, d);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            if (relu && !(o[e] > 0.f)) g[e] = 0.f;
+            if (MASK == 2) o[e] = v[e] * ms[e] + mh[e];
+            if (MASK && !(o[e] > 0.f)) g[e] = 0.f;
             const float xh = (v[e] - mu[e]) * rs[e];
             const float r = c0[e] * (g[e] - c1[e] - xh * c2[e]);
             d[e] = accumulate ? d[e] + r : r;
@@ -289,15 +304,23 @@ extern "C" int mde_bn_apply(const void* x, int ldx, const float* scale, const fl
 }
 
 extern "C" int mde_bn_bwd_reduce(const void* dout, int ldd, const void* out, int ldo, const void* x, int ldx,
-                                 const float* save_mean, const float* save_rstd, int64_t M, int C, int relu,
-                                 float* part, void* stream) {
-    MDE_REQUIRE(dout && x && save_mean && save_rstd && part && (!relu || out), "mde_bn_bwd_reduce: null argument");
+                                 const float* save_mean, const float* save_rstd, const float* mask_scale,
+                                 const float* mask_shift, int64_t M, int C, int relu, float* part, void* stream) {
+    const bool recompute = relu && mask_scale && mask_shift;
+    MDE_REQUIRE(dout && x && save_mean && save_rstd && part && (!relu || recompute || out), "mde_bn_bwd_reduce: null argument");
+    MDE_REQUIRE((mask_scale == nullptr) == (mask_shift == nullptr), "mde_bn_bwd_reduce: mask_scale/mask_shift come in pairs");
     if (int rc = check_site("mde_bn_bwd_reduce", M, C)) return rc;
-    MDE_REQUIRE(al16(dout, ldd) && al16(x, ldx) && (!relu || al16(out, ldo)), "mde_bn_bwd_reduce: alignment");
+    MDE_REQUIRE(al16(dout, ldd) && al16(x, ldx) && (!relu || recompute || al16(out, ldo)), "mde_bn_bwd_reduce: alignment");
     int nblk, rows;
     reduce_geometry(M, C, &nblk, &rows);
-    bn_bwd_reduce_k<<<nblk, NT, 0, (hipStream_t)stream>>>((const bf16_t*)dout, ldd, (const bf16_t*)out, ldo,
-                                                         (const bf16_t*)x, ldx, save_mean, save_rstd, M, C, relu, part, rows);
+    hipStream_t st = (hipStream_t)stream;
+    const bf16_t *d = (const bf16_t*)dout, *o = (const bf16_t*)out, *xp = (const bf16_t*)x;
+    if (!relu)
+        bn_bwd_reduce_k<0><<<nblk, NT, 0, st>>>(d, ldd, o, ldo, xp, ldx, save_mean, save_rstd, nullptr, nullptr, M, C, part, rows);
+    else if (recompute)
+        bn_bwd_reduce_k<2><<<nblk, NT, 0, st>>>(d, ldd, o, ldo, xp, ldx, save_mean, save_rstd, mask_scale, mask_shift, M, C, part, rows);
+    else
+        bn_bwd_reduce_k<1><<<nblk, NT, 0, st>>>(d, ldd, o, ldo, xp, ldx, save_mean, save_rstd, nullptr, nullptr, M, C, part, rows);
     MDE_LAUNCH_CHECK("bn_bwd_reduce_k");
     return MDE_OK;
 }
@@ -311,16 +334,27 @@ extern "C" int mde_bn_bwd_finalize(float* part, int64_t M, int C, const float* g
 }
 
 extern "C" int mde_bn_bwd_apply(const void* dout, int ldd, const void* out, int ldo, const void* x, int ldx,
-                                const float* save_mean, const float* save_rstd, const float* coef, int64_t M,
-                                int C, int relu, void* dx, int ldxo, int accumulate_dx, void* dres, int ldres,
-                                void* stream) {
-    MDE_REQUIRE(dout && x && save_mean && save_rstd && coef && dx && (!relu || out), "mde_bn_bwd_apply: null argument");
+                                const float* save_mean, const float* save_rstd, const float* mask_scale,
+                                const float* mask_shift, const float* coef, int64_t M, int C, int relu, void* dx,
+                                int ldxo, int accumulate_dx, void* dres, int ldres, void* stream) {
+    const bool recompute = relu && mask_scale && mask_shift;
+    MDE_REQUIRE(dout && x && save_mean && save_rstd && coef && dx && (!relu || recompute || out), "mde_bn_bwd_apply: null argument");
+    MDE_REQUIRE((mask_scale == nullptr) == (mask_shift == nullptr), "mde_bn_bwd_apply: mask_scale/mask_shift come in pairs");
     if (int rc = check_site("mde_bn_bwd_apply", M, C)) return rc;
-    MDE_REQUIRE(al16(dout, ldd) && al16(x, ldx) && al16(dx, ldxo) && (!relu || al16(out, ldo)) && (!dres || al16(dres, ldres)),
-                "mde_bn_bwd_apply: alignment");
-    bn_bwd_apply_k<<<stream_grid(M, C), NT, 0, (hipStream_t)stream>>>(
-        (const bf16_t*)dout, ldd, (const bf16_t*)out, ldo, (const bf16_t*)x, ldx, save_mean, save_rstd, coef, M, C,
-        relu, (bf16_t*)dx, ldxo, accumulate_dx, (bf16_t*)dres, ldres);
+    MDE_REQUIRE(al16(dout, ldd) && al16(x, ldx) && al16(dx, ldxo) && (!relu || recompute || al16(out, ldo)) &&
+                    (!dres || al16(dres, ldres)), "mde_bn_bwd_apply: alignment");
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = stream_grid(M, C);
+    const bf16_t *d = (const bf16_t*)dout, *o = (const bf16_t*)out, *xp = (const bf16_t*)x;
+    if (!relu)
+        bn_bwd_apply_k<0><<<grid, NT, 0, st>>>(d, ldd, o, ldo, xp, ldx, save_mean, save_rstd, nullptr, nullptr, coef, M, C,
+                                               (bf16_t*)dx, ldxo, accumulate_dx, (bf16_t*)dres, ldres);
+    else if (recompute)
+        bn_bwd_apply_k<2><<<grid, NT, 0, st>>>(d, ldd, o, ldo, xp, ldx, save_mean, save_rstd, mask_scale, mask_shift, coef, M,
+                                               C, (bf16_t*)dx, ldxo, accumulate_dx, (bf16_t*)dres, ldres);
+    else
+        bn_bwd_apply_k<1><<<grid, NT, 0, st>>>(d, ldd, o, ldo, xp, ldx, save_mean, save_rstd, nullptr, nullptr, coef, M, C,
+                                               (bf16_t*)dx, ldxo, accumulate_dx, (bf16_t*)dres, ldres);
     MDE_LAUNCH_CHECK("bn_bwd_apply_k");
     return MDE_OK;
 }

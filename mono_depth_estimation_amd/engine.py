@@ -94,15 +94,18 @@ class BNSite:
         else:
             ops.bn_eval_scale_shift(self.gamma, self.beta, self.rmean, self.rvar, self.eps, self.C, self.scale, self.shift)
 
-    def backward(self, dout, out, x, relu, dx, accumulate=False, dres=None):
-        """g = dout*(out>0 if relu); writes dgamma/dbeta (+=), dx (bf16) and optionally dres = g."""
+    def backward(self, dout, out, x, relu, dx, accumulate=False, dres=None, mask_from_x=False):
+        """g = dout*(out>0 if relu); writes dgamma/dbeta (+=), dx (bf16) and optionally dres = g.
+        mask_from_x: out == relu(x*scale+shift) exactly (no residual), so the mask is recomputed
+        from x with this site's scale/shift and `out` is never read."""
         M, C = x.M, self.C
+        ms, mh = (self.scale, self.shift) if (relu and mask_from_x) else (None, None)
         ops.bn_bwd_reduce(dout, _ld(dout, out), out.t if out is not None else None, out.ld if out is not None else 0,
-                          x.t, x.ld, self.smean, self.srstd, M, C, relu, self.part)
+                          x.t, x.ld, self.smean, self.srstd, M, C, relu, self.part, ms, mh)
         ops.bn_bwd_finalize(self.part, M, C, self.gamma, self.srstd, self.dgamma, self.dbeta, self.coef)
         ops.bn_bwd_apply(dout, _ld(dout, out), out.t if out is not None else None, out.ld if out is not None else 0,
                          x.t, x.ld, self.smean, self.srstd, self.coef, M, C, relu, dx, _ld(dx, x), accumulate,
-                         dres, _ld(dres, x) if dres is not None else 0)
+                         dres, _ld(dres, x) if dres is not None else 0, ms, mh)
 
 
 def _ld(t, like):
@@ -393,7 +396,7 @@ class FCRNEngine:
                 on_progress(L.first_param_offset())
         ops.maxpool_bwd(self.pool.g, self.pool_idx, self.stem_a.g, self.N, self.stem_a.H, self.stem_a.W, 64)
         s = self.stem_site
-        s.backward(self.stem_a.g, self.stem_a, self.stem_c, True, self.stem_c.g)
+        s.backward(self.stem_a.g, self.stem_a, self.stem_c, True, self.stem_c.g, mask_from_x=True)
         ops.stem_conv_wgrad(self.x, self.stem_c.g, self.stem_w.dw)
         if on_progress is not None:
             on_progress(0)
@@ -447,7 +450,7 @@ class ConvBN:
             assert not dres_to.gw, "identity-residual gradient must be the first writer"
             dres = dres_to.g
             dres_to.gw = True
-        self.site.backward(self.out.g, self.out, self.c, self.relu, self.c.g, dres=dres)
+        self.site.backward(self.out.g, self.out, self.c, self.relu, self.c.g, dres=dres, mask_from_x=self.res is None)
         self.c.gw = True
 
     def conv_bwd(self):
@@ -561,7 +564,7 @@ class UpProjLayer:
         c2.bn_bwd()                                                         # d(out) -> d(c2.c)
         self.site_b.backward(c2.out.g, c2.out, self.y_b, True, yg[..., C:])  # join's second site -> d(y55[:, C:])
         c2.conv_bwd()                                                       # -> d(a1), dW(conv2)
-        self.site_u.backward(self.a1.g, self.a1, self.y_u, True, yg[..., :C])
+        self.site_u.backward(self.a1.g, self.a1, self.y_u, True, yg[..., :C], mask_from_x=True)
         ops.conv_wgrad(self.wdesc, x.t, yg, self.w55.dw)
         self.ddesc.accumulate = int(x.gw)
         ops.conv_gemm(self.ddesc, yg, self.w55.wd, x.g)

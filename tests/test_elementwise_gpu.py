@@ -92,9 +92,10 @@ def test_bn_train_forward_backward(N, H, Wd, C, relu, res):
     dgamma, dbeta = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
     dx = torch.empty_like(xd)
     dres = torch.empty_like(xd) if res == 1 else None
-    ops.bn_bwd_reduce(dyd, C, out, C, xd, C, smean, srstd, M, C, relu, part)
+    mk = dict(mask_scale=scale, mask_shift=shift) if (relu and res == 0) else {}   # recomputed mask: never reads `out`
+    ops.bn_bwd_reduce(dyd, C, None if mk else out, C, xd, C, smean, srstd, M, C, relu, part, **mk)
     ops.bn_bwd_finalize(part, M, C, gamma, srstd, dgamma, dbeta, coef)
-    ops.bn_bwd_apply(dyd, C, out, C, xd, C, smean, srstd, coef, M, C, relu, dx, C, dres=dres, ldres=C)
+    ops.bn_bwd_apply(dyd, C, None if mk else out, C, xd, C, smean, srstd, coef, M, C, relu, dx, C, dres=dres, ldres=C, **mk)
     torch.cuda.synchronize()
     _close_bf16(_nchw(dx), x.grad, "bn dx", tol=2.0 ** -7)
     tolp = dict(rtol=2e-2, atol=2e-2 * float(bn.weight.grad.abs().max()))
