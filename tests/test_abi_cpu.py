@@ -1,0 +1,63 @@
+"""CPU-only checks of the C-ABI boundary: the library builds/loads without a GPU, exports every
+symbol include/mde_hip.h declares, the ctypes structs match the C layout, and argument
+validation fails loudly (no compute is launched here)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from mono_depth_estimation_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    return _lib.load()
+
+
+def test_every_declared_symbol_is_exported_and_bound(lib):
+    from mono_depth_estimation_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "mde_hip.h")).read()
+    declared = set(re.findall(r"\b(mde_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.mde_abi_version() == _lib.ABI_VERSION
+    assert lib.mde_stat_slots() == 32
+
+
+def test_struct_layouts_match_header():
+    """sizeof / field offsets as a C compiler lays the header's structs out."""
+    from mono_depth_estimation_amd._lib import ConvDesc, WgradDesc, MAX_TAPS
+    assert MAX_TAPS == 32
+    assert C.sizeof(ConvDesc) == 6 * 4 + 5 * 4 + 3 * 2 * MAX_TAPS + 4 + 3 * 4 + 4 * 4 + 2 * 4
+    assert ConvDesc.dy.offset == 44 and ConvDesc.wtaps_total.offset == 44 + 6 * MAX_TAPS
+    assert C.sizeof(WgradDesc) == 9 * 4 + 2 * 4 + 3 * 4 + 3 * 2 * MAX_TAPS + 3 * 4
+    assert WgradDesc.dy.offset == 56
+
+
+def test_argument_validation_without_a_gpu(lib):
+    from mono_depth_estimation_amd import _lib, ops
+    d = ops.fwd_desc(1, 4, 4, 48, 48, 4 * 4 * 48 * 2, 1, 1, 0, 64, 64)          # C not a multiple of 64
+    rc = lib.mde_conv_gemm(C.byref(d), C.c_void_p(16), C.c_void_p(16), C.c_void_p(16), None, None)
+    assert rc == -1 and b"multiple of 64" in lib.mde_last_error()
+    assert lib.mde_conv_gemm(None, None, None, None, None, None) == -1
+    assert lib.mde_bn_stats(C.c_void_p(16), 10, 12, 12, C.c_void_p(16), None) == -1   # C % 8 != 0
+    assert b"C=12" in lib.mde_last_error()
+    assert lib.mde_head_conv_fwd(C.c_void_p(16), C.c_void_p(16), C.c_void_p(16), 1, 4, 4, 64, 33, None) == -1
+    with pytest.raises(_lib.MdeError):
+        _lib.check(-1, "x")
+
+
+def test_product_has_no_oracle_dependency():
+    """The shipped package must never import the CPU oracle (no fallback path)."""
+    pkg = os.path.join(ROOT, "mono_depth_estimation_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), os.path.join(dirpath, f)
