@@ -35,6 +35,17 @@ def synthetic(n, seed, device):
     return rgb, depth.masked_fill(hole, 0.0)
 
 
+def measured_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the rocprofv3 PMC passes committed under profiles/
+    (counters cannot be read from inside the process; collection + gfx950 FETCH_SIZE x2
+    correction are documented in that file).  None when the file is absent."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")) as f:
+            return round(json.load(f)[kernel]["hbm_bytes_per_launch"])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def host_cores():
     """Cores this process may actually use: affinity mask capped by the cgroup CPU quota
     (the GPU box shows 256 CPUs but grants a 16-core share)."""
@@ -186,7 +197,7 @@ def main():
             out["roofline"] = {
                 "bound": "mfma", "kernel": "conv_gemm_nt (implicit-GEMM conv fwd/dgrad/up-projection, bf16 MFMA)",
                 "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
-                "traffic": None, "launches": n, "avg_launch_us": round(1e6 * sec / max(n, 1), 2),
+                "traffic": measured_traffic("conv_gemm_nt"), "launches": n, "avg_launch_us": round(1e6 * sec / max(n, 1), 2),
                 "avg_launch_gflop": round(fl / max(n, 1) / 1e9, 3),
                 "share_of_step_time": round(sec / dt, 4),
             }
