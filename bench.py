@@ -108,8 +108,10 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
-    if world > 1:
+    use_dist = world > 1 or "RANK" in os.environ          # launched by torch.distributed.run (also with 1 rank)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from mono_depth_estimation_amd import dp, ops
@@ -122,7 +124,7 @@ def main():
     x, tgt = synthetic(args.batch, 1234 + rank, dev)
     eng = net._engine(x)
     store = net._store
-    if world > 1:
+    if use_dist:
         dist.broadcast(store.P, 0)
         dist.broadcast(store.B, 0)
     reducer = dp.FlatGradReducer(store.G, eng.grad_boundaries(), target_bytes=64 << 20)
@@ -140,7 +142,7 @@ def main():
         store.adam_step(lr, 10 * lr, grad_scale=1.0 / world)
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -163,7 +165,7 @@ def main():
     dt = time.perf_counter() - t0
     ops.TIMER = None
     tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt)
     final_loss = float(loss)
@@ -209,7 +211,7 @@ def main():
             log("timing the CPU oracle baseline on %d host cores" % host_cores())
             out["cpu_baseline"] = cpu_baseline(host_cores())
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -17,5 +17,7 @@ for src in *.hip; do
     fi
 done
 for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o $OUT "${objs[@]}"
+$HIPCC --offload-arch=gfx950 -shared -fPIC -Wl,--no-undefined -o $OUT "${objs[@]}"
+# every kernel referenced by a host stub must exist (hipcc can drop a stub silently)
+if nm "$OUT" | grep -q " U .*__device_stub__"; then echo "ERROR: undefined kernel stubs in $OUT" >&2; exit 1; fi
 echo "built $(readlink -f $OUT)"

@@ -255,35 +255,45 @@ __global__ __launch_bounds__(NT, 2) void conv_gemm_nt(const KArgs a) {
         const int wv = __builtin_amdgcn_readfirstlane(wave);
         const int lr = lane >> 3;
         const int k8 = (lane & 7) ^ ((((wv & 1) << 2) + (lr >> 1)) & 7);   // source k-slot of this lane
-        int dx_base[XR], dx_yx[XR], dw_base[WR];
+        // per row: byte offset of the tap-origin pixel and a bitmask of the taps that stay inside
+        // the image, computed once per tile so the K-loop spends ~3 VALU per DMA, not ~9
+        uint32_t dx_base[XR], dx_ok[XR], dw_base[WR];
 #pragma unroll
         for (int q = 0; q < XR; ++q) {
             const int row = (wv + q * NW) * 8 + lr;
-            dx_base[q] = s_inbase[row] + k8 * 8;
-            dx_yx[q] = s_yx[row];
+            dx_base[q] = (uint32_t)(s_inbase[row] + k8 * 8) * 2u;
+            const int yx = s_yx[row];
+            const int iy0 = (int)((uint32_t)yx >> 16), ix0 = yx & 0xFFFF;
+            uint32_t m = 0;
+            for (int t = 0; t < d.ntaps; ++t) {
+                const int dydx = s_tap[2 * MDE_MAX_TAPS + t];
+                const int iy = iy0 + (dydx >> 16), ix = ix0 + (int)(short)(dydx & 0xFFFF);
+                m |= (uint32_t)(((uint32_t)iy < (uint32_t)d.H) & ((uint32_t)ix < (uint32_t)d.W)) << t;
+            }
+            dx_ok[q] = m;
         }
 #pragma unroll
-        for (int q = 0; q < WR; ++q) dw_base[q] = (n0 + (wv + q * NW) * 8 + lr) * wrow_len + k8 * 8;
+        for (int q = 0; q < WR; ++q) dw_base[q] = (uint32_t)((n0 + (wv + q * NW) * 8 + lr) * wrow_len + k8 * 8) * 2u;
         typedef __attribute__((address_space(3))) void* lds_ptr;
         auto issue_dma = [&](int buf) {
-            const int c0 = lcs * BK;
-            const int tapoff = s_tap[ltap] + c0;
-            const int woff = s_tap[MDE_MAX_TAPS + ltap] + c0;
-            const int dydx = s_tap[2 * MDE_MAX_TAPS + ltap];
-            const int tdy = dydx >> 16, tdx = (int)(short)(dydx & 0xFFFF);
+            // per-tap offsets in bytes (LDS broadcast reads)
+            const uint32_t c0b = (uint32_t)(lcs * BK) * 2u;
+            const uint32_t tapoff = (uint32_t)s_tap[ltap] * 2u + c0b;
+            const uint32_t woff = (uint32_t)s_tap[MDE_MAX_TAPS + ltap] * 2u + c0b;
+            const uint32_t bit = 1u << ltap;
             char* xbuf = smem + buf * BUF_BYTES + wv * 1024;
 #pragma unroll
             for (int q = 0; q < XR; ++q) {
-                const int iy = (int)((uint32_t)dx_yx[q] >> 16) + tdy;
-                const int ix = (dx_yx[q] & 0xFFFF) + tdx;
-                const bool ok = ((uint32_t)iy < (uint32_t)d.H) & ((uint32_t)ix < (uint32_t)d.W);
-                const uint32_t off = ok ? (uint32_t)(dx_base[q] + tapoff) * 2u : MDE_OOB_OFFSET;
+                const uint32_t off = (dx_ok[q] & bit) ? dx_base[q] + tapoff : MDE_OOB_OFFSET;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr)(xbuf + q * NW * 1024), 16, off, 0, 0, 0);
             }
 #pragma unroll
-            for (int q = 0; q < WR; ++q)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr)(xbuf + XT_BYTES + q * NW * 1024), 16,
-                                                         (uint32_t)(dw_base[q] + woff) * 2u, 0, 0, 0);
+            for (int q = 0; q < WR; ++q) {
+                // (named temporary on purpose: with the bare sum as the builtin's argument hipcc 7.2's
+                //  host pass drops this kernel's stub without a diagnostic; build.sh checks for that)
+                const uint32_t offw = dw_base[q] + woff;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr)(xbuf + XT_BYTES + q * NW * 1024), 16, offw, 0, 0, 0);
+            }
             if (++lcs == csteps) { lcs = 0; ++ltap; }
         };
         constexpr int IPS = XR + WR;          // DMA instructions per wave per K-step

@@ -9,6 +9,8 @@ backward has passed the bucket's first element, overlapping the exchange with th
 backward.  Few, large messages: xGMI is point-to-point, a ring is bound by one link.
 The averaging (1/world) is folded into the optimiser's grad_scale, not a separate pass.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -38,6 +40,9 @@ class FlatGradReducer:
     def __init__(self, flat, boundaries, target_bytes=64 << 20, group=None):
         self.flat, self.group = flat, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # MDE_DP_FORCE=1: run the collectives even with one rank (rehearses the RCCL / stream / event
+        # path on a single GPU; an all-reduce over one rank is the identity)
+        self.active = self.world > 1 or (dist.is_initialized() and os.environ.get("MDE_DP_FORCE") == "1")
         self.buckets = make_buckets(flat.numel(), boundaries, target_bytes, flat.element_size())
         self.stream = torch.cuda.Stream() if flat.is_cuda else None
         self.reset()
@@ -57,14 +62,14 @@ class FlatGradReducer:
             self.works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def ready(self, offset):
-        if self.world == 1:
+        if not self.active:
             return
         while self.next < len(self.buckets) and self.buckets[self.next][0] >= offset:
             self._launch(*self.buckets[self.next])
             self.next += 1
 
     def finish(self):
-        if self.world > 1:
+        if self.active:
             self.ready(0)
             for w in self.works:
                 w.wait()
