@@ -2,8 +2,8 @@
 //   stem  7x7/2, 3 -> 64   on the raw fp32 NCHW image (torchvision conv1, used at reference
 //         network/FCRN.py:308,353)  — forward + weight gradient (no input gradient needed)
 //   head  3x3,  Cin -> Cout<=32  with fp32 output (conv3, FCRN.py:340,368) — fwd, dgrad, wgrad
-// Both are a few % of the network's MACs; they run on the vector ALUs in fp32 with
-// LDS-staged operands and fully coalesced global traffic.
+// The stem runs on MFMA with its im2col fragments built on the fly from an LDS image patch; the
+// head runs on the vector ALUs in fp32.  Both use LDS-staged operands and coalesced global traffic.
 #include "mde_common.h"
 
 namespace {
@@ -26,15 +26,42 @@ __device__ __forceinline__ void stem_load_patch(float* patch, const float* __res
     }
 }
 
-__global__ __launch_bounds__(NT) void stem_fwd_k(const float* __restrict__ x, const float* __restrict__ w,
-                                                 bf16_t* __restrict__ out, int N, int H, int W, int OH, int OW) {
-    __shared__ __attribute__((aligned(16))) float wT[SK * 64];   // [k][ch]
+// MFMA formulation.  K = 147 (k = (kh*7+kw)*3+c, the OHWI weight order) padded to 160 = 5 steps of
+// v_mfma_f32_16x16x32_bf16.  A operand = weights (rows = 64 output channels, register resident for
+// the whole persistent workgroup), B operand = pixels: its fragments are built on the fly from the
+// fp32 image patch in LDS (lane (px = l&15, g = l>>4) needs patch[c][kh][2*px + kw] for the 8 k's
+// of its group; the 40 LDS offsets are per-lane constants).  The image is split into bf16 hi + lo
+// parts (two MFMAs) so the stem keeps ~fp32 accuracy on the raw input; weights are bf16.
+constexpr int SKP = 160;
+constexpr int SKS = SKP / 32;      // 5 MFMA k-steps
+
+__device__ __forceinline__ int stem_patch_off(int k) {   // k -> offset of tap (kh,kw), channel c in the patch
+    const int c = k % 3, kw = (k / 3) % 7, kh = k / 21;
+    return (c * 7 + kh) * SPW + kw;
+}
+
+__device__ __forceinline__ void split_bf16(float v, bf16_t& hi, bf16_t& lo) {
+    hi = (bf16_t)v;
+    lo = (bf16_t)(v - (float)hi);
+}
+
+__global__ __launch_bounds__(NT, 2) void stem_fwd_k(const float* __restrict__ x, const float* __restrict__ w,
+                                                    bf16_t* __restrict__ out, int N, int H, int W, int OH, int OW) {
     __shared__ float patch[3 * 7 * SPW];
-    for (int i = threadIdx.x; i < 64 * SK; i += NT) {
-        const int ch = i / SK, k = i % SK;
-        wT[k * 64 + ch] = w[i];
-    }
-    const int px = threadIdx.x & 63, cg = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lr = lane & 15, lg = lane >> 4;
+    // A fragments: weights of channels cb*16 + lr, k = ks*32 + 8*lg + j
+    bf16x8_t wa[4][SKS];
+    int poff[SKS][8];
+#pragma unroll
+    for (int ks = 0; ks < SKS; ++ks)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = ks * 32 + 8 * lg + j;
+            poff[ks][j] = k < SK ? stem_patch_off(k) : -1;
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) wa[cb][ks][j] = (bf16_t)(k < SK ? w[(cb * 16 + lr) * SK + k] : 0.f);
+        }
     const int tiles_x = (OW + STILE - 1) / STILE;
     const int64_t ntiles = (int64_t)N * OH * tiles_x;
     for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
@@ -45,53 +72,69 @@ __global__ __launch_bounds__(NT) void stem_fwd_k(const float* __restrict__ x, co
         __syncthreads();
         stem_load_patch(patch, x, n, oy, ox0, H, W);
         __syncthreads();
-        float acc[16];
+        const int px = wave * 16 + lr;            // this lane's pixel inside the 64-pixel tile
+        f32x4_t acc[4];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-        for (int kh = 0; kh < 7; ++kh)
+        for (int cb = 0; cb < 4; ++cb) acc[cb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int kw = 0; kw < 7; ++kw)
+        for (int ks = 0; ks < SKS; ++ks) {
+            bf16x8_t bh, bl;
 #pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    const float v = patch[(c * 7 + kh) * SPW + 2 * px + kw];
-                    const float* wr = wT + ((kh * 7 + kw) * 3 + c) * 64 + cg * 16;
+            for (int j = 0; j < 8; ++j) {
+                const float v = poff[ks][j] >= 0 ? patch[poff[ks][j] + 2 * px] : 0.f;
+                bf16_t hi, lo;
+                split_bf16(v, hi, lo);
+                bh[j] = hi;
+                bl[j] = lo;
+            }
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const f32x4_t ww = *reinterpret_cast<const f32x4_t*>(wr + q * 4);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) acc[q * 4 + e] += v * ww[e];
-                    }
-                }
+            for (int cb = 0; cb < 4; ++cb) {
+                acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[cb][ks], bh, acc[cb], 0, 0, 0);
+                acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[cb][ks], bl, acc[cb], 0, 0, 0);
+            }
+        }
+        // D: col = pixel (lane&15), rows = channels cb*16 + lg*4 + r
         if (ox0 + px < OW) {
-            bf16_t* o = out + ((((int64_t)n * OH + oy) * OW) + ox0 + px) * 64 + cg * 16;
-            bf16x8_t a, b;
+            bf16_t* o = out + ((((int64_t)n * OH + oy) * OW) + ox0 + px) * 64 + lg * 4;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { a[e] = (bf16_t)acc[e]; b[e] = (bf16_t)acc[8 + e]; }
-            *reinterpret_cast<bf16x8_t*>(o) = a;
-            *reinterpret_cast<bf16x8_t*>(o + 8) = b;
+            for (int cb = 0; cb < 4; ++cb) {
+                bf16x4_t v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = (bf16_t)acc[cb][r];
+                *reinterpret_cast<bf16x4_t*>(o + cb * 16) = v;
+            }
         }
     }
 }
 
-// dw[ch][k] += sum_px dY[px][ch] * patch[px][k].  Thread = (channel pair, 1/8 of the k range).
-__global__ __launch_bounds__(NT) void stem_wgrad_k(const float* __restrict__ x, const bf16_t* __restrict__ dout,
-                                                   float* __restrict__ dw, int N, int H, int W, int OH, int OW) {
+// dw[ch][k] += sum_px dY[px][ch] * patch[px][k]:  A[ch][px] comes from the [pixel][channel] dY tile
+// by transposed LDS reads (as in conv_wgrad.hip), B[px][k] from the patch (hi + lo parts).
+// Wave w owns the k-column fragments {w, w+4, w+8}; all 4 channel fragments.
+__device__ __forceinline__ int stem_dy_off(int row, int ch) {   // [64 px][64 ch] bf16, 128-B rows, XOR swizzle
+    return row * 128 + 16 * (ch ^ ((((row >> 1) & 1) | (((row >> 3) & 1) << 1)) << 1));
+}
+
+__global__ __launch_bounds__(NT, 2) void stem_wgrad_k(const float* __restrict__ x, const bf16_t* __restrict__ dout,
+                                                      float* __restrict__ dw, int N, int H, int W, int OH, int OW) {
     __shared__ float patch[3 * 7 * SPW];
-    __shared__ float dy[STILE * 64];   // [px][ch]
-    const int cp = threadIdx.x & 31, kq = threadIdx.x >> 5;   // channels cp, cp+32; k = kq + 8*i
-    constexpr int NK = (SK + 7) / 8;   // 19
-    int poff[NK];
+    __shared__ __attribute__((aligned(16))) char dyt[STILE * 128];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lr = lane & 15, lg = lane >> 4;
+    constexpr int NF = 3;                    // k-column fragments per wave (10 in total: wave, wave+4, wave+8)
+    int poff[NF];
 #pragma unroll
-    for (int i = 0; i < NK; ++i) {
-        const int k = kq + 8 * i;
-        const int c = k % 3, kw = (k / 3) % 7, kh = k / 21;
-        poff[i] = k < SK ? (c * 7 + kh) * SPW + kw : 0;
+    for (int f = 0; f < NF; ++f) {
+        const int k = (wave + 4 * f) * 16 + lr;
+        poff[f] = (wave + 4 * f < SKP / 16 && k < SK) ? stem_patch_off(k) : -1;
     }
-    float a0[NK], a1[NK];
+    f32x4_t acc[4][NF];
 #pragma unroll
-    for (int i = 0; i < NK; ++i) a0[i] = a1[i] = 0.f;
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+        for (int f = 0; f < NF; ++f) acc[cb][f] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     const int tiles_x = (OW + STILE - 1) / STILE;
     const int64_t ntiles = (int64_t)N * OH * tiles_x;
+    typedef __attribute__((address_space(3))) s16x4_t* lds_ptr;
     for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
         const int tx = (int)(t % tiles_x);
         const int oy = (int)((t / tiles_x) % OH);
@@ -99,34 +142,59 @@ __global__ __launch_bounds__(NT) void stem_wgrad_k(const float* __restrict__ x, 
         const int ox0 = tx * STILE;
         __syncthreads();
         stem_load_patch(patch, x, n, oy, ox0, H, W);
-        for (int i = threadIdx.x; i < STILE * 8; i += NT) {   // 8 chunks of 8 channels per pixel
+        for (int i = threadIdx.x; i < STILE * 8; i += NT) {   // dY tile: 64 px x 8 chunks of 8 channels
             const int p = i >> 3, ch8 = i & 7;
-            bf16x8_t g;
+            i32x4_t g = {0, 0, 0, 0};
             if (ox0 + p < OW)
-                g = *reinterpret_cast<const bf16x8_t*>(dout + ((((int64_t)n * OH + oy) * OW) + ox0 + p) * 64 + ch8 * 8);
-            else
-                for (int e = 0; e < 8; ++e) g[e] = (bf16_t)0.f;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) dy[p * 64 + ch8 * 8 + e] = (float)g[e];
+                g = *reinterpret_cast<const i32x4_t*>(dout + ((((int64_t)n * OH + oy) * OW) + ox0 + p) * 64 + ch8 * 8);
+            *reinterpret_cast<i32x4_t*>(dyt + stem_dy_off(p, ch8)) = g;
         }
         __syncthreads();
-        for (int p = 0; p < STILE; ++p) {
-            const float g0 = dy[p * 64 + cp], g1 = dy[p * 64 + cp + 32];
 #pragma unroll
-            for (int i = 0; i < NK; ++i) {
-                const float v = patch[poff[i] + 2 * p];
-                a0[i] += g0 * v;
-                a1[i] += g1 * v;
+        for (int kk = 0; kk < STILE; kk += 32) {
+            // A fragments (channels cb*16 + lr as rows, pixels kk + 8*lg + j as k): two transposed reads each
+            bf16x8_t fa[4];
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) {
+                const int q = lr >> 2, pp = lr & 3;
+                const int row = kk + 8 * lg + q, ch = cb * 2 + (pp >> 1), sub = (pp & 1) * 8;
+                const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(uintptr_t)(uint32_t)(uintptr_t)(dyt + stem_dy_off(row, ch) + sub));
+                const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(uintptr_t)(uint32_t)(uintptr_t)(dyt + stem_dy_off(row + 4, ch) + sub));
+                union { struct { s16x4_t a, b; } s; bf16x8_t v; } u;
+                u.s.a = lo;
+                u.s.b = hi;
+                fa[cb] = u.v;
+            }
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+                if (wave + 4 * f >= SKP / 16) continue;      // wave-uniform
+                bf16x8_t bh, bl;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int px = kk + 8 * lg + j;
+                    const float v = poff[f] >= 0 ? patch[poff[f] + 2 * px] : 0.f;
+                    bf16_t h, l;
+                    split_bf16(v, h, l);
+                    bh[j] = h;
+                    bl[j] = l;
+                }
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb) {
+                    acc[cb][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[cb], bh, acc[cb][f], 0, 0, 0);
+                    acc[cb][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[cb], bl, acc[cb][f], 0, 0, 0);
+                }
             }
         }
     }
+    // D: col = k index (lane&15), rows = channels cb*16 + lg*4 + r
 #pragma unroll
-    for (int i = 0; i < NK; ++i) {
-        const int k = kq + 8 * i;
-        if (k < SK) {
-            atomicAdd(dw + cp * SK + k, a0[i]);
-            atomicAdd(dw + (cp + 32) * SK + k, a1[i]);
-        }
+    for (int f = 0; f < NF; ++f) {
+        const int k = (wave + 4 * f) * 16 + lr;
+        if (wave + 4 * f >= SKP / 16 || k >= SK) continue;
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) atomicAdd(dw + (cb * 16 + lg * 4 + r) * SK + k, acc[cb][f][r]);
     }
 }
 

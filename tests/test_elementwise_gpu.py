@@ -259,7 +259,9 @@ def test_cast_and_pack():
 def test_stem_conv(N, H, Wd):
     from mono_depth_estimation_amd import ops
     x = W.uniform(14, "x", (N, 3, H, Wd))
-    w = W.normal(14, "w", (64, 3, 7, 7), (2.0 / (49 * 64)) ** 0.5).requires_grad_(True)
+    # the kernel multiplies bf16 weights (as every MFMA conv here) with the image split into
+    # bf16 hi+lo parts (~fp32): the reference uses bf16-representable weights and the fp32 image
+    w = _bf(W.normal(14, "w", (64, 3, 7, 7), (2.0 / (49 * 64)) ** 0.5)).requires_grad_(True)
     y = F.conv2d(x, w, stride=2, padding=3)
     dy = _bf(W.normal(14, "dy", tuple(y.shape)))
     y.backward(dy)

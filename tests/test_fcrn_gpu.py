@@ -145,9 +145,11 @@ def test_train_loss_and_running_stats(setup, golden):
     print("train silog hip %.5f reference %.5f" % (float(loss), float(g["train_silog"])))
     assert abs(float(loss) - float(g["train_silog"])) <= 1e-2 * float(g["train_silog"])
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in hip.parameters())
-    # first BN sees only the (fp32) stem conv: running stats after one step match tightly
-    assert torch.allclose(hip.bn1.running_mean.cpu(), torch.from_numpy(g["after_bn1_running_mean"]), rtol=1e-3, atol=1e-5)
-    assert torch.allclose(hip.bn1.running_var.cpu(), torch.from_numpy(g["after_bn1_running_var"]), rtol=1e-3, atol=1e-6)
+    # first BN sees only the stem conv (bf16 weights, ~fp32 image): running stats after one step
+    # match the reference to bf16 weight-rounding level
+    rm, rv = torch.from_numpy(g["after_bn1_running_mean"]), torch.from_numpy(g["after_bn1_running_var"])
+    assert torch.allclose(hip.bn1.running_mean.cpu(), rm, rtol=2e-2, atol=2e-3 * float(rv.max().sqrt()))
+    assert torch.allclose(hip.bn1.running_var.cpu(), rv, rtol=2e-2, atol=1e-6)
     assert int(hip.bn1.num_batches_tracked) == int(cal["bn1.num_batches_tracked"]) + 1
     assert int(hip.layer4[2].bn3.num_batches_tracked) == int(cal["layer4.2.bn3.num_batches_tracked"]) + 1
 
