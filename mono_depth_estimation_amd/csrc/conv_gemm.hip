@@ -32,9 +32,20 @@
 #include "mde_common.h"
 
 // MDE_ABLATE (timing-only diagnostic builds, results are wrong): 1 = no global loads in the
-// K-loop, 2 = also no LDS staging writes, 3 = no MFMAs, 4 = no barriers in the K-loop.
+// K-loop, 2 = also no LDS staging writes, 3 = no MFMAs, 4 = no barriers in the K-loop (register
+// path), 5 = no LDS-DMA in the K-loop (DMA path: LDS reads + MFMA + barrier only).
 #ifndef MDE_ABLATE
 #define MDE_ABLATE 0
+#endif
+// Schedule knobs of the DMA loop, A/B-tested with tools/conv_microbench.py (M=153600 N=256 K=2304):
+//   8-wave 256x256: issue the next tile's DMAs BETWEEN the two MFMA halves of a K-step (+8 %) and
+//   s_setprio(1) around each MFMA cluster (+4 %), together 842 -> 921-937 TFLOP/s;
+//   4-wave 128x128 (two workgroups per CU): mid-step issue -6 %, setprio neutral -> both off.
+#ifndef MDE_DMA_MID
+#define MDE_DMA_MID (NT == 512)
+#endif
+#ifndef MDE_SETPRIO
+#define MDE_SETPRIO (NT == 512)
 #endif
 
 namespace {
@@ -209,33 +220,35 @@ __global__ __launch_bounds__(NT, 2) void conv_gemm_nt(const KArgs a) {
 #pragma unroll
         for (int p = 0; p < WP; ++p) *reinterpret_cast<i32x4_t*>(wbuf + st_off[p]) = wr[p];
     };
-    auto compute = [&](int buf) {
+    auto compute_half = [&](int buf, int kb) {
         const char* xbuf = smem + buf * BUF_BYTES + wp * (PF * 2048);
         const char* wbuf = smem + buf * BUF_BYTES + XT_BYTES + wc * (CF * 2048);
+        bf16x8_t fa[CF], fb[PF];
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-            bf16x8_t fa[CF], fb[PF];
+        for (int i = 0; i < CF; ++i)
+            fa[i] = *reinterpret_cast<const bf16x8_t*>(wbuf + i * 2048 + rd_off[kb]);
 #pragma unroll
-            for (int i = 0; i < CF; ++i)
-                fa[i] = *reinterpret_cast<const bf16x8_t*>(wbuf + i * 2048 + rd_off[kb]);
-#pragma unroll
-            for (int j = 0; j < PF; ++j)
-                fb[j] = *reinterpret_cast<const bf16x8_t*>(xbuf + j * 2048 + rd_off[kb]);
+        for (int j = 0; j < PF; ++j)
+            fb[j] = *reinterpret_cast<const bf16x8_t*>(xbuf + j * 2048 + rd_off[kb]);
 #if MDE_ABLATE == 3
 #pragma unroll
-            for (int i = 0; i < CF; ++i) asm volatile("" ::"v"(fa[i]));
+        for (int i = 0; i < CF; ++i) asm volatile("" ::"v"(fa[i]));
 #pragma unroll
-            for (int j = 0; j < PF; ++j) asm volatile("" ::"v"(fb[j]));
+        for (int j = 0; j < PF; ++j) asm volatile("" ::"v"(fb[j]));
 #else
+        if constexpr (MDE_SETPRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-            for (int i = 0; i < CF; ++i)
+        for (int i = 0; i < CF; ++i)
 #pragma unroll
-                for (int j = 0; j < PF; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < PF; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        if constexpr (MDE_SETPRIO) __builtin_amdgcn_s_setprio(0);
 #endif
-        }
     };
-
+    auto compute = [&](int buf) {
+        compute_half(buf, 0);
+        compute_half(buf, 1);
+    };
 #if MDE_ABLATE == 1 || MDE_ABLATE == 2
 #define LOOP_LOADS(...)
 #else
@@ -310,8 +323,20 @@ __global__ __launch_bounds__(NT, 2) void conv_gemm_nt(const KArgs a) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();     // every wave's DMA of step s is in; everyone left step s-1
             __builtin_amdgcn_sched_barrier(0);
-            if (s + DIST < nsteps) { issue_dma(lbuf); lbuf = lbuf + 1 == NBUF ? 0 : lbuf + 1; }
-            compute(cbuf);
+            if constexpr (MDE_DMA_MID) {
+                compute_half(cbuf, 0);            // reads -> MFMAs start right behind the barrier ...
+                __builtin_amdgcn_sched_barrier(0);
+#if MDE_ABLATE != 5
+                if (s + DIST < nsteps) { issue_dma(lbuf); lbuf = lbuf + 1 == NBUF ? 0 : lbuf + 1; }   // ... DMA issue under them
+#endif
+                __builtin_amdgcn_sched_barrier(0);
+                compute_half(cbuf, 1);
+            } else {
+#if MDE_ABLATE != 5
+                if (s + DIST < nsteps) { issue_dma(lbuf); lbuf = lbuf + 1 == NBUF ? 0 : lbuf + 1; }
+#endif
+                compute(cbuf);
+            }
             cbuf = cbuf + 1 == NBUF ? 0 : cbuf + 1;
         }
         __syncthreads();                      // staging ring is free for the epilogue
@@ -483,11 +508,19 @@ int pick_and_launch(KArgs& ka, int64_t M, hipStream_t st) {
     }
     const int n = ka.d.ncols;
     if (n <= 64) return reg ? launch<128, 64, 256, false, 2>(ka, M, st) : launch<128, 64, 256, true, 3>(ka, M, st);
-    const int64_t t256 = (int64_t)mde_cdiv(M, 256) * mde_cdiv(n, 256), t128 = (int64_t)mde_cdiv(M, 256) * mde_cdiv(n, 128);
-    // measured (tools/conv_microbench.py): two independent 4-wave 128x128 groups per CU beat one
-    // 8-wave 256x128 group; 256x256 pays only when its grid still covers the chip > 2x.
-    (void)t128;
-    if (forced == 1 || (forced == 0 && n >= 256 && t256 >= 560))
+    // Tile choice by a rounds model fitted to in-network timings: a CU runs either one
+    // 8-wave 256x256 workgroup (about 1.15x the per-flop rate) or two 4-wave 128x128 workgroups;
+    // what decides is the tail: rounds = ceil(tiles / slots).  256x128 never won.
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+    }
+    const int64_t t256 = (int64_t)mde_cdiv(M, 256) * mde_cdiv(n, 256), t128 = (int64_t)mde_cdiv(M, 128) * mde_cdiv(n, 128);
+    const int64_t r256 = (t256 + cus - 1) / cus, r128 = (t128 + 2 * cus - 1) / (2 * cus);
+    const bool big = n >= 256 && r256 * 200 < r128 * 115;      // r256 * 65536 / 1.15  <  r128 * 2 * 16384
+    if (forced == 1 || (forced == 0 && big))
         return reg ? launch<256, 256, 512, false, 2>(ka, M, st) : launch<256, 256, 512, true, 2>(ka, M, st);
     if (forced == 2)
         return reg ? launch<256, 128, 512, false, 2>(ka, M, st) : launch<256, 128, 512, true, 3>(ka, M, st);
