@@ -502,7 +502,7 @@ int pick_and_launch(KArgs& ka, int64_t M, hipStream_t st) {
     static int forced = -1, reg = 0;
     if (forced < 0) {
         const char* e = getenv("MDE_CONV_TILE");
-        forced = !e ? 0 : !strcmp(e, "256x256") ? 1 : !strcmp(e, "256x128") ? 2 : !strcmp(e, "128x128") ? 3 : 0;
+        forced = !e ? 0 : !strcmp(e, "256x256") ? 1 : !strcmp(e, "256x128") ? 2 : !strcmp(e, "128x128") ? 3 : !strcmp(e, "128x128x3") ? 4 : 0;
         const char* q = getenv("MDE_CONV_PATH");
         reg = q && !strcmp(q, "reg");
     }
@@ -522,6 +522,7 @@ int pick_and_launch(KArgs& ka, int64_t M, hipStream_t st) {
     const bool big = n >= 256 && r256 * 200 < r128 * 115;      // r256 * 65536 / 1.15  <  r128 * 2 * 16384
     if (forced == 1 || (forced == 0 && big))
         return reg ? launch<256, 256, 512, false, 2>(ka, M, st) : launch<256, 256, 512, true, 2>(ka, M, st);
+    if (forced == 4) return launch<128, 128, 256, true, 3>(ka, M, st);
     if (forced == 2)
         return reg ? launch<256, 128, 512, false, 2>(ka, M, st) : launch<256, 128, 512, true, 3>(ka, M, st);
     return reg ? launch<128, 128, 256, false, 2>(ka, M, st) : launch<128, 128, 256, true, 2>(ka, M, st);

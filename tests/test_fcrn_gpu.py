@@ -268,3 +268,54 @@ def test_torch_optimizer_drop_in(setup):
         losses.append(float(loss))
     print("losses", losses)
     assert np.isfinite(losses).all() and losses[-1] < losses[0]
+
+
+def test_multichannel_output_and_shape_switching():
+    """out_channels > 1 (the reference default is 20), and one module serving two input shapes
+    (train batch / validation batch) from the same flat parameter store."""
+    from mono_depth_estimation_amd.network import FCRN
+    size = (64, 96)
+    ora = ofcrn.FCRNOracle(50, size, out_channels=3)
+    W.fcrn_conditioned_state(ora, 9)
+    rgb2, _ = W.synthetic_batch(9, 2, *size)
+    rgb1, _ = W.synthetic_batch(10, 1, *size)
+    W.calibrate_running_stats(ora, rgb2)
+    hip = FCRN.ResNet(layers=50, output_size=size, out_channels=3, pretrained=False)
+    hip.load_state_dict(ora.state_dict())
+    hip = hip.cuda().eval()
+    ora.eval()
+    with torch.no_grad():
+        for x in (rgb2, rgb1, rgb2):
+            y, ref = hip(x.cuda()), ora(x)
+            assert y.shape == ref.shape == (x.shape[0], 3, *size)
+            d = (y.cpu() - ref).abs()
+            assert d.max() <= 2e-2 and d.mean() <= 3e-3, (float(d.max()), float(d.mean()))
+    assert len(hip._engines) == 2 and hip._store.storage_is_current()
+    # gradients flow for every output channel
+    hip.train()
+    y = hip(rgb2.cuda())
+    y[:, 2].sum().backward()
+    assert float(hip.conv3.weight.grad[2].abs().sum()) > 0 and float(hip.conv3.weight.grad[0].abs().sum()) == 0
+
+
+def test_state_dict_round_trip(setup):
+    """Parameters are views of flat storage (conv weights channels_last): saving and loading a
+    state_dict must preserve values and keep the views attached."""
+    import io
+    hip, _, sd, rgb, _, _ = setup
+    hip.load_state_dict(sd)
+    hip.eval()
+    with torch.no_grad():
+        y0 = hip(rgb.cuda()).clone()
+    buf = io.BytesIO()
+    torch.save(hip.state_dict(), buf)
+    buf.seek(0)
+    loaded = torch.load(buf)
+    assert list(loaded.keys()) == list(sd.keys())
+    for k in sd:
+        assert torch.equal(loaded[k].cpu(), sd[k]) or k.endswith("num_batches_tracked"), k
+    hip.load_state_dict({k: torch.zeros_like(v) if v.dtype.is_floating_point else v for k, v in loaded.items()})
+    hip.load_state_dict(loaded)
+    assert hip._store.storage_is_current()
+    with torch.no_grad():
+        assert torch.equal(hip(rgb.cuda()), y0)
