@@ -13,6 +13,8 @@
 // network/FCRN.py:180-188,334 and the torchvision Bottleneck convs) including the
 // up-projection 5x5, whose zero-stuffed input (FCRN.py:31-44) becomes a stride-2 gather on
 // the dY side.
+#include <stdlib.h>
+
 #include "mde_common.h"
 
 namespace {
@@ -63,7 +65,10 @@ __device__ __forceinline__ bf16x8_t read_frag_tr(const char* tile, int k0, int c
 }
 
 // GA: the gathered tensor supplies the A operand (rows of dw); otherwise the direct one does.
-template <int BA, int BB, bool GA>
+// DMA: tiles are filled by LDS-DMA (buffer_load ... lds; one wave-instruction = 1 KiB = 4 rows x 256 B
+// or 8 rows x 128 B) instead of VGPR staging + ds_write; the destination is lane-linear, so the XOR
+// chunk swizzle of tile_off<> is applied to the SOURCE chunk each lane fetches.
+template <int BA, int BB, bool GA, bool DMA>
 __global__ __launch_bounds__(NT, 2) void conv_wgrad_tn(const KArgs a) {
     constexpr int FA = BA / 32, FB = BB / 32;      // 16-wide fragments per wave along rows / cols
     constexpr int AT_BYTES = BKP * BA * 2, BT_BYTES = BKP * BB * 2;
@@ -109,13 +114,12 @@ __global__ __launch_bounds__(NT, 2) void conv_wgrad_tn(const KArgs a) {
         return m < kend ? (uint32_t)(m * d.ld_d + c) * 2u : MDE_OOB_OFFSET;
     };
     auto gathered_off = [&](int m, int c) -> uint32_t {
-        if (m >= kend) return MDE_OOB_OFFSET;
         const uint32_t n = mde_fastdiv((uint32_t)m, (uint32_t)(d.GH * d.GW), a.inv_ghw);
         const uint32_t rem = (uint32_t)m - n * (uint32_t)(d.GH * d.GW);
         const uint32_t gy = mde_fastdiv(rem, (uint32_t)d.GW, a.inv_gw);
         const uint32_t gx = rem - gy * (uint32_t)d.GW;
         const int iy = (int)gy * d.sy + tdy, ix = (int)gx * d.sx + tdx;
-        const bool ok = ((uint32_t)iy < (uint32_t)d.H) & ((uint32_t)ix < (uint32_t)d.W);
+        const bool ok = (m < kend) & ((uint32_t)iy < (uint32_t)d.H) & ((uint32_t)ix < (uint32_t)d.W);
         return ok ? (uint32_t)((((int)n * d.H + iy) * d.W + ix) * d.ld_g + c) * 2u : MDE_OOB_OFFSET;
     };
 
@@ -150,14 +154,7 @@ __global__ __launch_bounds__(NT, 2) void conv_wgrad_tn(const KArgs a) {
 #pragma unroll
         for (int j = 0; j < FB; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    issue_loads(0);
-    stage_write(0);
-    __syncthreads();
-
-    for (int s = 0; s < nsteps; ++s) {
-        const int buf = s & 1;
-        const bool more = s + 1 < nsteps;
-        if (more) issue_loads(s + 1);
+    auto compute = [&](int buf) {
         const char* at = smem + buf * BUF_BYTES;
         const char* bt = at + AT_BYTES;
 #pragma unroll
@@ -173,8 +170,71 @@ __global__ __launch_bounds__(NT, 2) void conv_wgrad_tn(const KArgs a) {
                 for (int j = 0; j < FB; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
         }
-        if (more) stage_write(buf ^ 1);
+    };
+
+    if constexpr (DMA) {
+        constexpr int RPI_A = 1024 / (BA * 2), RPI_B = 1024 / (BB * 2);   // tile rows per DMA piece (4 or 8)
+        constexpr int QA = BKP / RPI_A / 4, QB = BKP / RPI_B / 4;         // pieces per wave per K-step
+        const int wv = __builtin_amdgcn_readfirstlane(wave);
+        // this lane's tile-row inside a piece and the source chunk that lands at its lane-linear slot
+        const int a_lr = lane / CPR_A, b_lr = lane / CPR_B;
+        int a_sw, b_sw;
+        if constexpr (BA == 128) a_sw = (a_lr << 2) | (wv & 3); else a_sw = (((a_lr >> 1) & 1) | ((wv & 1) << 1)) << 1;
+        if constexpr (BB == 128) b_sw = (b_lr << 2) | (wv & 3); else b_sw = (((b_lr >> 1) & 1) | ((wv & 1) << 1)) << 1;
+        const int a_cs = row0 + ((lane % CPR_A) ^ a_sw) * 8, b_cs = col0 + ((lane % CPR_B) ^ b_sw) * 8;
+        typedef __attribute__((address_space(3))) void* lds_ptr;
+        // Gathered-operand addressing: the 64 pixels of a K-step are decoded ONCE per workgroup (one
+        // wave, one pixel per lane, two steps ahead, waves taking turns) into s_goff[step&1][64] =
+        // byte offset of the pixel's channel 0, or an out-of-range offset.  Decoding per lane and per
+        // DMA made this loop VALU-bound (~170 VALU per wave per K-step against 32 MFMAs).
+        uint32_t* s_goff = reinterpret_cast<uint32_t*>(smem + 2 * BUF_BYTES);
+        auto decode_step = [&](int s) {
+            const uint32_t o = gathered_off(kbeg + s * BKP + lane, 0);
+            s_goff[(s & 1) * BKP + lane] = o;
+        };
+        auto issue_dma = [&](int s, int buf) {
+            const int mb = kbeg + s * BKP;
+            char* at = smem + buf * BUF_BYTES + wv * 1024;
+            const uint32_t* go = s_goff + (s & 1) * BKP;
+#pragma unroll
+            for (int q = 0; q < QA; ++q) {
+                const int r = (wv + 4 * q) * RPI_A + a_lr;
+                // (an out-of-range pixel stays out of range after adding the small channel offset)
+                const uint32_t off = GA ? go[r] + (uint32_t)a_cs * 2u : direct_off(mb + r, a_cs);
+                if (GA) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_g, (lds_ptr)(at + q * 4096), 16, off, 0, 0, 0);
+                else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_d, (lds_ptr)(at + q * 4096), 16, off, 0, 0, 0);
+            }
+#pragma unroll
+            for (int q = 0; q < QB; ++q) {
+                const int r = (wv + 4 * q) * RPI_B + b_lr;
+                const uint32_t off = GA ? direct_off(mb + r, b_cs) : go[r] + (uint32_t)b_cs * 2u;
+                if (GA) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_d, (lds_ptr)(at + AT_BYTES + q * 4096), 16, off, 0, 0, 0);
+                else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_g, (lds_ptr)(at + AT_BYTES + q * 4096), 16, off, 0, 0, 0);
+            }
+        };
+        if (wv == 0) decode_step(0);
+        if (wv == 1 && nsteps > 1) decode_step(1);
         __syncthreads();
+        issue_dma(0, 0);
+        for (int s = 0; s < nsteps; ++s) {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();     // pieces of step s landed, offsets of step s+1 visible, everyone left step s-1
+            __builtin_amdgcn_sched_barrier(0);
+            if (s + 1 < nsteps) issue_dma(s + 1, (s + 1) & 1);
+            if (s + 2 < nsteps && wv == (s & 3)) decode_step(s + 2);   // slot (s&1) was last read before this barrier
+            compute(s & 1);
+        }
+    } else {
+        issue_loads(0);
+        stage_write(0);
+        __syncthreads();
+        for (int s = 0; s < nsteps; ++s) {
+            const bool more = s + 1 < nsteps;
+            if (more) issue_loads(s + 1);
+            compute(s & 1);
+            if (more) stage_write((s & 1) ^ 1);
+            __syncthreads();
+        }
     }
 
     // epilogue: fp32 atomic accumulation into dw[row][otap][col]
@@ -199,8 +259,14 @@ __global__ __launch_bounds__(NT, 2) void conv_wgrad_tn(const KArgs a) {
 
 template <int BA, int BB, bool GA>
 int launch(const KArgs& ka, int nblk, hipStream_t st) {
-    constexpr size_t smem = 2 * (size_t)BKP * (BA + BB) * 2;
-    conv_wgrad_tn<BA, BB, GA><<<dim3(nblk), dim3(NT), smem, st>>>(ka);
+    constexpr size_t smem = 2 * (size_t)BKP * (BA + BB) * 2 + 2 * BKP * sizeof(uint32_t);
+    static int reg = -1;                  // MDE_WGRAD_PATH=reg: register-staged main loop (diagnostics)
+    if (reg < 0) {
+        const char* e = getenv("MDE_WGRAD_PATH");
+        reg = e && !strcmp(e, "reg");
+    }
+    if (reg) conv_wgrad_tn<BA, BB, GA, false><<<dim3(nblk), dim3(NT), smem, st>>>(ka);
+    else conv_wgrad_tn<BA, BB, GA, true><<<dim3(nblk), dim3(NT), smem, st>>>(ka);
     MDE_LAUNCH_CHECK("conv_wgrad_tn");
     return MDE_OK;
 }
