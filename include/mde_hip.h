@@ -133,18 +133,22 @@ int mde_bn_eval_scale_shift(const float* gamma, const float* beta, const float* 
                             const float* running_var, float eps, int C, float* scale, float* shift,
                             void* stream);
 /* out = act( x*scale + shift  [+ r  |  + r*rscale + rshift] );  relu != 0 applies ReLU.
- * r may be NULL; rscale/rshift may be NULL (plain residual add).  All bf16, own ld each. */
+ * r may be NULL; rscale/rshift may be NULL (plain residual add).  All bf16, own ld each.
+ * relu_bits (optional, uint8 [M][C/8]): bit e of byte (row, c/8) = (out[row][c/8*8+e] > 0), the
+ * packed ReLU mask the backward passes can read instead of `out` (16x fewer bytes). */
 int mde_bn_apply(const void* x, int ldx, const float* scale, const float* shift, const void* r,
-                 int ldr, const float* rscale, const float* rshift, void* out, int ldo, int64_t M,
-                 int C, int relu, void* stream);
+                 int ldr, const float* rscale, const float* rshift, void* out, int ldo,
+                 uint8_t* relu_bits, int64_t M, int C, int relu, void* stream);
 /* Backward of  out = act(bn(x) [+ ...]):  g = dout * (relu ? out > 0 : 1).
  * If mask_scale/mask_shift are given (sites WITHOUT a residual), the ReLU mask is recomputed
  * as (x*mask_scale + mask_shift > 0) from the tensor already being read and `out` is not
- * touched (may be NULL): one full-tensor read less per pass.
+ * touched (may be NULL): one full-tensor read less per pass.  If relu_bits (from mde_bn_apply) is
+ * given, the mask is read from it and `out` is likewise not touched.
  * pass 1: part += (sum g, sum g*xhat) per channel, xhat = (x - save_mean)*save_rstd. */
 int mde_bn_bwd_reduce(const void* dout, int ldd, const void* out, int ldo, const void* x, int ldx,
                       const float* save_mean, const float* save_rstd, const float* mask_scale,
-                      const float* mask_shift, int64_t M, int C, int relu, float* part, void* stream);
+                      const float* mask_shift, const uint8_t* relu_bits, int64_t M, int C, int relu,
+                      float* part, void* stream);
 /* pass 2 (tiny): dgamma += sum g*xhat, dbeta += sum g; coef[3][C] = (gamma*rstd, mean g,
  * mean g*xhat); part is zeroed. */
 int mde_bn_bwd_finalize(float* part, int64_t M, int C, const float* gamma, const float* save_rstd,
@@ -153,8 +157,9 @@ int mde_bn_bwd_finalize(float* part, int64_t M, int C, const float* gamma, const
  *   dres (optional) receives g, the masked upstream gradient, for the residual branch. */
 int mde_bn_bwd_apply(const void* dout, int ldd, const void* out, int ldo, const void* x, int ldx,
                      const float* save_mean, const float* save_rstd, const float* mask_scale,
-                     const float* mask_shift, const float* coef, int64_t M, int C, int relu, void* dx,
-                     int ldxo, int accumulate_dx, void* dres, int ldres, void* stream);
+                     const float* mask_shift, const uint8_t* relu_bits, const float* coef, int64_t M,
+                     int C, int relu, void* dx, int ldxo, int accumulate_dx, void* dres, int ldres,
+                     void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Pooling / resize / pointwise.

@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MDE_LIB_PATH") or os.path.join(_HERE, "libmde_hip.so")   # override: diagnostic builds only
-ABI_VERSION = 1
+ABI_VERSION = 2
 MAX_TAPS = 32
 
 
@@ -60,10 +60,10 @@ SIGNATURES = {
     "mde_bn_stats": (_I, [_P, _L, _I, _I, _P, _P]),
     "mde_bn_finalize": (_I, [_P, _L, _I, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P]),
     "mde_bn_eval_scale_shift": (_I, [_P, _P, _P, _P, _F, _I, _P, _P, _P]),
-    "mde_bn_apply": (_I, [_P, _I, _P, _P, _P, _I, _P, _P, _P, _I, _L, _I, _I, _P]),
-    "mde_bn_bwd_reduce": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _P, _L, _I, _I, _P, _P]),
+    "mde_bn_apply": (_I, [_P, _I, _P, _P, _P, _I, _P, _P, _P, _I, _P, _L, _I, _I, _P]),
+    "mde_bn_bwd_reduce": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _P, _P, _L, _I, _I, _P, _P]),
     "mde_bn_bwd_finalize": (_I, [_P, _L, _I, _P, _P, _P, _P, _P, _P]),
-    "mde_bn_bwd_apply": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _P, _P, _L, _I, _I, _P, _I, _I, _P, _I, _P]),
+    "mde_bn_bwd_apply": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P, _I, _I, _P, _I, _P]),
     "mde_maxpool_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "mde_maxpool_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "mde_upsample_sigmoid_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),

@@ -106,7 +106,8 @@ template <int RES>
 __global__ __launch_bounds__(NT) void bn_apply_k(const bf16_t* __restrict__ x, int ldx, const float* __restrict__ scale,
                                                  const float* __restrict__ shift, const bf16_t* __restrict__ r, int ldr,
                                                  const float* __restrict__ rscale, const float* __restrict__ rshift,
-                                                 bf16_t* __restrict__ out, int ldo, int64_t M, int C, int relu) {
+                                                 bf16_t* __restrict__ out, int ldo, uint8_t* __restrict__ bits, int64_t M,
+                                                 int C, int relu) {
     const int cpr = C >> 3, rpb = NT / cpr, col = threadIdx.x % cpr, rl = threadIdx.x / cpr;
     float sc[8], sh[8], rsc[8], rsh[8];
     ldf8(scale + col * 8, sc);
@@ -127,17 +128,24 @@ __global__ __launch_bounds__(NT) void bn_apply_k(const bf16_t* __restrict__ x, i
             v[e] = relu ? fmaxf(y, 0.f) : y;
         }
         st8(out + row * ldo + col * 8, v);
+        if (bits) {
+            uint32_t m = 0;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) m |= (uint32_t)((float)(bf16_t)v[e] > 0.f) << e;   // of the STORED bf16 value
+            bits[row * cpr + col] = (uint8_t)m;
+        }
     }
 }
 
-// MASK: 0 no ReLU, 1 mask from `out` > 0, 2 mask recomputed from x*msc+msh > 0
+// MASK: 0 no ReLU, 1 mask from `out` > 0, 2 mask recomputed from x*msc+msh > 0, 3 packed mask bits
 template <int MASK>
 __global__ __launch_bounds__(NT) void bn_bwd_reduce_k(const bf16_t* __restrict__ dout, int ldd,
                                                       const bf16_t* __restrict__ out, int ldo,
                                                       const bf16_t* __restrict__ x, int ldx,
                                                       const float* __restrict__ smean, const float* __restrict__ srstd,
                                                       const float* __restrict__ msc, const float* __restrict__ msh,
-                                                      int64_t M, int C, float* part, int rows_per_blk) {
+                                                      const uint8_t* __restrict__ bits, int64_t M, int C, float* part,
+                                                      int rows_per_blk) {
     __shared__ float sh[2 * MAXC];
     const int cpr = C >> 3, rpb = NT / cpr, col = threadIdx.x % cpr, rl = threadIdx.x / cpr;
     float mu[8], rs[8], ms[8], mh[8];
@@ -155,9 +163,12 @@ __global__ __launch_bounds__(NT) void bn_bwd_reduce_k(const bf16_t* __restrict__
         ld8(dout + r * ldd + col * 8, g);
         ld8(x + r * ldx + col * 8, v);
         if (MASK == 1) ld8(out + r * ldo + col * 8, o);
+        uint32_t mb = 0;
+        if (MASK == 3) mb = bits[r * cpr + col];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             if (MASK == 2) o[e] = v[e] * ms[e] + mh[e];
+            if (MASK == 3) o[e] = (float)((mb >> e) & 1u);
             const float ge = (MASK && !(o[e] > 0.f)) ? 0.f : g[e];
             s1[e] += ge;
             s2[e] += ge * ((v[e] - mu[e]) * rs[e]);
@@ -191,8 +202,9 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_k(const bf16_t* __restrict__ 
                                                      const bf16_t* __restrict__ x, int ldx,
                                                      const float* __restrict__ smean, const float* __restrict__ srstd,
                                                      const float* __restrict__ msc, const float* __restrict__ msh,
-                                                     const float* __restrict__ coef, int64_t M, int C,
-                                                     bf16_t* dx, int ldxo, int accumulate, bf16_t* dres, int ldres) {
+                                                     const uint8_t* __restrict__ bits, const float* __restrict__ coef,
+                                                     int64_t M, int C, bf16_t* dx, int ldxo, int accumulate, bf16_t* dres,
+                                                     int ldres) {
     const int cpr = C >> 3, rpb = NT / cpr, col = threadIdx.x % cpr, rl = threadIdx.x / cpr;
     float mu[8], rs[8], c0[8], c1[8], c2[8], ms[8], mh[8];
     if (MASK == 2) {
@@ -210,9 +222,12 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_k(const bf16_t* __restrict__ 
         ld8(x + row * ldx + col * 8, v);
         if (MASK == 1) ld8(out + row * ldo + col * 8, o);
         if (accumulate) ld8(dx + row * ldxo + col * 8, d);
+        uint32_t mb = 0;
+        if (MASK == 3) mb = bits[row * cpr + col];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             if (MASK == 2) o[e] = v[e] * ms[e] + mh[e];
+            if (MASK == 3) o[e] = (float)((mb >> e) & 1u);
             if (MASK && !(o[e] > 0.f)) g[e] = 0.f;
             const float xh = (v[e] - mu[e]) * rs[e];
             const float r = c0[e] * (g[e] - c1[e] - xh * c2[e]);
@@ -284,8 +299,8 @@ extern "C" int mde_bn_eval_scale_shift(const float* gamma, const float* beta, co
 }
 
 extern "C" int mde_bn_apply(const void* x, int ldx, const float* scale, const float* shift, const void* r,
-                            int ldr, const float* rscale, const float* rshift, void* out, int ldo, int64_t M,
-                            int C, int relu, void* stream) {
+                            int ldr, const float* rscale, const float* rshift, void* out, int ldo,
+                            uint8_t* relu_bits, int64_t M, int C, int relu, void* stream) {
     MDE_REQUIRE(x && scale && shift && out, "mde_bn_apply: null argument");
     if (int rc = check_site("mde_bn_apply", M, C)) return rc;
     MDE_REQUIRE(al16(x, ldx) && al16(out, ldo) && (!r || al16(r, ldr)), "mde_bn_apply: tensors must be 16-byte aligned, ld %% 8 == 0");
@@ -294,33 +309,37 @@ extern "C" int mde_bn_apply(const void* x, int ldx, const float* scale, const fl
     hipStream_t st = (hipStream_t)stream;
     const bf16_t *xp = (const bf16_t*)x, *rp = (const bf16_t*)r;
     if (!r)
-        bn_apply_k<0><<<grid, NT, 0, st>>>(xp, ldx, scale, shift, nullptr, 0, nullptr, nullptr, (bf16_t*)out, ldo, M, C, relu);
+        bn_apply_k<0><<<grid, NT, 0, st>>>(xp, ldx, scale, shift, nullptr, 0, nullptr, nullptr, (bf16_t*)out, ldo, relu_bits, M, C, relu);
     else if (!rscale)
-        bn_apply_k<1><<<grid, NT, 0, st>>>(xp, ldx, scale, shift, rp, ldr, nullptr, nullptr, (bf16_t*)out, ldo, M, C, relu);
+        bn_apply_k<1><<<grid, NT, 0, st>>>(xp, ldx, scale, shift, rp, ldr, nullptr, nullptr, (bf16_t*)out, ldo, relu_bits, M, C, relu);
     else
-        bn_apply_k<2><<<grid, NT, 0, st>>>(xp, ldx, scale, shift, rp, ldr, rscale, rshift, (bf16_t*)out, ldo, M, C, relu);
+        bn_apply_k<2><<<grid, NT, 0, st>>>(xp, ldx, scale, shift, rp, ldr, rscale, rshift, (bf16_t*)out, ldo, relu_bits, M, C, relu);
     MDE_LAUNCH_CHECK("bn_apply_k");
     return MDE_OK;
 }
 
 extern "C" int mde_bn_bwd_reduce(const void* dout, int ldd, const void* out, int ldo, const void* x, int ldx,
                                  const float* save_mean, const float* save_rstd, const float* mask_scale,
-                                 const float* mask_shift, int64_t M, int C, int relu, float* part, void* stream) {
+                                 const float* mask_shift, const uint8_t* relu_bits, int64_t M, int C, int relu,
+                                 float* part, void* stream) {
     const bool recompute = relu && mask_scale && mask_shift;
-    MDE_REQUIRE(dout && x && save_mean && save_rstd && part && (!relu || recompute || out), "mde_bn_bwd_reduce: null argument");
+    const bool packed = relu && !recompute && relu_bits;
+    MDE_REQUIRE(dout && x && save_mean && save_rstd && part && (!relu || recompute || packed || out), "mde_bn_bwd_reduce: null argument");
     MDE_REQUIRE((mask_scale == nullptr) == (mask_shift == nullptr), "mde_bn_bwd_reduce: mask_scale/mask_shift come in pairs");
     if (int rc = check_site("mde_bn_bwd_reduce", M, C)) return rc;
-    MDE_REQUIRE(al16(dout, ldd) && al16(x, ldx) && (!relu || recompute || al16(out, ldo)), "mde_bn_bwd_reduce: alignment");
+    MDE_REQUIRE(al16(dout, ldd) && al16(x, ldx) && (!relu || recompute || packed || al16(out, ldo)), "mde_bn_bwd_reduce: alignment");
     int nblk, rows;
     reduce_geometry(M, C, &nblk, &rows);
     hipStream_t st = (hipStream_t)stream;
     const bf16_t *d = (const bf16_t*)dout, *o = (const bf16_t*)out, *xp = (const bf16_t*)x;
     if (!relu)
-        bn_bwd_reduce_k<0><<<nblk, NT, 0, st>>>(d, ldd, o, ldo, xp, ldx, save_mean, save_rstd, nullptr, nullptr, M, C, part, rows);
+        bn_bwd_reduce_k<0><<<nblk, NT, 0, st>>>(d, ldd, o, ldo, xp, ldx, save_mean, save_rstd, nullptr, nullptr, nullptr, M, C, part, rows);
     else if (recompute)
-        bn_bwd_reduce_k<2><<<nblk, NT, 0, st>>>(d, ldd, o, ldo, xp, ldx, save_mean, save_rstd, mask_scale, mask_shift, M, C, part, rows);
+        bn_bwd_reduce_k<2><<<nblk, NT, 0, st>>>(d, ldd, o, ldo, xp, ldx, save_mean, save_rstd, mask_scale, mask_shift, nullptr, M, C, part, rows);
+    else if (packed)
+        bn_bwd_reduce_k<3><<<nblk, NT, 0, st>>>(d, ldd, o, ldo, xp, ldx, save_mean, save_rstd, nullptr, nullptr, relu_bits, M, C, part, rows);
     else
-        bn_bwd_reduce_k<1><<<nblk, NT, 0, st>>>(d, ldd, o, ldo, xp, ldx, save_mean, save_rstd, nullptr, nullptr, M, C, part, rows);
+        bn_bwd_reduce_k<1><<<nblk, NT, 0, st>>>(d, ldd, o, ldo, xp, ldx, save_mean, save_rstd, nullptr, nullptr, nullptr, M, C, part, rows);
     MDE_LAUNCH_CHECK("bn_bwd_reduce_k");
     return MDE_OK;
 }
@@ -335,25 +354,30 @@ extern "C" int mde_bn_bwd_finalize(float* part, int64_t M, int C, const float* g
 
 extern "C" int mde_bn_bwd_apply(const void* dout, int ldd, const void* out, int ldo, const void* x, int ldx,
                                 const float* save_mean, const float* save_rstd, const float* mask_scale,
-                                const float* mask_shift, const float* coef, int64_t M, int C, int relu, void* dx,
-                                int ldxo, int accumulate_dx, void* dres, int ldres, void* stream) {
+                                const float* mask_shift, const uint8_t* relu_bits, const float* coef, int64_t M,
+                                int C, int relu, void* dx, int ldxo, int accumulate_dx, void* dres, int ldres,
+                                void* stream) {
     const bool recompute = relu && mask_scale && mask_shift;
-    MDE_REQUIRE(dout && x && save_mean && save_rstd && coef && dx && (!relu || recompute || out), "mde_bn_bwd_apply: null argument");
+    const bool packed = relu && !recompute && relu_bits;
+    MDE_REQUIRE(dout && x && save_mean && save_rstd && coef && dx && (!relu || recompute || packed || out), "mde_bn_bwd_apply: null argument");
     MDE_REQUIRE((mask_scale == nullptr) == (mask_shift == nullptr), "mde_bn_bwd_apply: mask_scale/mask_shift come in pairs");
     if (int rc = check_site("mde_bn_bwd_apply", M, C)) return rc;
-    MDE_REQUIRE(al16(dout, ldd) && al16(x, ldx) && al16(dx, ldxo) && (!relu || recompute || al16(out, ldo)) &&
+    MDE_REQUIRE(al16(dout, ldd) && al16(x, ldx) && al16(dx, ldxo) && (!relu || recompute || packed || al16(out, ldo)) &&
                     (!dres || al16(dres, ldres)), "mde_bn_bwd_apply: alignment");
     hipStream_t st = (hipStream_t)stream;
     const int grid = stream_grid(M, C);
     const bf16_t *d = (const bf16_t*)dout, *o = (const bf16_t*)out, *xp = (const bf16_t*)x;
     if (!relu)
-        bn_bwd_apply_k<0><<<grid, NT, 0, st>>>(d, ldd, o, ldo, xp, ldx, save_mean, save_rstd, nullptr, nullptr, coef, M, C,
+        bn_bwd_apply_k<0><<<grid, NT, 0, st>>>(d, ldd, o, ldo, xp, ldx, save_mean, save_rstd, nullptr, nullptr, nullptr, coef, M, C,
                                                (bf16_t*)dx, ldxo, accumulate_dx, (bf16_t*)dres, ldres);
     else if (recompute)
-        bn_bwd_apply_k<2><<<grid, NT, 0, st>>>(d, ldd, o, ldo, xp, ldx, save_mean, save_rstd, mask_scale, mask_shift, coef, M,
+        bn_bwd_apply_k<2><<<grid, NT, 0, st>>>(d, ldd, o, ldo, xp, ldx, save_mean, save_rstd, mask_scale, mask_shift, nullptr, coef,
+                                               M, C, (bf16_t*)dx, ldxo, accumulate_dx, (bf16_t*)dres, ldres);
+    else if (packed)
+        bn_bwd_apply_k<3><<<grid, NT, 0, st>>>(d, ldd, o, ldo, xp, ldx, save_mean, save_rstd, nullptr, nullptr, relu_bits, coef, M,
                                                C, (bf16_t*)dx, ldxo, accumulate_dx, (bf16_t*)dres, ldres);
     else
-        bn_bwd_apply_k<1><<<grid, NT, 0, st>>>(d, ldd, o, ldo, xp, ldx, save_mean, save_rstd, nullptr, nullptr, coef, M, C,
+        bn_bwd_apply_k<1><<<grid, NT, 0, st>>>(d, ldd, o, ldo, xp, ldx, save_mean, save_rstd, nullptr, nullptr, nullptr, coef, M, C,
                                                (bf16_t*)dx, ldxo, accumulate_dx, (bf16_t*)dres, ldres);
     MDE_LAUNCH_CHECK("bn_bwd_apply_k");
     return MDE_OK;

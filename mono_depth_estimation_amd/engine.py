@@ -94,18 +94,18 @@ class BNSite:
         else:
             ops.bn_eval_scale_shift(self.gamma, self.beta, self.rmean, self.rvar, self.eps, self.C, self.scale, self.shift)
 
-    def backward(self, dout, out, x, relu, dx, accumulate=False, dres=None, mask_from_x=False):
+    def backward(self, dout, out, x, relu, dx, accumulate=False, dres=None, mask_from_x=False, relu_bits=None):
         """g = dout*(out>0 if relu); writes dgamma/dbeta (+=), dx (bf16) and optionally dres = g.
         mask_from_x: out == relu(x*scale+shift) exactly (no residual), so the mask is recomputed
         from x with this site's scale/shift and `out` is never read."""
         M, C = x.M, self.C
         ms, mh = (self.scale, self.shift) if (relu and mask_from_x) else (None, None)
         ops.bn_bwd_reduce(dout, _ld(dout, out), out.t if out is not None else None, out.ld if out is not None else 0,
-                          x.t, x.ld, self.smean, self.srstd, M, C, relu, self.part, ms, mh)
+                          x.t, x.ld, self.smean, self.srstd, M, C, relu, self.part, ms, mh, relu_bits)
         ops.bn_bwd_finalize(self.part, M, C, self.gamma, self.srstd, self.dgamma, self.dbeta, self.coef)
         ops.bn_bwd_apply(dout, _ld(dout, out), out.t if out is not None else None, out.ld if out is not None else 0,
                          x.t, x.ld, self.smean, self.srstd, self.coef, M, C, relu, dx, _ld(dx, x), accumulate,
-                         dres, _ld(dres, x) if dres is not None else 0, ms, mh)
+                         dres, _ld(dres, x) if dres is not None else 0, ms, mh, relu_bits)
 
 
 def _ld(t, like):
@@ -413,6 +413,9 @@ class ConvBN:
         OH, OW = ops.out_size(x.H, k, stride, pad), ops.out_size(x.W, k, stride, pad)
         self.c = Act(dev, x.N, OH, OW, Cout)      # pre-BN
         self.out = Act(dev, x.N, OH, OW, Cout) if has_out else None   # post BN / residual / ReLU
+        # residual joins keep a bit-packed ReLU mask (1 byte per 8 channels) for the backward passes
+        self.bits = (torch.empty(x.N * OH * OW * (Cout // 8), dtype=torch.uint8, device=dev)
+                     if (relu and res is not None and has_out) else None)
         self.fdesc = ops.fwd_desc(x.N, x.H, x.W, x.ld, x.C, x.nbytes, k, stride, pad, Cout, Cout)
         self.ddescs, self.dzero = ops.dgrad_descs(x.N, x.H, x.W, x.ld, x.C, OH, OW, Cout, Cout, self.c.nbytes, k, stride, pad)
         ks = eng._ksplit(self.c.M, Cout, x.C, k * k)
@@ -437,11 +440,12 @@ class ConvBN:
         if self.res is None:
             ops.bn_apply(c.t, c.ld, s.scale, s.shift, o.t, o.ld, c.M, c.C, self.relu)
         elif self.res_site is None:
-            ops.bn_apply(c.t, c.ld, s.scale, s.shift, o.t, o.ld, c.M, c.C, self.relu, r=self.res.t, ldr=self.res.ld)
+            ops.bn_apply(c.t, c.ld, s.scale, s.shift, o.t, o.ld, c.M, c.C, self.relu, r=self.res.t, ldr=self.res.ld,
+                         relu_bits=self.bits if train else None)
         else:
             rs = self.res_site
             ops.bn_apply(c.t, c.ld, s.scale, s.shift, o.t, o.ld, c.M, c.C, self.relu, r=self.res.t, ldr=self.res.ld,
-                         rscale=rs.scale, rshift=rs.shift)
+                         rscale=rs.scale, rshift=rs.shift, relu_bits=self.bits if train else None)
 
     def bn_bwd(self, dres_to=None):
         """d(out) -> d(c) (in self.c.g); optionally routes the masked gradient to an identity residual."""
@@ -450,7 +454,8 @@ class ConvBN:
             assert not dres_to.gw, "identity-residual gradient must be the first writer"
             dres = dres_to.g
             dres_to.gw = True
-        self.site.backward(self.out.g, self.out, self.c, self.relu, self.c.g, dres=dres, mask_from_x=self.res is None)
+        self.site.backward(self.out.g, self.out, self.c, self.relu, self.c.g, dres=dres, mask_from_x=self.res is None,
+                           relu_bits=self.bits)
         self.c.gw = True
 
     def conv_bwd(self):
@@ -509,7 +514,7 @@ class Bottleneck:
         else:
             c.bn_bwd()
             # second BN site of the join: same masked gradient, statistics of the shortcut conv
-            ds.site.backward(c.out.g, c.out, ds.c, True, ds.c.g)
+            ds.site.backward(c.out.g, c.out, ds.c, True, ds.c.g, relu_bits=c.bits)
             ds.c.gw = True
             ds.conv_bwd()
         c.conv_bwd()
@@ -562,7 +567,7 @@ class UpProjLayer:
         yg = y.g
         C = self.site_u.C
         c2.bn_bwd()                                                         # d(out) -> d(c2.c)
-        self.site_b.backward(c2.out.g, c2.out, self.y_b, True, yg[..., C:])  # join's second site -> d(y55[:, C:])
+        self.site_b.backward(c2.out.g, c2.out, self.y_b, True, yg[..., C:], relu_bits=c2.bits)  # join's second site
         c2.conv_bwd()                                                       # -> d(a1), dW(conv2)
         self.site_u.backward(self.a1.g, self.a1, self.y_u, True, yg[..., :C], mask_from_x=True)
         ops.conv_wgrad(self.wdesc, x.t, yg, self.w55.dw)

@@ -230,14 +230,16 @@ def bn_eval_scale_shift(gamma, beta, rmean, rvar, eps, C_, scale, shift):
                                               _stream()), "mde_bn_eval_scale_shift")
 
 
-def bn_apply(x, ldx, scale, shift, out, ldo, M, C_, relu, r=None, ldr=0, rscale=None, rshift=None):
+def bn_apply(x, ldx, scale, shift, out, ldo, M, C_, relu, r=None, ldr=0, rscale=None, rshift=None, relu_bits=None):
     check(_lib.load().mde_bn_apply(_p(x), ldx, _p(scale), _p(shift), _p(r), ldr, _p(rscale), _p(rshift), _p(out), ldo,
-                                   M, C_, int(relu), _stream()), "mde_bn_apply")
+                                   _p(relu_bits), M, C_, int(relu), _stream()), "mde_bn_apply")
 
 
-def bn_bwd_reduce(dout, ldd, out, ldo, x, ldx, smean, srstd, M, C_, relu, part, mask_scale=None, mask_shift=None):
+def bn_bwd_reduce(dout, ldd, out, ldo, x, ldx, smean, srstd, M, C_, relu, part, mask_scale=None, mask_shift=None,
+                  relu_bits=None):
     check(_lib.load().mde_bn_bwd_reduce(_p(dout), ldd, _p(out), ldo, _p(x), ldx, _p(smean), _p(srstd), _p(mask_scale),
-                                        _p(mask_shift), M, C_, int(relu), _p(part), _stream()), "mde_bn_bwd_reduce")
+                                        _p(mask_shift), _p(relu_bits), M, C_, int(relu), _p(part), _stream()),
+          "mde_bn_bwd_reduce")
 
 
 def bn_bwd_finalize(part, M, C_, gamma, srstd, dgamma, dbeta, coef):
@@ -246,9 +248,9 @@ def bn_bwd_finalize(part, M, C_, gamma, srstd, dgamma, dbeta, coef):
 
 
 def bn_bwd_apply(dout, ldd, out, ldo, x, ldx, smean, srstd, coef, M, C_, relu, dx, ldxo, accumulate=False, dres=None,
-                 ldres=0, mask_scale=None, mask_shift=None):
+                 ldres=0, mask_scale=None, mask_shift=None, relu_bits=None):
     check(_lib.load().mde_bn_bwd_apply(_p(dout), ldd, _p(out), ldo, _p(x), ldx, _p(smean), _p(srstd), _p(mask_scale),
-                                       _p(mask_shift), _p(coef), M, C_, int(relu), _p(dx), ldxo, int(accumulate),
+                                       _p(mask_shift), _p(relu_bits), _p(coef), M, C_, int(relu), _p(dx), ldxo, int(accumulate),
                                        _p(dres), ldres, _stream()), "mde_bn_bwd_apply")
 
 

@@ -71,15 +71,16 @@ def test_bn_train_forward_backward(N, H, Wd, C, relu, res):
     ops.bn_finalize(part, M, C, gamma, beta, rmean, rvar, 0.1, 1e-5, scale, shift, smean, srstd)
     assert float(part.abs().max()) == 0.0, "finalize must re-zero the partial buffer"
     out = torch.empty_like(xd)
+    bits = torch.zeros(M * C // 8, dtype=torch.uint8, device=dev) if (relu and res) else None   # packed ReLU mask
     if res == 2:
         part2 = ops.new_stat_buffer(C)
         g2, b2 = f(bn2.weight), f(bn2.bias)
         sc2, sh2, sm2, sr2 = (torch.empty(C, device=dev) for _ in range(4))
         ops.bn_stats(rd, M, C, C, part2)
         ops.bn_finalize(part2, M, C, g2, b2, None, None, 0.1, 1e-5, sc2, sh2, sm2, sr2)
-        ops.bn_apply(xd, C, scale, shift, out, C, M, C, relu, r=rd, ldr=C, rscale=sc2, rshift=sh2)
+        ops.bn_apply(xd, C, scale, shift, out, C, M, C, relu, r=rd, ldr=C, rscale=sc2, rshift=sh2, relu_bits=bits)
     elif res == 1:
-        ops.bn_apply(xd, C, scale, shift, out, C, M, C, relu, r=rd, ldr=C)
+        ops.bn_apply(xd, C, scale, shift, out, C, M, C, relu, r=rd, ldr=C, relu_bits=bits)
     else:
         ops.bn_apply(xd, C, scale, shift, out, C, M, C, relu)
     torch.cuda.synchronize()
@@ -93,6 +94,11 @@ def test_bn_train_forward_backward(N, H, Wd, C, relu, res):
     dx = torch.empty_like(xd)
     dres = torch.empty_like(xd) if res == 1 else None
     mk = dict(mask_scale=scale, mask_shift=shift) if (relu and res == 0) else {}   # recomputed mask: never reads `out`
+    if bits is not None:
+        want = (out.float() > 0).reshape(M, C // 8, 8).to(torch.int32)
+        want = (want << torch.arange(8, device=dev, dtype=torch.int32)).sum(-1).to(torch.uint8).reshape(-1)
+        assert torch.equal(bits, want), "packed ReLU mask differs from (out > 0)"
+        mk = dict(relu_bits=bits)
     ops.bn_bwd_reduce(dyd, C, None if mk else out, C, xd, C, smean, srstd, M, C, relu, part, **mk)
     ops.bn_bwd_finalize(part, M, C, gamma, srstd, dgamma, dbeta, coef)
     ops.bn_bwd_apply(dyd, C, None if mk else out, C, xd, C, smean, srstd, coef, M, C, relu, dx, C, dres=dres, ldres=C, **mk)
@@ -105,9 +111,9 @@ def test_bn_train_forward_backward(N, H, Wd, C, relu, res):
         _close_bf16(_nchw(dres), r.grad, "bn dres")
     if res == 2:
         dr = torch.empty_like(xd)
-        ops.bn_bwd_reduce(dyd, C, out, C, rd, C, sm2, sr2, M, C, relu, part2)
+        ops.bn_bwd_reduce(dyd, C, None, C, rd, C, sm2, sr2, M, C, relu, part2, relu_bits=bits)
         ops.bn_bwd_finalize(part2, M, C, g2, sr2, None, None, coef)
-        ops.bn_bwd_apply(dyd, C, out, C, rd, C, sm2, sr2, coef, M, C, relu, dr, C)
+        ops.bn_bwd_apply(dyd, C, None, C, rd, C, sm2, sr2, coef, M, C, relu, dr, C, relu_bits=bits)
         torch.cuda.synchronize()
         _close_bf16(_nchw(dr), r.grad, "bn2 dx", tol=2.0 ** -7)
 
