@@ -60,6 +60,8 @@ struct KArgs {
     uint32_t w_bytes;
     uint32_t out_bytes;
     int32_t M;        // N*GH*GW
+    int32_t m_begin;  // first pixel row of this launch (a layer may be split into two launches by pixel range)
+    int32_t m_end;    // one past the last pixel row of this launch
     int32_t nP, nC;   // tiles along pixels / columns
     int32_t vec_ok;   // 16-byte stores allowed
 };
@@ -118,13 +120,13 @@ __global__ __launch_bounds__(NT, 2) void conv_gemm_nt(const KArgs a) {
 
     const uint32_t bid = mde_xcd_remap(blockIdx.x, (uint32_t)(a.nP * a.nC));
     const int pi = bid % a.nP, ci = bid / a.nP;
-    const int m0 = pi * BP, n0 = ci * BC;
+    const int m0 = a.m_begin + pi * BP, n0 = ci * BC;
 
     // ---- per-row decode, once per workgroup
     for (int r = tid; r < BP; r += NT) {
         const int m = m0 + r;
         int inbase = 0, yx = 0x7FFF7FFF, oo = -1;
-        if (m < a.M) {
+        if (m < a.m_end) {
             const int gw = d.GW, ghw = d.GH * d.GW;
             const int n = m / ghw, rem = m - n * ghw;
             const int gy = rem / gw, gx = rem - gy * gw;
@@ -488,7 +490,8 @@ int launch(KArgs& ka, int64_t M, hipStream_t st) {
         if (rc) return rc;
         attr_done = true;
     }
-    ka.nP = mde_cdiv(M, BP);
+    (void)M;
+    ka.nP = mde_cdiv(ka.m_end - ka.m_begin, BP);
     ka.nC = mde_cdiv(ka.d.ncols, BC);
     conv_gemm_nt<BP, BC, NT, DMA, NBUF><<<dim3(ka.nP * ka.nC), dim3(NT), smem, st>>>(ka);
     MDE_LAUNCH_CHECK("conv_gemm_nt");
@@ -517,9 +520,27 @@ int pick_and_launch(KArgs& ka, int64_t M, hipStream_t st) {
         hipDeviceProp_t prop;
         cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
     }
-    const int64_t t256 = (int64_t)mde_cdiv(M, 256) * mde_cdiv(n, 256), t128 = (int64_t)mde_cdiv(M, 128) * mde_cdiv(n, 128);
+    const int nc256 = mde_cdiv(n, 256);
+    const int64_t p256 = mde_cdiv(M, 256), t256 = p256 * nc256, t128 = (int64_t)mde_cdiv(M, 128) * mde_cdiv(n, 128);
     const int64_t r256 = (t256 + cus - 1) / cus, r128 = (t128 + 2 * cus - 1) / (2 * cus);
     const bool big = n >= 256 && r256 * 200 < r128 * 115;      // r256 * 65536 / 1.15  <  r128 * 2 * 16384
+    // Tail splitting: when the 256x256 grid ends in a mostly empty round, run the full rounds with
+    // 256x256 tiles and the remaining pixel rows with 128x128 tiles (a second launch on the same
+    // stream).  E.g. 600 tiles on 256 CUs = 3 rounds at 78 % -> 2 full rounds + a short 128x128 launch.
+    if (forced == 0 && !reg && n >= 256 && t256 > cus) {
+        const int64_t full_tiles = (t256 / cus) * cus;               // tiles in complete rounds
+        const int64_t p1 = full_tiles / nc256;                       // pixel tiles given to the 256x256 launch
+        const int64_t rem_tiles = t256 - p1 * nc256;
+        if (p1 > 0 && p1 < p256 && rem_tiles * 10 <= (int64_t)cus * 7) {   // last round would be <= 70 % full
+            const int32_t split = (int32_t)(p1 * 256);
+            KArgs k1 = ka, k2 = ka;
+            k1.m_end = split;
+            k2.m_begin = split;
+            int rc = launch<256, 256, 512, true, 2>(k1, M, st);
+            if (rc) return rc;
+            return launch<128, 128, 256, true, 2>(k2, M, st);
+        }
+    }
     if (forced == 1 || (forced == 0 && big))
         return reg ? launch<256, 256, 512, false, 2>(ka, M, st) : launch<256, 256, 512, true, 2>(ka, M, st);
     if (forced == 4) return launch<128, 128, 256, true, 3>(ka, M, st);
@@ -561,6 +582,8 @@ extern "C" int mde_conv_gemm(const mde_conv_desc* d, const void* in, const void*
     ka.w_bytes = (uint32_t)wbytes;
     ka.out_bytes = (uint32_t)(out_elems * 2);
     ka.M = (int32_t)M;
+    ka.m_begin = 0;
+    ka.m_end = (int32_t)M;
     ka.vec_ok = (d->ld_out % 8 == 0) && (((uintptr_t)out % 16) == 0);
     return pick_and_launch(ka, M, reinterpret_cast<hipStream_t>(stream));
 }

@@ -46,6 +46,7 @@ def _assert_close(got, ref, what, tol=2.0 ** -8):
     (1, 13, 17, 64, 192, 3, 2, 1),     # stride 2, odd sizes, ragged column tile
     (2, 9, 11, 192, 320, 1, 2, 0),     # 1x1 stride 2 (downsample)
     (1, 10, 10, 64, 72, 5, 1, 2),      # 25 taps, columns not a multiple of the tile
+    (2, 160, 241, 64, 256, 1, 1, 0),   # 302 tiles of 256x256 > 256 CUs: full rounds + 128x128 tail launch
 ])
 def test_conv_forward(N, H, Wd, Cin, Cout, k, s, p):
     from mono_depth_estimation_amd import ops
@@ -74,6 +75,7 @@ def test_conv_forward(N, H, Wd, Cin, Cout, k, s, p):
     (1, 13, 17, 128, 64, 3, 2, 1),     # odd input size
     (2, 10, 12, 64, 128, 1, 2, 0),     # 1x1 stride 2: three empty phases -> zero fill
     (2, 8, 8, 192, 64, 1, 1, 0),
+    (2, 160, 241, 256, 64, 1, 1, 0),   # split launch (256x256 rounds + 128x128 tail), also with accumulate
 ])
 def test_conv_dgrad(N, H, Wd, Cin, Cout, k, s, p):
     from mono_depth_estimation_amd import ops
