@@ -510,7 +510,20 @@ int pick_and_launch(KArgs& ka, int64_t M, hipStream_t st) {
         reg = q && !strcmp(q, "reg");
     }
     const int n = ka.d.ncols;
-    if (n <= 64) return reg ? launch<128, 64, 256, false, 2>(ka, M, st) : launch<128, 64, 256, true, 3>(ka, M, st);
+    static int n64 = -1;                  // MDE_CONV_N64=a|b|c: tile experiments for <=64-column layers
+    if (n64 < 0) {
+        const char* e = getenv("MDE_CONV_N64");
+        n64 = !e ? 0 : e[0] == 'a' ? 1 : e[0] == 'b' ? 2 : e[0] == 'c' ? 3 : 0;
+    }
+    if (n <= 64) {
+        if (reg) return launch<128, 64, 256, false, 2>(ka, M, st);
+        if (n64 == 1) return launch<256, 64, 512, true, 2>(ka, M, st);   // 8 waves x (32 px x 64 ch)
+        if (n64 == 2) return launch<256, 64, 256, true, 2>(ka, M, st);   // 4 waves x (64 px x 64 ch)
+        if (n64 == 3) return launch<128, 64, 256, true, 3>(ka, M, st);   // 3-deep ring, 2 workgroups per CU
+        // default: 2-deep ring = 48 KB LDS = three workgroups per CU (489/537 vs 357/347 TFLOP/s for the 3-deep
+        // ring on M=2457600/614400, 64->64 3x3): occupancy beats prefetch depth, as for the 128x128 tile
+        return launch<128, 64, 256, true, 2>(ka, M, st);
+    }
     // Tile choice by a rounds model fitted to in-network timings: a CU runs either one
     // 8-wave 256x256 workgroup (about 1.15x the per-flop rate) or two 4-wave 128x128 workgroups;
     // what decides is the tail: rounds = ceil(tiles / slots).  256x128 never won.
