@@ -64,6 +64,7 @@ struct KArgs {
     int32_t m_end;    // one past the last pixel row of this launch
     int32_t nP, nC;   // tiles along pixels / columns
     int32_t vec_ok;   // 16-byte stores allowed
+    int32_t col_fastest;  // tile order: 1 = all column tiles of a pixel tile are neighbours (activation tile reused from L2)
 };
 
 // byte offset of the 16-byte chunk (row, kslot8) inside a swizzled tile
@@ -119,7 +120,8 @@ __global__ __launch_bounds__(NT, 2) void conv_gemm_nt(const KArgs a) {
     const int wp = wave / WAVES_C;       // wave position along pixels
 
     const uint32_t bid = mde_xcd_remap(blockIdx.x, (uint32_t)(a.nP * a.nC));
-    const int pi = bid % a.nP, ci = bid / a.nP;
+    const int pi = a.col_fastest ? bid / a.nC : bid % a.nP;
+    const int ci = a.col_fastest ? bid % a.nC : bid / a.nP;
     const int m0 = a.m_begin + pi * BP, n0 = ci * BC;
 
     // ---- per-row decode, once per workgroup
@@ -597,6 +599,14 @@ extern "C" int mde_conv_gemm(const mde_conv_desc* d, const void* in, const void*
     ka.M = (int32_t)M;
     ka.m_begin = 0;
     ka.m_end = (int32_t)M;
+    {
+        static int order = -1;             // MDE_CONV_ORDER=pix restores pixel-fastest tile order (A/B)
+        if (order < 0) {
+            const char* e = getenv("MDE_CONV_ORDER");
+            order = !(e && !strcmp(e, "pix"));
+        }
+        ka.col_fastest = order;
+    }
     ka.vec_ok = (d->ld_out % 8 == 0) && (((uintptr_t)out % 16) == 0);
     return pick_and_launch(ka, M, reinterpret_cast<hipStream_t>(stream));
 }
