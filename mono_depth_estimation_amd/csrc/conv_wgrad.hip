@@ -83,8 +83,9 @@ __global__ __launch_bounds__(NT, 2) void conv_wgrad_tn(const KArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wa = wave >> 1, wb = wave & 1;
 
-    // block -> (tap, tileB, tileA, kslice), tap fastest so neighbours share operand tiles in L2
-    uint32_t b = blockIdx.x;
+    // block -> (tap, tileB, tileA, kslice), tap fastest so neighbours share operand tiles; the XCD remap
+    // keeps those neighbours on ONE XCD (one L2) instead of dealing them round-robin over the eight
+    uint32_t b = mde_xcd_remap(blockIdx.x, gridDim.x);
     const int tap = b % d.ntaps; b /= d.ntaps;
     const int tb = b % a.nB; b /= a.nB;
     const int ta = b % a.nA; b /= a.nA;
