@@ -312,9 +312,9 @@ class FCRNEngine:
                       self.B[bo:bo + C], self.B[bv:bv + C], bns[0], bns[0].eps)
 
     def _ksplit(self, pixels, rows, cols, ntaps):
-        rt = rows // (128 if rows % 128 == 0 else 64)
-        ct = cols // (128 if cols % 128 == 0 else 64)
-        return ops.choose_ksplit(pixels, rt, ct, ntaps, self.cus)
+        ba, bb = (128 if rows % 128 == 0 else 64), (128 if cols % 128 == 0 else 64)
+        lds = 2 * 64 * (ba + bb) * 2 + 512           # conv_wgrad_tn's staging ring + offset table
+        return ops.choose_ksplit(pixels, rows // ba, cols // bb, ntaps, self.cus, wg_per_cu=min(8, (160 * 1024) // lds))
 
     # ------------------------------------------------------------------ the plan
     def _plan(self):

@@ -186,13 +186,26 @@ def conv_wgrad(desc, direct, gathered, dw):
         "K=%d Cd=%d Cg=%d taps=%d ks=%d" % (desc.N * desc.GH * desc.GW, desc.Cd, desc.Cg, desc.ntaps, desc.ksplit))
 
 
-def choose_ksplit(pixels, row_tiles, col_tiles, ntaps, cus=256, min_steps=8):
-    """Split the pixel (K) range so the grid reaches ~3 workgroups per CU, each keeping at
-    least `min_steps` 64-pixel K-steps."""
+def choose_ksplit(pixels, row_tiles, col_tiles, ntaps, cus=256, min_steps=8, wg_per_cu=2):
+    """Split-K factor for the weight-gradient GEMM.  The grid is ntaps*row_tiles*col_tiles*ksplit
+    workgroups on cus*wg_per_cu resident slots: pick the factor whose LAST round is fullest (the
+    kernel time is rounds x per-workgroup time), among factors that cover the chip at least once
+    when the pixel range allows it and keep >= min_steps 64-pixel K-steps per workgroup; ties go
+    to the smaller factor (fewer atomics)."""
     base = max(1, row_tiles * col_tiles * ntaps)
-    want = max(1, (3 * cus + base - 1) // base)
+    slots = cus * wg_per_cu
     cap = max(1, pixels // (64 * min_steps))
-    return max(1, min(want, cap))
+    hi = min(cap, max(1, (4 * slots + base - 1) // base))
+    best, best_key = 1, None
+    for ks in range(1, hi + 1):
+        blocks = base * ks
+        rounds = -(-blocks // slots)
+        fill = blocks / (rounds * slots)
+        covers = blocks >= slots
+        key = (covers, round(fill, 3), -ks)
+        if best_key is None or key > best_key:
+            best, best_key = ks, key
+    return best
 
 
 # ------------------------------------------------------------------------------ small convs

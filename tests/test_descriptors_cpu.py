@@ -140,8 +140,15 @@ def test_wgrad_descriptors():
 
 def test_ksplit_and_buckets():
     from mono_depth_estimation_amd import dp
-    assert ops.choose_ksplit(2457600, 1, 1, 9) >= 32
-    assert ops.choose_ksplit(9600, 8, 8, 25) == 1
+    def fill(base, ks, slots=512):
+        b = base * ks
+        return b / (-(-b // slots) * slots)
+    assert ops.choose_ksplit(2457600, 1, 1, 9) >= 32            # huge pixel range, tiny tile grid: split hard
+    assert ops.choose_ksplit(9600, 8, 8, 25) <= 2               # 1600 tiles already cover the chip 3x
+    assert ops.choose_ksplit(640, 1, 1, 1) == 1                 # never fewer than 8 K-steps per workgroup
+    for px, rt, ct, taps in [(38400, 2, 2, 9), (153600, 2, 2, 25), (9600, 4, 4, 9), (614400, 1, 1, 25)]:
+        ks = ops.choose_ksplit(px, rt, ct, taps)
+        assert fill(rt * ct * taps, ks) > 0.95 and px // (64 * ks) >= 8
     b = dp.make_buckets(1000, [0, 100, 300, 600, 900], 800)
     assert b == [(600, 1000), (300, 600), (100, 300), (0, 100)]
     assert dp.make_buckets(10, [], 1 << 20) == [(0, 10)]
