@@ -98,7 +98,7 @@ __global__ __launch_bounds__(NT, 2) void conv_gemm_nt(const KArgs a) {
     // the epilogue re-tiles through LDS; when the whole tile does not fit, in EPASS pixel slabs
     constexpr int EPASS = (BP * ROWB <= 2 * BUF_BYTES) ? 1 : 2;
     constexpr int EROWS = BP / EPASS;    // pixel rows per epilogue pass
-    static_assert(WAVES_P * WAVES_C == NW && PF * 16 * WAVES_P == BP && CF * 16 * WAVES_C == BC, "wave tiling");
+    static_assert(WAVES_P * WAVES_C == NW && PF * 16 * WAVES_P == BP && CF * 16 * WAVES_C == BC && PF >= 2 && PF <= 4, "wave tiling");
     static_assert(XP >= 1 && WP >= 1 && XP * RPL == BP && WP * RPL == BC, "load tiling");
     static_assert(EROWS * ROWB <= 2 * BUF_BYTES && (WAVES_P % EPASS) == 0, "epilogue slab fits in the staging buffers");
     static_assert(NBUF == 2 || (DMA && NBUF == 3), "register staging uses two LDS buffers");
@@ -507,7 +507,7 @@ int pick_and_launch(KArgs& ka, int64_t M, hipStream_t st) {
     static int forced = -1, reg = 0;
     if (forced < 0) {
         const char* e = getenv("MDE_CONV_TILE");
-        forced = !e ? 0 : !strcmp(e, "256x256") ? 1 : !strcmp(e, "256x128") ? 2 : !strcmp(e, "128x128") ? 3 : !strcmp(e, "128x128x3") ? 4 : 0;
+        forced = !e ? 0 : !strcmp(e, "256x256") ? 1 : !strcmp(e, "256x128") ? 2 : !strcmp(e, "128x128") ? 3 : !strcmp(e, "128x128x3") ? 4 : !strcmp(e, "192x256") ? 5 : 0;
         const char* q = getenv("MDE_CONV_PATH");
         reg = q && !strcmp(q, "reg");
     }
@@ -535,30 +535,46 @@ int pick_and_launch(KArgs& ka, int64_t M, hipStream_t st) {
         hipDeviceProp_t prop;
         cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
     }
-    const int nc256 = mde_cdiv(n, 256);
-    const int64_t p256 = mde_cdiv(M, 256), t256 = p256 * nc256, t128 = (int64_t)mde_cdiv(M, 128) * mde_cdiv(n, 128);
-    const int64_t r256 = (t256 + cus - 1) / cus, r128 = (t128 + 2 * cus - 1) / (2 * cus);
-    const bool big = n >= 256 && r256 * 200 < r128 * 115;      // r256 * 65536 / 1.15  <  r128 * 2 * 16384
-    // Tail splitting: when the 256x256 grid ends in a mostly empty round, run the full rounds with
-    // 256x256 tiles and the remaining pixel rows with 128x128 tiles (a second launch on the same
-    // stream).  E.g. 600 tiles on 256 CUs = 3 rounds at 78 % -> 2 full rounds + a short 128x128 launch.
-    if (forced == 0 && !reg && n >= 256 && t256 > cus) {
-        const int64_t full_tiles = (t256 / cus) * cus;               // tiles in complete rounds
-        const int64_t p1 = full_tiles / nc256;                       // pixel tiles given to the 256x256 launch
-        const int64_t rem_tiles = t256 - p1 * nc256;
-        if (p1 > 0 && p1 < p256 && rem_tiles * 10 <= (int64_t)cus * 7) {   // last round would be <= 70 % full
-            const int32_t split = (int32_t)(p1 * 256);
-            KArgs k1 = ka, k2 = ka;
-            k1.m_end = split;
-            k2.m_begin = split;
-            int rc = launch<256, 256, 512, true, 2>(k1, M, st);
-            if (rc) return rc;
-            return launch<128, 128, 256, true, 2>(k2, M, st);
+    // Cost model fitted to in-network timings: kernel time = rounds x work per resident
+    // slot per round / per-flop rate; a CU hosts one 8-wave workgroup (256x256: rate 1.15, 192x256: 1.10)
+    // or two 4-wave 128x128 workgroups (rate 1.0).  What decides between them is the tail round.
+    const int nc256 = mde_cdiv(n, 256), nc128 = mde_cdiv(n, 128);
+    const int64_t p256 = mde_cdiv(M, 256), t256 = p256 * nc256;
+    auto rounds = [](int64_t tiles, int64_t slots) { return (tiles + slots - 1) / slots; };
+    const double c128 = (double)rounds((int64_t)mde_cdiv(M, 128) * nc128, 2 * cus) * 32768.0;
+    double best = c128;
+    int pick = 0;                                               // 0: 128x128, 1: 256x256, 2: 192x256, 3: 256x256 + 128x128 tail
+    int32_t split = 0;
+    if (n >= 256 && !reg) {
+        const double c256 = (double)rounds(t256, cus) * 65536.0 / 1.15;
+        const double c192 = (double)rounds((int64_t)mde_cdiv(M, 192) * nc256, cus) * 49152.0 / 1.10;
+        if (c256 < best) { best = c256; pick = 1; }
+        if (c192 < best) { best = c192; pick = 2; }
+        if (t256 > cus) {                                       // full 256x256 rounds, remaining pixel rows on 128x128 tiles
+            const int64_t p1 = ((t256 / cus) * cus) / nc256;
+            if (p1 > 0 && p1 < p256) {
+                const int64_t rem_px = M - p1 * 256;
+                const double cs = (double)rounds(p1 * nc256, cus) * 65536.0 / 1.15 +
+                                  (double)rounds((int64_t)mde_cdiv(rem_px, 128) * nc128, 2 * cus) * 32768.0;
+                if (cs < best) { best = cs; pick = 3; split = (int32_t)(p1 * 256); }
+            }
         }
+    } else if (n >= 256) {
+        if ((double)rounds(t256, cus) * 65536.0 / 1.15 < best) pick = 1;
     }
-    if (forced == 1 || (forced == 0 && big))
+    if (forced == 0 && pick == 3) {
+        KArgs k1 = ka, k2 = ka;
+        k1.m_end = split;
+        k2.m_begin = split;
+        int rc = launch<256, 256, 512, true, 2>(k1, M, st);
+        if (rc) return rc;
+        return launch<128, 128, 256, true, 2>(k2, M, st);
+    }
+    if (forced == 0 && pick == 2) return launch<192, 256, 512, true, 2>(ka, M, st);
+    if (forced == 1 || (forced == 0 && pick == 1))
         return reg ? launch<256, 256, 512, false, 2>(ka, M, st) : launch<256, 256, 512, true, 2>(ka, M, st);
     if (forced == 4) return launch<128, 128, 256, true, 3>(ka, M, st);
+    if (forced == 5) return launch<192, 256, 512, true, 2>(ka, M, st);
     if (forced == 2)
         return reg ? launch<256, 128, 512, false, 2>(ka, M, st) : launch<256, 128, 512, true, 3>(ka, M, st);
     return reg ? launch<128, 128, 256, false, 2>(ka, M, st) : launch<128, 128, 256, true, 2>(ka, M, st);

@@ -47,6 +47,7 @@ def _assert_close(got, ref, what, tol=2.0 ** -8):
     (2, 9, 11, 192, 320, 1, 2, 0),     # 1x1 stride 2 (downsample)
     (1, 10, 10, 64, 72, 5, 1, 2),      # 25 taps, columns not a multiple of the tile
     (2, 160, 241, 64, 256, 1, 1, 0),   # 302 tiles of 256x256 > 256 CUs: full rounds + 128x128 tail launch
+    (2, 160, 121, 64, 256, 1, 1, 0),   # 152 tiles of 256x256 (59% fill): the cost model takes 192x256 (202 tiles, ragged)
 ])
 def test_conv_forward(N, H, Wd, Cin, Cout, k, s, p):
     from mono_depth_estimation_amd import ops
