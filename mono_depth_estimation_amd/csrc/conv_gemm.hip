@@ -398,11 +398,8 @@ __global__ __launch_bounds__(NT, 2) void conv_gemm_nt(const KArgs a) {
                     s1 += v;
                     s2 += v * v;
                 }
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) {
-                    s1 += __shfl_xor(s1, o, 64);
-                    s2 += __shfl_xor(s2, o, 64);
-                }
+                s1 = mde_row16_sum(s1);
+                s2 = mde_row16_sum(s2);
                 if ((lane & 15) == 0) {
                     const int ch = wc * (CF * 16) + i * 16 + (lane >> 4) * 4 + r;
                     s_stat[(wp * 2 + 0) * BC + ch] = s1;
@@ -507,7 +504,7 @@ int pick_and_launch(KArgs& ka, int64_t M, hipStream_t st) {
     static int forced = -1, reg = 0;
     if (forced < 0) {
         const char* e = getenv("MDE_CONV_TILE");
-        forced = !e ? 0 : !strcmp(e, "256x256") ? 1 : !strcmp(e, "256x128") ? 2 : !strcmp(e, "128x128") ? 3 : !strcmp(e, "128x128x3") ? 4 : !strcmp(e, "192x256") ? 5 : 0;
+        forced = !e ? 0 : !strcmp(e, "256x256") ? 1 : !strcmp(e, "256x128") ? 2 : !strcmp(e, "128x128") ? 3 : !strcmp(e, "128x128x3") ? 4 : !strcmp(e, "192x256") ? 5 : !strcmp(e, "128x64") ? 6 : 0;
         const char* q = getenv("MDE_CONV_PATH");
         reg = q && !strcmp(q, "reg");
     }
@@ -526,9 +523,6 @@ int pick_and_launch(KArgs& ka, int64_t M, hipStream_t st) {
         // ring on M=2457600/614400, 64->64 3x3): occupancy beats prefetch depth, as for the 128x128 tile
         return launch<128, 64, 256, true, 2>(ka, M, st);
     }
-    // Tile choice by a rounds model fitted to in-network timings: a CU runs either one
-    // 8-wave 256x256 workgroup (about 1.15x the per-flop rate) or two 4-wave 128x128 workgroups;
-    // what decides is the tail: rounds = ceil(tiles / slots).  256x128 never won.
     static int cus = 0;
     if (!cus) {
         int dev = 0;
@@ -575,6 +569,7 @@ int pick_and_launch(KArgs& ka, int64_t M, hipStream_t st) {
         return reg ? launch<256, 256, 512, false, 2>(ka, M, st) : launch<256, 256, 512, true, 2>(ka, M, st);
     if (forced == 4) return launch<128, 128, 256, true, 3>(ka, M, st);
     if (forced == 5) return launch<192, 256, 512, true, 2>(ka, M, st);
+    if (forced == 6) return launch<128, 64, 256, true, 2>(ka, M, st);
     if (forced == 2)
         return reg ? launch<256, 128, 512, false, 2>(ka, M, st) : launch<256, 128, 512, true, 3>(ka, M, st);
     return reg ? launch<128, 128, 256, false, 2>(ka, M, st) : launch<128, 128, 256, true, 2>(ka, M, st);

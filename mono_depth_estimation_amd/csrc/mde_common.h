@@ -47,6 +47,17 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t mde_rsrc(const void* p, uint32
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
 }
 
+// Sum over the 16 lanes of a DPP row (lanes sharing lane>>4), result in every lane of the row.
+// row_ror rotations are plain VALU DPP modifiers; __shfl_xor would go through the LDS crossbar
+// (ds_bpermute_b32), which cost ~6 us per 256x256 tile in the conv epilogue.
+__device__ __forceinline__ float mde_row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, false));  // row_ror:8
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xF, 0xF, false));  // row_ror:4
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xF, 0xF, false));  // row_ror:2
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xF, 0xF, false));  // row_ror:1
+    return v;
+}
+
 __device__ __forceinline__ float mde_wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

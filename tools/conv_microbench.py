@@ -22,7 +22,8 @@ def main():
         w = (torch.randn(Cout, k * k, Cin, device=dev) * 0.05).to(torch.bfloat16)
         out = torch.empty(N, H, W, Cout, dtype=torch.bfloat16, device=dev)
         d = ops.fwd_desc(N, H, W, Cin, Cin, x.numel() * 2, k, 1, pad, Cout, Cout)
-        fn = lambda: ops.conv_gemm(d, x, w, out)
+        stats = ops.new_stat_buffer(Cout) if os.environ.get("MB_STATS") else None   # BN partial sums in the epilogue
+        fn = lambda: ops.conv_gemm(d, x, w, out, stats)
         flops = 2.0 * N * H * W * Cout * k * k * Cin
     else:
         dy = torch.randn(N, H, W, Cout, device=dev).to(torch.bfloat16)
