@@ -386,26 +386,35 @@ __global__ __launch_bounds__(NT, 2) void conv_gemm_nt(const KArgs a) {
     // ---------------------------------------------------------------- epilogue
     // (the loop's last barrier guarantees every wave is done reading the staging tiles)
     if (a.stats) {
-        // per-wave channel sums over its pixels (rows beyond M are exact zeros)
+        // per-wave channel sums over its pixels (rows beyond M are exact zeros): packed fp32 over the
+        // wave's pixel fragments, then a DPP reduction over the 16 lanes that hold different pixels
+        constexpr int SG = CF < 4 ? CF : 4;      // column fragments reduced per group (bounds the live registers)
 #pragma unroll
-        for (int i = 0; i < CF; ++i)
+        for (int g = 0; g < CF; g += SG) {
+            f32x4_t t1[SG], t2[SG];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float s1 = 0.f, s2 = 0.f;
+            for (int i = 0; i < SG; ++i) {
+                f32x2_t s1a = {0.f, 0.f}, s1b = {0.f, 0.f}, s2a = {0.f, 0.f}, s2b = {0.f, 0.f};
 #pragma unroll
                 for (int j = 0; j < PF; ++j) {
-                    const float v = acc[i][j][r];
-                    s1 += v;
-                    s2 += v * v;
+                    const f32x2_t va = {acc[g + i][j][0], acc[g + i][j][1]}, vb = {acc[g + i][j][2], acc[g + i][j][3]};
+                    s1a += va;
+                    s1b += vb;
+                    s2a = __builtin_elementwise_fma(va, va, s2a);
+                    s2b = __builtin_elementwise_fma(vb, vb, s2b);
                 }
-                s1 = mde_row16_sum(s1);
-                s2 = mde_row16_sum(s2);
-                if ((lane & 15) == 0) {
-                    const int ch = wc * (CF * 16) + i * 16 + (lane >> 4) * 4 + r;
-                    s_stat[(wp * 2 + 0) * BC + ch] = s1;
-                    s_stat[(wp * 2 + 1) * BC + ch] = s2;
+                t1[i] = f32x4_t{mde_row16_sum(s1a[0]), mde_row16_sum(s1a[1]), mde_row16_sum(s1b[0]), mde_row16_sum(s1b[1])};
+                t2[i] = f32x4_t{mde_row16_sum(s2a[0]), mde_row16_sum(s2a[1]), mde_row16_sum(s2b[0]), mde_row16_sum(s2b[1])};
+            }
+            if ((lane & 15) == 0) {
+                const int ch = wc * (CF * 16) + (lane >> 4) * 4 + g * 16;
+#pragma unroll
+                for (int i = 0; i < SG; ++i) {
+                    *reinterpret_cast<f32x4_t*>(s_stat + (wp * 2 + 0) * BC + ch + i * 16) = t1[i];
+                    *reinterpret_cast<f32x4_t*>(s_stat + (wp * 2 + 1) * BC + ch + i * 16) = t2[i];
                 }
             }
+        }
     }
     constexpr int CPR = BC / 8;          // 16-byte chunks per pixel row
     constexpr int RPP = NT / CPR;        // rows per store pass

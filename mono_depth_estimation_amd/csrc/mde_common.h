@@ -13,6 +13,7 @@ typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
 typedef __attribute__((ext_vector_type(4))) int i32x4_t;
 typedef __attribute__((ext_vector_type(2))) int i32x2_t;
 
@@ -51,10 +52,16 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t mde_rsrc(const void* p, uint32
 // row_ror rotations are plain VALU DPP modifiers; __shfl_xor would go through the LDS crossbar
 // (ds_bpermute_b32), which cost ~6 us per 256x256 tile in the conv epilogue.
 __device__ __forceinline__ float mde_row16_sum(float v) {
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, false));  // row_ror:8
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xF, 0xF, false));  // row_ror:4
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xF, 0xF, false));  // row_ror:2
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xF, 0xF, false));  // row_ror:1
+    // (the empty asm keeps each add scalar: paired up by the SLP vectorizer they become
+    //  v_mov + 2 x v_mov_b32_dpp + v_pk_add_f32 instead of two fused v_add_f32_dpp)
+#define MDE_DPP_ADD(ctrl)                                                                                           \
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xF, 0xF, false)); \
+    asm("" : "+v"(v));
+    MDE_DPP_ADD(0x128)  // row_ror:8
+    MDE_DPP_ADD(0x124)  // row_ror:4
+    MDE_DPP_ADD(0x122)  // row_ror:2
+    MDE_DPP_ADD(0x121)  // row_ror:1
+#undef MDE_DPP_ADD
     return v;
 }
 
