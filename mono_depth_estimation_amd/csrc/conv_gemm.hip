@@ -30,6 +30,7 @@
 #include <stdlib.h>
 
 #include "mde_common.h"
+#include <type_traits>
 
 // MDE_ABLATE (timing-only diagnostic builds, results are wrong): 1 = no global loads in the
 // K-loop, 2 = also no LDS staging writes, 3 = no MFMAs, 4 = no barriers in the K-loop (register
@@ -454,20 +455,49 @@ __global__ __launch_bounds__(NT, 2) void conv_gemm_nt(const KArgs a) {
         const int col = n0 + chunk * 8;
         if (col < d.ncols) {
             const bool full = a.vec_ok && (col + 8 <= d.ncols);
-#pragma unroll 4
-            for (int r = r0; r < EROWS; r += RPP) {
-                const int oo = s_out[ep * EROWS + r];
-                if (oo < 0) continue;
-                bf16x8_t v = *reinterpret_cast<const bf16x8_t*>(smem + r * ROWB + chunk * 16);
-                bf16_t* dst = outp + (size_t)oo + col;
-                if (full) {
-                    if (d.accumulate) {
-                        const bf16x8_t old = *reinterpret_cast<const bf16x8_t*>(dst);
+            if (full) {
+                // Batches of RB rows.  For accumulate, every LOAD of a batch is issued before the batch's
+                // first STORE: loads and stores retire through one in-order counter (vmcnt), so a load
+                // issued behind a store waits for it.  The loads are unconditional (rows past the end
+                // read row 0 and are not stored): a load under a per-lane condition becomes its own
+                // block with a full vmcnt(0) wait, which serialised the old read-modify-write loop.
+                constexpr int ROWS_PT = EROWS / RPP;                 // rows per thread per pass
+                constexpr int RB = ROWS_PT % 4 == 0 ? 4 : ROWS_PT % 3 == 0 ? 3 : ROWS_PT % 2 == 0 ? 2 : 1;   // bounded by registers
+                static_assert(ROWS_PT * RPP == EROWS && ROWS_PT % RB == 0, "store batches");
+                auto store_rows = [&](auto acc_tag) {
+                    constexpr bool ACC = decltype(acc_tag)::value;
+#pragma unroll 1
+                    for (int rb = 0; rb < ROWS_PT; rb += RB) {
+                        int oo[RB];
+                        i32x4_t oldv[ACC ? RB : 1];
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] = (bf16_t)((float)v[e] + (float)old[e]);
+                        for (int q = 0; q < RB; ++q) {
+                            oo[q] = s_out[ep * EROWS + r0 + (rb + q) * RPP];
+                            if constexpr (ACC) oldv[q] = *reinterpret_cast<const i32x4_t*>(outp + (size_t)max(oo[q], 0) + col);
+                        }
+#pragma unroll
+                        for (int q = 0; q < RB; ++q) {
+                            const int r = r0 + (rb + q) * RPP;
+                            bf16x8_t v = *reinterpret_cast<const bf16x8_t*>(smem + r * ROWB + chunk * 16);
+                            if constexpr (ACC) {
+                                const bf16x8_t old = __builtin_bit_cast(bf16x8_t, oldv[q]);
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) v[e] = (bf16_t)((float)v[e] + (float)old[e]);
+                            }
+                            if (oo[q] >= 0) *reinterpret_cast<bf16x8_t*>(outp + (size_t)oo[q] + col) = v;
+                        }
                     }
-                    *reinterpret_cast<bf16x8_t*>(dst) = v;
-                } else {
+                };
+                if (d.accumulate)
+                    store_rows(std::true_type{});
+                else
+                    store_rows(std::false_type{});
+            } else {
+                for (int r = r0; r < EROWS; r += RPP) {
+                    const int oo = s_out[ep * EROWS + r];
+                    if (oo < 0) continue;
+                    const bf16x8_t v = *reinterpret_cast<const bf16x8_t*>(smem + r * ROWB + chunk * 16);
+                    bf16_t* dst = outp + (size_t)oo + col;
                     const int nv = min(8, d.ncols - col);
                     for (int e = 0; e < nv; ++e) {
                         float x = (float)v[e];
