@@ -97,8 +97,11 @@ int mde_conv_wgrad(const mde_wgrad_desc* d, const void* direct, const void* gath
 
 /* Stem 7x7/2 convolution on the raw image (torchvision conv1, used at FCRN.py:308,353).
  * x: fp32 NCHW [N][3][H][W] (the tensor the LightningModule hands to model(x), laina.py:18)
- * w: fp32 [64][7][7][3] (OHWI).  out: bf16 NHWC [N][H/2][W/2][64].  H, W even. */
-int mde_stem_conv_fwd(const float* x, const float* w, void* out, int N, int H, int W, void* stream);
+ * w: fp32 [64][7][7][3] (OHWI).  out: bf16 NHWC [N][H/2][W/2][64].  H, W even.
+ * stats (optional, may be NULL): BatchNorm partial-sum buffer fp32 [mde_stat_slots()][2][64]
+ * that receives the per-channel sum / sum of squares of the fp32 results (as mde_conv_gemm). */
+int mde_stem_conv_fwd(const float* x, const float* w, void* out, float* stats, int N, int H, int W,
+                      void* stream);
 /* dw (fp32 [64][7][7][3], caller-zeroed) += wgrad from dout bf16 [N][H/2][W/2][64]. */
 int mde_stem_conv_wgrad(const float* x, const void* dout, float* dw, int N, int H, int W, void* stream);
 

@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MDE_LIB_PATH") or os.path.join(_HERE, "libmde_hip.so")   # override: diagnostic builds only
-ABI_VERSION = 2
+ABI_VERSION = 3
 MAX_TAPS = 32
 
 
@@ -52,7 +52,7 @@ SIGNATURES = {
     "mde_device_cu_count": (_I, [C.POINTER(_I)]),
     "mde_conv_gemm": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P]),
     "mde_conv_wgrad": (_I, [C.POINTER(WgradDesc), _P, _P, _P, _P]),
-    "mde_stem_conv_fwd": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "mde_stem_conv_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "mde_stem_conv_wgrad": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "mde_head_conv_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "mde_head_conv_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),

@@ -5,119 +5,318 @@
 // The stem runs on MFMA with its im2col fragments built on the fly from an LDS image patch; the
 // head runs on the vector ALUs in fp32.  Both use LDS-staged operands and coalesced global traffic.
 #include "mde_common.h"
+#include <type_traits>
 
 namespace {
 
 constexpr int NT = 256;
 
 // =================================================================== stem 7x7 / stride 2 / pad 3
+// MFMA formulation (v_mfma_f32_16x16x32_bf16).  A persistent workgroup walks tiles of TY x 64
+// output pixels; the fp32 NCHW image patch of a tile (3 x (2*TY+5) x 133) is staged in LDS ONCE,
+// already split into bf16 hi + lo parts packed in one 32-bit word (two MFMAs per product keep
+// ~fp32 accuracy on the raw image; weights are bf16 as everywhere).  Even and odd image columns
+// live in separate planes of a patch row, so the 16 pixels of a fragment (image columns
+// 2*px + kw) read consecutive words.  The next tile's patch is prefetched into registers while
+// the current one is computed.  All global loads are unconditional buffer loads (an out-of-image
+// element gets an out-of-range offset and reads as 0): a load under a per-lane condition
+// compiles to its own block with a full vmcnt(0) wait.
 constexpr int SK = 147;            // 7*7*3, weight layout [64][7][7][3] -> k = (kh*7+kw)*3+c
-constexpr int SPW = 136;           // patch row pitch (133 used)
-constexpr int STILE = 64;          // output pixels per tile (one output-row segment)
+constexpr int STX = 64;            // output pixels per tile row
+constexpr int SPC = 2 * STX + 5;   // 133 input columns
+static_assert(SPC == 128 + 5, "the patch loader covers columns 0..127 plus a 5-column tail");
+constexpr int SPH = 68;            // words per column plane (even columns, then odd columns)
+constexpr int SPW = 2 * SPH;       // patch row pitch (words)
 
-__device__ __forceinline__ void stem_load_patch(float* patch, const float* __restrict__ x, int n, int oy, int ox0,
-                                                int H, int W) {
-    for (int i = threadIdx.x; i < 3 * 7 * 133; i += NT) {
-        const int j = i % 133, r = i / 133, kh = r % 7, c = r / 7;
-        const int iy = 2 * oy - 3 + kh, ix = 2 * ox0 - 3 + j;
-        float v = 0.f;
-        if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = x[(((int64_t)n * 3 + c) * H + iy) * W + ix];
-        patch[(c * 7 + kh) * SPW + j] = v;
+// Patch geometry for TY output rows per tile
+template <int TY>
+struct StemGeo {
+    static constexpr int PR = 2 * TY + 5;          // input rows per channel
+    static constexpr int ROWS = 3 * PR;            // patch rows (channel-major)
+    static constexpr int WORDS = ROWS * SPW;
+    // zero words behind the patch (target of padded k): last tile row, odd plane, last pixel, 4 words
+    static constexpr int ZPAD = 2 * (TY - 1) * SPW + SPH + STX + 8;
+};
+
+// Tile walk of a persistent workgroup: (n, ty, tx) advanced by the grid size with scalar carries
+// (a 64-bit t % tiles_x per tile costs ~130 instructions of software division, three times over).
+struct StemTile { int n, oy0, ox0; };
+template <int TY>
+struct StemWalk {
+    int tx, ty, n, dx, dy, dn, tiles_x, tiles_y;
+    __device__ __forceinline__ void init(int first, int step, int tiles_x_, int tiles_y_) {
+        tiles_x = tiles_x_;
+        tiles_y = tiles_y_;
+        tx = first % tiles_x;
+        ty = (first / tiles_x) % tiles_y;
+        n = first / (tiles_x * tiles_y);
+        dx = step % tiles_x;
+        dy = (step / tiles_x) % tiles_y;
+        dn = step / (tiles_x * tiles_y);
     }
+    __device__ __forceinline__ StemTile tile() const { return StemTile{n, ty * TY, tx * STX}; }
+    __device__ __forceinline__ void next() {
+        tx += dx;
+        int c = tx >= tiles_x;
+        tx -= c ? tiles_x : 0;
+        ty += dy + c;
+        c = ty >= tiles_y;
+        ty -= c ? tiles_y : 0;
+        n += dn + c;
+    }
+};
+
+__device__ __forceinline__ int stem_patch_word(int row, int col) {   // word of image column `col` in patch row `row`
+    return row * SPW + (col & 1) * SPH + (col >> 1);
 }
 
-// MFMA formulation.  K = 147 (k = (kh*7+kw)*3+c, the OHWI weight order) padded to 160 = 5 steps of
-// v_mfma_f32_16x16x32_bf16.  A operand = weights (rows = 64 output channels, register resident for
-// the whole persistent workgroup), B operand = pixels: its fragments are built on the fly from the
-// fp32 image patch in LDS (lane (px = l&15, g = l>>4) needs patch[c][kh][2*px + kw] for the 8 k's
-// of its group; the 40 LDS offsets are per-lane constants).  The image is split into bf16 hi + lo
-// parts (two MFMAs) so the stem keeps ~fp32 accuracy on the raw input; weights are bf16.
-constexpr int SKP = 160;
-constexpr int SKS = SKP / 32;      // 5 MFMA k-steps
-
-__device__ __forceinline__ int stem_patch_off(int k) {   // k -> offset of tap (kh,kw), channel c in the patch
-    const int c = k % 3, kw = (k / 3) % 7, kh = k / 21;
-    return (c * 7 + kh) * SPW + kw;
+__device__ __forceinline__ uint32_t pack_hilo(float v) {  // bf16(v) | bf16(v - bf16(v)) << 16
+    const bf16_t hi = (bf16_t)v;
+    const bf16_t lo = (bf16_t)(v - (float)hi);
+    return (uint32_t)__builtin_bit_cast(unsigned short, hi) | ((uint32_t)__builtin_bit_cast(unsigned short, lo) << 16);
 }
 
-__device__ __forceinline__ void split_bf16(float v, bf16_t& hi, bf16_t& lo) {
-    hi = (bf16_t)v;
-    lo = (bf16_t)(v - (float)hi);
+// Patch loader for NTT threads.  Thread -> (rp = tid >> 7, column j = tid & 127) covers columns
+// 0..127 of rows RP*q + rp; the 5 remaining columns of every row are one more load for the first
+// ROWS*5 threads.  The image-relative word offset and the row-within-channel of every load are
+// per-thread constants built once; per tile a load costs an add, a row-range compare and a select.
+template <int NTT, int TY>
+struct StemLoader {
+    using G = StemGeo<TY>;
+    static constexpr int RP = NTT / 128;                       // patch rows per pass
+    static constexpr int Q = (G::ROWS + RP - 1) / RP + 1;      // loads per thread (last: tail columns)
+    static_assert(G::ROWS * 5 <= NTT && G::PR < 31, "tail columns fit one pass");
+    int relpr[Q];      // ((c*H + pr)*W + column) | pr << 27; pr = 31: no such row
+    int col, tcol;
+
+    __device__ __forceinline__ void init(int H, int W) {
+        const int rp = threadIdx.x >> 7;
+        col = threadIdx.x & 127;
+#pragma unroll
+        for (int q = 0; q < Q - 1; ++q) {
+            const int r = RP * q + rp, c = r / G::PR, pr = r - c * G::PR;
+            relpr[q] = r < G::ROWS ? (((c * H + pr) * W + col) | (pr << 27)) : (31 << 27);
+        }
+        const int r = threadIdx.x / 5, c = r / G::PR, pr = r - c * G::PR;
+        tcol = 128 + threadIdx.x % 5;
+        relpr[Q - 1] = r < G::ROWS ? (((c * H + pr) * W + tcol) | (pr << 27)) : (31 << 27);
+    }
+    __device__ __forceinline__ void issue(float (&pv)[Q], const __amdgpu_buffer_rsrc_t rs, const StemTile tl, int H, int W) const {
+        const int iy0 = 2 * tl.oy0 - 3, ix0 = 2 * tl.ox0 - 3;
+        const int base = (tl.n * 3 * H + iy0) * W + ix0;
+        const int lo = -iy0, hi = min(H - iy0, G::PR);         // image rows: pr in [lo, hi); pr = 31 (no row) fails
+        const bool okx = (unsigned)(ix0 + col) < (unsigned)W, okt = (unsigned)(ix0 + tcol) < (unsigned)W;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const int pr = (int)((uint32_t)relpr[q] >> 27), rel = relpr[q] & 0x7FFFFFF;
+            const bool ok = (q < Q - 1 ? okx : okt) & (pr >= lo) & (pr < hi);
+            const uint32_t off = ok ? (uint32_t)(base + rel) * 4u : MDE_OOB_OFFSET;
+            pv[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, off, 0, 0));
+        }
+    }
+    __device__ __forceinline__ void write(uint32_t* patch, const float (&pv)[Q]) const {
+        const int rp = threadIdx.x >> 7;
+#pragma unroll
+        for (int q = 0; q < Q - 1; ++q) {
+            const int r = RP * q + rp;
+            if (r < G::ROWS) patch[stem_patch_word(r, col)] = pack_hilo(pv[q]);
+        }
+        if (threadIdx.x < G::ROWS * 5) patch[stem_patch_word(threadIdx.x / 5, tcol)] = pack_hilo(pv[Q - 1]);
+    }
+    // words the loader never writes (plane tails) must hold finite values: they meet zero weights
+    __device__ __forceinline__ static void clear_tails(uint32_t* patch) {
+        for (int r = threadIdx.x; r < G::ROWS; r += NTT) {
+            patch[r * SPW + SPH - 1] = 0u;                     // even plane: columns 0..132 fill indices 0..66
+            patch[r * SPW + 2 * SPH - 2] = patch[r * SPW + 2 * SPH - 1] = 0u;   // odd plane: indices 0..65
+        }
+    }
+};
+
+// eight packed words (hi | lo << 16) -> the hi and lo bf16x8 fragments
+__device__ __forceinline__ void stem_unpack8(const uint32_t (&wv)[8], bf16x8_t& bh, bf16x8_t& bl) {
+    i32x4_t h, l;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        h[i] = (int)__builtin_amdgcn_perm(wv[2 * i + 1], wv[2 * i], 0x05040100u);
+        l[i] = (int)__builtin_amdgcn_perm(wv[2 * i + 1], wv[2 * i], 0x07060302u);
+    }
+    bh = __builtin_bit_cast(bf16x8_t, h);
+    bl = __builtin_bit_cast(bf16x8_t, l);
 }
 
-__global__ __launch_bounds__(NT, 2) void stem_fwd_k(const float* __restrict__ x, const float* __restrict__ w,
-                                                    bf16_t* __restrict__ out, int N, int H, int W, int OH, int OW) {
-    __shared__ float patch[3 * 7 * SPW];
+// Forward.  K is re-ordered for the gather: k' = g*8 + e with g = c*7 + kh (21 groups, padded to
+// 24 = 6 MFMA k-steps) and e = kw (e = 7: zero weight), so the 8 k's of a lane group are the image
+// columns 2*px .. 2*px+7 of ONE patch row: four consecutive words of the even plane and four of
+// the odd plane, read with immediates from one per-k-step base (the plain (kh,kw,c) order needs
+// 40 per-lane offsets and an address add per word: measured issue-bound, MFMA pipe 22 % busy;
+// profiles/).  8 waves, two per SIMD; wave w owns output row w of the 8 x 64 tile and all 64
+// channels (A operand = weights, register resident for the whole persistent workgroup).
+// stats (optional): BatchNorm partial sums of the fp32 results, kept in registers across tiles.
+constexpr int NTF = 512;
+constexpr int FTY = 8;             // output rows per forward tile
+constexpr int FKS = 6;             // k-steps of 32 (24 groups of 8)
+#ifndef MDE_STEM_ABLATE
+#define MDE_STEM_ABLATE 0   // diagnostics: 1 no output stores, 2 no MFMAs, 4 no patch loads (bit mask)
+#endif
+__global__ __launch_bounds__(NTF, 1) void stem_fwd_k(const float* __restrict__ x, const float* __restrict__ w,
+                                                     bf16_t* __restrict__ out, float* stats, int N, int H, int W, int OH,
+                                                     int OW) {
+    using G = StemGeo<FTY>;
+    __shared__ uint32_t patch[2][G::WORDS + G::ZPAD];
+    __shared__ float s_red[NTF / 64][2][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lr = lane & 15, lg = lane >> 4;
-    // A fragments: weights of channels cb*16 + lr, k = ks*32 + 8*lg + j
-    bf16x8_t wa[4][SKS];
-    int poff[SKS][8];
+    bf16x8_t wa[4][FKS];
+    int poffb[FKS];                          // byte offset of the lane's group row (even plane, its pixel) in a patch buffer
 #pragma unroll
-    for (int ks = 0; ks < SKS; ++ks)
+    for (int ks = 0; ks < FKS; ++ks) {
+        const int g = ks * 4 + lg, c = g / 7, kh = g - c * 7;
+        poffb[ks] = ((g < 21 ? (c * G::PR + kh) * SPW : G::WORDS) + 2 * wave * SPW + lr) * 4;   // padded groups: the zero words
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int k = ks * 32 + 8 * lg + j;
-            poff[ks][j] = k < SK ? stem_patch_off(k) : -1;
+        for (int e = 0; e < 8; ++e)
 #pragma unroll
-            for (int cb = 0; cb < 4; ++cb) wa[cb][ks][j] = (bf16_t)(k < SK ? w[(cb * 16 + lr) * SK + k] : 0.f);
+            for (int cb = 0; cb < 4; ++cb)
+                wa[cb][ks][e] = (bf16_t)((g < 21 && e < 7) ? w[(cb * 16 + lr) * SK + (kh * 7 + e) * 3 + c] : 0.f);
+    }
+    for (int i = threadIdx.x; i < G::ZPAD; i += NTF) patch[0][G::WORDS + i] = patch[1][G::WORDS + i] = 0u;
+    StemLoader<NTF, FTY>::clear_tails(patch[0]);
+    StemLoader<NTF, FTY>::clear_tails(patch[1]);
+    f32x4_t s1[4], s2[4];
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) s1[cb] = s2[cb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    const int tiles_x = (OW + STX - 1) / STX, tiles_y = (OH + FTY - 1) / FTY;
+    const int ntiles = N * tiles_y * tiles_x;
+    const __amdgpu_buffer_rsrc_t rs_x = mde_rsrc(x, (uint32_t)((int64_t)N * 3 * H * W * 4));
+    StemLoader<NTF, FTY> ld;
+    ld.init(H, W);
+    StemWalk<FTY> walk;
+    walk.init(blockIdx.x, gridDim.x, tiles_x, tiles_y);
+    float pv[StemLoader<NTF, FTY>::Q];
+    if ((int)blockIdx.x < ntiles) {
+        ld.issue(pv, rs_x, walk.tile(), H, W);
+        ld.write(patch[0], pv);
+    }
+    __syncthreads();
+    StemTile tl;
+    auto compute = [&](auto cur_tag) {
+        constexpr int CUR = decltype(cur_tag)::value;
+        const char* pb = reinterpret_cast<const char*>(&patch[CUR][0]);
+        const int oy = tl.oy0 + wave;
+        if (oy >= OH) return;
+#pragma unroll
+        for (int f = 0; f < STX / 16; ++f) {
+            if (tl.ox0 + f * 16 >= OW) break;
+            f32x4_t acc[4];
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) acc[cb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < FKS; ++ks) {
+                const uint32_t* pe = reinterpret_cast<const uint32_t*>(pb + poffb[ks] + f * 64);
+                uint32_t wv[8];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    wv[2 * i] = pe[i];                // image column 2*px + 2i
+                    wv[2 * i + 1] = pe[SPH + i];      // image column 2*px + 2i + 1
+                }
+                bf16x8_t bh, bl;
+                stem_unpack8(wv, bh, bl);
+#if MDE_STEM_ABLATE & 2
+                acc[0][0] += (float)bh[0] + (float)bl[1];
+                acc[1][1] += (float)bh[2] + (float)bl[3] + (float)bh[4] + (float)bl[5] + (float)bh[6] + (float)bl[7];
+#else
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[cb][ks], bh, acc[cb], 0, 0, 0);
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[cb][ks], bl, acc[cb], 0, 0, 0);
+#endif
+            }
+            // D: col = pixel (lane&15), rows = channels cb*16 + lg*4 + r
+            const int ox = tl.ox0 + f * 16 + lr;
+            if (ox < OW) {
+                bf16_t* o = out + ((((int64_t)tl.n * OH + oy) * OW) + ox) * 64 + lg * 4;
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb) {
+                    bf16x4_t v;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = (bf16_t)acc[cb][r];
+                    if (!(MDE_STEM_ABLATE & 1) || v[0] == (bf16_t)123.f) *reinterpret_cast<bf16x4_t*>(o + cb * 16) = v;
+                    s1[cb] += acc[cb];
+                    s2[cb] += acc[cb] * acc[cb];
+                }
+            }
         }
-    const int tiles_x = (OW + STILE - 1) / STILE;
-    const int64_t ntiles = (int64_t)N * OH * tiles_x;
-    for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
-        const int tx = (int)(t % tiles_x);
-        const int oy = (int)((t / tiles_x) % OH);
-        const int n = (int)(t / ((int64_t)tiles_x * OH));
-        const int ox0 = tx * STILE;
+    };
+    int cur = 0;
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        tl = walk.tile();
+        if (t + (int)gridDim.x < ntiles) walk.next();                     // last round: reload the same tile (unused)
+        if (!(MDE_STEM_ABLATE & 4)) ld.issue(pv, rs_x, walk.tile(), H, W);
+        if (cur)
+            compute(std::integral_constant<int, 1>{});
+        else
+            compute(std::integral_constant<int, 0>{});
+        ld.write(patch[cur ^ 1], pv);
         __syncthreads();
-        stem_load_patch(patch, x, n, oy, ox0, H, W);
+        cur ^= 1;
+    }
+    if (stats) {
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float a1 = mde_row16_sum(s1[cb][r]), a2 = mde_row16_sum(s2[cb][r]);
+                if (lr == 0) {
+                    s_red[wave][0][cb * 16 + lg * 4 + r] = a1;
+                    s_red[wave][1][cb * 16 + lg * 4 + r] = a2;
+                }
+            }
         __syncthreads();
-        const int px = wave * 16 + lr;            // this lane's pixel inside the 64-pixel tile
-        f32x4_t acc[4];
+        if (threadIdx.x < 128) {
+            const int which = threadIdx.x >> 6, ch = threadIdx.x & 63;
+            float v = 0.f;
 #pragma unroll
-        for (int cb = 0; cb < 4; ++cb) acc[cb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ks = 0; ks < SKS; ++ks) {
-            bf16x8_t bh, bl;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float v = poff[ks][j] >= 0 ? patch[poff[ks][j] + 2 * px] : 0.f;
-                bf16_t hi, lo;
-                split_bf16(v, hi, lo);
-                bh[j] = hi;
-                bl[j] = lo;
-            }
-#pragma unroll
-            for (int cb = 0; cb < 4; ++cb) {
-                acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[cb][ks], bh, acc[cb], 0, 0, 0);
-                acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[cb][ks], bl, acc[cb], 0, 0, 0);
-            }
-        }
-        // D: col = pixel (lane&15), rows = channels cb*16 + lg*4 + r
-        if (ox0 + px < OW) {
-            bf16_t* o = out + ((((int64_t)n * OH + oy) * OW) + ox0 + px) * 64 + lg * 4;
-#pragma unroll
-            for (int cb = 0; cb < 4; ++cb) {
-                bf16x4_t v;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = (bf16_t)acc[cb][r];
-                *reinterpret_cast<bf16x4_t*>(o + cb * 16) = v;
-            }
+            for (int q = 0; q < NTF / 64; ++q) v += s_red[q][which][ch];
+            atomicAdd(stats + ((size_t)(blockIdx.x % MDE_STAT_SLOTS) * 2 + which) * 64 + ch, v);
         }
     }
+}
+
+// ---- weight gradient (NT threads, tiles of WTY x 64 pixels, the plain k = (kh*7+kw)*3+c column order)
+constexpr int SKP = 160;           // 147 output columns padded to 10 fragments of 16
+constexpr int WTY = 4;
+__device__ __forceinline__ int stem_patch_off(int k) {   // k -> word offset of tap (kh,kw), channel c for pixel (0,0)
+    const int c = k % 3, kw = (k / 3) % 7, kh = k / 21;
+    return stem_patch_word(c * StemGeo<WTY>::PR + kh, kw);
 }
 
 // dw[ch][k] += sum_px dY[px][ch] * patch[px][k]:  A[ch][px] comes from the [pixel][channel] dY tile
-// by transposed LDS reads (as in conv_wgrad.hip), B[px][k] from the patch (hi + lo parts).
-// Wave w owns the k-column fragments {w, w+4, w+8}; all 4 channel fragments.
-__device__ __forceinline__ int stem_dy_off(int row, int ch) {   // [64 px][64 ch] bf16, 128-B rows, XOR swizzle
+// by transposed LDS reads (as in conv_wgrad.hip), B[px][k] from the packed patch (hi + lo parts).
+// Wave w owns the k-column fragments {w, w+4, w+8}; all 4 channel fragments.  Patch and dY tile of
+// the next tile are prefetched into registers during the MFMAs.
+__device__ __forceinline__ int stem_dy_off(int row, int ch) {   // [px][64 ch] bf16, 128-B rows, XOR swizzle
     return row * 128 + 16 * (ch ^ ((((row >> 1) & 1) | (((row >> 3) & 1) << 1)) << 1));
+}
+constexpr int SDQ = WTY * STX * 8 / NT;   // 16-byte dY chunks per thread per tile (8)
+
+__device__ __forceinline__ void stem_dy_issue(i32x4_t (&dv)[SDQ], const __amdgpu_buffer_rsrc_t rs, const StemTile tl,
+                                              int OH, int OW) {
+#pragma unroll
+    for (int q = 0; q < SDQ; ++q) {
+        const int i = threadIdx.x + q * NT;
+        const int p = i >> 3, ch8 = i & 7;
+        const int oy = tl.oy0 + p / STX, ox = tl.ox0 + p % STX;       // p < WTY * STX
+        const bool ok = (oy < OH) & (ox < OW);                       // pixels outside the image read as zeros
+        const uint32_t off = ok ? (uint32_t)(((tl.n * OH + oy) * OW + ox) * 64 + ch8 * 8) * 2u : MDE_OOB_OFFSET;
+        dv[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+    }
 }
 
 __global__ __launch_bounds__(NT, 2) void stem_wgrad_k(const float* __restrict__ x, const bf16_t* __restrict__ dout,
                                                       float* __restrict__ dw, int N, int H, int W, int OH, int OW) {
-    __shared__ float patch[3 * 7 * SPW];
-    __shared__ __attribute__((aligned(16))) char dyt[STILE * 128];
+    using G = StemGeo<WTY>;
+    __shared__ uint32_t patch[G::WORDS + G::ZPAD];
+    __shared__ __attribute__((aligned(16))) char dyt[WTY * STX * 128];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lr = lane & 15, lg = lane >> 4;
     constexpr int NF = 3;                    // k-column fragments per wave (10 in total: wave, wave+4, wave+8)
@@ -125,33 +324,44 @@ __global__ __launch_bounds__(NT, 2) void stem_wgrad_k(const float* __restrict__ 
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
         const int k = (wave + 4 * f) * 16 + lr;
-        poff[f] = (wave + 4 * f < SKP / 16 && k < SK) ? stem_patch_off(k) : -1;
+        poff[f] = (wave + 4 * f < SKP / 16 && k < SK) ? stem_patch_off(k) : G::WORDS;
     }
+    for (int i = threadIdx.x; i < G::ZPAD; i += NT) patch[G::WORDS + i] = 0u;
+    StemLoader<NT, WTY>::clear_tails(patch);
     f32x4_t acc[4][NF];
 #pragma unroll
     for (int cb = 0; cb < 4; ++cb)
 #pragma unroll
         for (int f = 0; f < NF; ++f) acc[cb][f] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    const int tiles_x = (OW + STILE - 1) / STILE;
-    const int64_t ntiles = (int64_t)N * OH * tiles_x;
+    const int tiles_x = (OW + STX - 1) / STX, tiles_y = (OH + WTY - 1) / WTY;
+    const int ntiles = N * tiles_y * tiles_x;
     typedef __attribute__((address_space(3))) s16x4_t* lds_ptr;
-    for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
-        const int tx = (int)(t % tiles_x);
-        const int oy = (int)((t / tiles_x) % OH);
-        const int n = (int)(t / ((int64_t)tiles_x * OH));
-        const int ox0 = tx * STILE;
-        __syncthreads();
-        stem_load_patch(patch, x, n, oy, ox0, H, W);
-        for (int i = threadIdx.x; i < STILE * 8; i += NT) {   // dY tile: 64 px x 8 chunks of 8 channels
-            const int p = i >> 3, ch8 = i & 7;
-            i32x4_t g = {0, 0, 0, 0};
-            if (ox0 + p < OW)
-                g = *reinterpret_cast<const i32x4_t*>(dout + ((((int64_t)n * OH + oy) * OW) + ox0 + p) * 64 + ch8 * 8);
-            *reinterpret_cast<i32x4_t*>(dyt + stem_dy_off(p, ch8)) = g;
+    const __amdgpu_buffer_rsrc_t rs_x = mde_rsrc(x, (uint32_t)((int64_t)N * 3 * H * W * 4));
+    const __amdgpu_buffer_rsrc_t rs_d = mde_rsrc(dout, (uint32_t)((int64_t)N * OH * OW * 64 * 2));
+    StemLoader<NT, WTY> ld;
+    ld.init(H, W);
+    StemWalk<WTY> walk;
+    walk.init(blockIdx.x, gridDim.x, tiles_x, tiles_y);
+    float pv[StemLoader<NT, WTY>::Q];
+    i32x4_t dv[SDQ];
+    if ((int)blockIdx.x < ntiles) {
+        ld.issue(pv, rs_x, walk.tile(), H, W);
+        stem_dy_issue(dv, rs_d, walk.tile(), OH, OW);
+    }
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        __syncthreads();                               // everyone is done with the previous tile's LDS
+        ld.write(patch, pv);
+#pragma unroll
+        for (int q = 0; q < SDQ; ++q) {
+            const int i = threadIdx.x + q * NT;
+            *reinterpret_cast<i32x4_t*>(dyt + stem_dy_off(i >> 3, i & 7)) = dv[q];
         }
         __syncthreads();
-#pragma unroll
-        for (int kk = 0; kk < STILE; kk += 32) {
+        if (t + (int)gridDim.x < ntiles) walk.next();
+        ld.issue(pv, rs_x, walk.tile(), H, W);
+        stem_dy_issue(dv, rs_d, walk.tile(), OH, OW);
+#pragma unroll 2
+        for (int kk = 0; kk < WTY * STX; kk += 32) {
             // A fragments (channels cb*16 + lr as rows, pixels kk + 8*lg + j as k): two transposed reads each
             bf16x8_t fa[4];
 #pragma unroll
@@ -165,19 +375,16 @@ __global__ __launch_bounds__(NT, 2) void stem_wgrad_k(const float* __restrict__ 
                 u.s.b = hi;
                 fa[cb] = u.v;
             }
+            // pixels kk + 8*lg + j: tile row kk/64, columns (kk%64) + 8*lg + j
+            const uint32_t* P = patch + 2 * (kk / STX) * SPW + ((kk % STX) + 8 * lg);
 #pragma unroll
             for (int f = 0; f < NF; ++f) {
                 if (wave + 4 * f >= SKP / 16) continue;      // wave-uniform
-                bf16x8_t bh, bl;
+                uint32_t wv[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int px = kk + 8 * lg + j;
-                    const float v = poff[f] >= 0 ? patch[poff[f] + 2 * px] : 0.f;
-                    bf16_t h, l;
-                    split_bf16(v, h, l);
-                    bh[j] = h;
-                    bl[j] = l;
-                }
+                for (int j = 0; j < 8; ++j) wv[j] = P[poff[f] + j];
+                bf16x8_t bh, bl;
+                stem_unpack8(wv, bh, bl);
 #pragma unroll
                 for (int cb = 0; cb < 4; ++cb) {
                     acc[cb][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[cb], bh, acc[cb][f], 0, 0, 0);
@@ -337,6 +544,16 @@ __global__ __launch_bounds__(NT) void head_wgrad_k(const bf16_t* __restrict__ x,
     }
 }
 
+int cu_count() {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+    }
+    return cus;
+}
+
 int px_grid(int64_t npx, int ppb) {
     int64_t nb = (npx + ppb - 1) / ppb;
     return (int)(nb > 256 * 8 ? 256 * 8 : (nb < 1 ? 1 : nb));
@@ -380,13 +597,18 @@ int head_check(const char* who, int N, int H, int W, int Cin, int Cout) {
 
 }  // namespace
 
-extern "C" int mde_stem_conv_fwd(const float* x, const float* w, void* out, int N, int H, int W, void* stream) {
+extern "C" int mde_stem_conv_fwd(const float* x, const float* w, void* out, float* stats, int N, int H, int W,
+                                 void* stream) {
     MDE_REQUIRE(x && w && out && N > 0 && H > 0 && W > 0, "mde_stem_conv_fwd: bad argument");
     MDE_REQUIRE(((uintptr_t)out % 16) == 0, "mde_stem_conv_fwd: out must be 16-byte aligned");
     const int OH = (H + 6 - 7) / 2 + 1, OW = (W + 6 - 7) / 2 + 1;
-    const int64_t ntiles = (int64_t)N * OH * ((OW + STILE - 1) / STILE);
-    const int grid = (int)(ntiles > 2048 ? 2048 : ntiles);
-    stem_fwd_k<<<grid, NT, 0, (hipStream_t)stream>>>(x, w, (bf16_t*)out, N, H, W, OH, OW);
+    MDE_REQUIRE((int64_t)N * 3 * H * W * 4 < MDE_OOB_OFFSET && (int64_t)N * OH * OW < (1 << 30),
+                "mde_stem_conv_fwd: image tensor must be < 2 GiB");
+    const int64_t ntiles = (int64_t)N * ((OH + FTY - 1) / FTY) * ((OW + STX - 1) / STX);
+    MDE_REQUIRE((int64_t)3 * H * W < (1 << 27), "mde_stem_conv_fwd: image plane too large");
+    const int64_t cap = cu_count();                         // persistent: one 8-wave workgroup per CU
+    const int grid = (int)(ntiles > cap ? cap : ntiles);
+    stem_fwd_k<<<grid, NTF, 0, (hipStream_t)stream>>>(x, w, (bf16_t*)out, stats, N, H, W, OH, OW);
     MDE_LAUNCH_CHECK("stem_fwd_k");
     return MDE_OK;
 }
@@ -394,9 +616,13 @@ extern "C" int mde_stem_conv_fwd(const float* x, const float* w, void* out, int 
 extern "C" int mde_stem_conv_wgrad(const float* x, const void* dout, float* dw, int N, int H, int W, void* stream) {
     MDE_REQUIRE(x && dout && dw && N > 0 && H > 0 && W > 0, "mde_stem_conv_wgrad: bad argument");
     MDE_REQUIRE(((uintptr_t)dout % 16) == 0, "mde_stem_conv_wgrad: dout must be 16-byte aligned");
+    MDE_REQUIRE((int64_t)3 * H * W < (1 << 27), "mde_stem_conv_wgrad: image plane too large");
+    MDE_REQUIRE((int64_t)N * 3 * H * W * 4 < MDE_OOB_OFFSET && (int64_t)N * (H / 2 + 1) * (W / 2 + 1) * 128 < MDE_OOB_OFFSET,
+                "mde_stem_conv_wgrad: tensors must be < 2 GiB");
     const int OH = (H + 6 - 7) / 2 + 1, OW = (W + 6 - 7) / 2 + 1;
-    const int64_t ntiles = (int64_t)N * OH * ((OW + STILE - 1) / STILE);
-    const int grid = (int)(ntiles > 1024 ? 1024 : ntiles);
+    const int64_t ntiles = (int64_t)N * ((OH + WTY - 1) / WTY) * ((OW + STX - 1) / STX);
+    const int64_t cap = 2 * (int64_t)cu_count();
+    const int grid = (int)(ntiles > cap ? cap : ntiles);
     stem_wgrad_k<<<grid, NT, 0, (hipStream_t)stream>>>(x, (const bf16_t*)dout, dw, N, H, W, OH, OW);
     MDE_LAUNCH_CHECK("stem_wgrad_k");
     return MDE_OK;

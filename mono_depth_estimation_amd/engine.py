@@ -354,10 +354,8 @@ class FCRNEngine:
         assert x.shape == (self.N, 3, self.H, self.W) and x.dtype == torch.float32 and x.is_contiguous()
         self.store.refresh_weights()
         self.x = x
-        ops.stem_conv_fwd(x, self.stem_w.w32, self.stem_c.t)
         s = self.stem_site
-        if train:
-            ops.bn_stats(self.stem_c.t, self.stem_c.M, 64, 64, s.part)
+        ops.stem_conv_fwd(x, self.stem_w.w32, self.stem_c.t, s.part if train else None)
         s.finalize(self.stem_c.M, train)
         ops.bn_apply(self.stem_c.t, 64, s.scale, s.shift, self.stem_a.t, 64, self.stem_c.M, 64, True)
         ops.maxpool_fwd(self.stem_a.t, self.pool.t, self.pool_idx, self.N, self.stem_a.H, self.stem_a.W, 64)

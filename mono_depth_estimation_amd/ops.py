@@ -209,9 +209,9 @@ def choose_ksplit(pixels, row_tiles, col_tiles, ntaps, cus=256, min_steps=8, wg_
 
 
 # ------------------------------------------------------------------------------ small convs
-def stem_conv_fwd(x, w, out):
+def stem_conv_fwd(x, w, out, stats=None):
     N, _, H, W = x.shape
-    check(_lib.load().mde_stem_conv_fwd(_p(x), _p(w), _p(out), N, H, W, _stream()), "mde_stem_conv_fwd")
+    check(_lib.load().mde_stem_conv_fwd(_p(x), _p(w), _p(out), _p(stats), N, H, W, _stream()), "mde_stem_conv_fwd")
 
 
 def stem_conv_wgrad(x, dout, dw):

@@ -35,7 +35,7 @@ def _pack_dgrad(w):  # OIHW -> [I][kh*kw][O]
 def _assert_close(got, ref, what, tol=2.0 ** -8):
     err = (got - ref).abs()
     bound = tol * ref.abs() + tol * ref.pow(2).mean().sqrt()
-    bad = (err > bound).sum().item()
+    bad = (~(err <= bound)).sum().item()          # NaN/Inf compare False: they count as bad
     assert bad == 0, "%s: %d/%d outside tolerance, max err %.4g (ref rms %.4g)" % (
         what, bad, ref.numel(), err.max().item(), ref.pow(2).mean().sqrt().item())
 
