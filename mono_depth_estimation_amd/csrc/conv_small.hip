@@ -544,6 +544,216 @@ __global__ __launch_bounds__(NT) void head_wgrad_k(const bf16_t* __restrict__ x,
     }
 }
 
+// ------------------------------------------------------------------- head, Cin = 64 -> Cout = 1 (the FCRN case)
+// Eight lanes per pixel (lane c8 owns channels [c8*8, c8*8+8)); a lane group walks runs of HR
+// consecutive pixels of one row, so the 3x3 windows of neighbouring outputs share their loads
+// (18 instead of 36 per run).  All weights sit in registers; out-of-image taps are buffer loads
+// with an out-of-range offset (read as 0).
+constexpr int HR = 4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16pair_t;
+
+__device__ __forceinline__ float head_sum8(float v) {     // sum over the 8 lanes of a pixel, result in all of them
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
+    asm("" : "+v"(v));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));   // quad_perm [2,3,0,1]
+    asm("" : "+v"(v));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, false));  // row_half_mirror
+    return v;
+}
+
+// forward: weights as bf16 hi + lo pairs, v_dot2c_f32_bf16 against the bf16 activations (no conversions)
+__global__ __launch_bounds__(NT) void head1_fwd_k(const bf16_t* __restrict__ x, const float* __restrict__ w,
+                                                  float* __restrict__ out, int N, int H, int W) {
+    const int c8 = threadIdx.x & 7, grp = threadIdx.x >> 3;
+    bf16pair_t wh[9][4], wl[9][4];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const float v = w[t * 64 + c8 * 8 + 2 * i + h];
+                const bf16_t hi = (bf16_t)v;
+                wh[t][i][h] = hi;
+                wl[t][i][h] = (bf16_t)(v - (float)hi);
+            }
+    const __amdgpu_buffer_rsrc_t rs = mde_rsrc(x, (uint32_t)((int64_t)N * H * W * 128));
+    const int runs_x = (W + HR - 1) / HR;
+    const int nruns = N * H * runs_x;
+    for (int it = blockIdx.x * (NT / 8) + grp; it < nruns; it += gridDim.x * (NT / 8)) {
+        const int xb = it % runs_x, ny = it / runs_x, y = ny % H;
+        const int x0 = xb * HR;
+        float acc[HR];
+#pragma unroll
+        for (int p = 0; p < HR; ++p) acc[p] = 0.f;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int yy = y + ky - 1;
+            const bool rok = (unsigned)yy < (unsigned)H;
+            const int rowbase = ((ny - y + yy) * W) * 64 + c8 * 8;      // (n*H + yy) * W pixels
+            i32x4_t v[HR + 2];
+#pragma unroll
+            for (int j = 0; j < HR + 2; ++j) {
+                const int col = x0 - 1 + j;
+                const bool ok = rok & ((unsigned)col < (unsigned)W);
+                v[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? (uint32_t)(rowbase + col * 64) * 2u : MDE_OOB_OFFSET, 0, 0);
+            }
+#pragma unroll
+            for (int p = 0; p < HR; ++p)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int xi = v[p + kx][i];      // (scalar copy on purpose: __builtin_bit_cast applied to a
+                        const bf16pair_t xv = __builtin_bit_cast(bf16pair_t, xi);   //  vector-element expression reads element 0)
+                        acc[p] = __builtin_amdgcn_fdot2_f32_bf16(xv, wh[ky * 3 + kx][i], acc[p], false);
+                        acc[p] = __builtin_amdgcn_fdot2_f32_bf16(xv, wl[ky * 3 + kx][i], acc[p], false);
+                    }
+        }
+        float mine = 0.f;
+#pragma unroll
+        for (int p = 0; p < HR; ++p) {
+            const float sp = head_sum8(acc[p]);
+            mine = c8 == p ? sp : mine;
+        }
+        if (c8 < HR && x0 + c8 < W) out[(int64_t)ny * W + x0 + c8] = mine;
+    }
+}
+
+// input gradient: dx[p][c] = sum_tap dout[p - off(tap)] * w[tap][c]   (fp32 weights in registers)
+__global__ __launch_bounds__(NT) void head1_dgrad_k(const float* __restrict__ w, const float* __restrict__ dout,
+                                                    bf16_t* __restrict__ dx, int N, int H, int W) {
+    const int c8 = threadIdx.x & 7, grp = threadIdx.x >> 3;
+    f32x2_t wr[9][4];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wr[t][i] = f32x2_t{w[t * 64 + c8 * 8 + 2 * i], w[t * 64 + c8 * 8 + 2 * i + 1]};
+    const __amdgpu_buffer_rsrc_t rs = mde_rsrc(dout, (uint32_t)((int64_t)N * H * W * 4));
+    const int runs_x = (W + HR - 1) / HR;
+    const int nruns = N * H * runs_x;
+    for (int it = blockIdx.x * (NT / 8) + grp; it < nruns; it += gridDim.x * (NT / 8)) {
+        const int xb = it % runs_x, ny = it / runs_x, y = ny % H;
+        const int x0 = xb * HR;
+        f32x2_t acc[HR][4];
+#pragma unroll
+        for (int p = 0; p < HR; ++p)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[p][i] = f32x2_t{0.f, 0.f};
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            // tap (ky, kx) of output pixel q reads input pixel q + (ky-1, kx-1): q = p - (ky-1, kx-1)
+            const int yy = y - (ky - 1);
+            const bool rok = (unsigned)yy < (unsigned)H;
+            float d[HR + 2];
+#pragma unroll
+            for (int j = 0; j < HR + 2; ++j) {
+                const int col = x0 - 1 + j;
+                const bool ok = rok & ((unsigned)col < (unsigned)W);
+                d[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                    rs, ok ? (uint32_t)((ny - y + yy) * W + col) * 4u : MDE_OOB_OFFSET, 0, 0));
+            }
+#pragma unroll
+            for (int p = 0; p < HR; ++p)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const float dq = d[p + 2 - kx];                 // column x0 + p - (kx - 1)
+                    const f32x2_t dd = {dq, dq};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[p][i] = __builtin_elementwise_fma(dd, wr[ky * 3 + kx][i], acc[p][i]);
+                }
+        }
+#pragma unroll
+        for (int p = 0; p < HR; ++p) {
+            if (x0 + p >= W) break;
+            bf16x8_t o;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                o[2 * i] = (bf16_t)acc[p][i][0];
+                o[2 * i + 1] = (bf16_t)acc[p][i][1];
+            }
+            *reinterpret_cast<bf16x8_t*>(dx + ((int64_t)ny * W + x0 + p) * 64 + c8 * 8) = o;
+        }
+    }
+}
+
+// weight gradient, input-stationary: every activation is converted once and meets the nine dout
+// values around it:  dw[(ky,kx)][c] += dout[p - (ky-1, kx-1)] * x[p][c]
+__global__ __launch_bounds__(NT) void head1_wgrad_k(const bf16_t* __restrict__ x, const float* __restrict__ dout,
+                                                    float* __restrict__ dw, int N, int H, int W) {
+    __shared__ float red[NT / 64][9 * 64];
+    const int c8 = threadIdx.x & 7, grp = threadIdx.x >> 3;
+    f32x2_t acc[9][4];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[t][i] = f32x2_t{0.f, 0.f};
+    const __amdgpu_buffer_rsrc_t rs_d = mde_rsrc(dout, (uint32_t)((int64_t)N * H * W * 4));
+    const __amdgpu_buffer_rsrc_t rs_x = mde_rsrc(x, (uint32_t)((int64_t)N * H * W * 128));
+    const int runs_x = (W + HR - 1) / HR;
+    const int nruns = N * H * runs_x;
+    for (int it = blockIdx.x * (NT / 8) + grp; it < nruns; it += gridDim.x * (NT / 8)) {
+        const int xb = it % runs_x, ny = it / runs_x, y = ny % H;
+        const int x0 = xb * HR;
+        i32x4_t xv[HR];
+#pragma unroll
+        for (int p = 0; p < HR; ++p)
+            xv[p] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, x0 + p < W ? (uint32_t)((ny * W + x0 + p) * 64 + c8 * 8) * 2u : MDE_OOB_OFFSET, 0, 0);
+        float d[3][HR + 2];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int yy = y - (ky - 1);
+            const bool rok = (unsigned)yy < (unsigned)H;
+#pragma unroll
+            for (int j = 0; j < HR + 2; ++j) {
+                const int col = x0 - 1 + j;
+                const bool ok = rok & ((unsigned)col < (unsigned)W);
+                d[ky][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                    rs_d, ok ? (uint32_t)((ny - y + yy) * W + col) * 4u : MDE_OOB_OFFSET, 0, 0));
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < HR; ++p) {
+            f32x2_t xf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t u = (uint32_t)xv[p][i];
+                xf[i] = f32x2_t{__builtin_bit_cast(float, u << 16), __builtin_bit_cast(float, u & 0xFFFF0000u)};
+            }
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const float dq = d[ky][p + 2 - kx];
+                    const f32x2_t dd = {dq, dq};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[ky * 3 + kx][i] = __builtin_elementwise_fma(dd, xf[i], acc[ky * 3 + kx][i]);
+                }
+        }
+    }
+    // lanes with equal c8 inside the wave (pixel groups), then the waves through LDS, then one atomic per value
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                float s = acc[t][i][h];
+                s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x128, 0xF, 0xF, false));   // row_ror:8
+                s += __shfl_xor(s, 16, 64);
+                s += __shfl_xor(s, 32, 64);
+                if (lane < 8) red[wv][t * 64 + lane * 8 + 2 * i + h] = s;
+            }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 9 * 64; i += NT) {
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < NT / 64; ++q) s += red[q][i];
+        atomicAdd(dw + i, s);
+    }
+}
+
 int cu_count() {
     static int cus = 0;
     if (!cus) {
@@ -552,6 +762,12 @@ int cu_count() {
         cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
     }
     return cus;
+}
+
+int head1_grid(int N, int H, int W) {          // persistent-ish: up to 8 workgroups per CU over the pixel runs
+    const int64_t nruns = (int64_t)N * H * ((W + HR - 1) / HR);
+    const int64_t nb = (nruns + NT / 8 - 1) / (NT / 8), cap = 8 * (int64_t)cu_count();
+    return (int)(nb > cap ? cap : (nb < 1 ? 1 : nb));
 }
 
 int px_grid(int64_t npx, int ppb) {
@@ -634,6 +850,11 @@ extern "C" int mde_head_conv_fwd(const void* x, const float* w, float* out, int 
     if (int rc = head_check("mde_head_conv_fwd", N, H, W, Cin, Cout)) return rc;
     MDE_REQUIRE(((uintptr_t)x % 16) == 0, "mde_head_conv_fwd: x must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
+    if (Cout == 1 && Cin == 64 && (int64_t)N * H * W * 128 < MDE_OOB_OFFSET) {
+        head1_fwd_k<<<head1_grid(N, H, W), NT, 0, st>>>((const bf16_t*)x, w, out, N, H, W);
+        MDE_LAUNCH_CHECK("head1_fwd_k");
+        return MDE_OK;
+    }
     return HEAD_DISPATCH(head_fwd_launch, x, w, out, N, H, W, Cin, Cout, st);
 }
 
@@ -643,6 +864,18 @@ extern "C" int mde_head_conv_bwd(const void* x, const float* w, const float* dou
     if (int rc = head_check("mde_head_conv_bwd", N, H, W, Cin, Cout)) return rc;
     MDE_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)dx % 16) == 0, "mde_head_conv_bwd: x/dx must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
+    if (Cout == 1 && Cin == 64 && (int64_t)N * H * W * 128 < MDE_OOB_OFFSET) {
+        if (dx) {
+            head1_dgrad_k<<<head1_grid(N, H, W), NT, 0, st>>>(w, dout, (bf16_t*)dx, N, H, W);
+            MDE_LAUNCH_CHECK("head1_dgrad_k");
+        }
+        if (dw) {
+            const int g = head1_grid(N, H, W);
+            head1_wgrad_k<<<g > 1024 ? 1024 : g, NT, 0, st>>>((const bf16_t*)x, dout, dw, N, H, W);
+            MDE_LAUNCH_CHECK("head1_wgrad_k");
+        }
+        return MDE_OK;
+    }
     if (dx) {
         int rc = HEAD_DISPATCH(head_dgrad_launch, w, dout, dx, N, H, W, Cin, Cout, st);
         if (rc) return rc;
