@@ -210,6 +210,17 @@ int mde_adam_step(float* p, const float* g, float* m, float* v, void* p_bf16, in
 int mde_cast_bf16(const float* src, void* dst, int64_t n, void* stream);
 /* dst[i][t][o] = bf16(src[o][t][i])  — the dgrad ("transposed") weight packing. */
 int mde_pack_wt(const float* src, void* dst, int O, int T, int I, void* stream);
+/* The same for many weights of one flat parameter buffer in ONE launch: job j transposes
+ * src[off .. off + O*T*I) into dst[off ..) (same element offset in a flat bf16 buffer).
+ * jobs: DEVICE array sorted by first_block; first_block = sum over earlier jobs of
+ * ceil(I/32)*ceil(O/32)*T; nblocks = that sum over all jobs. */
+typedef struct mde_pack_job {
+    int64_t off;
+    int64_t O, T, I;
+    int64_t first_block;
+} mde_pack_job;
+int mde_pack_wt_batch(const float* src, void* dst, const mde_pack_job* jobs, int njobs, int64_t nblocks,
+                      void* stream);
 /* fp32 NCHW -> bf16 NHWC (and back) layout changes at the module boundary. */
 int mde_nchw_to_nhwc_bf16(const float* src, void* dst, int N, int C, int H, int W, void* stream);
 int mde_nhwc_bf16_to_nchw(const void* src, float* dst, int N, int C, int H, int W, void* stream);

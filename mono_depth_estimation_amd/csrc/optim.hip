@@ -77,6 +77,35 @@ __global__ void pack_wt_k(const float* __restrict__ src, bf16_t* __restrict__ ds
     }
 }
 
+// one launch for many weights: block b belongs to the last job whose first_block <= b
+__global__ void pack_wt_batch_k(const float* __restrict__ src, bf16_t* __restrict__ dst,
+                                const mde_pack_job* __restrict__ jobs, int njobs) {
+    __shared__ float tile[32][33];
+    int lo = 0, hi = njobs - 1;                      // uniform binary search (the table is L2-resident)
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].first_block <= (int64_t)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const mde_pack_job j = jobs[lo];
+    const int O = (int)j.O, T = (int)j.T, I = (int)j.I;
+    const int nib = (I + 31) / 32, nob = (O + 31) / 32;
+    const int local = (int)((int64_t)blockIdx.x - j.first_block);
+    const int ib = local % nib, ob = (local / nib) % nob, t = local / (nib * nob);
+    if (t >= T) return;
+    const float* s = src + j.off;
+    bf16_t* d = dst + j.off;
+    const int i0 = ib * 32, o0 = ob * 32;
+    for (int r = threadIdx.y; r < 32; r += 8) {
+        const int o = o0 + r, i = i0 + threadIdx.x;
+        tile[r][threadIdx.x] = (o < O && i < I) ? s[((size_t)o * T + t) * I + i] : 0.f;
+    }
+    __syncthreads();
+    for (int r = threadIdx.y; r < 32; r += 8) {
+        const int i = i0 + r, o = o0 + threadIdx.x;
+        if (i < I && o < O) d[((size_t)i * T + t) * O + o] = (bf16_t)tile[threadIdx.x][r];
+    }
+}
+
 int grid_for4(int64_t n) {
     int64_t nb = (n / 4 + NT - 1) / NT + 1;
     return (int)(nb > 256 * 8 ? 256 * 8 : nb);
@@ -104,6 +133,14 @@ extern "C" int mde_cast_bf16(const float* src, void* dst, int64_t n, void* strea
     MDE_REQUIRE(((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 8) == 0, "mde_cast_bf16: alignment");
     cast_k<<<grid_for4(n), NT, 0, (hipStream_t)stream>>>(src, (bf16_t*)dst, n);
     MDE_LAUNCH_CHECK("cast_k");
+    return MDE_OK;
+}
+
+extern "C" int mde_pack_wt_batch(const float* src, void* dst, const mde_pack_job* jobs, int njobs, int64_t nblocks,
+                                 void* stream) {
+    MDE_REQUIRE(src && dst && jobs && njobs > 0 && nblocks > 0 && nblocks < (1ll << 31), "mde_pack_wt_batch: bad argument");
+    pack_wt_batch_k<<<dim3((unsigned)nblocks), dim3(32, 8), 0, (hipStream_t)stream>>>(src, (bf16_t*)dst, jobs, njobs);
+    MDE_LAUNCH_CHECK("pack_wt_batch_k");
     return MDE_OK;
 }
 

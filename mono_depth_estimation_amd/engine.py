@@ -123,11 +123,8 @@ class Conv:
         self.w32 = store.P[off:off + n]
         self.wf = store.Pb[off:off + n]
         self.dw = store.G[off:off + n]
-        self.wd = torch.empty(n, dtype=torch.bfloat16, device=store.dev) if need_dgrad else None
-
-    def repack(self):
-        if self.wd is not None:
-            ops.pack_wt(self.w32, self.wd, self.O, self.T, self.I)
+        self.off = off
+        self.wd = store.WD[off:off + n] if need_dgrad else None    # slice of the flat transposed-weight buffer
 
 
 class ParamStore:
@@ -189,6 +186,8 @@ class ParamStore:
         self.P = torch.zeros(size, dtype=torch.float32, device=dev)
         self.G = torch.zeros(size, dtype=torch.float32, device=dev)
         self.Pb = torch.zeros(size, dtype=torch.bfloat16, device=dev)
+        self.WD = torch.zeros(size, dtype=torch.bfloat16, device=dev)     # transposed conv weights, same offsets as P
+        self._pack_jobs = None
         self.p_off = {}
         for (kind, ts), off in zip(plist, offs):
             o = off
@@ -255,15 +254,24 @@ class ParamStore:
             _, I, kh, kw = t0.shape
             c = Conv(self, self.p_off[id(t0)], O, kh * kw, I, need_dgrad)
             self.convs[id(t0)] = c
+            self._pack_jobs = None
         return c
 
     def refresh_weights(self, force=False):
         """bf16 shadow + transposed packings follow the fp32 masters (after any in-place update)."""
         if force or self.P._version != self.packed_version:
             ops.cast_bf16(self.P, self.Pb)
-            for c in self.convs.values():
-                c.repack()
+            self.repack()
             self.packed_version = self.P._version
+
+    def repack(self):
+        """Transposed ("dgrad") packings of every conv weight that needs one, in a single launch."""
+        if self._pack_jobs is None:
+            todo = sorted((c.off, c.O, c.T, c.I) for c in self.convs.values() if c.wd is not None)
+            self._pack_jobs = ops.pack_jobs(todo, self.dev) if todo else (None, 0)
+        jobs, nblocks = self._pack_jobs
+        if jobs is not None:
+            ops.pack_wt_batch(self.P, self.WD, jobs, nblocks)
 
     # fused Adam over the two flat ranges (encoder 1x LR, decoder 10x LR: modules/laina.py:51-57)
     def adam_step(self, lr_encoder, lr_decoder, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, grad_scale=1.0):
@@ -276,8 +284,7 @@ class ParamStore:
                       self.step_count)
         ops.adam_step(self.P[e:], self.G[e:], mom[e:], var[e:], self.Pb[e:], n - e, lr_decoder, betas[0], betas[1], eps,
                       weight_decay, grad_scale, self.step_count)
-        for c in self.convs.values():
-            c.repack()
+        self.repack()
         self.packed_version = self.P._version   # shadow + packings are current (torch saw no in-place op on P)
 
 

@@ -329,5 +329,18 @@ def cast_bf16(src, dst, n=None):
     check(_lib.load().mde_cast_bf16(_p(src), _p(dst), src.numel() if n is None else n, _stream()), "mde_cast_bf16")
 
 
+def pack_jobs(convs, device):
+    """Device job table (mde_pack_job rows) for mde_pack_wt_batch: convs = [(off, O, T, I)]."""
+    rows, first = [], 0
+    for off, O, T, I in convs:
+        rows.append([off, O, T, I, first])
+        first += ((I + 31) // 32) * ((O + 31) // 32) * T
+    return torch.tensor(rows, dtype=torch.int64, device=device), first
+
+
+def pack_wt_batch(src, dst, jobs, nblocks):
+    check(_lib.load().mde_pack_wt_batch(_p(src), _p(dst), _p(jobs), jobs.shape[0], nblocks, _stream()), "mde_pack_wt_batch")
+
+
 def pack_wt(src, dst, O, T, I):
     check(_lib.load().mde_pack_wt(_p(src), _p(dst), O, T, I, _stream()), "mde_pack_wt")

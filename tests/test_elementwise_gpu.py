@@ -252,6 +252,24 @@ def test_cast_and_pack():
     torch.cuda.synchronize()
     assert torch.equal(c.cpu(), w.to(torch.bfloat16))
     assert torch.equal(t.cpu(), w.permute(2, 1, 0).contiguous().to(torch.bfloat16))
+    # batched form: several weights of one flat buffer (with gaps between them) in one launch
+    shapes = [(70, 9, 130), (64, 1, 64), (33, 25, 40), (256, 1, 1024)]
+    offs, total = [], 8
+    for o, t_, i in shapes:
+        offs.append(total)
+        total += o * t_ * i + 24
+    flat = W.normal(13, "flat", (total,)).cuda()
+    dst = torch.full((total,), 7.0, dtype=torch.bfloat16, device="cuda")
+    jobs, nblocks = ops.pack_jobs([(off, o, t_, i) for off, (o, t_, i) in zip(offs, shapes)], "cuda")
+    ops.pack_wt_batch(flat, dst, jobs, nblocks)
+    torch.cuda.synchronize()
+    covered = torch.zeros(total, dtype=torch.bool)
+    for off, (o, t_, i) in zip(offs, shapes):
+        n = o * t_ * i
+        ref = flat[off:off + n].cpu().view(o, t_, i).permute(2, 1, 0).contiguous().to(torch.bfloat16)
+        assert torch.equal(dst[off:off + n].cpu().view(i, t_, o), ref)
+        covered[off:off + n] = True
+    assert (dst.cpu()[~covered].float() == 7.0).all(), "wrote outside the weights"
     x = W.normal(13, "x", (2, 5, 6, 7))
     xd = torch.empty(2, 6, 7, 5, dtype=torch.bfloat16, device="cuda")
     ops.nchw_to_nhwc_bf16(x.cuda(), xd)
