@@ -321,7 +321,8 @@ class FCRNEngine:
     def _ksplit(self, pixels, rows, cols, ntaps):
         ba, bb = (128 if rows % 128 == 0 else 64), (128 if cols % 128 == 0 else 64)
         lds = 2 * 64 * (ba + bb) * 2 + 512           # conv_wgrad_tn's staging ring + offset table
-        return ops.choose_ksplit(pixels, rows // ba, cols // bb, ntaps, self.cus, wg_per_cu=min(8, (160 * 1024) // lds))
+        return ops.choose_ksplit(pixels, rows // ba, cols // bb, ntaps, self.cus, wg_per_cu=min(8, (160 * 1024) // lds),
+                                 tile_elems=ba * bb)
 
     # ------------------------------------------------------------------ the plan
     def _plan(self):

@@ -186,25 +186,39 @@ def conv_wgrad(desc, direct, gathered, dw):
         "K=%d Cd=%d Cg=%d taps=%d ks=%d" % (desc.N * desc.GH * desc.GW, desc.Cd, desc.Cg, desc.ntaps, desc.ksplit))
 
 
-def choose_ksplit(pixels, row_tiles, col_tiles, ntaps, cus=256, min_steps=8, wg_per_cu=2):
-    """Split-K factor for the weight-gradient GEMM.  The grid is ntaps*row_tiles*col_tiles*ksplit
-    workgroups on cus*wg_per_cu resident slots: pick the factor whose LAST round is fullest (the
-    kernel time is rounds x per-workgroup time), among factors that cover the chip at least once
-    when the pixel range allows it and keep >= min_steps 64-pixel K-steps per workgroup; ties go
-    to the smaller factor (fewer atomics)."""
+def wgrad_time_model(pixels, row_tiles, col_tiles, ntaps, ks, cus=256, wg_per_cu=2, tile_elems=128 * 128):
+    """Estimated conv_wgrad_tn time (s) at split-K factor ks, fitted to MI355X sweeps (tools/conv_microbench.py
+    wgrad with MB_KS=...):  rounds of resident workgroups, a last round that is shorter
+    when it leaves CUs with fewer co-resident workgroups (a lone 4-wave workgroup reaches ~62 % of a CU), plus
+    the split-K reduction traffic: every workgroup adds its fp32 tile with atomics (~500 G elements/s chip-wide)."""
+    blocks = max(1, row_tiles * col_tiles * ntaps) * ks
+    slots = cus * wg_per_cu
+    rounds = -(-blocks // slots)
+    need = 2 if tile_elems >= 16384 else 3 if tile_elems >= 8192 else 4      # co-resident workgroups for full rate
+    f = lambda k: min(1.0, 0.62 + 0.38 * (k - 1) / (need - 1))               # CU throughput with k workgroups
+    full = wg_per_cu / f(wg_per_cu)
+    last = blocks - (rounds - 1) * slots
+    k = min(wg_per_cu, -(-last // cus))
+    h = (k / f(k)) / full                                                     # last round relative to a full one
+    rate = 750e12 if tile_elems >= 16384 else 600e12 if tile_elems >= 8192 else 560e12
+    t_round = 2.0 * (pixels / ks) * tile_elems * wg_per_cu / (rate / cus)
+    return t_round * ((rounds - 1) + h) + blocks * tile_elems / 500e9
+
+
+def choose_ksplit(pixels, row_tiles, col_tiles, ntaps, cus=256, min_steps=8, wg_per_cu=2, tile_elems=128 * 128):
+    """Split-K factor for the weight-gradient GEMM (grid = ntaps*row_tiles*col_tiles*ksplit workgroups):
+    the factor with the smallest modelled time (wgrad_time_model) among those that keep >= min_steps
+    64-pixel K-steps per workgroup.  Filling the last round matters, and so does the reduction: each extra
+    split adds one fp32 atomic per output element (the old fill-only rule chose 227 splits where 56 is 40 % faster)."""
     base = max(1, row_tiles * col_tiles * ntaps)
     slots = cus * wg_per_cu
     cap = max(1, pixels // (64 * min_steps))
     hi = min(cap, max(1, (4 * slots + base - 1) // base))
-    best, best_key = 1, None
+    best, best_t = 1, None
     for ks in range(1, hi + 1):
-        blocks = base * ks
-        rounds = -(-blocks // slots)
-        fill = blocks / (rounds * slots)
-        covers = blocks >= slots
-        key = (covers, round(fill, 3), -ks)
-        if best_key is None or key > best_key:
-            best, best_key = ks, key
+        t = wgrad_time_model(pixels, row_tiles, col_tiles, ntaps, ks, cus, wg_per_cu, tile_elems)
+        if best_t is None or t < best_t * (1.0 - 1e-9):
+            best, best_t = ks, t
     return best
 
 

@@ -140,15 +140,19 @@ def test_wgrad_descriptors():
 
 def test_ksplit_and_buckets():
     from mono_depth_estimation_amd import dp
-    def fill(base, ks, slots=512):
-        b = base * ks
-        return b / (-(-b // slots) * slots)
-    assert ops.choose_ksplit(2457600, 1, 1, 9) >= 32            # huge pixel range, tiny tile grid: split hard
+    assert ops.choose_ksplit(2457600, 1, 1, 9, wg_per_cu=4, tile_elems=64 * 64) >= 32   # huge pixel range, tiny tile grid: split hard
     assert ops.choose_ksplit(9600, 8, 8, 25) <= 2               # 1600 tiles already cover the chip 3x
     assert ops.choose_ksplit(640, 1, 1, 1) == 1                 # never fewer than 8 K-steps per workgroup
+    # measured optima on MI355X (tools/conv_microbench.py wgrad, MB_KS sweep): one nearly full round of
+    # workgroups beats several rounds of small ones because every split adds an fp32 atomic per output
+    assert 50 <= ops.choose_ksplit(153600, 1, 1, 9) <= 60       # 75 us at 56 vs 127 us at 227
+    assert 12 <= ops.choose_ksplit(38400, 2, 2, 9) <= 16        # 75 us at 14 vs 97 us at 28
+    assert 100 <= ops.choose_ksplit(614400, 1, 1, 9, wg_per_cu=4, tile_elems=64 * 64) <= 256   # 89 us at 113
     for px, rt, ct, taps in [(38400, 2, 2, 9), (153600, 2, 2, 25), (9600, 4, 4, 9), (614400, 1, 1, 25)]:
         ks = ops.choose_ksplit(px, rt, ct, taps)
-        assert fill(rt * ct * taps, ks) > 0.95 and px // (64 * ks) >= 8
+        assert px // (64 * ks) >= 8
+        t = ops.wgrad_time_model(px, rt, ct, taps, ks)
+        assert all(t <= ops.wgrad_time_model(px, rt, ct, taps, k) * (1 + 1e-6) for k in range(1, 65) if px // (64 * k) >= 8)
     b = dp.make_buckets(1000, [0, 100, 300, 600, 900], 800)
     assert b == [(600, 1000), (300, 600), (100, 300), (0, 100)]
     assert dp.make_buckets(10, [], 1 << 20) == [(0, 10)]

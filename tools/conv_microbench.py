@@ -30,7 +30,9 @@ def main():
         dw = torch.zeros(Cout, k * k, Cin, device=dev)
         rt = Cout // (128 if Cout % 128 == 0 else 64)
         ct = Cin // (128 if Cin % 128 == 0 else 64)
-        ks = ops.choose_ksplit(N * H * W, rt, ct, k * k)
+        ks = int(os.environ["MB_KS"]) if os.environ.get("MB_KS") else ops.choose_ksplit(
+            N * H * W, rt, ct, k * k, tile_elems=(Cout // rt) * (Cin // ct), wg_per_cu=min(8, 160 * 1024 // (256 * (Cout // rt + Cin // ct) + 512)))
+        print("ksplit", ks, end="  ")
         d = ops.conv_wgrad_desc(N, H, W, Cin, Cin, x.numel() * 2, H, W, Cout, Cout, dy.numel() * 2, k, 1, pad, ks)
         fn = lambda: ops.conv_wgrad(d, dy, x, dw)
         flops = 2.0 * N * H * W * Cout * k * k * Cin
