@@ -83,7 +83,7 @@ __device__ __forceinline__ int chunk_off(int row, int kslot8) {
 // each lane fetches and in the fragment read address (guide rule 21).  Out-of-image taps use
 // an out-of-range buffer offset: the DMA then writes zeros (tools/probes/lds_dma_probe.hip).
 template <int BP, int BC, int NT, bool DMA, int NBUF>
-__global__ __launch_bounds__(NT, 2) void conv_gemm_nt(const KArgs a) {
+__global__ __launch_bounds__(NT, (NT == 256 && BP * BC >= 256 * 256) ? 1 : 2) void conv_gemm_nt(const KArgs a) {
     constexpr int NW = NT / 64;
     constexpr int RPL = NT / 8;          // tile rows covered by one load pass (8 chunks per row)
     constexpr int XP = BP / RPL;         // X chunks per thread per K-step
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(NT, 2) void conv_gemm_nt(const KArgs a) {
     // the epilogue re-tiles through LDS; when the whole tile does not fit, in EPASS pixel slabs
     constexpr int EPASS = (BP * ROWB <= 2 * BUF_BYTES) ? 1 : 2;
     constexpr int EROWS = BP / EPASS;    // pixel rows per epilogue pass
-    static_assert(WAVES_P * WAVES_C == NW && PF * 16 * WAVES_P == BP && CF * 16 * WAVES_C == BC && PF >= 2 && PF <= 4, "wave tiling");
+    static_assert(WAVES_P * WAVES_C == NW && PF * 16 * WAVES_P == BP && CF * 16 * WAVES_C == BC && PF >= 2 && PF <= 8, "wave tiling");
     static_assert(XP >= 1 && WP >= 1 && XP * RPL == BP && WP * RPL == BC, "load tiling");
     static_assert(EROWS * ROWB <= 2 * BUF_BYTES && (WAVES_P % EPASS) == 0, "epilogue slab fits in the staging buffers");
     static_assert(NBUF == 2 || (DMA && NBUF == 3), "register staging uses two LDS buffers");
@@ -320,6 +320,122 @@ __global__ __launch_bounds__(NT, 2) void conv_gemm_nt(const KArgs a) {
 #pragma unroll
         for (int q = 0; q < DIST; ++q)
             if (q < nsteps) { issue_dma(lbuf); lbuf = lbuf + 1 == NBUF ? 0 : lbuf + 1; }
+        // One wave per SIMD (4 waves x 128x128 wave tiles): nothing else hides LDS latency, so the
+        // fragment reads are software-pipelined one fragment ahead of the MFMAs that use them (the
+        // compiler's own order was read -> wait -> 8 MFMAs per pixel fragment: pipe idle on every
+        // wait) and the next K-step's DMA instructions are spread over the second half's MFMAs.
+        constexpr bool W4 = (NW == 4 && PF == 8 && CF == 8);
+        if constexpr (W4) {
+            static_assert(!W4 || (XR == PF && WR == PF && DIST == 1), "one x and one w DMA per pixel fragment");
+            // The K-step barrier sits in the LAST pixel-fragment iteration of a step, after every LDS read of
+            // the current buffer has completed (lgkmcnt(0)): the first fragments of the next step are then
+            // fetched from the other buffer under that iteration's MFMAs, so a step starts with its operands
+            // in registers instead of behind vmcnt(0) + barrier + nine reads.
+            bf16x8_t fa0[CF], fa1[CF], fb[2];
+            {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                const char* xb = smem + wp * (PF * 2048);
+                const char* wb = smem + XT_BYTES + wc * (CF * 2048);
+#pragma unroll
+                for (int i = 0; i < CF; ++i) fa0[i] = *reinterpret_cast<const bf16x8_t*>(wb + i * 2048 + rd_off[0]);
+                fb[0] = *reinterpret_cast<const bf16x8_t*>(xb + rd_off[0]);
+            }
+            for (int s = 0; s < nsteps; ++s) {
+                __builtin_amdgcn_sched_barrier(0);
+                const char* xb = smem + cbuf * BUF_BYTES + wp * (PF * 2048);
+                const char* wb = smem + cbuf * BUF_BYTES + XT_BYTES + wc * (CF * 2048);
+                auto RA = [&](int kb, int i) { return *reinterpret_cast<const bf16x8_t*>(wb + i * 2048 + rd_off[kb]); };
+                auto RB = [&](int kb, int j) { return *reinterpret_cast<const bf16x8_t*>(xb + j * 2048 + rd_off[kb]); };
+                // the other buffer was released by the previous barrier: the next K-step's DMA goes out during
+                // k-half 0, one x and one w instruction per pixel fragment
+#if MDE_ABLATE == 5
+                const bool more = false;               // diagnostics: DMA instructions issue, nothing is fetched
+#else
+                const bool more = s + DIST < nsteps;
+#endif
+                const uint32_t c0b = (uint32_t)(lcs * BK) * 2u;
+                const uint32_t tapoff = (uint32_t)s_tap[ltap] * 2u + c0b;
+                const uint32_t woff = (uint32_t)s_tap[MDE_MAX_TAPS + ltap] * 2u + c0b;
+                const uint32_t bitm = more ? 1u << ltap : 0u;
+                char* dbuf = smem + lbuf * BUF_BYTES + wv * 1024;
+                __builtin_amdgcn_sched_barrier(0);
+                // sched_group_barrier masks: 0x008 MFMA, 0x100 LDS read, 0x020 VMEM read, 0x002 VALU.  Every
+                // non-MFMA instruction of an iteration is placed in the shadow of an MFMA (16 pipe cycles,
+                // 4 issue cycles): issued in a clump between MFMA groups they left the pipe idle.
+#pragma unroll
+                for (int j = 0; j < PF; ++j) {         // k-half 0; fetch B[j+1] and the j-th A fragment of half 1
+                    fb[(j + 1) & 1] = j + 1 < PF ? RB(0, j + 1) : RB(1, 0);
+                    fa1[j] = RA(1, j);
+                    {   // unconditional (a branch would split the scheduling region): after the last K-step the
+                        // offsets are out of range and the DMA writes zeros into the buffer nobody reads again
+                        const uint32_t off = (dx_ok[j] & bitm) ? dx_base[j] + tapoff : MDE_OOB_OFFSET;
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr)(dbuf + j * NW * 1024), 16, off, 0, 0, 0);
+                        const uint32_t offw = more ? dw_base[j] + woff : MDE_OOB_OFFSET;
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr)(dbuf + XT_BYTES + j * NW * 1024), 16, offw, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int i = 0; i < CF; ++i)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa0[i], fb[j & 1], acc[i][j], 0, 0, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int j = 0; j < PF - 1; ++j) {     // k-half 1
+                    fb[(j + 1) & 1] = RB(1, j + 1);
+#pragma unroll
+                    for (int i = 0; i < CF; ++i)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa1[i], fb[(PF + j) & 1], acc[i][j], 0, 0, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 7, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                // last iteration: every read of this buffer is in (lgkmcnt(0)), this wave's DMA of the next
+                // step landed (vmcnt(0)); after the barrier the other buffer is complete and this one is free
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#if MDE_ABLATE != 4
+                __builtin_amdgcn_s_barrier();
+#endif
+                __builtin_amdgcn_sched_barrier(0);
+                {
+                    const int nb = cbuf + 1 == NBUF ? 0 : cbuf + 1;
+                    const char* nxb = smem + nb * BUF_BYTES + wp * (PF * 2048);
+                    const char* nwb = smem + nb * BUF_BYTES + XT_BYTES + wc * (CF * 2048);
+#pragma unroll
+                    for (int i = 0; i < CF; ++i) fa0[i] = *reinterpret_cast<const bf16x8_t*>(nwb + i * 2048 + rd_off[0]);
+                    fb[0] = *reinterpret_cast<const bf16x8_t*>(nxb + rd_off[0]);
+#pragma unroll
+                    for (int i = 0; i < CF; ++i)
+                        acc[i][PF - 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa1[i], fb[(PF + PF - 1) & 1], acc[i][PF - 1], 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < CF; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (more) {
+                    if (++lcs == csteps) { lcs = 0; ++ltap; }
+                    lbuf = lbuf + 1 == NBUF ? 0 : lbuf + 1;
+                }
+                cbuf = cbuf + 1 == NBUF ? 0 : cbuf + 1;
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the trailing (zero) DMA must land before the epilogue reuses LDS
+        } else
         for (int s = 0; s < nsteps; ++s) {
             // step s landed once only the younger group(s) remain outstanding
             if (DIST == 2 && s + 1 < nsteps)
@@ -543,7 +659,7 @@ int pick_and_launch(KArgs& ka, int64_t M, hipStream_t st) {
     static int forced = -1, reg = 0;
     if (forced < 0) {
         const char* e = getenv("MDE_CONV_TILE");
-        forced = !e ? 0 : !strcmp(e, "256x256") ? 1 : !strcmp(e, "256x128") ? 2 : !strcmp(e, "128x128") ? 3 : !strcmp(e, "128x128x3") ? 4 : !strcmp(e, "192x256") ? 5 : !strcmp(e, "128x64") ? 6 : 0;
+        forced = !e ? 0 : !strcmp(e, "256x256") ? 1 : !strcmp(e, "256x128") ? 2 : !strcmp(e, "128x128") ? 3 : !strcmp(e, "128x128x3") ? 4 : !strcmp(e, "192x256") ? 5 : !strcmp(e, "128x64") ? 6 : !strcmp(e, "256x256w4") ? 7 : 0;
         const char* q = getenv("MDE_CONV_PATH");
         reg = q && !strcmp(q, "reg");
     }
@@ -609,6 +725,7 @@ int pick_and_launch(KArgs& ka, int64_t M, hipStream_t st) {
     if (forced == 4) return launch<128, 128, 256, true, 3>(ka, M, st);
     if (forced == 5) return launch<192, 256, 512, true, 2>(ka, M, st);
     if (forced == 6) return launch<128, 64, 256, true, 2>(ka, M, st);
+    if (forced == 7) return launch<256, 256, 256, true, 2>(ka, M, st);   // 4 waves x (128 px x 128 ch), one workgroup per CU
     if (forced == 2)
         return reg ? launch<256, 128, 512, false, 2>(ka, M, st) : launch<256, 128, 512, true, 3>(ka, M, st);
     return reg ? launch<128, 128, 256, false, 2>(ka, M, st) : launch<128, 128, 256, true, 2>(ka, M, st);
