@@ -163,6 +163,19 @@ int mde_bn_bwd_apply(const void* dout, int ldd, const void* out, int ldo, const 
                      const float* mask_shift, const uint8_t* relu_bits, const float* coef, int64_t M,
                      int C, int relu, void* dx, int ldxo, int accumulate_dx, void* dres, int ldres,
                      void* stream);
+/* The same two passes for a residual JOIN whose two summands are both BatchNorm outputs
+ * (out = relu(bn_a(xa) + bn_b(xb)): the downsample bottlenecks and every up-projection, FCRN.py:170-198):
+ * both sites see the same masked gradient g = dout * mask, so dout and the mask are read once per pass
+ * instead of once per site.  relu_bits may be NULL (no ReLU).  part_a/part_b, coef_a/coef_b as above. */
+int mde_bn_bwd_reduce2(const void* dout, int ldd, const void* xa, int ldxa, const void* xb, int ldxb,
+                       const float* save_mean_a, const float* save_rstd_a, const float* save_mean_b,
+                       const float* save_rstd_b, const uint8_t* relu_bits, int64_t M, int C,
+                       float* part_a, float* part_b, void* stream);
+int mde_bn_bwd_apply2(const void* dout, int ldd, const void* xa, int ldxa, const void* xb, int ldxb,
+                      const float* save_mean_a, const float* save_rstd_a, const float* save_mean_b,
+                      const float* save_rstd_b, const uint8_t* relu_bits, const float* coef_a,
+                      const float* coef_b, int64_t M, int C, void* dxa, int ldda, void* dxb, int lddb,
+                      void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Pooling / resize / pointwise.

@@ -62,6 +62,8 @@ SIGNATURES = {
     "mde_bn_eval_scale_shift": (_I, [_P, _P, _P, _P, _F, _I, _P, _P, _P]),
     "mde_bn_apply": (_I, [_P, _I, _P, _P, _P, _I, _P, _P, _P, _I, _P, _L, _I, _I, _P]),
     "mde_bn_bwd_reduce": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _P, _P, _L, _I, _I, _P, _P]),
+    "mde_bn_bwd_reduce2": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _P, _P, _L, _I, _P, _P, _P]),
+    "mde_bn_bwd_apply2": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _L, _I, _P, _I, _P, _I, _P]),
     "mde_bn_bwd_finalize": (_I, [_P, _L, _I, _P, _P, _P, _P, _P, _P]),
     "mde_bn_bwd_apply": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P, _I, _I, _P, _I, _P]),
     "mde_maxpool_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),

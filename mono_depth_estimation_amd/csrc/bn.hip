@@ -238,6 +238,94 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_k(const bf16_t* __restrict__ 
     }
 }
 
+// ---- residual join of two BN outputs: one masked gradient, two sites (see mde_bn_bwd_reduce2)
+__global__ __launch_bounds__(NT) void bn_bwd_reduce2_k(const bf16_t* __restrict__ dout, int ldd,
+                                                       const bf16_t* __restrict__ xa, int ldxa,
+                                                       const bf16_t* __restrict__ xb, int ldxb,
+                                                       const float* __restrict__ mean_a, const float* __restrict__ rstd_a,
+                                                       const float* __restrict__ mean_b, const float* __restrict__ rstd_b,
+                                                       const uint8_t* __restrict__ bits, int64_t M, int C, float* part_a,
+                                                       float* part_b, int rows_per_blk) {
+    __shared__ float sh[3 * MAXC];
+    const int cpr = C >> 3, rpb = NT / cpr, col = threadIdx.x % cpr, rl = threadIdx.x / cpr;
+    float mua[8], rsa[8], mub[8], rsb[8];
+    ldf8(mean_a + col * 8, mua);
+    ldf8(rstd_a + col * 8, rsa);
+    ldf8(mean_b + col * 8, mub);
+    ldf8(rstd_b + col * 8, rsb);
+    float s1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sa[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sb[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_blk;
+    const int64_t r1 = min(M, r0 + rows_per_blk);
+    for (int64_t r = r0 + rl; r < r1; r += rpb) {
+        float g[8], va[8], vb[8];
+        ld8(dout + r * ldd + col * 8, g);
+        ld8(xa + r * ldxa + col * 8, va);
+        ld8(xb + r * ldxb + col * 8, vb);
+        const uint32_t mb = bits ? bits[r * cpr + col] : 0xFFu;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float ge = ((mb >> e) & 1u) ? g[e] : 0.f;
+            s1[e] += ge;
+            sa[e] += ge * ((va[e] - mua[e]) * rsa[e]);
+            sb[e] += ge * ((vb[e] - mub[e]) * rsb[e]);
+        }
+    }
+    for (int i = threadIdx.x; i < 3 * C; i += NT) sh[i] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        atomicAdd(&sh[col * 8 + e], s1[e]);
+        atomicAdd(&sh[C + col * 8 + e], sa[e]);
+        atomicAdd(&sh[2 * C + col * 8 + e], sb[e]);
+    }
+    __syncthreads();
+    float* da = part_a + (size_t)(blockIdx.x % MDE_STAT_SLOTS) * 2 * C;
+    float* db = part_b + (size_t)(blockIdx.x % MDE_STAT_SLOTS) * 2 * C;
+    for (int i = threadIdx.x; i < C; i += NT) {
+        atomicAdd(da + i, sh[i]);
+        atomicAdd(db + i, sh[i]);
+        atomicAdd(da + C + i, sh[C + i]);
+        atomicAdd(db + C + i, sh[2 * C + i]);
+    }
+}
+
+__global__ __launch_bounds__(NT) void bn_bwd_apply2_k(const bf16_t* __restrict__ dout, int ldd,
+                                                      const bf16_t* __restrict__ xa, int ldxa,
+                                                      const bf16_t* __restrict__ xb, int ldxb,
+                                                      const float* __restrict__ mean_a, const float* __restrict__ rstd_a,
+                                                      const float* __restrict__ mean_b, const float* __restrict__ rstd_b,
+                                                      const uint8_t* __restrict__ bits, const float* __restrict__ coef_a,
+                                                      const float* __restrict__ coef_b, int64_t M, int C,
+                                                      bf16_t* __restrict__ dxa, int ldda, bf16_t* __restrict__ dxb, int lddb) {
+    const int cpr = C >> 3, rpb = NT / cpr, col = threadIdx.x % cpr, rl = threadIdx.x / cpr;
+    float mua[8], rsa[8], a0[8], a1[8], a2[8], mub[8], rsb[8], b0[8], b1[8], b2[8];
+    ldf8(mean_a + col * 8, mua);
+    ldf8(rstd_a + col * 8, rsa);
+    ldf8(coef_a + col * 8, a0);
+    ldf8(coef_a + C + col * 8, a1);
+    ldf8(coef_a + 2 * C + col * 8, a2);
+    ldf8(mean_b + col * 8, mub);
+    ldf8(rstd_b + col * 8, rsb);
+    ldf8(coef_b + col * 8, b0);
+    ldf8(coef_b + C + col * 8, b1);
+    ldf8(coef_b + 2 * C + col * 8, b2);
+    for (int64_t row = (int64_t)blockIdx.x * rpb + rl; row < M; row += (int64_t)gridDim.x * rpb) {
+        float g[8], va[8], vb[8], da[8], db[8];
+        ld8(dout + row * ldd + col * 8, g);
+        ld8(xa + row * ldxa + col * 8, va);
+        ld8(xb + row * ldxb + col * 8, vb);
+        const uint32_t mb = bits ? bits[row * cpr + col] : 0xFFu;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float ge = ((mb >> e) & 1u) ? g[e] : 0.f;
+            da[e] = a0[e] * (ge - a1[e] - ((va[e] - mua[e]) * rsa[e]) * a2[e]);
+            db[e] = b0[e] * (ge - b1[e] - ((vb[e] - mub[e]) * rsb[e]) * b2[e]);
+        }
+        st8(dxa + row * ldda + col * 8, da);
+        st8(dxb + row * lddb + col * 8, db);
+    }
+}
+
 int check_site(const char* who, int64_t M, int C) {
     MDE_REQUIRE(M > 0 && C > 0, "%s: non-positive size", who);
     MDE_REQUIRE(C % 8 == 0 && C <= MAXC && NT % (C / 8) == 0,
@@ -341,6 +429,40 @@ extern "C" int mde_bn_bwd_reduce(const void* dout, int ldd, const void* out, int
     else
         bn_bwd_reduce_k<1><<<nblk, NT, 0, st>>>(d, ldd, o, ldo, xp, ldx, save_mean, save_rstd, nullptr, nullptr, nullptr, M, C, part, rows);
     MDE_LAUNCH_CHECK("bn_bwd_reduce_k");
+    return MDE_OK;
+}
+
+extern "C" int mde_bn_bwd_reduce2(const void* dout, int ldd, const void* xa, int ldxa, const void* xb, int ldxb,
+                                  const float* save_mean_a, const float* save_rstd_a, const float* save_mean_b,
+                                  const float* save_rstd_b, const uint8_t* relu_bits, int64_t M, int C, float* part_a,
+                                  float* part_b, void* stream) {
+    MDE_REQUIRE(dout && xa && xb && save_mean_a && save_rstd_a && save_mean_b && save_rstd_b && part_a && part_b,
+                "mde_bn_bwd_reduce2: null argument");
+    if (int rc = check_site("mde_bn_bwd_reduce2", M, C)) return rc;
+    MDE_REQUIRE(al16(dout, ldd) && al16(xa, ldxa) && al16(xb, ldxb), "mde_bn_bwd_reduce2: alignment");
+    int nblk, rows;
+    reduce_geometry(M, C, &nblk, &rows);
+    bn_bwd_reduce2_k<<<nblk, NT, 0, (hipStream_t)stream>>>((const bf16_t*)dout, ldd, (const bf16_t*)xa, ldxa, (const bf16_t*)xb,
+                                                           ldxb, save_mean_a, save_rstd_a, save_mean_b, save_rstd_b, relu_bits,
+                                                           M, C, part_a, part_b, rows);
+    MDE_LAUNCH_CHECK("bn_bwd_reduce2_k");
+    return MDE_OK;
+}
+
+extern "C" int mde_bn_bwd_apply2(const void* dout, int ldd, const void* xa, int ldxa, const void* xb, int ldxb,
+                                 const float* save_mean_a, const float* save_rstd_a, const float* save_mean_b,
+                                 const float* save_rstd_b, const uint8_t* relu_bits, const float* coef_a,
+                                 const float* coef_b, int64_t M, int C, void* dxa, int ldda, void* dxb, int lddb,
+                                 void* stream) {
+    MDE_REQUIRE(dout && xa && xb && save_mean_a && save_rstd_a && save_mean_b && save_rstd_b && coef_a && coef_b && dxa && dxb,
+                "mde_bn_bwd_apply2: null argument");
+    if (int rc = check_site("mde_bn_bwd_apply2", M, C)) return rc;
+    MDE_REQUIRE(al16(dout, ldd) && al16(xa, ldxa) && al16(xb, ldxb) && al16(dxa, ldda) && al16(dxb, lddb),
+                "mde_bn_bwd_apply2: alignment");
+    bn_bwd_apply2_k<<<stream_grid(M, C), NT, 0, (hipStream_t)stream>>>(
+        (const bf16_t*)dout, ldd, (const bf16_t*)xa, ldxa, (const bf16_t*)xb, ldxb, save_mean_a, save_rstd_a, save_mean_b,
+        save_rstd_b, relu_bits, coef_a, coef_b, M, C, (bf16_t*)dxa, ldda, (bf16_t*)dxb, lddb);
+    MDE_LAUNCH_CHECK("bn_bwd_apply2_k");
     return MDE_OK;
 }
 

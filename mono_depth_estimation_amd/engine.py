@@ -108,6 +108,19 @@ class BNSite:
                          dres, _ld(dres, x) if dres is not None else 0, ms, mh, relu_bits)
 
 
+def bn_join_backward(sa, sb, dout, out, xa, xb, dxa, dxb, relu_bits):
+    """Backward of out = relu(bn_a(xa) + bn_b(xb)) for both sites at once: dout and the mask are read once
+    per pass (ops.bn_bwd_reduce2 / bn_bwd_apply2) instead of once per site."""
+    M, C = xa.M, sa.C
+    ldd = _ld(dout, out)
+    ops.bn_bwd_reduce2(dout, ldd, xa.t, xa.ld, xb.t, xb.ld, sa.smean, sa.srstd, sb.smean, sb.srstd, relu_bits, M, C,
+                       sa.part, sb.part)
+    ops.bn_bwd_finalize(sa.part, M, C, sa.gamma, sa.srstd, sa.dgamma, sa.dbeta, sa.coef)
+    ops.bn_bwd_finalize(sb.part, M, C, sb.gamma, sb.srstd, sb.dgamma, sb.dbeta, sb.coef)
+    ops.bn_bwd_apply2(dout, ldd, xa.t, xa.ld, xb.t, xb.ld, sa.smean, sa.srstd, sb.smean, sb.srstd, relu_bits, sa.coef,
+                      sb.coef, M, C, dxa, _ld(dxa, xa), dxb, _ld(dxb, xb))
+
+
 def _ld(t, like):
     """Pixel stride (elements) of a gradient/activation tensor view."""
     return t.stride(2) if t is not None and t.dim() == 4 else like.ld
@@ -518,10 +531,9 @@ class Bottleneck:
         if ds is None:
             c.bn_bwd(dres_to=self.x)         # identity shortcut: d(x) = masked d(out)
         else:
-            c.bn_bwd()
-            # second BN site of the join: same masked gradient, statistics of the shortcut conv
-            ds.site.backward(c.out.g, c.out, ds.c, True, ds.c.g, relu_bits=c.bits)
-            ds.c.gw = True
+            # both BN sites of the join (conv3 and the shortcut conv) see the same masked gradient
+            bn_join_backward(c.site, ds.site, c.out.g, c.out, c.c, ds.c, c.c.g, ds.c.g, c.bits)
+            c.c.gw = ds.c.gw = True
             ds.conv_bwd()
         c.conv_bwd()
         self.b.bwd()
@@ -572,8 +584,9 @@ class UpProjLayer:
         x, y, c2 = self.x, self.y55, self.c2
         yg = y.g
         C = self.site_u.C
-        c2.bn_bwd()                                                         # d(out) -> d(c2.c)
-        self.site_b.backward(c2.out.g, c2.out, self.y_b, True, yg[..., C:], relu_bits=c2.bits)  # join's second site
+        # join of bn2(conv3x3) and bn(bottom 5x5): d(out) -> d(c2.c) and d(y55 lower half) in one pair of passes
+        bn_join_backward(c2.site, self.site_b, c2.out.g, c2.out, c2.c, self.y_b, c2.c.g, yg[..., C:], c2.bits)
+        c2.c.gw = True
         c2.conv_bwd()                                                       # -> d(a1), dW(conv2)
         self.site_u.backward(self.a1.g, self.a1, self.y_u, True, yg[..., :C], mask_from_x=True)
         ops.conv_wgrad(self.wdesc, x.t, yg, self.w55.dw)

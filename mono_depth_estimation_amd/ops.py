@@ -269,6 +269,19 @@ def bn_bwd_reduce(dout, ldd, out, ldo, x, ldx, smean, srstd, M, C_, relu, part, 
           "mde_bn_bwd_reduce")
 
 
+def bn_bwd_reduce2(dout, ldd, xa, ldxa, xb, ldxb, mean_a, rstd_a, mean_b, rstd_b, relu_bits, M, C_, part_a, part_b):
+    check(_lib.load().mde_bn_bwd_reduce2(_p(dout), ldd, _p(xa), ldxa, _p(xb), ldxb, _p(mean_a), _p(rstd_a), _p(mean_b),
+                                         _p(rstd_b), _p(relu_bits), M, C_, _p(part_a), _p(part_b), _stream()),
+          "mde_bn_bwd_reduce2")
+
+
+def bn_bwd_apply2(dout, ldd, xa, ldxa, xb, ldxb, mean_a, rstd_a, mean_b, rstd_b, relu_bits, coef_a, coef_b, M, C_, dxa, ldda,
+                  dxb, lddb):
+    check(_lib.load().mde_bn_bwd_apply2(_p(dout), ldd, _p(xa), ldxa, _p(xb), ldxb, _p(mean_a), _p(rstd_a), _p(mean_b),
+                                        _p(rstd_b), _p(relu_bits), _p(coef_a), _p(coef_b), M, C_, _p(dxa), ldda, _p(dxb), lddb,
+                                        _stream()), "mde_bn_bwd_apply2")
+
+
 def bn_bwd_finalize(part, M, C_, gamma, srstd, dgamma, dbeta, coef):
     check(_lib.load().mde_bn_bwd_finalize(_p(part), M, C_, _p(gamma), _p(srstd), _p(dgamma), _p(dbeta), _p(coef),
                                           _stream()), "mde_bn_bwd_finalize")

@@ -278,6 +278,51 @@ def test_cast_and_pack():
     assert torch.equal(back.cpu(), _bf(x))
 
 
+@pytest.mark.parametrize("N,H,Wd,C", [(2, 9, 11, 64), (1, 5, 7, 2048), (3, 16, 20, 256)])
+def test_bn_join_backward_two_sites(N, H, Wd, C):
+    """mde_bn_bwd_reduce2 / apply2 (a residual join of two BN outputs, one masked gradient) against the
+    single-site kernels run twice: sums to 1e-4 relative (fp32 atomics, order not fixed), dx to one bf16 ulp
+    of their scale."""
+    from mono_depth_estimation_amd import ops
+    M = N * H * Wd
+    ld_b = C + 24                                             # second site is a channel slice of a wider tensor
+    dout = _bf(W.normal(21, "dout", (M, C))).to(torch.bfloat16).cuda()
+    xa = _bf(W.normal(21, "xa", (M, C)) * 1.5 + 0.2).to(torch.bfloat16).cuda()
+    xb_full = _bf(W.normal(21, "xb", (M, ld_b)) * 0.7 - 0.1).to(torch.bfloat16).cuda()
+    xb = xb_full[:, 8:8 + C]
+    bits = (W.uniform(21, "bits", (M, C // 8)) * 256).to(torch.uint8).cuda()
+    stats = [[(W.normal(21, "m%d" % i, (C,)) * 0.3).cuda(), (W.uniform(21, "r%d" % i, (C,)) + 0.5).cuda(),
+              (W.normal(21, "g%d" % i, (C,)) * 0.5 + 1.0).cuda()] for i in range(2)]
+    xs, lds = [xa, xb], [C, ld_b]
+    # reference: the single-site kernels, once per site
+    ref_dx, ref_coef, ref_dg, ref_db = [], [], [], []
+    for i in range(2):
+        part = ops.new_stat_buffer(C)
+        coef, dg, db = torch.empty(3, C, device="cuda"), torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+        dx = torch.empty(M, C, dtype=torch.bfloat16, device="cuda")
+        ops.bn_bwd_reduce(dout, C, None, 0, xs[i], lds[i], stats[i][0], stats[i][1], M, C, True, part, relu_bits=bits)
+        ops.bn_bwd_finalize(part, M, C, stats[i][2], stats[i][1], dg, db, coef)
+        ops.bn_bwd_apply(dout, C, None, 0, xs[i], lds[i], stats[i][0], stats[i][1], coef, M, C, True, dx, C, relu_bits=bits)
+        ref_dx.append(dx); ref_coef.append(coef); ref_dg.append(dg); ref_db.append(db)
+    pa, pb = ops.new_stat_buffer(C), ops.new_stat_buffer(C)
+    ops.bn_bwd_reduce2(dout, C, xa, C, xb, ld_b, stats[0][0], stats[0][1], stats[1][0], stats[1][1], bits, M, C, pa, pb)
+    got_dx = [torch.empty(M, C, dtype=torch.bfloat16, device="cuda"), torch.full((M, C + 8), 5.0, dtype=torch.bfloat16, device="cuda")]
+    coefs = []
+    for i, part in enumerate((pa, pb)):
+        coef, dg, db = torch.empty(3, C, device="cuda"), torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+        ops.bn_bwd_finalize(part, M, C, stats[i][2], stats[i][1], dg, db, coef)
+        coefs.append(coef)
+        scale = float(ref_dg[i].abs().max()) + float(ref_db[i].abs().max())
+        assert torch.allclose(dg, ref_dg[i], rtol=1e-4, atol=1e-4 * scale) and torch.allclose(db, ref_db[i], rtol=1e-4, atol=1e-4 * scale)
+        assert torch.allclose(coef, ref_coef[i], rtol=1e-4, atol=1e-6)
+    ops.bn_bwd_apply2(dout, C, xa, C, xb, ld_b, stats[0][0], stats[0][1], stats[1][0], stats[1][1], bits, coefs[0], coefs[1],
+                      M, C, got_dx[0], C, got_dx[1], C + 8)
+    torch.cuda.synchronize()
+    _close_bf16(got_dx[0].float().cpu(), ref_dx[0].float().cpu(), "join dx a")
+    _close_bf16(got_dx[1][:, :C].float().cpu(), ref_dx[1].float().cpu(), "join dx b")
+    assert (got_dx[1][:, C:].float() == 5.0).all(), "wrote outside its channel slice"
+
+
 # ------------------------------------------------------------------------------------ stem / head convs
 @pytest.mark.parametrize("N,H,Wd", [(2, 32, 48), (1, 30, 200), (3, 62, 260), (40, 64, 256)])
 def test_stem_conv(N, H, Wd):
