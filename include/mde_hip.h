@@ -204,6 +204,23 @@ int mde_silog_fwd(const float* est, const float* gt, int64_t n, float variance_f
                   float* loss, void* stream);
 int mde_silog_bwd(const float* est, const float* gt, int64_t n, float variance_focus, const void* ws,
                   const float* gscale, float* grad, void* stream);
+/* Masked pointwise losses (criteria.py:67-90 MaskedMSELoss / MaskedL1Loss, :113-133 berHuLoss), mask = target > 0.
+ * kind 0: mean |t-p|; 1: mean (t-p)^2; 2: reverse Huber exactly as the reference computes it (threshold
+ * c = 0.2*max(pred-target) over ALL pixels, loss = mean(cat(|d|, |d|[|d|>c]^2))).  An empty mask gives NaN, as there.
+ * ws >= mde_masked_loss_ws_bytes(), written by fwd and read by bwd; grad = d loss / d pred * (*gscale or 1). */
+size_t mde_masked_loss_ws_bytes(void);
+int mde_masked_loss_fwd(int kind, const float* pred, const float* target, int64_t n, void* ws, float* loss,
+                        void* stream);
+int mde_masked_loss_bwd(int kind, const float* pred, const float* target, int64_t n, const void* ws,
+                        const float* gscale, float* grad, void* stream);
+/* MaskedDepthLoss (criteria.py:17-64, the loss modules/eigen.py pairs with Eigen): linear-space scale-invariant
+ * term over the per-image masked residuals + masked forward-difference gradient MSE in y and x.
+ * pred/target: fp32 [N][H][W] (or [N][1][H][W]).  ws >= mde_masked_depth_ws_bytes(N). */
+size_t mde_masked_depth_ws_bytes(int N);
+int mde_masked_depth_fwd(const float* pred, const float* target, int N, int H, int W, void* ws, float* loss,
+                         void* stream);
+int mde_masked_depth_bwd(const float* pred, const float* target, int N, int H, int W, const void* ws,
+                         const float* gscale, float* grad, void* stream);
 /* Depth metrics (metrics.py:58-109): out[6] = absrel, 'rmse' (= mean sqrt((p-t)^2/t), sic),
  * delta1, delta2, delta3, log10.  ws >= mde_metrics_ws_bytes(). */
 size_t mde_metrics_ws_bytes(void);

@@ -73,6 +73,12 @@ SIGNATURES = {
     "mde_silog_ws_bytes": (_Z, []),
     "mde_silog_fwd": (_I, [_P, _P, _L, _F, _P, _P, _P]),
     "mde_silog_bwd": (_I, [_P, _P, _L, _F, _P, _P, _P, _P]),
+    "mde_masked_loss_ws_bytes": (_Z, []),
+    "mde_masked_loss_fwd": (_I, [_I, _P, _P, _L, _P, _P, _P]),
+    "mde_masked_loss_bwd": (_I, [_I, _P, _P, _L, _P, _P, _P, _P]),
+    "mde_masked_depth_ws_bytes": (_Z, [_I]),
+    "mde_masked_depth_fwd": (_I, [_P, _P, _I, _I, _I, _P, _P, _P]),
+    "mde_masked_depth_bwd": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P]),
     "mde_metrics_ws_bytes": (_Z, []),
     "mde_depth_metrics": (_I, [_P, _P, _L, _P, _P, _P]),
     "mde_adam_step": (_I, [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _F, _I, _P]),

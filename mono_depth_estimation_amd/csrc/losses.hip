@@ -1,6 +1,8 @@
 // Per-pixel depth losses and metrics as wavefront-reduced streaming kernels (gfx950).
 //   SILog           reference criteria.py:724-732
 //   depth metrics   reference metrics.py:58-109 (absrel, 'rmse' (sic), delta1-3, log10)
+//   MaskedL1Loss / MaskedMSELoss / berHuLoss   reference criteria.py:67-90,113-133
+//   MaskedDepthLoss (Eigen)                    reference criteria.py:17-64
 // fp32 in, per-thread fp32 partials over a short strided run, wave/workgroup reduction in
 // double, one fp64 atomic per workgroup and quantity.  HBM-bound: 2 x 4 B read per pixel.
 #include "mde_common.h"
@@ -113,6 +115,195 @@ __global__ void metrics_finalize_k(const MetricWs* ws, float* out) {
     if (k < 6) out[k] = (float)(ws->s[k] / ws->s[6]);
 }
 
+// ------------------------------------------------------------------ masked pointwise losses (criteria.py:67-133)
+// kind 0: mean |t-p| over t > 0; kind 1: mean (t-p)^2; kind 2 (reverse Huber as the reference writes it):
+// c = 0.2 * max(p - t) over ALL pixels, loss = mean(cat(|d|, |d|[|d| > c]^2)) over valid pixels.
+struct MaskedWs {
+    double s1, s2, n1, n2;   // sum of the first-order terms / of the squared berHu terms, their counts
+    int cmax_key;            // max(p - t) as an order-preserving integer key
+    float c, loss, inv;      // berHu threshold; result; 1 / (n1 + n2)
+};
+
+__device__ __forceinline__ int float_key(float f) {       // monotone float -> int map for atomicMax
+    const int i = __builtin_bit_cast(int, f);
+    return i >= 0 ? i : i ^ 0x7FFFFFFF;
+}
+__device__ __forceinline__ float key_float(int k) { return __builtin_bit_cast(float, k >= 0 ? k : k ^ 0x7FFFFFFF); }
+
+__global__ void masked_init_k(MaskedWs* ws) {
+    ws->s1 = ws->s2 = ws->n1 = ws->n2 = 0.0;
+    ws->cmax_key = float_key(-__builtin_inff());
+    ws->c = ws->loss = ws->inv = 0.f;
+}
+
+__global__ __launch_bounds__(NT) void masked_max_k(const float* __restrict__ pred, const float* __restrict__ tgt, int64_t n,
+                                                   MaskedWs* ws) {
+    __shared__ float sh[NT / 64];
+    float m = -__builtin_inff();
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) m = fmaxf(m, pred[i] - tgt[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < NT / 64; ++i) m = fmaxf(m, sh[i]);
+        atomicMax(&ws->cmax_key, float_key(m));
+    }
+}
+
+__global__ void masked_threshold_k(MaskedWs* ws) { ws->c = 0.2f * key_float(ws->cmax_key); }
+
+template <int KIND>
+__global__ __launch_bounds__(NT) void masked_reduce_k(const float* __restrict__ pred, const float* __restrict__ tgt, int64_t n,
+                                                      MaskedWs* ws) {
+    const float c = KIND == 2 ? ws->c : 0.f;
+    float a[4] = {0, 0, 0, 0};
+    double acc[4] = {0, 0, 0, 0};
+    int run = 0;
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
+        const float t = tgt[i];
+        if (t > 0.f) {
+            const float d = fabsf(t - pred[i]);
+            a[0] += KIND == 1 ? d * d : d;
+            a[2] += 1.f;
+            if (KIND == 2 && d > c) {
+                a[1] += d * d;
+                a[3] += 1.f;
+            }
+        }
+        if (++run == 64) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { acc[k] += a[k]; a[k] = 0.f; }
+            run = 0;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[k] += a[k];
+    block_atomic_add<4>(acc, &ws->s1);
+}
+
+__global__ void masked_finalize_k(MaskedWs* ws, float* loss) {
+    const double cnt = ws->n1 + ws->n2;
+    const float l = (float)((ws->s1 + ws->s2) / cnt);       // empty mask: 0/0 = NaN, as the reference's mean of nothing
+    ws->loss = l;
+    ws->inv = (float)(1.0 / cnt);
+    *loss = l;
+}
+
+template <int KIND>
+__global__ __launch_bounds__(NT) void masked_bwd_k(const float* __restrict__ pred, const float* __restrict__ tgt, int64_t n,
+                                                   const MaskedWs* __restrict__ ws, const float* __restrict__ gscale,
+                                                   float* __restrict__ grad) {
+    const float k = (gscale ? *gscale : 1.f) * ws->inv, c = ws->c;
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
+        const float t = tgt[i];
+        float r = 0.f;
+        if (t > 0.f) {
+            const float e = t - pred[i], d = fabsf(e);
+            const float sg = e > 0.f ? -1.f : (e < 0.f ? 1.f : 0.f);     // d|e|/dp (0 at e = 0, as autograd)
+            if (KIND == 0) r = k * sg;
+            if (KIND == 1) r = -2.f * k * e;
+            if (KIND == 2) r = k * sg * (1.f + (d > c ? 2.f * d : 0.f));
+        }
+        grad[i] = r;
+    }
+}
+
+// ------------------------------------------------------------------ MaskedDepthLoss (criteria.py:17-64)
+// ws: double g[4] = {sum mi*gi^2, sum mi, sum mj*gj^2, sum mj}; float out[4] = {1/D, 1/Mi, 1/Mj, loss};
+//     double img[N][3] = {n_b, sum d, sum d^2}
+struct DepthWsHead { double g[4]; float inv_d, inv_mi, inv_mj, loss; };
+
+__global__ __launch_bounds__(NT) void mdepth_reduce_k(const float* __restrict__ pred, const float* __restrict__ tgt, int H, int W,
+                                                      int blocks_per_img, DepthWsHead* head, double* img) {
+    const int b = blockIdx.x / blocks_per_img, blk = blockIdx.x % blocks_per_img;
+    const int64_t hw = (int64_t)H * W;
+    const float* p = pred + b * hw;
+    const float* t = tgt + b * hw;
+    float a[7] = {0, 0, 0, 0, 0, 0, 0};
+    double acc[7] = {0, 0, 0, 0, 0, 0, 0};
+    int run = 0;
+    for (int64_t i = (int64_t)blk * NT + threadIdx.x; i < hw; i += (int64_t)blocks_per_img * NT) {
+        const int y = (int)(i / W), x = (int)(i - (int64_t)y * W);
+        const float ti = t[i], pi = p[i];
+        const bool m = ti > 0.f;
+        if (m) {
+            const float d = pi - ti;
+            a[0] += 1.f;
+            a[1] += d;
+            a[2] += d * d;
+        }
+        if (y + 1 < H) {
+            const float t2 = t[i + W];
+            if (m && t2 > 0.f) {
+                const float gi = (p[i + W] - pi) - (t2 - ti);
+                a[3] += gi * gi;
+                a[4] += 1.f;
+            }
+        }
+        if (x + 1 < W) {
+            const float t2 = t[i + 1];
+            if (m && t2 > 0.f) {
+                const float gj = (p[i + 1] - pi) - (t2 - ti);
+                a[5] += gj * gj;
+                a[6] += 1.f;
+            }
+        }
+        if (++run == 64) {
+#pragma unroll
+            for (int k = 0; k < 7; ++k) { acc[k] += a[k]; a[k] = 0.f; }
+            run = 0;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 7; ++k) acc[k] += a[k];
+    double lo[3] = {acc[0], acc[1], acc[2]}, hi[4] = {acc[3], acc[4], acc[5], acc[6]};
+    block_atomic_add<3>(lo, img + 3 * b);
+    __syncthreads();
+    block_atomic_add<4>(hi, head->g);
+}
+
+__global__ void mdepth_finalize_k(DepthWsHead* head, const double* img, int N, float* loss) {
+    double num = 0.0, half = 0.0, den = 0.0;
+    for (int b = 0; b < N; ++b) {
+        const double n = img[3 * b], s1 = img[3 * b + 1], s2 = img[3 * b + 2];
+        num += n * s2;
+        half += s1 * s1;
+        den += n * n;
+    }
+    const double l = (num - 0.5 * half) / den + head->g[0] / head->g[1] + head->g[2] / head->g[3];
+    head->inv_d = (float)(1.0 / den);
+    head->inv_mi = (float)(1.0 / head->g[1]);
+    head->inv_mj = (float)(1.0 / head->g[3]);
+    head->loss = (float)l;
+    *loss = (float)l;
+}
+
+__global__ __launch_bounds__(NT) void mdepth_bwd_k(const float* __restrict__ pred, const float* __restrict__ tgt, int N, int H,
+                                                   int W, const DepthWsHead* __restrict__ head, const double* __restrict__ img,
+                                                   const float* __restrict__ gscale, float* __restrict__ grad) {
+    const float gs = gscale ? *gscale : 1.f;
+    const float kd = gs * head->inv_d, ki = 2.f * gs * head->inv_mi, kj = 2.f * gs * head->inv_mj;
+    const int64_t hw = (int64_t)H * W, n = hw * N;
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
+        const int b = (int)(i / hw);
+        const int64_t r = i - b * hw;
+        const int y = (int)(r / W), x = (int)(r - (int64_t)y * W);
+        const float ti = tgt[i], pi = pred[i];
+        const bool m = ti > 0.f;
+        float g = 0.f;
+        if (m) {
+            g = kd * (2.f * (float)img[3 * b] * (pi - ti) - (float)img[3 * b + 1]);
+            // vertical pairs (y-1, y) and (y, y+1); horizontal pairs (x-1, x) and (x, x+1)
+            if (y > 0 && tgt[i - W] > 0.f) g += ki * ((pi - pred[i - W]) - (ti - tgt[i - W]));
+            if (y + 1 < H && tgt[i + W] > 0.f) g -= ki * ((pred[i + W] - pi) - (tgt[i + W] - ti));
+            if (x > 0 && tgt[i - 1] > 0.f) g += kj * ((pi - pred[i - 1]) - (ti - tgt[i - 1]));
+            if (x + 1 < W && tgt[i + 1] > 0.f) g -= kj * ((pred[i + 1] - pi) - (tgt[i + 1] - ti));
+        }
+        grad[i] = g;
+    }
+}
+
 int grid_for(int64_t n) {
     int64_t nb = (n + NT - 1) / NT;
     return (int)(nb > 256 * 8 ? 256 * 8 : (nb < 1 ? 1 : nb));
@@ -140,6 +331,78 @@ extern "C" int mde_silog_bwd(const float* est, const float* gt, int64_t n, float
     MDE_REQUIRE(est && gt && ws && grad && n > 0, "mde_silog_bwd: bad argument");
     silog_bwd_k<<<grid_for(n), NT, 0, (hipStream_t)stream>>>(est, gt, n, variance_focus, (const SilogWs*)ws, gscale, grad);
     MDE_LAUNCH_CHECK("silog_bwd_k");
+    return MDE_OK;
+}
+
+extern "C" size_t mde_masked_loss_ws_bytes(void) { return sizeof(MaskedWs); }
+
+extern "C" int mde_masked_loss_fwd(int kind, const float* pred, const float* target, int64_t n, void* ws, float* loss,
+                                   void* stream) {
+    MDE_REQUIRE(pred && target && ws && loss && n > 0, "mde_masked_loss_fwd: bad argument");
+    MDE_REQUIRE(kind >= 0 && kind <= 2, "mde_masked_loss_fwd: kind=%d (0 L1, 1 MSE, 2 berHu)", kind);
+    MDE_REQUIRE(((uintptr_t)ws % 8) == 0, "mde_masked_loss_fwd: ws must be 8-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    MaskedWs* w = (MaskedWs*)ws;
+    masked_init_k<<<1, 1, 0, st>>>(w);
+    if (kind == 2) {
+        masked_max_k<<<grid_for(n), NT, 0, st>>>(pred, target, n, w);
+        masked_threshold_k<<<1, 1, 0, st>>>(w);
+        masked_reduce_k<2><<<grid_for(n), NT, 0, st>>>(pred, target, n, w);
+    } else if (kind == 1) {
+        masked_reduce_k<1><<<grid_for(n), NT, 0, st>>>(pred, target, n, w);
+    } else {
+        masked_reduce_k<0><<<grid_for(n), NT, 0, st>>>(pred, target, n, w);
+    }
+    MDE_LAUNCH_CHECK("masked_reduce_k");
+    masked_finalize_k<<<1, 1, 0, st>>>(w, loss);
+    MDE_LAUNCH_CHECK("masked_finalize_k");
+    return MDE_OK;
+}
+
+extern "C" int mde_masked_loss_bwd(int kind, const float* pred, const float* target, int64_t n, const void* ws,
+                                   const float* gscale, float* grad, void* stream) {
+    MDE_REQUIRE(pred && target && ws && grad && n > 0, "mde_masked_loss_bwd: bad argument");
+    MDE_REQUIRE(kind >= 0 && kind <= 2, "mde_masked_loss_bwd: kind=%d (0 L1, 1 MSE, 2 berHu)", kind);
+    hipStream_t st = (hipStream_t)stream;
+    const MaskedWs* w = (const MaskedWs*)ws;
+    if (kind == 2)
+        masked_bwd_k<2><<<grid_for(n), NT, 0, st>>>(pred, target, n, w, gscale, grad);
+    else if (kind == 1)
+        masked_bwd_k<1><<<grid_for(n), NT, 0, st>>>(pred, target, n, w, gscale, grad);
+    else
+        masked_bwd_k<0><<<grid_for(n), NT, 0, st>>>(pred, target, n, w, gscale, grad);
+    MDE_LAUNCH_CHECK("masked_bwd_k");
+    return MDE_OK;
+}
+
+extern "C" size_t mde_masked_depth_ws_bytes(int N) { return sizeof(DepthWsHead) + (size_t)(N > 0 ? N : 0) * 3 * sizeof(double); }
+
+extern "C" int mde_masked_depth_fwd(const float* pred, const float* target, int N, int H, int W, void* ws, float* loss,
+                                    void* stream) {
+    MDE_REQUIRE(pred && target && ws && loss && N > 0 && H > 0 && W > 0, "mde_masked_depth_fwd: bad argument");
+    MDE_REQUIRE(((uintptr_t)ws % 8) == 0, "mde_masked_depth_fwd: ws must be 8-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    if (int rc = mde_check_hip(hipMemsetAsync(ws, 0, mde_masked_depth_ws_bytes(N), st), "hipMemsetAsync(masked depth ws)")) return rc;
+    DepthWsHead* head = (DepthWsHead*)ws;
+    double* img = (double*)(head + 1);
+    const int64_t hw = (int64_t)H * W;
+    int bpi = (int)((hw + NT * 16 - 1) / (NT * 16));
+    const int cap = (2048 + N - 1) / N;
+    bpi = bpi < 1 ? 1 : (bpi > cap ? cap : bpi);
+    mdepth_reduce_k<<<N * bpi, NT, 0, st>>>(pred, target, H, W, bpi, head, img);
+    MDE_LAUNCH_CHECK("mdepth_reduce_k");
+    mdepth_finalize_k<<<1, 1, 0, st>>>(head, img, N, loss);
+    MDE_LAUNCH_CHECK("mdepth_finalize_k");
+    return MDE_OK;
+}
+
+extern "C" int mde_masked_depth_bwd(const float* pred, const float* target, int N, int H, int W, const void* ws,
+                                    const float* gscale, float* grad, void* stream) {
+    MDE_REQUIRE(pred && target && ws && grad && N > 0 && H > 0 && W > 0, "mde_masked_depth_bwd: bad argument");
+    const DepthWsHead* head = (const DepthWsHead*)ws;
+    const double* img = (const double*)(head + 1);
+    mdepth_bwd_k<<<grid_for((int64_t)N * H * W), NT, 0, (hipStream_t)stream>>>(pred, target, N, H, W, head, img, gscale, grad);
+    MDE_LAUNCH_CHECK("mdepth_bwd_k");
     return MDE_OK;
 }
 

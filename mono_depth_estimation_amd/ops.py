@@ -337,6 +337,36 @@ def silog_bwd(est, gt, variance_focus, ws, gscale, grad):
                                     _stream()), "mde_silog_bwd")
 
 
+MASKED_KINDS = {"l1": 0, "mse": 1, "berhu": 2}
+
+
+def masked_loss_ws(device="cuda"):
+    return torch.zeros((_lib.load().mde_masked_loss_ws_bytes() + 7) // 8, dtype=torch.float64, device=device)
+
+
+def masked_loss_fwd(kind, pred, target, ws, loss):
+    check(_lib.load().mde_masked_loss_fwd(MASKED_KINDS[kind], _p(pred), _p(target), pred.numel(), _p(ws), _p(loss), _stream()),
+          "mde_masked_loss_fwd")
+
+
+def masked_loss_bwd(kind, pred, target, ws, gscale, grad):
+    check(_lib.load().mde_masked_loss_bwd(MASKED_KINDS[kind], _p(pred), _p(target), pred.numel(), _p(ws), _p(gscale), _p(grad),
+                                          _stream()), "mde_masked_loss_bwd")
+
+
+def masked_depth_ws(N, device="cuda"):
+    return torch.zeros((_lib.load().mde_masked_depth_ws_bytes(N) + 7) // 8, dtype=torch.float64, device=device)
+
+
+def masked_depth_fwd(pred, target, N, H, W, ws, loss):
+    check(_lib.load().mde_masked_depth_fwd(_p(pred), _p(target), N, H, W, _p(ws), _p(loss), _stream()), "mde_masked_depth_fwd")
+
+
+def masked_depth_bwd(pred, target, N, H, W, ws, gscale, grad):
+    check(_lib.load().mde_masked_depth_bwd(_p(pred), _p(target), N, H, W, _p(ws), _p(gscale), _p(grad), _stream()),
+          "mde_masked_depth_bwd")
+
+
 def metrics_ws(device="cuda"):
     return torch.zeros((_lib.load().mde_metrics_ws_bytes() + 7) // 8, dtype=torch.float64, device=device)
 

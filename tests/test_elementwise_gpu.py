@@ -211,6 +211,57 @@ def test_silog_large_matches_oracle():
     assert torch.allclose(grad.cpu(), e.grad, rtol=2e-3, atol=1e-9)
 
 
+_MASKED = {"masked_l1": ("MaskedL1Loss", OL.masked_l1), "masked_mse": ("MaskedMSELoss", OL.masked_mse),
+           "berhu": ("berHuLoss", OL.berhu), "masked_depth": ("MaskedDepthLoss", OL.masked_depth)}
+
+
+@pytest.mark.parametrize("name", sorted(_MASKED))
+def test_masked_losses_golden(golden, name):
+    """criteria.MaskedL1Loss / MaskedMSELoss / berHuLoss / MaskedDepthLoss (HIP) against the values and
+    gradients the reference's own classes produced (tests/golden/losses.npz, minted by gen_golden.py)."""
+    from mono_depth_estimation_amd import criteria
+    g = golden("losses")
+    pred = torch.from_numpy(g["g2_pred"]).cuda().requires_grad_(True)
+    tgt = torch.from_numpy(g["g2_tgt"]).cuda()
+    crit = getattr(criteria, _MASKED[name][0])()
+    loss = crit(pred, tgt)
+    (0.5 * loss).backward()                                   # upstream gradient != 1 on purpose
+    assert loss.dim() == 0 and crit.loss is loss
+    assert np.allclose(loss.item(), g["g2_" + name], rtol=2e-5), (loss.item(), g["g2_" + name])
+    ref = 0.5 * g["g2_" + name + "_grad"]
+    assert np.allclose(pred.grad.cpu().numpy(), ref, rtol=2e-4, atol=1e-6 * np.abs(ref).max())
+
+
+@pytest.mark.parametrize("name", sorted(_MASKED))
+def test_masked_losses_large_match_oracle(name):
+    """Bench-sized maps (8 x 1 x 480 x 640, 10 % invalid pixels) against the oracle's autograd."""
+    from mono_depth_estimation_amd import criteria
+    pred = W.uniform(31, "pred", (8, 1, 480, 640), 0.05, 1.0)
+    _, tgt = W.synthetic_batch(31, 8, 480, 640)
+    p = pred.clone().requires_grad_(True)
+    ref = _MASKED[name][1](p, tgt)
+    ref.backward()
+    pd = pred.cuda().requires_grad_(True)
+    loss = getattr(criteria, _MASKED[name][0])()(pd, tgt.cuda())
+    loss.backward()
+    assert np.allclose(loss.item(), ref.item(), rtol=2e-5), (loss.item(), ref.item())
+    assert torch.allclose(pd.grad.cpu(), p.grad, rtol=2e-3, atol=1e-6 * float(p.grad.abs().max()))
+
+
+def test_masked_losses_edge_cases():
+    from mono_depth_estimation_amd import criteria
+    pred = W.uniform(32, "pred", (2, 5, 7), 0.1, 1.0).cuda().requires_grad_(True)      # 3-D input, odd sizes
+    tgt = W.uniform(32, "tgt", (2, 5, 7), 0.1, 1.0)
+    tgt[0, :2] = 0.0
+    ref = OL.masked_depth(pred.detach().cpu().requires_grad_(True), tgt)
+    loss = criteria.MaskedDepthLoss()(pred, tgt.cuda())
+    assert np.allclose(loss.item(), ref.item(), rtol=2e-5)
+    empty = torch.zeros(2, 1, 4, 4, device="cuda")                                       # no valid pixel: NaN, as the reference
+    assert torch.isnan(criteria.MaskedL1Loss()(pred.detach().reshape(2, 1, 5, 7)[:, :, :4, :4].contiguous(), empty))
+    with pytest.raises(RuntimeError):
+        criteria.berHuLoss()(torch.ones(1, 1, 2, 2), torch.ones(1, 1, 2, 2))           # CPU tensors: no fallback
+
+
 def test_metrics_golden(golden):
     from mono_depth_estimation_amd import ops
     g = golden("metrics")
