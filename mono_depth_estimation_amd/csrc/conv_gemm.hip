@@ -659,24 +659,16 @@ int pick_and_launch(KArgs& ka, int64_t M, hipStream_t st) {
     static int forced = -1, reg = 0;
     if (forced < 0) {
         const char* e = getenv("MDE_CONV_TILE");
-        forced = !e ? 0 : !strcmp(e, "256x256") ? 1 : !strcmp(e, "256x128") ? 2 : !strcmp(e, "128x128") ? 3 : !strcmp(e, "128x128x3") ? 4 : !strcmp(e, "192x256") ? 5 : !strcmp(e, "128x64") ? 6 : !strcmp(e, "256x256w4") ? 7 : 0;
+        forced = !e ? 0 : !strcmp(e, "256x256") ? 1 : !strcmp(e, "128x128") ? 3 : !strcmp(e, "192x256") ? 5 : !strcmp(e, "128x64") ? 6 : !strcmp(e, "256x256w4") ? 7 : 0;
         const char* q = getenv("MDE_CONV_PATH");
         reg = q && !strcmp(q, "reg");
     }
     const int n = ka.d.ncols;
-    static int n64 = -1;                  // MDE_CONV_N64=a|b|c: tile experiments for <=64-column layers
-    if (n64 < 0) {
-        const char* e = getenv("MDE_CONV_N64");
-        n64 = !e ? 0 : e[0] == 'a' ? 1 : e[0] == 'b' ? 2 : e[0] == 'c' ? 3 : 0;
-    }
     if (n <= 64) {
-        if (reg) return launch<128, 64, 256, false, 2>(ka, M, st);
-        if (n64 == 1) return launch<256, 64, 512, true, 2>(ka, M, st);   // 8 waves x (32 px x 64 ch)
-        if (n64 == 2) return launch<256, 64, 256, true, 2>(ka, M, st);   // 4 waves x (64 px x 64 ch)
-        if (n64 == 3) return launch<128, 64, 256, true, 3>(ka, M, st);   // 3-deep ring, 2 workgroups per CU
-        // default: 2-deep ring = 48 KB LDS = three workgroups per CU (489/537 vs 357/347 TFLOP/s for the 3-deep
-        // ring on M=2457600/614400, 64->64 3x3): occupancy beats prefetch depth, as for the 128x128 tile
-        return launch<128, 64, 256, true, 2>(ka, M, st);
+        // 2-deep ring = 48 KB LDS = three workgroups per CU.  Measured alternatives, all slower on M = 2 457 600 / 614 400,
+        // 64->64 3x3: 256x64 with 8 waves (423 / 423 TFLOP/s), 256x64 with 4 waves (365 / 343), 3-deep ring at two
+        // workgroups per CU (443 / 456) against 487 / 576: occupancy beats prefetch depth and bigger tiles here.
+        return reg ? launch<128, 64, 256, false, 2>(ka, M, st) : launch<128, 64, 256, true, 2>(ka, M, st);
     }
     static int cus = 0;
     if (!cus) {
@@ -722,12 +714,9 @@ int pick_and_launch(KArgs& ka, int64_t M, hipStream_t st) {
     if (forced == 0 && pick == 2) return launch<192, 256, 512, true, 2>(ka, M, st);
     if (forced == 1 || (forced == 0 && pick == 1))
         return reg ? launch<256, 256, 512, false, 2>(ka, M, st) : launch<256, 256, 512, true, 2>(ka, M, st);
-    if (forced == 4) return launch<128, 128, 256, true, 3>(ka, M, st);
     if (forced == 5) return launch<192, 256, 512, true, 2>(ka, M, st);
     if (forced == 6) return launch<128, 64, 256, true, 2>(ka, M, st);
     if (forced == 7) return launch<256, 256, 256, true, 2>(ka, M, st);   // 4 waves x (128 px x 128 ch), one workgroup per CU
-    if (forced == 2)
-        return reg ? launch<256, 128, 512, false, 2>(ka, M, st) : launch<256, 128, 512, true, 3>(ka, M, st);
     return reg ? launch<128, 128, 256, false, 2>(ka, M, st) : launch<128, 128, 256, true, 2>(ka, M, st);
 }
 
