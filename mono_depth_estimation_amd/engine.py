@@ -16,6 +16,8 @@ Design:
     fused into the BN apply; the zero-insertion Unpool never materialises (four output
     phases of the 5x5 convs); both 5x5 branches of an UpProj module run as one GEMM.
 """
+import os
+
 import torch
 
 from . import ops
@@ -311,6 +313,8 @@ class FCRNEngine:
         self.out_channels = module.conv3.out_channels
         self.OH, self.OW = module.output_size
         self.cus = torch.cuda.get_device_properties(self.dev).multi_processor_count
+        self.side = torch.cuda.Stream(self.dev) if os.environ.get("MDE_WGRAD_STREAM", "1") != "0" else None
+        self.side_busy = False
         self._plan()
 
     def _blocks(self):
@@ -397,6 +401,24 @@ class FCRNEngine:
         offs.append(self.store.p_off[id(self.m.conv3.weight)])
         return sorted(offs)
 
+    def wgrad(self, desc, a, b, dw):
+        """Weight-gradient GEMM of one conv.  It only reads dY and the activation, so it can run beside the
+        input-gradient GEMM of the same layer: on a second stream its workgroups fill the CUs that the other
+        kernel's partial last round leaves idle (MDE_WGRAD_STREAM=0 keeps everything on one stream)."""
+        if self.side is None:
+            ops.conv_wgrad(desc, a, b, dw)
+            return
+        cur = torch.cuda.current_stream()
+        self.side.wait_stream(cur)                  # dY (and everything before it) is ready
+        with torch.cuda.stream(self.side):
+            ops.conv_wgrad(desc, a, b, dw)
+        self.side_busy = True
+
+    def join_side(self):
+        if self.side is not None and self.side_busy:
+            torch.cuda.current_stream().wait_stream(self.side)
+            self.side_busy = False
+
     def backward(self, dy, on_progress=None):
         """dy: fp32 NCHW gradient w.r.t. the output.  Adds parameter gradients into self.G.
         on_progress(offset), if given, is called whenever every gradient element >= offset of
@@ -412,11 +434,13 @@ class FCRNEngine:
         for L in reversed(self.layers):
             L.bwd()
             if on_progress is not None:
+                self.join_side()                       # the layer's weight gradients must be final too
                 on_progress(L.first_param_offset())
         ops.maxpool_bwd(self.pool.g, self.pool_idx, self.stem_a.g, self.N, self.stem_a.H, self.stem_a.W, 64)
         s = self.stem_site
         s.backward(self.stem_a.g, self.stem_a, self.stem_c, True, self.stem_c.g, mask_from_x=True)
         ops.stem_conv_wgrad(self.x, self.stem_c.g, self.stem_w.dw)
+        self.join_side()
         if on_progress is not None:
             on_progress(0)
 
@@ -479,7 +503,7 @@ class ConvBN:
 
     def conv_bwd(self):
         x, eng = self.x, self.eng
-        ops.conv_wgrad(self.wdesc, self.c.g, x.t, self.conv.dw)
+        eng.wgrad(self.wdesc, self.c.g, x.t, self.conv.dw)
         acc = x.gw
         if self.dzero and not acc:
             x.g.zero_()
@@ -589,7 +613,7 @@ class UpProjLayer:
         c2.c.gw = True
         c2.conv_bwd()                                                       # -> d(a1), dW(conv2)
         self.site_u.backward(self.a1.g, self.a1, self.y_u, True, yg[..., :C], mask_from_x=True)
-        ops.conv_wgrad(self.wdesc, x.t, yg, self.w55.dw)
+        self.eng.wgrad(self.wdesc, x.t, yg, self.w55.dw)
         self.ddesc.accumulate = int(x.gw)
         ops.conv_gemm(self.ddesc, yg, self.w55.wd, x.g)
         x.gw = True
