@@ -127,7 +127,7 @@ def main():
     if use_dist:
         dist.broadcast(store.P, 0)
         dist.broadcast(store.B, 0)
-    reducer = dp.FlatGradReducer(store.G, eng.grad_boundaries(), target_bytes=64 << 20)
+    reducer = dp.FlatGradReducer(store.G, eng.grad_boundaries(), target_bytes=64 << 20, extra_streams=[eng.side])
     ws, loss = ops.silog_ws(dev), torch.empty(1, device=dev)
     dy = torch.empty(args.batch, 1, H, W, device=dev)
     lr = 1e-4
@@ -137,7 +137,7 @@ def main():
         ops.silog_fwd(y, tgt, 0.85, ws, loss)
         ops.silog_bwd(y, tgt, 0.85, ws, None, dy)
         store.G.zero_()
-        eng.backward(dy, reducer.ready)
+        eng.backward(dy, reducer.ready, consumer_waits_side=True)
         reducer.finish()
         store.adam_step(lr, 10 * lr, grad_scale=1.0 / world)
 

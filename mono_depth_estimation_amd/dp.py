@@ -37,8 +37,12 @@ class FlatGradReducer:
     ready(offset): backward promises every gradient element >= offset is final.
     finish(): wait for all buckets (call before the optimiser step)."""
 
-    def __init__(self, flat, boundaries, target_bytes=64 << 20, group=None):
+    def __init__(self, flat, boundaries, target_bytes=64 << 20, group=None, extra_streams=()):
+        """extra_streams: streams besides the current one that also write gradients (the engine's
+        weight-gradient stream); a bucket's all-reduce waits for the work queued on them as well, so the
+        producer does not have to join them into the main stream at every layer."""
         self.flat, self.group = flat, group
+        self.extra_streams = [s for s in extra_streams if s is not None]
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         # MDE_DP_FORCE=1: run the collectives even with one rank (rehearses the RCCL / stream / event
         # path on a single GPU; an all-reduce over one rank is the identity)
@@ -57,6 +61,8 @@ class FlatGradReducer:
             ev.record(torch.cuda.current_stream())
             with torch.cuda.stream(self.stream):
                 self.stream.wait_event(ev)
+                for s in self.extra_streams:
+                    self.stream.wait_stream(s)
                 self.works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         else:
             self.works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))

@@ -419,10 +419,13 @@ class FCRNEngine:
             torch.cuda.current_stream().wait_stream(self.side)
             self.side_busy = False
 
-    def backward(self, dy, on_progress=None):
+    def backward(self, dy, on_progress=None, consumer_waits_side=False):
         """dy: fp32 NCHW gradient w.r.t. the output.  Adds parameter gradients into self.G.
         on_progress(offset), if given, is called whenever every gradient element >= offset of
-        the flat buffer is final (backward walks the forward-ordered buffer from its tail)."""
+        the flat buffer is final (backward walks the forward-ordered buffer from its tail) once the
+        work queued so far on the current stream AND on self.side (the weight-gradient stream) has run.
+        consumer_waits_side: the callback orders itself behind self.side (dp.FlatGradReducer(extra_streams=
+        [eng.side])); otherwise the side stream is joined into the current one before every call."""
         assert dy.shape == self.y.shape and dy.dtype == torch.float32 and dy.is_contiguous()
         f = self.feat
         for L in self.layers:
@@ -434,7 +437,8 @@ class FCRNEngine:
         for L in reversed(self.layers):
             L.bwd()
             if on_progress is not None:
-                self.join_side()                       # the layer's weight gradients must be final too
+                if not consumer_waits_side:
+                    self.join_side()                   # the layer's weight gradients must be final too
                 on_progress(L.first_param_offset())
         ops.maxpool_bwd(self.pool.g, self.pool_idx, self.stem_a.g, self.N, self.stem_a.H, self.stem_a.W, 64)
         s = self.stem_site
