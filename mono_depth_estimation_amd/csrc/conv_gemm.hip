@@ -38,12 +38,16 @@
 #ifndef MDE_ABLATE
 #define MDE_ABLATE 0
 #endif
-// Schedule knobs of the DMA loop, A/B-tested with tools/conv_microbench.py (M=153600 N=256 K=2304):
-//   8-wave 256x256: issue the next tile's DMAs BETWEEN the two MFMA halves of a K-step (+8 %) and
-//   s_setprio(1) around each MFMA cluster (+4 %), together 842 -> 921-937 TFLOP/s;
+// Schedule knobs of the DMA loop, A/B-tested with tools/conv_microbench.py (M=153600 N=256 K=2304) and bench.py:
+//   8-wave tiles: s_setprio(1) around each MFMA cluster (+4 %).  Issuing the next tile's DMAs BETWEEN the two MFMA
+//   halves of a K-step is +7 % on the microbenchmark (operands warm in L2/MALL: 941 vs 878 TFLOP/s) but LOSES in the
+//   network, where operands come from HBM: issuing them at the top of the step, a full step ahead, is 0.8 ms/step
+//   faster (991 -> 1015 images/s).  Latency cover beats issue placement once the data is cold -> default off.
 //   4-wave 128x128 (two workgroups per CU): mid-step issue -6 %, setprio neutral -> both off.
+//   A four-stage ring of 32-channel stages (same LDS, DMA 1.5 steps ahead) was built and measured: correct, but
+//   twice the barriers and LDS-latency exposures per MFMA: -15 % microbench, -3 % in-network (32.75 vs 31.9 ms/step).
 #ifndef MDE_DMA_MID
-#define MDE_DMA_MID (NT == 512)
+#define MDE_DMA_MID 0
 #endif
 #ifndef MDE_SETPRIO
 #define MDE_SETPRIO (NT == 512)

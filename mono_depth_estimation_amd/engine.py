@@ -313,7 +313,9 @@ class FCRNEngine:
         self.out_channels = module.conv3.out_channels
         self.OH, self.OW = module.output_size
         self.cus = torch.cuda.get_device_properties(self.dev).multi_processor_count
-        self.side = torch.cuda.Stream(self.dev) if os.environ.get("MDE_WGRAD_STREAM", "1") != "0" else None
+        # opt-in (MDE_WGRAD_STREAM=1): ~1 % faster, but per-kernel durations then include the overlap with
+        # the other stream, so the roofline leg of bench.py and the rocprofv3 summaries stop describing one kernel
+        self.side = torch.cuda.Stream(self.dev) if os.environ.get("MDE_WGRAD_STREAM", "0") == "1" else None
         self.side_busy = False
         self._plan()
 
@@ -404,7 +406,7 @@ class FCRNEngine:
     def wgrad(self, desc, a, b, dw):
         """Weight-gradient GEMM of one conv.  It only reads dY and the activation, so it can run beside the
         input-gradient GEMM of the same layer: on a second stream its workgroups fill the CUs that the other
-        kernel's partial last round leaves idle (MDE_WGRAD_STREAM=0 keeps everything on one stream)."""
+        kernel's partial last round leaves idle (opt-in: MDE_WGRAD_STREAM=1; measured 32.9 -> 32.6 ms/step)."""
         if self.side is None:
             ops.conv_wgrad(desc, a, b, dw)
             return
