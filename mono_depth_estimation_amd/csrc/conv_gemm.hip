@@ -29,6 +29,8 @@
 // to one of MDE_STAT_SLOTS rows) so the BN statistics pass over the conv output is not needed.
 #include <stdlib.h>
 
+#include <stdio.h>
+
 #include "mde_common.h"
 #include <type_traits>
 
@@ -48,6 +50,10 @@
 //   twice the barriers and LDS-latency exposures per MFMA: -15 % microbench, -3 % in-network (32.75 vs 31.9 ms/step).
 #ifndef MDE_DMA_MID
 #define MDE_DMA_MID 0
+#endif
+#ifndef MDE_RATE_256
+#define MDE_RATE_256 1.15   // fitted per-flop rates of the 8-wave tiles relative to 128x128 (pick_and_launch)
+#define MDE_RATE_192 1.10
 #endif
 #ifndef MDE_SETPRIO
 #define MDE_SETPRIO (NT == 512)
@@ -683,6 +689,12 @@ int pick_and_launch(KArgs& ka, int64_t M, hipStream_t st) {
     // Cost model fitted to in-network timings: kernel time = rounds x work per resident
     // slot per round / per-flop rate; a CU hosts one 8-wave workgroup (256x256: rate 1.15, 192x256: 1.10)
     // or two 4-wave 128x128 workgroups (rate 1.0).  What decides between them is the tail round.
+    static double r256 = 0.0, r192 = 0.0;                       // per-flop rates relative to the 128x128 tile
+    if (r256 == 0.0) {
+        r256 = MDE_RATE_256;
+        r192 = MDE_RATE_192;
+        if (const char* e = getenv("MDE_CONV_RATES")) sscanf(e, "%lf,%lf", &r256, &r192);   // diagnostics: refit
+    }
     const int nc256 = mde_cdiv(n, 256), nc128 = mde_cdiv(n, 128);
     const int64_t p256 = mde_cdiv(M, 256), t256 = p256 * nc256;
     auto rounds = [](int64_t tiles, int64_t slots) { return (tiles + slots - 1) / slots; };
@@ -691,21 +703,21 @@ int pick_and_launch(KArgs& ka, int64_t M, hipStream_t st) {
     int pick = 0;                                               // 0: 128x128, 1: 256x256, 2: 192x256, 3: 256x256 + 128x128 tail
     int32_t split = 0;
     if (n >= 256 && !reg) {
-        const double c256 = (double)rounds(t256, cus) * 65536.0 / 1.15;
-        const double c192 = (double)rounds((int64_t)mde_cdiv(M, 192) * nc256, cus) * 49152.0 / 1.10;
+        const double c256 = (double)rounds(t256, cus) * 65536.0 / r256;
+        const double c192 = (double)rounds((int64_t)mde_cdiv(M, 192) * nc256, cus) * 49152.0 / r192;
         if (c256 < best) { best = c256; pick = 1; }
         if (c192 < best) { best = c192; pick = 2; }
         if (t256 > cus) {                                       // full 256x256 rounds, remaining pixel rows on 128x128 tiles
             const int64_t p1 = ((t256 / cus) * cus) / nc256;
             if (p1 > 0 && p1 < p256) {
                 const int64_t rem_px = M - p1 * 256;
-                const double cs = (double)rounds(p1 * nc256, cus) * 65536.0 / 1.15 +
+                const double cs = (double)rounds(p1 * nc256, cus) * 65536.0 / r256 +
                                   (double)rounds((int64_t)mde_cdiv(rem_px, 128) * nc128, 2 * cus) * 32768.0;
                 if (cs < best) { best = cs; pick = 3; split = (int32_t)(p1 * 256); }
             }
         }
     } else if (n >= 256) {
-        if ((double)rounds(t256, cus) * 65536.0 / 1.15 < best) pick = 1;
+        if ((double)rounds(t256, cus) * 65536.0 / r256 < best) pick = 1;
     }
     if (forced == 0 && pick == 3) {
         KArgs k1 = ka, k2 = ka;

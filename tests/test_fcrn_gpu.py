@@ -270,6 +270,49 @@ def test_torch_optimizer_drop_in(setup):
     assert np.isfinite(losses).all() and losses[-1] < losses[0]
 
 
+def test_checkpoint_bridge_optimizer_state(setup, tmp_path):
+    """the engine's flat Adam moments as a torch.optim.Adam state_dict in the reference's
+    parameter order (laina.py:51-57), written into / read back from a Lightning-style checkpoint."""
+    from mono_depth_estimation_amd import checkpoint, criteria
+    from mono_depth_estimation_amd.network import FCRN
+    hip, _, sd, rgb, tgt, _ = setup
+    hip.load_state_dict(sd)
+    hip.train()
+    x, t = rgb.cuda(), tgt.cuda()
+    hip._store = None                                          # fresh flat store: moments start at zero
+    hip.zero_grad(set_to_none=True)
+    criteria.silog_loss(0.85)(hip(x), t).backward()
+    grads = {n: p.grad.detach().clone() for n, p in hip.named_parameters()}
+    hip._store.adam_step(1e-4, 1e-3)
+    osd = checkpoint.adam_state_dict(hip, 1e-4)
+    params = [p for g in checkpoint._param_groups(hip) for p in g]
+    names = {id(p): n for n, p in hip.named_parameters()}
+    assert [len(g["params"]) for g in osd["param_groups"]] == [len(list(hip.get_1x_lr_params())), len(list(hip.get_10x_lr_params()))]
+    assert osd["param_groups"][0]["lr"] == 1e-4 and abs(osd["param_groups"][1]["lr"] - 1e-3) < 1e-12
+    for i in (0, 1, 7, len(params) // 2, len(params) - 1):      # first Adam step from zero moments, in OIHW
+        g = grads[names[id(params[i])]].cpu()
+        st = osd["state"][i]
+        assert int(st["step"]) == 1 and st["exp_avg"].shape == params[i].shape
+        assert torch.allclose(st["exp_avg"], 0.1 * g, rtol=1e-5, atol=1e-12), names[id(params[i])]
+        assert torch.allclose(st["exp_avg_sq"], 0.001 * g * g, rtol=1e-4, atol=1e-20)
+    # torch.optim.Adam accepts it as is (same groups, same order)
+    ref = FCRN.ResNet(layers=50, output_size=SIZE, out_channels=1, pretrained=False)
+    opt = torch.optim.Adam([{"params": ref.get_1x_lr_params(), "lr": 1e-4}, {"params": ref.get_10x_lr_params(), "lr": 1e-3}], lr=1e-4)
+    opt.load_state_dict(osd)
+    # through a checkpoint file into a second module
+    path = str(tmp_path / "last.ckpt")
+    checkpoint.save_checkpoint(hip, path, epoch=1, global_step=1, optimizer_states=[osd])
+    other = FCRN.ResNet(layers=50, output_size=SIZE, out_channels=1, pretrained=False).cuda()
+    ck = checkpoint.load_checkpoint(other, path)
+    other.train()
+    other(x)                                                   # builds its flat store
+    checkpoint.load_adam_state_dict(other, ck["optimizer_states"][0])
+    assert other._store.step_count == 1
+    for a, b in zip(hip._store.adam_state, other._store.adam_state):
+        assert torch.equal(a, b)
+    assert torch.equal(other._store.P, hip._store.P)
+
+
 def test_multichannel_output_and_shape_switching():
     """out_channels > 1 (the reference default is 20), and one module serving two input shapes
     (train batch / validation batch) from the same flat parameter store."""
