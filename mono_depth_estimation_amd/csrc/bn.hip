@@ -14,6 +14,9 @@ namespace {
 
 constexpr int NT = 256;
 constexpr int MAXC = 2048;
+#ifndef MDE_BN_RED_ROWS
+#define MDE_BN_RED_ROWS 32
+#endif
 
 __device__ __forceinline__ void ld8(const bf16_t* p, float (&v)[8]) {
     const bf16x8_t t = *reinterpret_cast<const bf16x8_t*>(p);
@@ -335,8 +338,10 @@ int check_site(const char* who, int64_t M, int C) {
 bool al16(const void* p, int ld) { return ((uintptr_t)p % 16) == 0 && ld % 8 == 0; }
 
 void reduce_geometry(int64_t M, int C, int* nblk, int* rows_per_blk) {
+    // at least MDE_BN_RED_ROWS row groups per workgroup (amortises the LDS + global-atomic flush), at most 2048
+    // workgroups.  In-network sweep (ms/step): 4 -> 33.26, 8 -> 32.95, 16 -> 32.75, 32 -> 32.74, 64 -> 33.15.
     const int rpb = NT / (C / 8);
-    int64_t nb = (M + (int64_t)rpb * 32 - 1) / ((int64_t)rpb * 32);
+    int64_t nb = (M + (int64_t)rpb * MDE_BN_RED_ROWS - 1) / ((int64_t)rpb * MDE_BN_RED_ROWS);
     nb = nb < 1 ? 1 : (nb > 2048 ? 2048 : nb);
     int64_t rows = (M + nb - 1) / nb;
     rows = (rows + rpb - 1) / rpb * rpb;
