@@ -221,6 +221,23 @@ int mde_masked_depth_fwd(const float* pred, const float* target, int N, int H, i
                          void* stream);
 int mde_masked_depth_bwd(const float* pred, const float* target, int N, int H, int W, const void* ws,
                          const float* gscale, float* grad, void* stream);
+/* MiDaS losses (criteria.py:154-332), pred/target fp32 [N][H][W], mask = target > 0:
+ *   q = scale_b*pred + shift_b when ssi (compute_scale_and_shift, per-image closed-form least squares; det == 0 -> 0, 0)
+ *   loss = data_weight * data(q) + alpha * sum_{k < scales} gradient_loss(q[::2^k, ::2^k])
+ *          (MidasLoss.forward: data_weight 1; GradientLoss alone: data_weight 0, alpha 1)
+ *   data_kind 0: mse_loss, 1: l1_loss == trimmed_mae_loss (the reference's trimming is a no-op), both
+ *   reduction_batch_based on 2*M; the gradient term is batch-based or image-based (batch_based = 0).
+ * mde_midas_bwd: grad = d loss / d pred * (*gscale or 1), including the dependence of scale and shift on pred.
+ * ws >= mde_midas_ws_bytes(N): zeroed and written by fwd, read (and completed) by bwd. */
+size_t mde_midas_ws_bytes(int N);
+int mde_midas_fwd(const float* pred, const float* target, int N, int H, int W, int ssi, int data_kind,
+                  float data_weight, float alpha, int scales, int batch_based, void* ws, float* loss,
+                  void* stream);
+int mde_midas_bwd(const float* pred, const float* target, int N, int H, int W, int ssi, int data_kind,
+                  int scales, void* ws, const float* gscale, float* grad, void* stream);
+/* compute_scale_and_shift alone (criteria.py:154-176): scale[N], shift[N]. */
+int mde_scale_and_shift(const float* pred, const float* target, int N, int H, int W, void* ws, float* scale,
+                        float* shift, void* stream);
 /* Depth metrics (metrics.py:58-109): out[6] = absrel, 'rmse' (= mean sqrt((p-t)^2/t), sic),
  * delta1, delta2, delta3, log10.  ws >= mde_metrics_ws_bytes(). */
 size_t mde_metrics_ws_bytes(void);

@@ -79,6 +79,10 @@ SIGNATURES = {
     "mde_masked_depth_ws_bytes": (_Z, [_I]),
     "mde_masked_depth_fwd": (_I, [_P, _P, _I, _I, _I, _P, _P, _P]),
     "mde_masked_depth_bwd": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P]),
+    "mde_midas_ws_bytes": (_Z, [_I]),
+    "mde_midas_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _F, _F, _I, _I, _P, _P, _P]),
+    "mde_midas_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
+    "mde_scale_and_shift": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P]),
     "mde_metrics_ws_bytes": (_Z, []),
     "mde_depth_metrics": (_I, [_P, _P, _L, _P, _P, _P]),
     "mde_adam_step": (_I, [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _F, _I, _P]),

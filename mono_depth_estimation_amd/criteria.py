@@ -5,6 +5,12 @@ kernels in csrc/losses.hip; no CPU fallback):
   silog_loss(variance_focus)(depth_est, depth_gt)      criteria.py:724-732   (the FCRN bench loss)
   MaskedL1Loss()(pred, target), MaskedMSELoss(), berHuLoss()   criteria.py:67-90,113-133
   MaskedDepthLoss()(pred, target)                      criteria.py:17-64    (Eigen's loss)
+  compute_scale_and_shift(prediction, target, mask=None)       criteria.py:154-176
+  GradientLoss(scales, reduction)(prediction, target, mask)    criteria.py:227-244,283-303
+  MidasLoss(alpha, scales, loss, reduction)(prediction, target)   criteria.py:306-332
+      loss in {'mse','l1','trim','ssimse','ssil1','ssitrim'}; as in the reference, 'trim' computes the plain
+      L1 term (its sort-and-slice trims nothing) and only the batch-based reduction is well-formed for the
+      data terms; every mask is target > 0.
 """
 import torch
 import torch.nn as nn
@@ -123,3 +129,94 @@ class MaskedDepthLoss(nn.Module):
             raise NotImplementedError("MaskedDepthLoss: single-channel depth maps only (as the reference's slicing assumes)")
         self.loss = _MaskedDepthFunction.apply(pred, target)
         return self.loss
+
+
+def _squeeze_pair(prediction, target):
+    if prediction.dim() == 4:
+        prediction = prediction.squeeze(1)
+    if target.dim() == 4:
+        target = target.squeeze(1)
+    if prediction.dim() != 3 or prediction.shape != target.shape:
+        raise ValueError("expected [N][H][W] (or [N][1][H][W]) depth maps of equal shape, got %s and %s"
+                         % (tuple(prediction.shape), tuple(target.shape)))
+    return prediction.contiguous().float(), target.contiguous().float()
+
+
+def _check_mask(mask, target, who):
+    """The HIP kernels derive the mask as target > 0 (what MidasLoss does); an explicit mask must be that one."""
+    if mask is not None and not torch.equal(mask.reshape(target.shape) > 0, target > 0):
+        raise NotImplementedError("%s: only the mask (target > 0) is supported on the HIP path" % who)
+
+
+def compute_scale_and_shift(prediction, target, mask=None):
+    """criteria.py:154-176: per-image closed-form least squares (scale, shift); zeros where det == 0."""
+    _need_gpu(prediction, "compute_scale_and_shift")
+    p, t = _squeeze_pair(prediction, target)
+    _check_mask(mask, t, "compute_scale_and_shift")
+    N, H, W = p.shape
+    scale, shift = torch.empty(N, device=p.device), torch.empty(N, device=p.device)
+    ops.scale_and_shift(p, t, N, H, W, ops.midas_ws(N, p.device), scale, shift)
+    return scale, shift
+
+
+class _MidasFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, prediction, target, ssi, data_kind, data_weight, alpha, scales, batch_based):
+        p, t = _squeeze_pair(prediction, target)
+        N, H, W = p.shape
+        ws = ops.midas_ws(N, p.device)
+        loss = torch.empty(1, device=p.device)
+        ops.midas_fwd(p, t, N, H, W, ssi, data_kind, data_weight, alpha, scales, batch_based, ws, loss)
+        ctx.save_for_backward(p, t, ws)
+        ctx.cfg = (ssi, data_kind, scales, prediction.shape)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, gout):
+        p, t, ws = ctx.saved_tensors
+        ssi, data_kind, scales, shape = ctx.cfg
+        grad = torch.empty_like(p)
+        ops.midas_bwd(p, t, p.shape[0], p.shape[1], p.shape[2], ssi, data_kind, scales, ws,
+                      gout.contiguous().float().reshape(1), grad)
+        return grad.reshape(shape), None, None, None, None, None, None, None
+
+
+class GradientLoss(nn.Module):
+    """criteria.py:283-303: sum over `scales` sub-samplings [::2^k] of the masked absolute forward differences
+    of mask*(prediction - target), reduced batch-based or image-based."""
+
+    def __init__(self, scales=4, reduction='batch-based'):
+        super().__init__()
+        if not 0 <= scales <= 4:
+            raise NotImplementedError("GradientLoss: up to 4 scales on the HIP path")
+        self.scales, self.batch_based = scales, reduction == 'batch-based'
+
+    def forward(self, prediction, target, mask):
+        _need_gpu(prediction, "GradientLoss")
+        _check_mask(mask, target.squeeze(1) if target.dim() == 4 else target, "GradientLoss")
+        return _MidasFunction.apply(prediction, target, False, 0, 0.0, 1.0, self.scales, self.batch_based)
+
+
+class MidasLoss(nn.Module):
+    """criteria.py:306-332 (modules/midas.py:29-37 uses it batch-based)."""
+
+    def __init__(self, alpha=0.5, scales=4, loss='ssimse', reduction='batch-based'):
+        super().__init__()
+        self.loss = loss
+        if 'trim' in loss or 'l1' in loss:
+            self.data_kind = 1            # TrimmedMAELoss never trims (criteria.py:214-216): identical to L1Loss
+        elif 'mse' in loss:
+            self.data_kind = 0
+        else:
+            raise ValueError()
+        if reduction != 'batch-based':
+            raise NotImplementedError("MidasLoss: the reference's data terms are only well-formed with the batch-based "
+                                      "reduction (image-based indexes a per-pixel map with per-image counts)")
+        if not 0 <= scales <= 4:
+            raise NotImplementedError("MidasLoss: up to 4 scales on the HIP path")
+        self.alpha, self.scales = float(alpha), scales
+
+    def forward(self, prediction, target):
+        _need_gpu(prediction, "MidasLoss")
+        return _MidasFunction.apply(prediction, target, "ssi" in self.loss, self.data_kind, 1.0,
+                                    self.alpha if self.alpha > 0 else 0.0, self.scales, True)

@@ -3,6 +3,7 @@
 //   depth metrics   reference metrics.py:58-109 (absrel, 'rmse' (sic), delta1-3, log10)
 //   MaskedL1Loss / MaskedMSELoss / berHuLoss   reference criteria.py:67-90,113-133
 //   MaskedDepthLoss (Eigen)                    reference criteria.py:17-64
+//   compute_scale_and_shift, mse / l1 / trimmed data terms, GradientLoss, MidasLoss   reference criteria.py:154-332
 // fp32 in, per-thread fp32 partials over a short strided run, wave/workgroup reduction in
 // double, one fp64 atomic per workgroup and quantity.  HBM-bound: 2 x 4 B read per pixel.
 #include "mde_common.h"
@@ -304,6 +305,226 @@ __global__ __launch_bounds__(NT) void mdepth_bwd_k(const float* __restrict__ pre
     }
 }
 
+// ------------------------------------------------------------------ MiDaS losses (criteria.py:154-332)
+// q = scale_b * pred + shift_b (per-image least squares, or q = pred), mask = target > 0
+//   data term   sum_b sum m r^2 / (2 sum_b M_b)   or   sum m |r| / (2 sum_b M_b)   (r = q - t; the reference's
+//               "trimmed" MAE never trims: criteria.py:214-216 slices the (values, indices) tuple)
+//   gradient    sum over scales k = 1,2,4,..: on the [::k, ::k] sub-grid, d = m*(q - t),
+//               sum |d(x+k) - d(x)| m m' + sum |d(y+k) - d(y)| m m', reduced batch-based (/ sum_b M_{b,k})
+//               or image-based (mean_b of / M_{b,k})
+constexpr int MSC = 4;              // scales supported (reference default 4)
+struct MidasImg {
+    double ls[5];                   // a00, a01, a11, b0, b1
+    double data, M;                 // data-term sum, valid pixels
+    double gsum[MSC], gM[MSC];      // gradient sums and valid sub-grid pixels per scale
+    double sg, sgp;                 // sum g, sum g*pred   (g = dL/dq), for the chain through scale / shift
+    float scale, shift, det_ok, pad;
+    float w[MSC];                   // backward weight of scale k for this image (alpha / divisor)
+};
+struct MidasHead { float loss, inv_data, pad0, pad1; };
+
+__global__ __launch_bounds__(NT) void midas_ls_k(const float* __restrict__ pred, const float* __restrict__ tgt, int64_t hw,
+                                                 int blocks_per_img, MidasImg* img) {
+    const int b = blockIdx.x / blocks_per_img, blk = blockIdx.x % blocks_per_img;
+    const float* p = pred + b * hw;
+    const float* t = tgt + b * hw;
+    float a[5] = {0, 0, 0, 0, 0};
+    double acc[5] = {0, 0, 0, 0, 0};
+    int run = 0;
+    for (int64_t i = (int64_t)blk * NT + threadIdx.x; i < hw; i += (int64_t)blocks_per_img * NT) {
+        const float ti = t[i];
+        if (ti > 0.f) {
+            const float pi = p[i];
+            a[0] += pi * pi; a[1] += pi; a[2] += 1.f; a[3] += pi * ti; a[4] += ti;
+        }
+        if (++run == 64) {
+#pragma unroll
+            for (int k = 0; k < 5; ++k) { acc[k] += a[k]; a[k] = 0.f; }
+            run = 0;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 5; ++k) acc[k] += a[k];
+    block_atomic_add<5>(acc, img[b].ls);
+}
+
+__global__ void midas_fit_k(MidasImg* img, int N, int ssi) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= N) return;
+    MidasImg& im = img[b];
+    float s = 1.f, h = 0.f, ok = 0.f;
+    if (ssi) {
+        // the reference solves in fp32 on fp32 sums; the sums here are fp64, the solve follows its formula
+        const double a00 = im.ls[0], a01 = im.ls[1], a11 = im.ls[2], b0 = im.ls[3], b1 = im.ls[4];
+        const double det = a00 * a11 - a01 * a01;
+        s = 0.f;
+        if (det != 0.0) {
+            s = (float)((a11 * b0 - a01 * b1) / det);
+            h = (float)((-a01 * b0 + a00 * b1) / det);
+            ok = 1.f;
+        }
+    }
+    im.scale = s;
+    im.shift = h;
+    im.det_ok = ok;
+}
+
+// residual-like quantity d = m * (q - t) at pixel j of image row-major (needs scale/shift)
+__device__ __forceinline__ float midas_d(const float* __restrict__ p, const float* __restrict__ t, int64_t j, float s, float h) {
+    const float tj = t[j];
+    return tj > 0.f ? (s * p[j] + h - tj) : 0.f;
+}
+
+template <int L1>
+__global__ __launch_bounds__(NT) void midas_terms_k(const float* __restrict__ pred, const float* __restrict__ tgt, int H, int W,
+                                                    int scales, int blocks_per_img, MidasImg* img) {
+    const int b = blockIdx.x / blocks_per_img, blk = blockIdx.x % blocks_per_img;
+    const int64_t hw = (int64_t)H * W;
+    const float* p = pred + b * hw;
+    const float* t = tgt + b * hw;
+    const float s = img[b].scale, h = img[b].shift;
+    float a[2 + 2 * MSC];
+    double acc[2 + 2 * MSC];
+#pragma unroll
+    for (int k = 0; k < 2 + 2 * MSC; ++k) { a[k] = 0.f; acc[k] = 0.0; }
+    int run = 0;
+    for (int64_t i = (int64_t)blk * NT + threadIdx.x; i < hw; i += (int64_t)blocks_per_img * NT) {
+        const int y = (int)(i / W), x = (int)(i - (int64_t)y * W);
+        const bool m = t[i] > 0.f;
+        const float d = midas_d(p, t, i, s, h);
+        if (m) {
+            a[0] += L1 ? fabsf(d) : d * d;
+            a[1] += 1.f;
+        }
+#pragma unroll
+        for (int sc = 0; sc < MSC; ++sc) {
+            const int k = 1 << sc;
+            if (sc >= scales || (y & (k - 1)) || (x & (k - 1))) continue;
+            if (m) a[2 + MSC + sc] += 1.f;
+            if (x + k < W && m && t[i + k] > 0.f) a[2 + sc] += fabsf(midas_d(p, t, i + k, s, h) - d);
+            if (y + k < H && m && t[i + (int64_t)k * W] > 0.f) a[2 + sc] += fabsf(midas_d(p, t, i + (int64_t)k * W, s, h) - d);
+        }
+        if (++run == 32) {
+#pragma unroll
+            for (int k = 0; k < 2 + 2 * MSC; ++k) { acc[k] += a[k]; a[k] = 0.f; }
+            run = 0;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 2 + 2 * MSC; ++k) acc[k] += a[k];
+    double lo[2] = {acc[0], acc[1]}, g[MSC], gm[MSC];
+#pragma unroll
+    for (int k = 0; k < MSC; ++k) { g[k] = acc[2 + k]; gm[k] = acc[2 + MSC + k]; }
+    block_atomic_add<2>(lo, &img[b].data);
+    __syncthreads();
+    block_atomic_add<MSC>(g, img[b].gsum);
+    __syncthreads();
+    block_atomic_add<MSC>(gm, img[b].gM);
+}
+
+__global__ void midas_loss_k(MidasHead* head, MidasImg* img, int N, float data_weight, float alpha, int scales, int batch_based,
+                             float* loss) {
+    double data = 0.0, M = 0.0;
+    for (int b = 0; b < N; ++b) { data += img[b].data; M += img[b].M; }
+    double total = M != 0.0 ? (double)data_weight * data / (2.0 * M) : 0.0;     // reduction_batch_based on (., 2M)
+    head->inv_data = M != 0.0 ? (float)((double)data_weight / (2.0 * M)) : 0.f;
+    for (int sc = 0; sc < scales; ++sc) {
+        if (batch_based) {
+            double g = 0.0, gm = 0.0;
+            for (int b = 0; b < N; ++b) { g += img[b].gsum[sc]; gm += img[b].gM[sc]; }
+            if (alpha > 0.f && gm != 0.0) total += (double)alpha * g / gm;
+            for (int b = 0; b < N; ++b) img[b].w[sc] = (alpha > 0.f && gm != 0.0) ? (float)(alpha / gm) : 0.f;
+        } else {
+            double acc = 0.0;
+            for (int b = 0; b < N; ++b) {
+                const double gm = img[b].gM[sc];
+                acc += gm != 0.0 ? img[b].gsum[sc] / gm : img[b].gsum[sc];
+                img[b].w[sc] = alpha > 0.f ? (float)(alpha / (gm != 0.0 ? gm : 1.0) / N) : 0.f;
+            }
+            if (alpha > 0.f) total += (double)alpha * acc / N;
+        }
+    }
+    head->loss = (float)total;
+    *loss = (float)total;
+}
+
+__device__ __forceinline__ float sgnf(float v) { return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f); }
+
+// g = dL/dq at pixel i of image b
+template <int L1>
+__device__ __forceinline__ float midas_g(const float* __restrict__ p, const float* __restrict__ t, int64_t i, int y, int x, int H, int W,
+                                         int scales, float s, float h, float inv_data, const float* __restrict__ w) {
+    if (!(t[i] > 0.f)) return 0.f;
+    const float d = s * p[i] + h - t[i];
+    float g = L1 ? sgnf(d) * inv_data : 2.f * d * inv_data;
+#pragma unroll
+    for (int sc = 0; sc < MSC; ++sc) {
+        const int k = 1 << sc;
+        if (sc >= scales || (y & (k - 1)) || (x & (k - 1))) continue;
+        float acc = 0.f;
+        if (x + k < W && t[i + k] > 0.f) acc -= sgnf(midas_d(p, t, i + k, s, h) - d);
+        if (x - k >= 0 && t[i - k] > 0.f) acc += sgnf(d - midas_d(p, t, i - k, s, h));
+        if (y + k < H && t[i + (int64_t)k * W] > 0.f) acc -= sgnf(midas_d(p, t, i + (int64_t)k * W, s, h) - d);
+        if (y - k >= 0 && t[i - (int64_t)k * W] > 0.f) acc += sgnf(d - midas_d(p, t, i - (int64_t)k * W, s, h));
+        g += w[sc] * acc;
+    }
+    return g;
+}
+
+template <int L1>
+__global__ __launch_bounds__(NT) void midas_gsum_k(const float* __restrict__ pred, const float* __restrict__ tgt, int H, int W,
+                                                   int scales, int blocks_per_img, const MidasHead* __restrict__ head, MidasImg* img) {
+    const int b = blockIdx.x / blocks_per_img, blk = blockIdx.x % blocks_per_img;
+    const int64_t hw = (int64_t)H * W;
+    const float* p = pred + b * hw;
+    const float* t = tgt + b * hw;
+    const float s = img[b].scale, h = img[b].shift, inv_data = head->inv_data;
+    float wsc[MSC];
+#pragma unroll
+    for (int k = 0; k < MSC; ++k) wsc[k] = img[b].w[k];
+    float a0 = 0.f, a1 = 0.f;
+    double acc[2] = {0.0, 0.0};
+    int run = 0;
+    for (int64_t i = (int64_t)blk * NT + threadIdx.x; i < hw; i += (int64_t)blocks_per_img * NT) {
+        const int y = (int)(i / W), x = (int)(i - (int64_t)y * W);
+        const float g = midas_g<L1>(p, t, i, y, x, H, W, scales, s, h, inv_data, wsc);
+        a0 += g;
+        a1 += g * p[i];
+        if (++run == 64) { acc[0] += a0; acc[1] += a1; a0 = a1 = 0.f; run = 0; }
+    }
+    acc[0] += a0; acc[1] += a1;
+    block_atomic_add<2>(acc, &img[b].sg);
+}
+
+// dL/dpred_i = s*g_i + (ds/dp_i) * sum_j g_j p_j + (dh/dp_i) * sum_j g_j   (scale and shift are functions of pred)
+template <int L1>
+__global__ __launch_bounds__(NT) void midas_bwd_k(const float* __restrict__ pred, const float* __restrict__ tgt, int N, int H, int W,
+                                                  int scales, int ssi, const MidasHead* __restrict__ head,
+                                                  const MidasImg* __restrict__ img, const float* __restrict__ gscale,
+                                                  float* __restrict__ grad) {
+    const float gs = gscale ? *gscale : 1.f, inv_data = head->inv_data;
+    const int64_t hw = (int64_t)H * W, n = hw * N;
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
+        const int b = (int)(i / hw);
+        const int64_t r = i - b * hw;
+        const int y = (int)(r / W), x = (int)(r - (int64_t)y * W);
+        const MidasImg& im = img[b];
+        const float* p = pred + b * hw;
+        const float* t = tgt + b * hw;
+        float out = im.scale * midas_g<L1>(p, t, r, y, x, H, W, scales, im.scale, im.shift, inv_data, im.w);
+        if (ssi && im.det_ok != 0.f && t[r] > 0.f) {
+            const double a00 = im.ls[0], a01 = im.ls[1], a11 = im.ls[2], b0 = im.ls[3], b1 = im.ls[4];
+            const double det = a00 * a11 - a01 * a01;
+            const double pi = p[r], ti = t[r];
+            const double ddet = 2.0 * pi * a11 - 2.0 * a01;
+            const double ds = (a11 * ti - b1 - (double)im.scale * ddet) / det;
+            const double dh = (-b0 - a01 * ti + 2.0 * pi * b1 - (double)im.shift * ddet) / det;
+            out += (float)(ds * im.sgp + dh * im.sg);
+        }
+        grad[i] = gs * out;
+    }
+}
+
 int grid_for(int64_t n) {
     int64_t nb = (n + NT - 1) / NT;
     return (int)(nb > 256 * 8 ? 256 * 8 : (nb < 1 ? 1 : nb));
@@ -404,6 +625,90 @@ extern "C" int mde_masked_depth_bwd(const float* pred, const float* target, int 
     mdepth_bwd_k<<<grid_for((int64_t)N * H * W), NT, 0, (hipStream_t)stream>>>(pred, target, N, H, W, head, img, gscale, grad);
     MDE_LAUNCH_CHECK("mdepth_bwd_k");
     return MDE_OK;
+}
+
+extern "C" size_t mde_midas_ws_bytes(int N) { return sizeof(MidasHead) + (size_t)(N > 0 ? N : 0) * sizeof(MidasImg); }
+
+namespace {
+int midas_bpi(int N, int64_t hw) {
+    int bpi = (int)((hw + NT * 16 - 1) / (NT * 16));
+    const int cap = (2048 + N - 1) / N;
+    return bpi < 1 ? 1 : (bpi > cap ? cap : bpi);
+}
+int midas_check(const char* who, const void* pred, const void* target, int N, int H, int W, int data_kind, int scales, const void* ws) {
+    MDE_REQUIRE(pred && target && ws && N > 0 && H > 0 && W > 0, "%s: bad argument", who);
+    MDE_REQUIRE(data_kind == 0 || data_kind == 1, "%s: data_kind=%d (0 mse, 1 l1 / trimmed)", who, data_kind);
+    MDE_REQUIRE(scales >= 0 && scales <= MSC, "%s: scales=%d (0..%d)", who, scales, MSC);
+    MDE_REQUIRE(((uintptr_t)ws % 8) == 0, "%s: ws must be 8-byte aligned", who);
+    return MDE_OK;
+}
+}  // namespace
+
+extern "C" int mde_midas_fwd(const float* pred, const float* target, int N, int H, int W, int ssi, int data_kind,
+                             float data_weight, float alpha, int scales, int batch_based, void* ws, float* loss, void* stream) {
+    if (int rc = midas_check("mde_midas_fwd", pred, target, N, H, W, data_kind, scales, ws)) return rc;
+    MDE_REQUIRE(loss, "mde_midas_fwd: null loss");
+    hipStream_t st = (hipStream_t)stream;
+    if (int rc = mde_check_hip(hipMemsetAsync(ws, 0, mde_midas_ws_bytes(N), st), "hipMemsetAsync(midas ws)")) return rc;
+    MidasHead* head = (MidasHead*)ws;
+    MidasImg* img = (MidasImg*)(head + 1);
+    const int64_t hw = (int64_t)H * W;
+    const int bpi = midas_bpi(N, hw);
+    if (ssi) {
+        midas_ls_k<<<N * bpi, NT, 0, st>>>(pred, target, hw, bpi, img);
+        MDE_LAUNCH_CHECK("midas_ls_k");
+    }
+    midas_fit_k<<<(N + 63) / 64, 64, 0, st>>>(img, N, ssi);
+    if (data_kind)
+        midas_terms_k<1><<<N * bpi, NT, 0, st>>>(pred, target, H, W, scales, bpi, img);
+    else
+        midas_terms_k<0><<<N * bpi, NT, 0, st>>>(pred, target, H, W, scales, bpi, img);
+    MDE_LAUNCH_CHECK("midas_terms_k");
+    midas_loss_k<<<1, 1, 0, st>>>(head, img, N, data_weight, alpha, scales, batch_based, loss);
+    MDE_LAUNCH_CHECK("midas_loss_k");
+    return MDE_OK;
+}
+
+extern "C" int mde_midas_bwd(const float* pred, const float* target, int N, int H, int W, int ssi, int data_kind, int scales,
+                             void* ws, const float* gscale, float* grad, void* stream) {
+    if (int rc = midas_check("mde_midas_bwd", pred, target, N, H, W, data_kind, scales, ws)) return rc;
+    MDE_REQUIRE(grad, "mde_midas_bwd: null grad");
+    hipStream_t st = (hipStream_t)stream;
+    MidasHead* head = (MidasHead*)ws;
+    MidasImg* img = (MidasImg*)(head + 1);
+    const int64_t hw = (int64_t)H * W;
+    const int bpi = midas_bpi(N, hw);
+    if (ssi) {
+        if (data_kind)
+            midas_gsum_k<1><<<N * bpi, NT, 0, st>>>(pred, target, H, W, scales, bpi, head, img);
+        else
+            midas_gsum_k<0><<<N * bpi, NT, 0, st>>>(pred, target, H, W, scales, bpi, head, img);
+        MDE_LAUNCH_CHECK("midas_gsum_k");
+    }
+    if (data_kind)
+        midas_bwd_k<1><<<grid_for(hw * N), NT, 0, st>>>(pred, target, N, H, W, scales, ssi, head, img, gscale, grad);
+    else
+        midas_bwd_k<0><<<grid_for(hw * N), NT, 0, st>>>(pred, target, N, H, W, scales, ssi, head, img, gscale, grad);
+    MDE_LAUNCH_CHECK("midas_bwd_k");
+    return MDE_OK;
+}
+
+extern "C" int mde_scale_and_shift(const float* pred, const float* target, int N, int H, int W, void* ws, float* scale,
+                                   float* shift, void* stream) {
+    MDE_REQUIRE(pred && target && ws && scale && shift && N > 0 && H > 0 && W > 0, "mde_scale_and_shift: bad argument");
+    MDE_REQUIRE(((uintptr_t)ws % 8) == 0, "mde_scale_and_shift: ws must be 8-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    if (int rc = mde_check_hip(hipMemsetAsync(ws, 0, mde_midas_ws_bytes(N), st), "hipMemsetAsync(midas ws)")) return rc;
+    MidasImg* img = (MidasImg*)((MidasHead*)ws + 1);
+    const int64_t hw = (int64_t)H * W;
+    const int bpi = midas_bpi(N, hw);
+    midas_ls_k<<<N * bpi, NT, 0, st>>>(pred, target, hw, bpi, img);
+    MDE_LAUNCH_CHECK("midas_ls_k");
+    midas_fit_k<<<(N + 63) / 64, 64, 0, st>>>(img, N, 1);
+    if (int rc = mde_check_hip(hipMemcpy2DAsync(scale, sizeof(float), &img[0].scale, sizeof(MidasImg), sizeof(float), N,
+                                                hipMemcpyDeviceToDevice, st), "hipMemcpy2DAsync(scale)")) return rc;
+    return mde_check_hip(hipMemcpy2DAsync(shift, sizeof(float), &img[0].shift, sizeof(MidasImg), sizeof(float), N,
+                                          hipMemcpyDeviceToDevice, st), "hipMemcpy2DAsync(shift)");
 }
 
 extern "C" size_t mde_metrics_ws_bytes(void) { return sizeof(MetricWs); }

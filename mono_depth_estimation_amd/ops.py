@@ -367,6 +367,25 @@ def masked_depth_bwd(pred, target, N, H, W, ws, gscale, grad):
           "mde_masked_depth_bwd")
 
 
+def midas_ws(N, device="cuda"):
+    return torch.zeros((_lib.load().mde_midas_ws_bytes(N) + 7) // 8, dtype=torch.float64, device=device)
+
+
+def midas_fwd(pred, target, N, H, W, ssi, data_kind, data_weight, alpha, scales, batch_based, ws, loss):
+    check(_lib.load().mde_midas_fwd(_p(pred), _p(target), N, H, W, int(ssi), data_kind, data_weight, alpha, scales,
+                                    int(batch_based), _p(ws), _p(loss), _stream()), "mde_midas_fwd")
+
+
+def midas_bwd(pred, target, N, H, W, ssi, data_kind, scales, ws, gscale, grad):
+    check(_lib.load().mde_midas_bwd(_p(pred), _p(target), N, H, W, int(ssi), data_kind, scales, _p(ws), _p(gscale), _p(grad),
+                                    _stream()), "mde_midas_bwd")
+
+
+def scale_and_shift(pred, target, N, H, W, ws, scale, shift):
+    check(_lib.load().mde_scale_and_shift(_p(pred), _p(target), N, H, W, _p(ws), _p(scale), _p(shift), _stream()),
+          "mde_scale_and_shift")
+
+
 def metrics_ws(device="cuda"):
     return torch.zeros((_lib.load().mde_metrics_ws_bytes() + 7) // 8, dtype=torch.float64, device=device)
 

@@ -262,6 +262,57 @@ def test_masked_losses_edge_cases():
         criteria.berHuLoss()(torch.ones(1, 1, 2, 2), torch.ones(1, 1, 2, 2))           # CPU tensors: no fallback
 
 
+@pytest.mark.parametrize("loss", ["mse", "l1", "trim", "ssimse", "ssil1", "ssitrim"])
+def test_midas_loss_golden(golden, loss):
+    """criteria.MidasLoss (HIP) against the reference's own values and gradients (losses.npz, alpha 0.5, 4 scales)."""
+    from mono_depth_estimation_amd import criteria
+    g = golden("losses")
+    pred = torch.from_numpy(g["g2_pred"]).cuda().requires_grad_(True)
+    tgt = torch.from_numpy(g["g2_tgt"]).cuda()
+    out = criteria.MidasLoss(alpha=0.5, loss=loss)(pred, tgt)
+    (2.0 * out).backward()
+    assert np.allclose(out.item(), g["g2_midas_" + loss], rtol=5e-5), (out.item(), g["g2_midas_" + loss])
+    ref = 2.0 * g["g2_midas_" + loss + "_grad"]
+    err = np.abs(pred.grad.cpu().numpy() - ref)
+    assert err.max() <= 2e-3 * np.abs(ref).max() and err.mean() <= 2e-5 * np.abs(ref).max(), (err.max(), err.mean(), np.abs(ref).max())
+
+
+def test_scale_shift_and_gradient_loss_golden(golden):
+    from mono_depth_estimation_amd import criteria
+    g = golden("losses")
+    pred, tgt = torch.from_numpy(g["g2_pred"]).cuda(), torch.from_numpy(g["g2_tgt"]).cuda()
+    s, h = criteria.compute_scale_and_shift(pred, tgt)
+    assert np.allclose(s.cpu().numpy(), g["g2_scale"], rtol=1e-4) and np.allclose(h.cpu().numpy(), g["g2_shift"], rtol=1e-4, atol=1e-6)
+    mask = (tgt > 0).float()
+    for red, key in (("batch-based", "g2_gradient_batch"), ("image-based", "g2_gradient_image")):
+        p = pred.clone().requires_grad_(True)
+        out = criteria.GradientLoss(scales=4, reduction=red)(p, tgt, mask)
+        out.backward()
+        assert np.allclose(out.item(), g[key], rtol=5e-5), (red, out.item(), g[key])
+        ref = g[key + "_grad"]
+        assert np.abs(p.grad.cpu().numpy().reshape(ref.shape) - ref).max() <= 1e-4 * np.abs(ref).max() + 1e-9
+
+
+@pytest.mark.parametrize("loss", ["ssimse", "ssitrim", "mse"])
+def test_midas_loss_large_matches_oracle(loss):
+    """MiDaS-sized maps (4 x 384 x 384, 10 % invalid) against the oracle's autograd."""
+    from mono_depth_estimation_amd import criteria
+    pred = W.uniform(41, "pred", (4, 1, 384, 384), 0.05, 1.0)
+    _, tgt = W.synthetic_batch(41, 4, 384, 384)
+    tgt = tgt * (1.0 + 0.5 * W.uniform(41, "ramp", (4, 1, 384, 384)))       # decorrelate scale from 1
+    p = pred.clone().requires_grad_(True)
+    ref = OL.midas_loss(p, tgt, alpha=0.5, loss=loss)
+    ref.backward()
+    pd = pred.cuda().requires_grad_(True)
+    out = criteria.MidasLoss(alpha=0.5, loss=loss)(pd, tgt.cuda())
+    out.backward()
+    assert np.allclose(out.item(), ref.item(), rtol=1e-4), (out.item(), ref.item())
+    err = (pd.grad.cpu() - p.grad).abs()
+    scale = float(p.grad.abs().max())
+    # sign() terms flip where two neighbouring residuals differ by rounding noise: a few isolated pixels
+    assert float(err.mean()) <= 2e-5 * scale and float((err > 1e-3 * scale).float().mean()) < 1e-3, (float(err.max()), float(err.mean()), scale)
+
+
 def test_metrics_golden(golden):
     from mono_depth_estimation_amd import ops
     g = golden("metrics")
