@@ -341,6 +341,37 @@ def test_multichannel_output_and_shape_switching():
     assert float(hip.conv3.weight.grad[2].abs().sum()) > 0 and float(hip.conv3.weight.grad[0].abs().sum()) == 0
 
 
+def test_resnet101_trunk_conditioned_eval_and_train_step():
+    """The reference's `layers=` argument (FCRN.py:297-323): the engine plans ResNet-101 (blocks [3,4,23,3]) from
+    the same building blocks.  Conditioned weights (as in the AbsRel parity fixture) so that eval outputs are
+    comparable: HIP vs the fp32 oracle within bf16 noise; one train step produces finite gradients for every
+    parameter and a loss equal to the oracle's to bf16 accuracy."""
+    from mono_depth_estimation_amd import criteria
+    from mono_depth_estimation_amd.network import FCRN
+    size = (64, 96)
+    ora = ofcrn.FCRNOracle(101, size, out_channels=1)
+    W.fcrn_conditioned_state(ora, 12)
+    rgb, tgt = W.synthetic_batch(12, 2, *size)
+    W.calibrate_running_stats(ora, rgb)
+    hip = FCRN.ResNet(layers=101, output_size=size, out_channels=1, pretrained=False)
+    assert list(hip.state_dict()) == list(ora.state_dict())
+    hip.load_state_dict(ora.state_dict())
+    hip = hip.cuda().eval()
+    ora.eval()
+    with torch.no_grad():
+        d = (hip(rgb.cuda()).cpu() - ora(rgb)).abs()
+    assert d.max() <= 2e-2 and d.mean() <= 3e-3, (float(d.max()), float(d.mean()))
+    hip.train()
+    ora.train()
+    loss = criteria.silog_loss(0.85)(hip(rgb.cuda()), tgt.cuda())
+    loss.backward()
+    ref = OL.silog(ora(rgb), tgt, 0.85)
+    assert abs(float(loss) - float(ref)) <= 2e-2 * abs(float(ref)), (float(loss), float(ref))
+    for n, p in hip.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), n
+    assert float(hip.layer3[22].conv2.weight.grad.abs().sum()) > 0
+
+
 def test_state_dict_round_trip(setup):
     """Parameters are views of flat storage (conv weights channels_last): saving and loading a
     state_dict must preserve values and keep the views attached."""
