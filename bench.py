@@ -127,7 +127,8 @@ def main():
     if use_dist:
         dist.broadcast(store.P, 0)
         dist.broadcast(store.B, 0)
-    reducer = dp.FlatGradReducer(store.G, eng.grad_boundaries(), target_bytes=64 << 20, extra_streams=[eng.side])
+    reducer = dp.FlatGradReducer(store.G, eng.grad_boundaries(), target_bytes=int(os.environ.get("MDE_DP_BUCKET_MB", "64")) << 20,
+                                 extra_streams=[eng.side])
     ws, loss = ops.silog_ws(dev), torch.empty(1, device=dev)
     dy = torch.empty(args.batch, 1, H, W, device=dev)
     lr = 1e-4
