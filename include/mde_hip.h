@@ -235,6 +235,18 @@ int mde_midas_fwd(const float* pred, const float* target, int N, int H, int W, i
                   void* stream);
 int mde_midas_bwd(const float* pred, const float* target, int N, int H, int W, int ssi, int data_kind,
                   int scales, void* ws, const float* gscale, float* grad, void* stream);
+/* TrimmedProcrustesLoss (criteria.py:335-363): prediction and target are robustly normalised per image
+ * (normalize_prediction_robust, criteria.py:135-152: subtract the lower median of mask*x over all H*W values, divide
+ * by the mean absolute deviation over valid pixels clamped at 1e-6), then the reference's "trimmed" MAE (it never
+ * trims) + alpha * multi-scale gradient loss, all masks = target > 0 of the original target.
+ * pred_n / target_n: caller-owned fp32 [N][H][W] scratch that fwd fills (the normalised maps) and bwd reads;
+ * gtmp: another such scratch for bwd.  ws >= mde_procrustes_ws_bytes(N). */
+size_t mde_procrustes_ws_bytes(int N);
+int mde_procrustes_fwd(const float* pred, const float* target, int N, int H, int W, float alpha, int scales,
+                       int batch_based, void* ws, float* pred_n, float* target_n, float* loss, void* stream);
+int mde_procrustes_bwd(const float* pred, const float* target, int N, int H, int W, int scales, void* ws,
+                       const float* pred_n, const float* target_n, const float* gscale, float* gtmp,
+                       float* grad, void* stream);
 /* compute_scale_and_shift alone (criteria.py:154-176): scale[N], shift[N]. */
 int mde_scale_and_shift(const float* pred, const float* target, int N, int H, int W, void* ws, float* scale,
                         float* shift, void* stream);

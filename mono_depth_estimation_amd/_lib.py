@@ -82,6 +82,9 @@ SIGNATURES = {
     "mde_midas_ws_bytes": (_Z, [_I]),
     "mde_midas_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _F, _F, _I, _I, _P, _P, _P]),
     "mde_midas_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
+    "mde_procrustes_ws_bytes": (_Z, [_I]),
+    "mde_procrustes_fwd": (_I, [_P, _P, _I, _I, _I, _F, _I, _I, _P, _P, _P, _P, _P]),
+    "mde_procrustes_bwd": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "mde_scale_and_shift": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P]),
     "mde_metrics_ws_bytes": (_Z, []),
     "mde_depth_metrics": (_I, [_P, _P, _L, _P, _P, _P]),

@@ -11,6 +11,7 @@ kernels in csrc/losses.hip; no CPU fallback):
       loss in {'mse','l1','trim','ssimse','ssil1','ssitrim'}; as in the reference, 'trim' computes the plain
       L1 term (its sort-and-slice trims nothing) and only the batch-based reduction is well-formed for the
       data terms; every mask is target > 0.
+  TrimmedProcrustesLoss(alpha, scales, reduction)(prediction, target)   criteria.py:335-363 (+ :135-152)
 """
 import torch
 import torch.nn as nn
@@ -220,3 +221,45 @@ class MidasLoss(nn.Module):
         _need_gpu(prediction, "MidasLoss")
         return _MidasFunction.apply(prediction, target, "ssi" in self.loss, self.data_kind, 1.0,
                                     self.alpha if self.alpha > 0 else 0.0, self.scales, True)
+
+
+class _ProcrustesFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, prediction, target, alpha, scales, batch_based):
+        p, t = _squeeze_pair(prediction, target)
+        N, H, W = p.shape
+        ws = ops.procrustes_ws(N, p.device)
+        pn, tn, loss = torch.empty_like(p), torch.empty_like(p), torch.empty(1, device=p.device)
+        ops.procrustes_fwd(p, t, N, H, W, alpha, scales, batch_based, ws, pn, tn, loss)
+        ctx.save_for_backward(p, t, ws, pn, tn)
+        ctx.cfg = (scales, prediction.shape)
+        return loss.reshape(()), pn
+
+    @staticmethod
+    def backward(ctx, gout, _gpn):
+        p, t, ws, pn, tn = ctx.saved_tensors
+        scales, shape = ctx.cfg
+        gtmp, grad = torch.empty_like(p), torch.empty_like(p)
+        ops.procrustes_bwd(p, t, p.shape[0], p.shape[1], p.shape[2], scales, ws, pn, tn,
+                           gout.contiguous().float().reshape(1), gtmp, grad)
+        return grad.reshape(shape), None, None, None, None
+
+
+class TrimmedProcrustesLoss(nn.Module):
+    """criteria.py:335-363.  `prediction_ssi` holds the robustly normalised prediction of the last call
+    (detached), as the reference's property does."""
+
+    def __init__(self, alpha=0.5, scales=4, reduction="batch-based"):
+        super().__init__()
+        if reduction != "batch-based":
+            raise NotImplementedError("TrimmedProcrustesLoss: the reference's data term is only well-formed batch-based")
+        if not 0 <= scales <= 4:
+            raise NotImplementedError("TrimmedProcrustesLoss: up to 4 scales on the HIP path")
+        self.alpha, self.scales = float(alpha), scales
+        self.prediction_ssi = None
+
+    def forward(self, prediction, target):
+        _need_gpu(prediction, "TrimmedProcrustesLoss")
+        loss, pn = _ProcrustesFunction.apply(prediction, target, self.alpha if self.alpha > 0 else 0.0, self.scales, True)
+        self.prediction_ssi = pn.detach()
+        return loss

@@ -369,19 +369,21 @@ __global__ void midas_fit_k(MidasImg* img, int N, int ssi) {
     im.det_ok = ok;
 }
 
-// residual-like quantity d = m * (q - t) at pixel j of image row-major (needs scale/shift)
-__device__ __forceinline__ float midas_d(const float* __restrict__ p, const float* __restrict__ t, int64_t j, float s, float h) {
-    const float tj = t[j];
-    return tj > 0.f ? (s * p[j] + h - tj) : 0.f;
+// residual-like quantity d = m * (q - t) at pixel j of image row-major (needs scale/shift); mk: mask source (> 0)
+__device__ __forceinline__ float midas_d(const float* __restrict__ p, const float* __restrict__ t, const float* __restrict__ mk,
+                                         int64_t j, float s, float h) {
+    return mk[j] > 0.f ? (s * p[j] + h - t[j]) : 0.f;
 }
 
 template <int L1>
-__global__ __launch_bounds__(NT) void midas_terms_k(const float* __restrict__ pred, const float* __restrict__ tgt, int H, int W,
-                                                    int scales, int blocks_per_img, MidasImg* img) {
+__global__ __launch_bounds__(NT) void midas_terms_k(const float* __restrict__ pred, const float* __restrict__ tgt,
+                                                    const float* __restrict__ msk, int H, int W, int scales, int blocks_per_img,
+                                                    MidasImg* img) {
     const int b = blockIdx.x / blocks_per_img, blk = blockIdx.x % blocks_per_img;
     const int64_t hw = (int64_t)H * W;
     const float* p = pred + b * hw;
     const float* t = tgt + b * hw;
+    const float* mk = msk + b * hw;
     const float s = img[b].scale, h = img[b].shift;
     float a[2 + 2 * MSC];
     double acc[2 + 2 * MSC];
@@ -390,8 +392,8 @@ __global__ __launch_bounds__(NT) void midas_terms_k(const float* __restrict__ pr
     int run = 0;
     for (int64_t i = (int64_t)blk * NT + threadIdx.x; i < hw; i += (int64_t)blocks_per_img * NT) {
         const int y = (int)(i / W), x = (int)(i - (int64_t)y * W);
-        const bool m = t[i] > 0.f;
-        const float d = midas_d(p, t, i, s, h);
+        const bool m = mk[i] > 0.f;
+        const float d = midas_d(p, t, mk, i, s, h);
         if (m) {
             a[0] += L1 ? fabsf(d) : d * d;
             a[1] += 1.f;
@@ -401,8 +403,8 @@ __global__ __launch_bounds__(NT) void midas_terms_k(const float* __restrict__ pr
             const int k = 1 << sc;
             if (sc >= scales || (y & (k - 1)) || (x & (k - 1))) continue;
             if (m) a[2 + MSC + sc] += 1.f;
-            if (x + k < W && m && t[i + k] > 0.f) a[2 + sc] += fabsf(midas_d(p, t, i + k, s, h) - d);
-            if (y + k < H && m && t[i + (int64_t)k * W] > 0.f) a[2 + sc] += fabsf(midas_d(p, t, i + (int64_t)k * W, s, h) - d);
+            if (x + k < W && m && mk[i + k] > 0.f) a[2 + sc] += fabsf(midas_d(p, t, mk, i + k, s, h) - d);
+            if (y + k < H && m && mk[i + (int64_t)k * W] > 0.f) a[2 + sc] += fabsf(midas_d(p, t, mk, i + (int64_t)k * W, s, h) - d);
         }
         if (++run == 32) {
 #pragma unroll
@@ -452,9 +454,10 @@ __device__ __forceinline__ float sgnf(float v) { return v > 0.f ? 1.f : (v < 0.f
 
 // g = dL/dq at pixel i of image b
 template <int L1>
-__device__ __forceinline__ float midas_g(const float* __restrict__ p, const float* __restrict__ t, int64_t i, int y, int x, int H, int W,
-                                         int scales, float s, float h, float inv_data, const float* __restrict__ w) {
-    if (!(t[i] > 0.f)) return 0.f;
+__device__ __forceinline__ float midas_g(const float* __restrict__ p, const float* __restrict__ t, const float* __restrict__ mk,
+                                         int64_t i, int y, int x, int H, int W, int scales, float s, float h, float inv_data,
+                                         const float* __restrict__ w) {
+    if (!(mk[i] > 0.f)) return 0.f;
     const float d = s * p[i] + h - t[i];
     float g = L1 ? sgnf(d) * inv_data : 2.f * d * inv_data;
 #pragma unroll
@@ -462,22 +465,24 @@ __device__ __forceinline__ float midas_g(const float* __restrict__ p, const floa
         const int k = 1 << sc;
         if (sc >= scales || (y & (k - 1)) || (x & (k - 1))) continue;
         float acc = 0.f;
-        if (x + k < W && t[i + k] > 0.f) acc -= sgnf(midas_d(p, t, i + k, s, h) - d);
-        if (x - k >= 0 && t[i - k] > 0.f) acc += sgnf(d - midas_d(p, t, i - k, s, h));
-        if (y + k < H && t[i + (int64_t)k * W] > 0.f) acc -= sgnf(midas_d(p, t, i + (int64_t)k * W, s, h) - d);
-        if (y - k >= 0 && t[i - (int64_t)k * W] > 0.f) acc += sgnf(d - midas_d(p, t, i - (int64_t)k * W, s, h));
+        if (x + k < W && mk[i + k] > 0.f) acc -= sgnf(midas_d(p, t, mk, i + k, s, h) - d);
+        if (x - k >= 0 && mk[i - k] > 0.f) acc += sgnf(d - midas_d(p, t, mk, i - k, s, h));
+        if (y + k < H && mk[i + (int64_t)k * W] > 0.f) acc -= sgnf(midas_d(p, t, mk, i + (int64_t)k * W, s, h) - d);
+        if (y - k >= 0 && mk[i - (int64_t)k * W] > 0.f) acc += sgnf(d - midas_d(p, t, mk, i - (int64_t)k * W, s, h));
         g += w[sc] * acc;
     }
     return g;
 }
 
 template <int L1>
-__global__ __launch_bounds__(NT) void midas_gsum_k(const float* __restrict__ pred, const float* __restrict__ tgt, int H, int W,
-                                                   int scales, int blocks_per_img, const MidasHead* __restrict__ head, MidasImg* img) {
+__global__ __launch_bounds__(NT) void midas_gsum_k(const float* __restrict__ pred, const float* __restrict__ tgt,
+                                                   const float* __restrict__ msk, int H, int W, int scales, int blocks_per_img,
+                                                   const MidasHead* __restrict__ head, MidasImg* img) {
     const int b = blockIdx.x / blocks_per_img, blk = blockIdx.x % blocks_per_img;
     const int64_t hw = (int64_t)H * W;
     const float* p = pred + b * hw;
     const float* t = tgt + b * hw;
+    const float* mk = msk + b * hw;
     const float s = img[b].scale, h = img[b].shift, inv_data = head->inv_data;
     float wsc[MSC];
 #pragma unroll
@@ -487,7 +492,7 @@ __global__ __launch_bounds__(NT) void midas_gsum_k(const float* __restrict__ pre
     int run = 0;
     for (int64_t i = (int64_t)blk * NT + threadIdx.x; i < hw; i += (int64_t)blocks_per_img * NT) {
         const int y = (int)(i / W), x = (int)(i - (int64_t)y * W);
-        const float g = midas_g<L1>(p, t, i, y, x, H, W, scales, s, h, inv_data, wsc);
+        const float g = midas_g<L1>(p, t, mk, i, y, x, H, W, scales, s, h, inv_data, wsc);
         a0 += g;
         a1 += g * p[i];
         if (++run == 64) { acc[0] += a0; acc[1] += a1; a0 = a1 = 0.f; run = 0; }
@@ -498,8 +503,9 @@ __global__ __launch_bounds__(NT) void midas_gsum_k(const float* __restrict__ pre
 
 // dL/dpred_i = s*g_i + (ds/dp_i) * sum_j g_j p_j + (dh/dp_i) * sum_j g_j   (scale and shift are functions of pred)
 template <int L1>
-__global__ __launch_bounds__(NT) void midas_bwd_k(const float* __restrict__ pred, const float* __restrict__ tgt, int N, int H, int W,
-                                                  int scales, int ssi, const MidasHead* __restrict__ head,
+__global__ __launch_bounds__(NT) void midas_bwd_k(const float* __restrict__ pred, const float* __restrict__ tgt,
+                                                  const float* __restrict__ msk, int N, int H, int W, int scales, int ssi,
+                                                  const MidasHead* __restrict__ head,
                                                   const MidasImg* __restrict__ img, const float* __restrict__ gscale,
                                                   float* __restrict__ grad) {
     const float gs = gscale ? *gscale : 1.f, inv_data = head->inv_data;
@@ -511,8 +517,9 @@ __global__ __launch_bounds__(NT) void midas_bwd_k(const float* __restrict__ pred
         const MidasImg& im = img[b];
         const float* p = pred + b * hw;
         const float* t = tgt + b * hw;
-        float out = im.scale * midas_g<L1>(p, t, r, y, x, H, W, scales, im.scale, im.shift, inv_data, im.w);
-        if (ssi && im.det_ok != 0.f && t[r] > 0.f) {
+        const float* mk = msk + b * hw;
+        float out = im.scale * midas_g<L1>(p, t, mk, r, y, x, H, W, scales, im.scale, im.shift, inv_data, im.w);
+        if (ssi && im.det_ok != 0.f && mk[r] > 0.f) {
             const double a00 = im.ls[0], a01 = im.ls[1], a11 = im.ls[2], b0 = im.ls[3], b1 = im.ls[4];
             const double det = a00 * a11 - a01 * a01;
             const double pi = p[r], ti = t[r];
@@ -520,6 +527,154 @@ __global__ __launch_bounds__(NT) void midas_bwd_k(const float* __restrict__ pred
             const double ds = (a11 * ti - b1 - (double)im.scale * ddet) / det;
             const double dh = (-b0 - a01 * ti + 2.0 * pi * b1 - (double)im.shift * ddet) / det;
             out += (float)(ds * im.sgp + dh * im.sg);
+        }
+        grad[i] = gs * out;
+    }
+}
+
+// ------------------------------------------------------------------ robust normalisation (criteria.py:135-152)
+// per image: med = torch.median(mask * x) (lower median over ALL H*W values, masked-out pixels count as 0),
+// s = clamp(sum m |x - med| / sum m, 1e-6) (med = 0, s = 1 for an image without valid pixels), x' = (x - med) / s.
+struct RobustImg {
+    unsigned int hist[256];
+    unsigned int prefix, rank, pad0, pad1;
+    double cnt, sq, sgn, eq;         // sum m, sum m|x-med|, sum m*sign(x-med), #{valid pixels with x == med}
+    double sg, sgp;                  // backward: sum g', sum g' * x'
+    float med, s, clamped, valid;
+};
+
+__device__ __forceinline__ unsigned int order_key(float v) {
+    const unsigned int u = __builtin_bit_cast(unsigned int, v);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float order_val(unsigned int k) {
+    return __builtin_bit_cast(float, (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
+}
+
+__global__ void robust_init_k(RobustImg* img, int N, unsigned int rank) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < N) { img[b].prefix = 0u; img[b].rank = rank; }
+}
+
+// histogram of byte `pass` (0 = most significant) of the keys whose higher bytes equal the prefix found so far
+__global__ __launch_bounds__(NT) void robust_hist_k(const float* __restrict__ x, const float* __restrict__ msk, int64_t hw,
+                                                    int blocks_per_img, int pass, RobustImg* img) {
+    __shared__ unsigned int sh[256];
+    const int b = blockIdx.x / blocks_per_img, blk = blockIdx.x % blocks_per_img;
+    sh[threadIdx.x] = 0u;
+    __syncthreads();
+    const unsigned int prefix = img[b].prefix;
+    const int shift = 24 - 8 * pass;
+    const float* xi = x + b * hw;
+    const float* mk = msk + b * hw;
+    for (int64_t i = (int64_t)blk * NT + threadIdx.x; i < hw; i += (int64_t)blocks_per_img * NT) {
+        const unsigned int k = order_key(mk[i] > 0.f ? xi[i] : 0.f);
+        if (pass == 0 || (k >> (shift + 8)) == prefix) atomicAdd(&sh[(k >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    if (sh[threadIdx.x]) atomicAdd(&img[b].hist[threadIdx.x], sh[threadIdx.x]);
+}
+
+__global__ void robust_select_k(RobustImg* img, int N, int pass) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= N) return;
+    RobustImg& im = img[b];
+    unsigned int r = im.rank, bin = 0;
+    for (; bin < 255u; ++bin) {
+        if (r < im.hist[bin]) break;
+        r -= im.hist[bin];
+    }
+    im.rank = r;
+    im.prefix = (im.prefix << 8) | bin;
+    for (int i = 0; i < 256; ++i) im.hist[i] = 0u;
+    if (pass == 3) im.med = order_val(im.prefix);
+}
+
+__global__ __launch_bounds__(NT) void robust_stats_k(const float* __restrict__ x, const float* __restrict__ msk, int64_t hw,
+                                                     int blocks_per_img, RobustImg* img) {
+    const int b = blockIdx.x / blocks_per_img, blk = blockIdx.x % blocks_per_img;
+    const float med = img[b].med;
+    const float* xi = x + b * hw;
+    const float* mk = msk + b * hw;
+    float a[4] = {0, 0, 0, 0};
+    double acc[4] = {0, 0, 0, 0};
+    int run = 0;
+    for (int64_t i = (int64_t)blk * NT + threadIdx.x; i < hw; i += (int64_t)blocks_per_img * NT) {
+        if (mk[i] > 0.f) {
+            const float d = xi[i] - med;
+            a[0] += 1.f; a[1] += fabsf(d); a[2] += sgnf(d); a[3] += d == 0.f ? 1.f : 0.f;
+        }
+        if (++run == 64) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { acc[k] += a[k]; a[k] = 0.f; }
+            run = 0;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[k] += a[k];
+    block_atomic_add<4>(acc, &img[b].cnt);
+}
+
+__global__ void robust_scale_k(RobustImg* img, int N) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= N) return;
+    RobustImg& im = img[b];
+    if (im.cnt > 0.0) {
+        const float raw = (float)(im.sq / im.cnt);
+        im.s = raw < 1e-6f ? 1e-6f : raw;
+        im.clamped = raw < 1e-6f ? 1.f : 0.f;
+        im.valid = 1.f;
+    } else {
+        im.med = 0.f;
+        im.s = 1.f;
+        im.clamped = 1.f;
+        im.valid = 0.f;
+    }
+}
+
+__global__ __launch_bounds__(NT) void robust_apply_k(const float* __restrict__ x, int64_t hw, int64_t n, const RobustImg* __restrict__ img,
+                                                     float* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
+        const RobustImg& im = img[i / hw];
+        out[i] = (x[i] - im.med) / im.s;
+    }
+}
+
+__global__ __launch_bounds__(NT) void robust_bwd_sums_k(const float* __restrict__ g, const float* __restrict__ xn, int64_t hw,
+                                                        int blocks_per_img, RobustImg* img) {
+    const int b = blockIdx.x / blocks_per_img, blk = blockIdx.x % blocks_per_img;
+    const float* gi = g + b * hw;
+    const float* xi = xn + b * hw;
+    float a0 = 0.f, a1 = 0.f;
+    double acc[2] = {0.0, 0.0};
+    int run = 0;
+    for (int64_t i = (int64_t)blk * NT + threadIdx.x; i < hw; i += (int64_t)blocks_per_img * NT) {
+        a0 += gi[i];
+        a1 += gi[i] * xi[i];
+        if (++run == 64) { acc[0] += a0; acc[1] += a1; a0 = a1 = 0.f; run = 0; }
+    }
+    acc[0] += a0; acc[1] += a1;
+    block_atomic_add<2>(acc, &img[b].sg);
+}
+
+// x' = (x - med)/s:  dL/dx_i = g'_i/s - (sum g')/s * dmed/dx_i - (sum g' x')/s * ds/dx_i
+//   dmed/dx_i = [valid_i and x_i == med] / #such ;  ds/dx_i = (m_i sign(x_i - med) - (sum m sign) dmed/dx_i)/cnt  (0 if clamped)
+__global__ __launch_bounds__(NT) void robust_bwd_k(const float* __restrict__ g, const float* __restrict__ x, const float* __restrict__ msk,
+                                                   int64_t hw, int64_t n, const RobustImg* __restrict__ img,
+                                                   const float* __restrict__ gscale, float* __restrict__ grad) {
+    const float gs = gscale ? *gscale : 1.f;
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
+        const RobustImg& im = img[i / hw];
+        const float inv_s = 1.f / im.s;
+        float out = g[i] * inv_s;
+        if (im.valid != 0.f && msk[i] > 0.f) {
+            const float d = x[i] - im.med;
+            const float dmed = (d == 0.f && im.eq > 0.0) ? (float)(1.0 / im.eq) : 0.f;
+            out -= (float)im.sg * inv_s * dmed;
+            if (im.clamped == 0.f) {
+                const float ds = (sgnf(d) - (float)im.sgn * dmed) / (float)im.cnt;
+                out -= (float)im.sgp * inv_s * ds;
+            }
         }
         grad[i] = gs * out;
     }
@@ -644,11 +799,9 @@ int midas_check(const char* who, const void* pred, const void* target, int N, in
 }
 }  // namespace
 
-extern "C" int mde_midas_fwd(const float* pred, const float* target, int N, int H, int W, int ssi, int data_kind,
-                             float data_weight, float alpha, int scales, int batch_based, void* ws, float* loss, void* stream) {
-    if (int rc = midas_check("mde_midas_fwd", pred, target, N, H, W, data_kind, scales, ws)) return rc;
-    MDE_REQUIRE(loss, "mde_midas_fwd: null loss");
-    hipStream_t st = (hipStream_t)stream;
+namespace {
+int midas_fwd_impl(const float* pred, const float* target, const float* msk, int N, int H, int W, int ssi, int data_kind,
+                   float data_weight, float alpha, int scales, int batch_based, void* ws, float* loss, hipStream_t st) {
     if (int rc = mde_check_hip(hipMemsetAsync(ws, 0, mde_midas_ws_bytes(N), st), "hipMemsetAsync(midas ws)")) return rc;
     MidasHead* head = (MidasHead*)ws;
     MidasImg* img = (MidasImg*)(head + 1);
@@ -660,36 +813,105 @@ extern "C" int mde_midas_fwd(const float* pred, const float* target, int N, int 
     }
     midas_fit_k<<<(N + 63) / 64, 64, 0, st>>>(img, N, ssi);
     if (data_kind)
-        midas_terms_k<1><<<N * bpi, NT, 0, st>>>(pred, target, H, W, scales, bpi, img);
+        midas_terms_k<1><<<N * bpi, NT, 0, st>>>(pred, target, msk, H, W, scales, bpi, img);
     else
-        midas_terms_k<0><<<N * bpi, NT, 0, st>>>(pred, target, H, W, scales, bpi, img);
+        midas_terms_k<0><<<N * bpi, NT, 0, st>>>(pred, target, msk, H, W, scales, bpi, img);
     MDE_LAUNCH_CHECK("midas_terms_k");
     midas_loss_k<<<1, 1, 0, st>>>(head, img, N, data_weight, alpha, scales, batch_based, loss);
     MDE_LAUNCH_CHECK("midas_loss_k");
     return MDE_OK;
 }
 
-extern "C" int mde_midas_bwd(const float* pred, const float* target, int N, int H, int W, int ssi, int data_kind, int scales,
-                             void* ws, const float* gscale, float* grad, void* stream) {
-    if (int rc = midas_check("mde_midas_bwd", pred, target, N, H, W, data_kind, scales, ws)) return rc;
-    MDE_REQUIRE(grad, "mde_midas_bwd: null grad");
-    hipStream_t st = (hipStream_t)stream;
+int midas_bwd_impl(const float* pred, const float* target, const float* msk, int N, int H, int W, int ssi, int data_kind,
+                   int scales, void* ws, const float* gscale, float* grad, hipStream_t st) {
     MidasHead* head = (MidasHead*)ws;
     MidasImg* img = (MidasImg*)(head + 1);
     const int64_t hw = (int64_t)H * W;
     const int bpi = midas_bpi(N, hw);
     if (ssi) {
         if (data_kind)
-            midas_gsum_k<1><<<N * bpi, NT, 0, st>>>(pred, target, H, W, scales, bpi, head, img);
+            midas_gsum_k<1><<<N * bpi, NT, 0, st>>>(pred, target, msk, H, W, scales, bpi, head, img);
         else
-            midas_gsum_k<0><<<N * bpi, NT, 0, st>>>(pred, target, H, W, scales, bpi, head, img);
+            midas_gsum_k<0><<<N * bpi, NT, 0, st>>>(pred, target, msk, H, W, scales, bpi, head, img);
         MDE_LAUNCH_CHECK("midas_gsum_k");
     }
     if (data_kind)
-        midas_bwd_k<1><<<grid_for(hw * N), NT, 0, st>>>(pred, target, N, H, W, scales, ssi, head, img, gscale, grad);
+        midas_bwd_k<1><<<grid_for(hw * N), NT, 0, st>>>(pred, target, msk, N, H, W, scales, ssi, head, img, gscale, grad);
     else
-        midas_bwd_k<0><<<grid_for(hw * N), NT, 0, st>>>(pred, target, N, H, W, scales, ssi, head, img, gscale, grad);
+        midas_bwd_k<0><<<grid_for(hw * N), NT, 0, st>>>(pred, target, msk, N, H, W, scales, ssi, head, img, gscale, grad);
     MDE_LAUNCH_CHECK("midas_bwd_k");
+    return MDE_OK;
+}
+
+// robust normalisation of x (mask source msk) into out; fills img
+int robust_normalize(const float* x, const float* msk, int N, int H, int W, RobustImg* img, float* out, hipStream_t st) {
+    const int64_t hw = (int64_t)H * W;
+    const int bpi = midas_bpi(N, hw);
+    robust_init_k<<<(N + 63) / 64, 64, 0, st>>>(img, N, (unsigned int)((hw - 1) / 2));
+    for (int pass = 0; pass < 4; ++pass) {
+        robust_hist_k<<<N * bpi, NT, 0, st>>>(x, msk, hw, bpi, pass, img);
+        MDE_LAUNCH_CHECK("robust_hist_k");
+        robust_select_k<<<(N + 63) / 64, 64, 0, st>>>(img, N, pass);
+    }
+    robust_stats_k<<<N * bpi, NT, 0, st>>>(x, msk, hw, bpi, img);
+    MDE_LAUNCH_CHECK("robust_stats_k");
+    robust_scale_k<<<(N + 63) / 64, 64, 0, st>>>(img, N);
+    robust_apply_k<<<grid_for(hw * N), NT, 0, st>>>(x, hw, hw * N, img, out);
+    MDE_LAUNCH_CHECK("robust_apply_k");
+    return MDE_OK;
+}
+}  // namespace
+
+extern "C" int mde_midas_fwd(const float* pred, const float* target, int N, int H, int W, int ssi, int data_kind,
+                             float data_weight, float alpha, int scales, int batch_based, void* ws, float* loss, void* stream) {
+    if (int rc = midas_check("mde_midas_fwd", pred, target, N, H, W, data_kind, scales, ws)) return rc;
+    MDE_REQUIRE(loss, "mde_midas_fwd: null loss");
+    return midas_fwd_impl(pred, target, target, N, H, W, ssi, data_kind, data_weight, alpha, scales, batch_based, ws, loss,
+                          (hipStream_t)stream);
+}
+
+extern "C" int mde_midas_bwd(const float* pred, const float* target, int N, int H, int W, int ssi, int data_kind, int scales,
+                             void* ws, const float* gscale, float* grad, void* stream) {
+    if (int rc = midas_check("mde_midas_bwd", pred, target, N, H, W, data_kind, scales, ws)) return rc;
+    MDE_REQUIRE(grad, "mde_midas_bwd: null grad");
+    return midas_bwd_impl(pred, target, target, N, H, W, ssi, data_kind, scales, ws, gscale, grad, (hipStream_t)stream);
+}
+
+// TrimmedProcrustesLoss (criteria.py:335-363): both maps robustly normalised, then the (never trimming) trimmed MAE
+// + alpha * multi-scale gradient loss, every mask = target > 0 of the ORIGINAL target.
+// ws layout: [midas ws][RobustImg pred x N][RobustImg target x N]
+extern "C" size_t mde_procrustes_ws_bytes(int N) {
+    return ((mde_midas_ws_bytes(N) + 15) / 16) * 16 + 2 * (size_t)(N > 0 ? N : 0) * sizeof(RobustImg);
+}
+
+extern "C" int mde_procrustes_fwd(const float* pred, const float* target, int N, int H, int W, float alpha, int scales,
+                                  int batch_based, void* ws, float* pred_n, float* target_n, float* loss, void* stream) {
+    if (int rc = midas_check("mde_procrustes_fwd", pred, target, N, H, W, 1, scales, ws)) return rc;
+    MDE_REQUIRE(pred_n && target_n && loss, "mde_procrustes_fwd: null argument");
+    hipStream_t st = (hipStream_t)stream;
+    RobustImg* rp = (RobustImg*)((char*)ws + ((mde_midas_ws_bytes(N) + 15) / 16) * 16);
+    RobustImg* rt = rp + N;
+    if (int rc = mde_check_hip(hipMemsetAsync(rp, 0, 2 * (size_t)N * sizeof(RobustImg), st), "hipMemsetAsync(procrustes ws)")) return rc;
+    if (int rc = robust_normalize(pred, target, N, H, W, rp, pred_n, st)) return rc;
+    if (int rc = robust_normalize(target, target, N, H, W, rt, target_n, st)) return rc;
+    return midas_fwd_impl(pred_n, target_n, target, N, H, W, 0, 1, 1.f, alpha, scales, batch_based, ws, loss, st);
+}
+
+// grad = d loss / d pred; gtmp: scratch N*H*W floats (d loss / d pred_n)
+extern "C" int mde_procrustes_bwd(const float* pred, const float* target, int N, int H, int W, int scales, void* ws,
+                                  const float* pred_n, const float* target_n, const float* gscale, float* gtmp, float* grad,
+                                  void* stream) {
+    if (int rc = midas_check("mde_procrustes_bwd", pred, target, N, H, W, 1, scales, ws)) return rc;
+    MDE_REQUIRE(pred_n && target_n && gtmp && grad, "mde_procrustes_bwd: null argument");
+    hipStream_t st = (hipStream_t)stream;
+    RobustImg* rp = (RobustImg*)((char*)ws + ((mde_midas_ws_bytes(N) + 15) / 16) * 16);
+    if (int rc = midas_bwd_impl(pred_n, target_n, target, N, H, W, 0, 1, scales, ws, nullptr, gtmp, st)) return rc;
+    const int64_t hw = (int64_t)H * W;
+    const int bpi = midas_bpi(N, hw);
+    robust_bwd_sums_k<<<N * bpi, NT, 0, st>>>(gtmp, pred_n, hw, bpi, rp);
+    MDE_LAUNCH_CHECK("robust_bwd_sums_k");
+    robust_bwd_k<<<grid_for(hw * N), NT, 0, st>>>(gtmp, pred, target, hw, hw * N, rp, gscale, grad);
+    MDE_LAUNCH_CHECK("robust_bwd_k");
     return MDE_OK;
 }
 

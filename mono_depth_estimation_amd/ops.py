@@ -381,6 +381,20 @@ def midas_bwd(pred, target, N, H, W, ssi, data_kind, scales, ws, gscale, grad):
                                     _stream()), "mde_midas_bwd")
 
 
+def procrustes_ws(N, device="cuda"):
+    return torch.zeros((_lib.load().mde_procrustes_ws_bytes(N) + 7) // 8, dtype=torch.float64, device=device)
+
+
+def procrustes_fwd(pred, target, N, H, W, alpha, scales, batch_based, ws, pred_n, target_n, loss):
+    check(_lib.load().mde_procrustes_fwd(_p(pred), _p(target), N, H, W, alpha, scales, int(batch_based), _p(ws), _p(pred_n),
+                                         _p(target_n), _p(loss), _stream()), "mde_procrustes_fwd")
+
+
+def procrustes_bwd(pred, target, N, H, W, scales, ws, pred_n, target_n, gscale, gtmp, grad):
+    check(_lib.load().mde_procrustes_bwd(_p(pred), _p(target), N, H, W, scales, _p(ws), _p(pred_n), _p(target_n), _p(gscale),
+                                         _p(gtmp), _p(grad), _stream()), "mde_procrustes_bwd")
+
+
 def scale_and_shift(pred, target, N, H, W, ws, scale, shift):
     check(_lib.load().mde_scale_and_shift(_p(pred), _p(target), N, H, W, _p(ws), _p(scale), _p(shift), _stream()),
           "mde_scale_and_shift")

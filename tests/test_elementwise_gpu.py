@@ -313,6 +313,39 @@ def test_midas_loss_large_matches_oracle(loss):
     assert float(err.mean()) <= 2e-5 * scale and float((err > 1e-3 * scale).float().mean()) < 1e-3, (float(err.max()), float(err.mean()), scale)
 
 
+def test_trimmed_procrustes_golden_and_large(golden):
+    """criteria.TrimmedProcrustesLoss (HIP: radix-select median, robust scale, chain rule through both) against the
+    reference's golden value and gradient, then on MiDaS-sized maps against the oracle's autograd."""
+    from mono_depth_estimation_amd import criteria
+    g = golden("losses")
+    pred = torch.from_numpy(g["g2_pred"]).cuda().requires_grad_(True)
+    tgt = torch.from_numpy(g["g2_tgt"]).cuda()
+    crit = criteria.TrimmedProcrustesLoss(alpha=0.5)
+    out = crit(pred, tgt)
+    out.backward()
+    assert np.allclose(out.item(), g["g2_procrustes"], rtol=5e-5), (out.item(), g["g2_procrustes"])
+    ref = g["g2_procrustes_grad"]
+    err = np.abs(pred.grad.cpu().numpy() - ref)
+    assert err.max() <= 2e-3 * np.abs(ref).max() and err.mean() <= 2e-5 * np.abs(ref).max(), (err.max(), err.mean(), np.abs(ref).max())
+    # the normalised prediction the reference exposes as .prediction_ssi
+    p3, t3 = torch.from_numpy(g["g2_pred"]).squeeze(1), torch.from_numpy(g["g2_tgt"]).squeeze(1)
+    pn = OL.normalize_robust(p3, (t3 > 0).float())
+    assert torch.allclose(crit.prediction_ssi.cpu(), pn, rtol=1e-4, atol=1e-5)
+    # large
+    pred = W.uniform(43, "pred", (3, 1, 384, 384), 0.05, 1.0)
+    _, tgt = W.synthetic_batch(43, 3, 384, 384)
+    p = pred.clone().requires_grad_(True)
+    refl = OL.trimmed_procrustes(p, tgt, alpha=0.5)
+    refl.backward()
+    pd = pred.cuda().requires_grad_(True)
+    outl = criteria.TrimmedProcrustesLoss(alpha=0.5)(pd, tgt.cuda())
+    outl.backward()
+    assert np.allclose(outl.item(), refl.item(), rtol=1e-4), (outl.item(), refl.item())
+    err = (pd.grad.cpu() - p.grad).abs()
+    scale = float(p.grad.abs().max())
+    assert float(err.mean()) <= 2e-5 * scale and float((err > 1e-3 * scale).float().mean()) < 1e-3, (float(err.max()), float(err.mean()), scale)
+
+
 def test_metrics_golden(golden):
     from mono_depth_estimation_amd import ops
     g = golden("metrics")
