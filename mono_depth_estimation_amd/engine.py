@@ -272,12 +272,19 @@ class ParamStore:
             self._pack_jobs = None
         return c
 
+    def params_version(self):
+        """Changes whenever torch modified a Parameter in place (optimizer.step, load_state_dict, p.data.copy_ ...).
+        The Parameters are views of the flat buffer P, but an in-place op on such a view bumps the PARAMETER's
+        version counter, not P's (``p.data = view`` keeps the parameter's own counter): P._version never moves."""
+        return sum(p._version for p in self.params) + self.P._version
+
     def refresh_weights(self, force=False):
         """bf16 shadow + transposed packings follow the fp32 masters (after any in-place update)."""
-        if force or self.P._version != self.packed_version:
+        v = self.params_version()
+        if force or v != self.packed_version:
             ops.cast_bf16(self.P, self.Pb)
             self.repack()
-            self.packed_version = self.P._version
+            self.packed_version = v
 
     def repack(self):
         """Transposed ("dgrad") packings of every conv weight that needs one, in a single launch."""
@@ -300,7 +307,7 @@ class ParamStore:
         ops.adam_step(self.P[e:], self.G[e:], mom[e:], var[e:], self.Pb[e:], n - e, lr_decoder, betas[0], betas[1], eps,
                       weight_decay, grad_scale, self.step_count)
         self.repack()
-        self.packed_version = self.P._version   # shadow + packings are current (torch saw no in-place op on P)
+        self.packed_version = self.params_version()   # shadow + packings are current (the kernels bump no version counter)
 
 
 class FCRNEngine:

@@ -313,6 +313,55 @@ def test_checkpoint_bridge_optimizer_state(setup, tmp_path):
     assert torch.equal(other._store.P, hip._store.P)
 
 
+def test_external_weight_updates_reach_the_kernels():
+    """Regression: conv weights changed by torch AFTER the first forward (load_state_dict, torch.optim) must reach
+    the bf16 / transposed copies the kernels read.  (The flat buffer's version counter does not move when a
+    Parameter view is updated in place; the engine has to watch the Parameters' own counters.)"""
+    from mono_depth_estimation_amd import criteria
+    from mono_depth_estimation_amd.network import FCRN
+    size = (64, 96)
+    ora = ofcrn.FCRNOracle(50, size, out_channels=1)
+    W.fcrn_conditioned_state(ora, 21)
+    rgb, tgt = W.synthetic_batch(21, 2, *size)
+    W.calibrate_running_stats(ora, rgb)
+    sd_a = {k: v.clone() for k, v in ora.state_dict().items()}
+    hip = FCRN.ResNet(layers=50, output_size=size, out_channels=1, pretrained=False)
+    hip.load_state_dict(sd_a)
+    hip = hip.cuda().eval()
+    ora.eval()
+    x = rgb.cuda()
+    with torch.no_grad():
+        ya = hip(x).cpu()                                        # first forward: packs state A
+        W.fcrn_conditioned_state(ora, 22)                        # different conv weights, same architecture
+        W.calibrate_running_stats(ora, rgb)
+        ora.eval()
+        hip.load_state_dict(ora.state_dict())
+        yb, ref_b = hip(x).cpu(), ora(rgb)
+    assert (yb - ref_b).abs().max() <= 2e-2 and (yb - ref_b).abs().mean() <= 3e-3, "load_state_dict after a forward was ignored"
+    assert (ya - ref_b).abs().mean() > 5 * (yb - ref_b).abs().mean(), "fixture states too similar to tell"
+    # torch.optim.Adam and the fused step must move the conv weights alike (first Adam steps: ~lr * sign(grad))
+    def run(mode):
+        net = FCRN.ResNet(layers=50, output_size=size, out_channels=1, pretrained=False)
+        net.load_state_dict(sd_a)
+        net = net.cuda().train()
+        opt = (torch.optim.Adam([{"params": net.get_1x_lr_params(), "lr": 1e-4}, {"params": net.get_10x_lr_params(), "lr": 1e-3}], lr=1e-4)
+               if mode == "torch" else None)
+        losses = []
+        for _ in range(3):
+            net.zero_grad(set_to_none=False) if opt is None else opt.zero_grad()
+            loss = criteria.silog_loss(0.85)(net(x), tgt.cuda())
+            loss.backward()
+            opt.step() if opt is not None else net._store.adam_step(1e-4, 1e-3)
+            losses.append(float(loss.detach()))
+        return losses, {n: p.detach().float().cpu() for n, p in net.named_parameters()}
+    lf, pf = run("fused")
+    lt, pt = run("torch")
+    assert abs(lf[-1] - lt[-1]) <= 0.05 * abs(lf[0] - lf[-1]) + 1e-3, (lf, lt)     # same trajectory, not just "decreasing"
+    for n in ("conv2.weight", "upSample.layer4.upper_branch.conv2.weight", "layer2.1.conv2.weight"):
+        moved = (pf[n] - sd_a[n]).abs().mean()
+        assert moved > 0 and (pf[n] - pt[n]).abs().mean() <= 0.2 * moved, (n, float(moved), float((pf[n] - pt[n]).abs().mean()))
+
+
 def test_multichannel_output_and_shape_switching():
     """out_channels > 1 (the reference default is 20), and one module serving two input shapes
     (train batch / validation batch) from the same flat parameter store."""
