@@ -244,16 +244,14 @@ class ParamStore:
         self.params = [p for p in m.parameters()]
 
     def attach_grads(self):
-        """Make every Parameter's .grad the matching view of the flat gradient buffer.
+        """Make the .grad of every Parameter that requires grad the matching view of the flat gradient buffer
+        (frozen parameters keep .grad = None, as under torch autograd; their slice of the buffer is scratch).
         Returns True if the buffer had to be (re)attached and zeroed."""
-        fresh = False
-        for p in self.params:
-            if p.grad is None or p.grad.data_ptr() != p._mde_grad.data_ptr():
-                fresh = True
-                break
+        live = [p for p in self.params if p.requires_grad]
+        fresh = any(p.grad is None or p.grad.data_ptr() != p._mde_grad.data_ptr() for p in live)
         if fresh:
             self.G.zero_()
-            for p in self.params:
+            for p in live:
                 p.grad = p._mde_grad
         return fresh
 

@@ -9,6 +9,7 @@ are parameter containers only: they keep the reference's names so checkpoints lo
 no arithmetic of their own (there is no PyTorch fallback path).
 """
 import collections
+import copy
 import math
 import os
 import warnings
@@ -196,6 +197,23 @@ class ResNet(nn.Module):
         own = self.state_dict()
         own.update({k: v for k, v in sd.items() if k in own and not k.startswith("fc.")})
         self.load_state_dict(own)
+
+    # The flat parameter store and the per-shape launch plans are caches keyed by THIS module's Parameter objects:
+    # a copy / unpickled module starts without them (its Parameters become ordinary tensors with the same values
+    # and channels_last strides) and rebuilds them at its first forward.
+    def __deepcopy__(self, memo):
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            if k not in ("_engines", "_store"):
+                new.__dict__[k] = copy.deepcopy(v, memo)
+        new._engines, new._store = {}, None
+        return new
+
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state["_engines"], state["_store"] = {}, None
+        return state
 
     def _engine(self, x):
         if x.dim() != 4 or x.shape[1] != 3:

@@ -362,6 +362,53 @@ def test_external_weight_updates_reach_the_kernels():
         assert moved > 0 and (pf[n] - pt[n]).abs().mean() <= 0.2 * moved, (n, float(moved), float((pf[n] - pt[n]).abs().mean()))
 
 
+def test_module_surface_behaviours():
+    """What a user of the reference does with the nn.Module besides forward/backward: accumulate gradients over two
+    backward calls, deepcopy / pickle the model (EMA copies, checkpointing), move it cpu <-> cuda, freeze the encoder."""
+    import copy
+    import io
+    import pickle
+    from mono_depth_estimation_amd import criteria
+    from mono_depth_estimation_amd.network import FCRN
+    size = (64, 96)
+    ora = ofcrn.FCRNOracle(50, size, out_channels=1)
+    W.fcrn_conditioned_state(ora, 31)
+    rgb, tgt = W.synthetic_batch(31, 2, *size)
+    W.calibrate_running_stats(ora, rgb)
+    net = FCRN.ResNet(layers=50, output_size=size, out_channels=1, pretrained=False)
+    net.load_state_dict(ora.state_dict())
+    net = net.cuda().train()
+    x, t, crit = rgb.cuda(), tgt.cuda(), criteria.silog_loss(0.85)
+    # gradient accumulation: a second backward adds onto the first
+    net.zero_grad(set_to_none=True)
+    crit(net(x), t).backward()
+    g1 = net.conv2.weight.grad.clone()
+    crit(net(x), t).backward()
+    assert torch.allclose(net.conv2.weight.grad, 2 * g1, rtol=0.2, atol=0.05 * float(g1.abs().max()))
+    # deepcopy and pickle: independent parameters, same function, caches rebuilt lazily
+    ref_y = net(x).detach()
+    for clone in (copy.deepcopy(net), pickle.loads(pickle.dumps(net))):
+        assert clone._store is None and clone._engines == {}
+        assert (clone(x).detach() - ref_y).abs().max() <= 5e-2
+        with torch.no_grad():
+            clone.conv2.weight.add_(1.0)
+        assert not torch.equal(clone.conv2.weight, net.conv2.weight)
+    torch.save(net.state_dict(), io.BytesIO())
+    # device round trip keeps the values and rebuilds the flat store
+    w0 = net.conv2.weight.detach().cpu().clone()
+    net = net.cpu().cuda()
+    assert torch.isfinite(net(x)).all() and torch.equal(net.conv2.weight.detach().cpu(), w0)
+    # frozen encoder: no .grad for frozen parameters (as under torch autograd), decoder still trains
+    for p in net.get_1x_lr_params():
+        p.requires_grad_(False)
+    net.zero_grad(set_to_none=True)
+    crit(net(x), t).backward()
+    assert net.conv1.weight.grad is None and net.layer3[2].conv2.weight.grad is None
+    assert float(net.conv2.weight.grad.abs().sum()) > 0
+    crit(net(x), t).backward()                                 # accumulation must survive the frozen parameters
+    assert float(net.conv2.weight.grad.abs().sum()) > 0
+
+
 def test_multichannel_output_and_shape_switching():
     """out_channels > 1 (the reference default is 20), and one module serving two input shapes
     (train batch / validation batch) from the same flat parameter store."""
