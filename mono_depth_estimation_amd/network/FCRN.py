@@ -198,10 +198,16 @@ class ResNet(nn.Module):
         own.update({k: v for k, v in sd.items() if k in own and not k.startswith("fc.")})
         self.load_state_dict(own)
 
-    # The flat parameter store and the per-shape launch plans are caches keyed by THIS module's Parameter objects:
-    # a copy / unpickled module starts without them (its Parameters become ordinary tensors with the same values
-    # and channels_last strides) and rebuilds them at its first forward.
+    # The flat parameter store and the per-shape launch plans are caches keyed by THIS module's Parameter objects, and
+    # once they exist the Parameters / buffers are VIEWS of a few big flat tensors.  A copy must not drag those along
+    # (copying or pickling a view copies its whole storage): every parameter and buffer is cloned into a standalone
+    # tensor (same values, same channels_last strides) and the copy rebuilds its own caches at its first forward.
     def __deepcopy__(self, memo):
+        with torch.no_grad():
+            for p in self.parameters():
+                memo[id(p)] = nn.Parameter(p.detach().clone(), requires_grad=p.requires_grad)
+            for b in self.buffers():
+                memo[id(b)] = b.detach().clone()
         new = self.__class__.__new__(self.__class__)
         memo[id(self)] = new
         for k, v in self.__dict__.items():
@@ -211,9 +217,11 @@ class ResNet(nn.Module):
         return new
 
     def __getstate__(self):
-        state = dict(self.__dict__)
-        state["_engines"], state["_store"] = {}, None
-        return state
+        if self._store is None:
+            state = dict(self.__dict__)
+            state["_engines"] = {}
+            return state
+        return copy.deepcopy(self).__dict__          # standalone tensors; pickling the views would write the flat buffers per tensor
 
     def _engine(self, x):
         if x.dim() != 4 or x.shape[1] != 3:
