@@ -69,10 +69,11 @@ class Act:
 class BNSite:
     """Per-BatchNorm device state: fp32 views into the flat stores + saved statistics."""
 
-    def __init__(self, eng, C, gamma, beta, dgamma, dbeta, rmean, rvar, bn, eps):
+    def __init__(self, eng, C, gamma, beta, g_off, b_off, rmean, rvar, bn, eps):
         dev = eng.dev
         self.C, self.bn, self.eps = C, bn, eps        # momentum is read from the module at run time
-        self.gamma, self.beta, self.dgamma, self.dbeta, self.rmean, self.rvar = gamma, beta, dgamma, dbeta, rmean, rvar
+        self.store, self.g_off, self.b_off = eng.store, g_off, b_off     # gradient slices: offsets into store.Gcur
+        self.gamma, self.beta, self.rmean, self.rvar = gamma, beta, rmean, rvar
         self.scale, self.shift, self.smean, self.srstd = (torch.empty(C, device=dev) for _ in range(4))
         self.part = ops.new_stat_buffer(C, dev)
         self.coef = torch.empty(3, C, device=dev)
@@ -82,11 +83,20 @@ class BNSite:
         h = self.C // 2
         s = BNSite.__new__(BNSite)
         s.C, s.bn, s.eps = h, self.bn, self.eps
-        for k in ("gamma", "beta", "dgamma", "dbeta", "rmean", "rvar", "scale", "shift", "smean", "srstd"):
+        s.store, s.g_off, s.b_off = self.store, self.g_off + i * h, self.b_off + i * h
+        for k in ("gamma", "beta", "rmean", "rvar", "scale", "shift", "smean", "srstd"):
             setattr(s, k, getattr(self, k)[i * h:(i + 1) * h])
         s.part = ops.new_stat_buffer(h, eng.dev)
         s.coef = torch.empty(3, h, device=eng.dev)
         return s
+
+    @property
+    def dgamma(self):
+        return self.store.Gcur[self.g_off:self.g_off + self.C]
+
+    @property
+    def dbeta(self):
+        return self.store.Gcur[self.b_off:self.b_off + self.C]
 
     def finalize(self, M, train):
         if train:
@@ -135,11 +145,14 @@ class Conv:
     def __init__(self, store, off, O, T, I, need_dgrad=True):
         n = O * T * I
         self.O, self.T, self.I = O, T, I
+        self.store, self.off, self.n = store, off, n
         self.w32 = store.P[off:off + n]
         self.wf = store.Pb[off:off + n]
-        self.dw = store.G[off:off + n]
-        self.off = off
         self.wd = store.WD[off:off + n] if need_dgrad else None    # slice of the flat transposed-weight buffer
+
+    @property
+    def dw(self):                         # gradient slice of the buffer the current backward accumulates into
+        return self.store.Gcur[self.off:self.off + self.n]
 
 
 class ParamStore:
@@ -200,6 +213,8 @@ class ParamStore:
             size = _round_up(size + sum(t.numel() for t in ts))
         self.P = torch.zeros(size, dtype=torch.float32, device=dev)
         self.G = torch.zeros(size, dtype=torch.float32, device=dev)
+        self.G2 = None                    # second gradient buffer, only for the autograd path (see begin_autograd_backward)
+        self.Gcur = self.G                # where the engine's backward accumulates parameter gradients
         self.Pb = torch.zeros(size, dtype=torch.bfloat16, device=dev)
         self.WD = torch.zeros(size, dtype=torch.bfloat16, device=dev)     # transposed conv weights, same offsets as P
         self._pack_jobs = None
@@ -255,6 +270,44 @@ class ParamStore:
                 p.grad = p._mde_grad
         return fresh
 
+    # ---- gradients handed to torch autograd (module path).  The engine's direct path (bench.py, eng.backward)
+    # accumulates into self.G and that is all.  Through autograd the Function must RETURN gradient tensors, otherwise
+    # nothing flows through AccumulateGrad and wrappers that hook it (DistributedDataParallel) never see gradients.
+    def _in(self, t, buf):
+        return buf is not None and buf.data_ptr() <= t.data_ptr() < buf.data_ptr() + buf.numel() * 4
+
+    def grad_buffer(self):
+        """The flat buffer the Parameters' .grad tensors live in (G unless autograd adopted views of G2)."""
+        for p in self.params:
+            if p.requires_grad and p.grad is not None:
+                return self.G2 if self._in(p.grad, self.G2) else self.G
+        return self.G
+
+    def begin_autograd_backward(self):
+        """Pick and zero the buffer this backward writes: the one that does NOT hold the live .grad tensors, so that
+        autograd can add the returned views onto them (accumulation) or adopt them without a copy (.grad is None)."""
+        held = None
+        for p in self.params:
+            if p.requires_grad and p.grad is not None:
+                held = p.grad
+                break
+        target = self.G
+        if held is not None and self._in(held, self.G):
+            if self.G2 is None:
+                self.G2 = torch.zeros_like(self.G)
+            target = self.G2
+        target.zero_()
+        self.Gcur = target
+        return target
+
+    def grad_view(self, p, buf):
+        """A FRESH tensor (nobody else references it: autograd may adopt it as .grad) viewing p's slice of buf."""
+        off, n = self.p_off[id(p)], p.numel()
+        if p.dim() == 4:
+            O, I, kh, kw = p.shape
+            return buf[off:off + n].view(O, kh, kw, I).permute(0, 3, 1, 2)
+        return buf[off:off + n].view(p.shape)
+
     def storage_is_current(self):
         p = self.m.conv1.weight
         return p.data_ptr() == self.P.data_ptr() + self.p_off[id(p)] * 4
@@ -300,9 +353,10 @@ class ParamStore:
         mom, var = self.adam_state
         self.step_count += 1
         e, n = self.encoder_numel, self.P.numel()
-        ops.adam_step(self.P, self.G, mom, var, self.Pb, e, lr_encoder, betas[0], betas[1], eps, weight_decay, grad_scale,
+        G = self.grad_buffer()
+        ops.adam_step(self.P, G, mom, var, self.Pb, e, lr_encoder, betas[0], betas[1], eps, weight_decay, grad_scale,
                       self.step_count)
-        ops.adam_step(self.P[e:], self.G[e:], mom[e:], var[e:], self.Pb[e:], n - e, lr_decoder, betas[0], betas[1], eps,
+        ops.adam_step(self.P[e:], G[e:], mom[e:], var[e:], self.Pb[e:], n - e, lr_decoder, betas[0], betas[1], eps,
                       weight_decay, grad_scale, self.step_count)
         self.repack()
         self.packed_version = self.params_version()   # shadow + packings are current (the kernels bump no version counter)
@@ -339,7 +393,7 @@ class FCRNEngine:
         C = sum(b.num_features for b in bns)
         po, pb = self.p_off[id(g0)], self.p_off[id(b0)]
         bo, bv = self.b_off[id(rm0)], self.b_off[id(rv0)]
-        return BNSite(self, C, self.P[po:po + C], self.P[pb:pb + C], self.G[po:po + C], self.G[pb:pb + C],
+        return BNSite(self, C, self.P[po:po + C], self.P[pb:pb + C], po, pb,
                       self.B[bo:bo + C], self.B[bv:bv + C], bns[0], bns[0].eps)
 
     def _ksplit(self, pixels, rows, cols, ntaps):

@@ -127,8 +127,10 @@ def choose_decoder(decoder, in_channels):
 
 class _FCRNFunction(torch.autograd.Function):
     """One autograd node for the whole network: forward/backward are the engine's plans.
-    Parameter gradients are accumulated straight into the flat gradient buffer that every
-    Parameter's .grad views, so backward hands autograd no tensors to copy."""
+    backward RETURNS the parameter gradients — fresh views of a flat gradient buffer, so autograd adopts them as
+    .grad without a copy when .grad is None (optimizer.zero_grad()), or adds them onto an existing .grad that lives
+    in the other flat buffer (gradient accumulation).  Returning None and writing .grad behind autograd's back would
+    bypass AccumulateGrad: DistributedDataParallel (what Lightning wraps the model in) then never reduces anything."""
 
     @staticmethod
     def forward(ctx, x, engine, train, *params):
@@ -139,9 +141,14 @@ class _FCRNFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         eng = ctx.engine
-        eng.attach_grads()
-        eng.backward(dy.contiguous())
-        return (None, None, None) + (None,) * len(eng.params)
+        st = eng.store
+        buf = st.begin_autograd_backward()
+        try:
+            eng.backward(dy.contiguous())
+        finally:
+            st.Gcur = st.G                       # the direct (non-autograd) path always accumulates into G
+        grads = tuple(st.grad_view(p, buf) if need else None for p, need in zip(eng.params, ctx.needs_input_grad[3:]))
+        return (None, None, None) + grads
 
 
 class ResNet(nn.Module):
@@ -222,6 +229,20 @@ class ResNet(nn.Module):
             state["_engines"] = {}
             return state
         return copy.deepcopy(self).__dict__          # standalone tensors; pickling the views would write the flat buffers per tensor
+
+    def _apply(self, fn, *args, **kwargs):
+        """.cuda() / .to(device) / .float(): after the move, build the flat parameter store right away when the
+        parameters sit on a GPU.  Wrappers that record parameter layouts at construction (DistributedDataParallel
+        lays out its gradient buckets with the parameters' strides) must see the final channels_last views, not
+        the contiguous tensors they replace at the first forward: with mismatched layouts DDP reduced the k>1 conv
+        gradients wrongly."""
+        out = super()._apply(fn, *args, **kwargs)
+        if getattr(self, "_engines", None) is not None:           # fully constructed
+            dev = self.conv1.weight.device
+            self._engines, self._store = {}, None
+            if dev.type == "cuda":
+                self._store = ParamStore(self, dev)
+        return out
 
     def _engine(self, x):
         if x.dim() != 4 or x.shape[1] != 3:

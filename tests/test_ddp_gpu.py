@@ -1,0 +1,67 @@
+"""The drop-in module inside torch.nn.parallel.DistributedDataParallel (what Lightning's Trainer(gpus=N) wraps the
+reference's model in, train.py:132-145): the gradients DDP leaves in .grad must be the average over ranks.
+
+Two ranks share the one GPU of the test box and talk over gloo (RCCL refuses two ranks on one device); each rank
+feeds different data.  Regression for two defects: (1) the engine used to write .grad itself and return None to
+autograd, so DDP's AccumulateGrad hooks never saw a gradient; (2) DDP lays out its buckets with the parameters'
+strides at construction, so the flat channels_last store must exist before the wrap (it is built on .cuda())."""
+import os
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import fcrn as ofcrn
+from oracle import weights as W
+
+pytestmark = pytest.mark.gpu
+
+SIZE = (64, 96)
+
+
+def _fresh(rank, state):
+    from mono_depth_estimation_amd import criteria
+    from mono_depth_estimation_amd.network import FCRN
+    torch.manual_seed(100 + rank)
+    x = torch.rand(2, 3, *SIZE, device="cuda")
+    t = torch.rand(2, 1, *SIZE, device="cuda") * 0.9 + 0.05
+    net = FCRN.ResNet(layers=50, output_size=SIZE, out_channels=1, pretrained=False)
+    net.load_state_dict(state)
+    return net.cuda().train(), x, t, criteria.silog_loss(0.85)
+
+
+def _worker(rank, world, path, port, out):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    state = torch.load(path)
+    net, x, t, crit = _fresh(rank, state)                      # each rank's own gradient, averaged by hand
+    crit(net(x), t).backward()
+    mine = {n: p.grad.detach().clone() for n, p in net.named_parameters()}
+    want = {}
+    for n, g in mine.items():
+        gg = g.contiguous().clone()
+        dist.all_reduce(gg)
+        want[n] = gg / world
+    net2, x, t, crit = _fresh(rank, state)                     # the same through DistributedDataParallel
+    ddp = torch.nn.parallel.DistributedDataParallel(net2, device_ids=[0])
+    crit(ddp(x), t).backward()
+    rel = sorted(float((p.grad - want[n]).abs().max() / (want[n].abs().max() + 1e-20)) for n, p in net2.named_parameters())
+    loc = sorted(float((mine[n] - want[n]).abs().max() / (want[n].abs().max() + 1e-20)) for n in mine)
+    crit(ddp(x), t).backward()                                  # a second iteration must not trip DDP's bookkeeping
+    if rank == 0:
+        torch.save({"worst": rel[-1], "median": rel[len(rel) // 2], "local_median": loc[len(loc) // 2]}, out)
+    dist.destroy_process_group()
+
+
+def test_ddp_averages_gradients(tmp_path):
+    ora = ofcrn.FCRNOracle(50, SIZE, out_channels=1)
+    W.fcrn_conditioned_state(ora, 51)
+    path, out = str(tmp_path / "state.pt"), str(tmp_path / "out.pt")
+    torch.save(ora.state_dict(), path)
+    mp.spawn(_worker, args=(2, path, 29571, out), nprocs=2, join=True)
+    r = torch.load(out)
+    print(r)
+    assert r["local_median"] > 0.3, "ranks' gradients too similar for the test to mean anything"
+    assert r["worst"] < 5e-2 and r["median"] < 2e-2, r       # bf16 run-to-run noise, not un-averaged gradients
