@@ -22,6 +22,7 @@ from . import ops
 class _SilogFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, est, gt, variance_focus):
+        ctx.in_dtype = est.dtype
         est = est.contiguous().float()
         gt = gt.contiguous().float()
         ws = ops.silog_ws(est.device)
@@ -36,7 +37,7 @@ class _SilogFunction(torch.autograd.Function):
         est, gt, ws = ctx.saved_tensors
         grad = torch.empty_like(est)
         ops.silog_bwd(est, gt, ctx.variance_focus, ws, gout.contiguous().float().reshape(1), grad)
-        return grad, None, None
+        return grad.to(ctx.in_dtype), None, None
 
 
 class silog_loss(nn.Module):
@@ -58,6 +59,7 @@ def _need_gpu(t, name):
 class _MaskedFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pred, target, kind):
+        ctx.in_dtype = pred.dtype
         pred, target = pred.contiguous().float(), target.contiguous().float()
         ws = ops.masked_loss_ws(pred.device)
         loss = torch.empty(1, device=pred.device)
@@ -71,7 +73,7 @@ class _MaskedFunction(torch.autograd.Function):
         pred, target, ws = ctx.saved_tensors
         grad = torch.empty_like(pred)
         ops.masked_loss_bwd(ctx.kind, pred, target, ws, gout.contiguous().float().reshape(1), grad)
-        return grad, None, None
+        return grad.to(ctx.in_dtype), None, None
 
 
 class _MaskedLoss(nn.Module):
@@ -102,6 +104,7 @@ class berHuLoss(_MaskedLoss):
 class _MaskedDepthFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pred, target):
+        ctx.in_dtype = pred.dtype
         pred, target = pred.contiguous().float(), target.contiguous().float()
         N, H, W = pred.shape[0], pred.shape[-2], pred.shape[-1]
         ws = ops.masked_depth_ws(N, pred.device)
@@ -116,7 +119,7 @@ class _MaskedDepthFunction(torch.autograd.Function):
         grad = torch.empty_like(pred)
         ops.masked_depth_bwd(pred, target, pred.shape[0], pred.shape[-2], pred.shape[-1], ws,
                              gout.contiguous().float().reshape(1), grad)
-        return grad, None
+        return grad.to(ctx.in_dtype), None
 
 
 class MaskedDepthLoss(nn.Module):
@@ -163,6 +166,7 @@ def compute_scale_and_shift(prediction, target, mask=None):
 class _MidasFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, prediction, target, ssi, data_kind, data_weight, alpha, scales, batch_based):
+        ctx.in_dtype = prediction.dtype
         p, t = _squeeze_pair(prediction, target)
         N, H, W = p.shape
         ws = ops.midas_ws(N, p.device)
@@ -179,7 +183,7 @@ class _MidasFunction(torch.autograd.Function):
         grad = torch.empty_like(p)
         ops.midas_bwd(p, t, p.shape[0], p.shape[1], p.shape[2], ssi, data_kind, scales, ws,
                       gout.contiguous().float().reshape(1), grad)
-        return grad.reshape(shape), None, None, None, None, None, None, None
+        return grad.reshape(shape).to(ctx.in_dtype), None, None, None, None, None, None, None
 
 
 class GradientLoss(nn.Module):
@@ -226,6 +230,7 @@ class MidasLoss(nn.Module):
 class _ProcrustesFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, prediction, target, alpha, scales, batch_based):
+        ctx.in_dtype = prediction.dtype
         p, t = _squeeze_pair(prediction, target)
         N, H, W = p.shape
         ws = ops.procrustes_ws(N, p.device)
@@ -242,7 +247,7 @@ class _ProcrustesFunction(torch.autograd.Function):
         gtmp, grad = torch.empty_like(p), torch.empty_like(p)
         ops.procrustes_bwd(p, t, p.shape[0], p.shape[1], p.shape[2], scales, ws, pn, tn,
                            gout.contiguous().float().reshape(1), gtmp, grad)
-        return grad.reshape(shape), None, None, None, None
+        return grad.reshape(shape).to(ctx.in_dtype), None, None, None, None
 
 
 class TrimmedProcrustesLoss(nn.Module):

@@ -260,6 +260,18 @@ def test_masked_losses_edge_cases():
     assert torch.isnan(criteria.MaskedL1Loss()(pred.detach().reshape(2, 1, 5, 7)[:, :, :4, :4].contiguous(), empty))
     with pytest.raises(RuntimeError):
         criteria.berHuLoss()(torch.ones(1, 1, 2, 2), torch.ones(1, 1, 2, 2))           # CPU tensors: no fallback
+    # half / bf16 / non-contiguous predictions (AMP users, channel slices as in base_module.py:156): gradient comes
+    # back in the prediction's dtype and layout
+    base = W.uniform(32, "p16", (2, 3, 6, 8), 0.1, 1.0).cuda()
+    tg = W.uniform(32, "t16", (2, 1, 6, 8), 0.1, 1.0).cuda()
+    for mk in (lambda: criteria.silog_loss(0.85), criteria.MaskedL1Loss, criteria.MaskedDepthLoss, criteria.MidasLoss,
+               criteria.TrimmedProcrustesLoss):
+        for dt in (torch.float16, torch.bfloat16, torch.float32):
+            p = base.detach().to(dt).clone().requires_grad_(True)
+            loss = mk()(p[:, 1:2], tg)                                                     # a non-contiguous channel slice
+            loss.backward()
+            assert p.grad.dtype == dt and torch.isfinite(p.grad.float()).all()
+            assert float(p.grad[:, 0].abs().sum()) == 0 and float(p.grad[:, 1].abs().sum()) > 0
 
 
 @pytest.mark.parametrize("loss", ["mse", "l1", "trim", "ssimse", "ssil1", "ssitrim"])
