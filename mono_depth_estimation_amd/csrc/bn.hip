@@ -14,6 +14,13 @@ namespace {
 
 constexpr int NT = 256;
 constexpr int MAXC = 2048;
+// Rows are walked back to front: the producers before a BN pass (conv epilogues, the previous BN pass) write front
+// to back, and the layer-1-sized tensors (315 MB) exceed the 256 MB Infinity Cache, so the END of the tensor is what
+// is still cached when the consumer starts; the next consumer in turn finds this pass's last-written rows at the
+// front.  Measured in-network: 32.26 -> 32.16 ms/step.
+#ifndef MDE_BN_SNAKE
+#define MDE_BN_SNAKE 1
+#endif
 #ifndef MDE_BN_RED_ROWS
 #define MDE_BN_RED_ROWS 32
 #endif
@@ -57,7 +64,8 @@ __global__ __launch_bounds__(NT) void bn_stats_k(const bf16_t* __restrict__ x, i
     float s1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_blk;
     const int64_t r1 = min(M, r0 + rows_per_blk);
-    for (int64_t r = r0 + rl; r < r1; r += rpb) {
+    for (int64_t r_ = r0 + rl; r_ < r1; r_ += rpb) {
+        const int64_t r = MDE_BN_SNAKE ? M - 1 - r_ : r_;
         float v[8];
         ld8(x + r * ld + col * 8, v);
 #pragma unroll
@@ -119,7 +127,8 @@ __global__ __launch_bounds__(NT) void bn_apply_k(const bf16_t* __restrict__ x, i
         ldf8(rscale + col * 8, rsc);
         ldf8(rshift + col * 8, rsh);
     }
-    for (int64_t row = (int64_t)blockIdx.x * rpb + rl; row < M; row += (int64_t)gridDim.x * rpb) {
+    for (int64_t row_ = (int64_t)blockIdx.x * rpb + rl; row_ < M; row_ += (int64_t)gridDim.x * rpb) {
+        const int64_t row = MDE_BN_SNAKE ? M - 1 - row_ : row_;
         float v[8], q[8];
         ld8(x + row * ldx + col * 8, v);
         if (RES) ld8(r + row * ldr + col * 8, q);
@@ -161,7 +170,8 @@ __global__ __launch_bounds__(NT) void bn_bwd_reduce_k(const bf16_t* __restrict__
     float s1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_blk;
     const int64_t r1 = min(M, r0 + rows_per_blk);
-    for (int64_t r = r0 + rl; r < r1; r += rpb) {
+    for (int64_t r_ = r0 + rl; r_ < r1; r_ += rpb) {
+        const int64_t r = MDE_BN_SNAKE ? M - 1 - r_ : r_;
         float g[8], v[8], o[8];
         ld8(dout + r * ldd + col * 8, g);
         ld8(x + r * ldx + col * 8, v);
@@ -219,7 +229,8 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_k(const bf16_t* __restrict__ 
     ldf8(coef + col * 8, c0);
     ldf8(coef + C + col * 8, c1);
     ldf8(coef + 2 * C + col * 8, c2);
-    for (int64_t row = (int64_t)blockIdx.x * rpb + rl; row < M; row += (int64_t)gridDim.x * rpb) {
+    for (int64_t row_ = (int64_t)blockIdx.x * rpb + rl; row_ < M; row_ += (int64_t)gridDim.x * rpb) {
+        const int64_t row = MDE_BN_SNAKE ? M - 1 - row_ : row_;
         float g[8], v[8], o[8], d[8];
         ld8(dout + row * ldd + col * 8, g);
         ld8(x + row * ldx + col * 8, v);
@@ -259,7 +270,8 @@ __global__ __launch_bounds__(NT) void bn_bwd_reduce2_k(const bf16_t* __restrict_
     float s1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sa[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sb[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_blk;
     const int64_t r1 = min(M, r0 + rows_per_blk);
-    for (int64_t r = r0 + rl; r < r1; r += rpb) {
+    for (int64_t r_ = r0 + rl; r_ < r1; r_ += rpb) {
+        const int64_t r = MDE_BN_SNAKE ? M - 1 - r_ : r_;
         float g[8], va[8], vb[8];
         ld8(dout + r * ldd + col * 8, g);
         ld8(xa + r * ldxa + col * 8, va);
@@ -312,7 +324,8 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply2_k(const bf16_t* __restrict__
     ldf8(coef_b + col * 8, b0);
     ldf8(coef_b + C + col * 8, b1);
     ldf8(coef_b + 2 * C + col * 8, b2);
-    for (int64_t row = (int64_t)blockIdx.x * rpb + rl; row < M; row += (int64_t)gridDim.x * rpb) {
+    for (int64_t row_ = (int64_t)blockIdx.x * rpb + rl; row_ < M; row_ += (int64_t)gridDim.x * rpb) {
+        const int64_t row = MDE_BN_SNAKE ? M - 1 - row_ : row_;
         float g[8], va[8], vb[8], da[8], db[8];
         ld8(dout + row * ldd + col * 8, g);
         ld8(xa + row * ldxa + col * 8, va);
