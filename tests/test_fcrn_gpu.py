@@ -437,6 +437,34 @@ def test_multichannel_output_and_shape_switching():
     assert float(hip.conv3.weight.grad[2].abs().sum()) > 0 and float(hip.conv3.weight.grad[0].abs().sum()) == 0
 
 
+@pytest.mark.parametrize("size", [(228, 304), (100, 140)])
+def test_sizes_not_divisible_by_32(size):
+    """The reference's native NYU resolution (228 x 304, its default output_size) and another size whose feature
+    maps are odd at several levels (114 -> 57 -> 29 -> 15 -> 8): conv / pool / up-projection edge handling end to
+    end.  Eval output vs the fp32 oracle within bf16 noise; train-mode SILog equal to the oracle's."""
+    from mono_depth_estimation_amd import criteria
+    from mono_depth_estimation_amd.network import FCRN
+    ora = ofcrn.FCRNOracle(50, size, out_channels=1)
+    W.fcrn_conditioned_state(ora, 61)
+    rgb, tgt = W.synthetic_batch(61, 2, *size)
+    W.calibrate_running_stats(ora, rgb)
+    net = FCRN.ResNet(layers=50, output_size=size, out_channels=1, pretrained=False)
+    net.load_state_dict(ora.state_dict())
+    net = net.cuda().eval()
+    ora.eval()
+    with torch.no_grad():
+        d = (net(rgb.cuda()).cpu() - ora(rgb)).abs()
+    assert d.max() <= 2e-2 and d.mean() <= 3e-3, (float(d.max()), float(d.mean()))
+    net.train()
+    ora.train()
+    loss = criteria.silog_loss(0.85)(net(rgb.cuda()), tgt.cuda())
+    loss.backward()
+    with torch.no_grad():
+        ref = OL.silog(ora(rgb), tgt, 0.85)
+    assert abs(float(loss.detach()) - float(ref)) <= 1e-3 * abs(float(ref)), (float(loss.detach()), float(ref))
+    assert all(torch.isfinite(p.grad).all() for p in net.parameters())
+
+
 def test_resnet101_trunk_conditioned_eval_and_train_step():
     """The reference's `layers=` argument (FCRN.py:297-323): the engine plans ResNet-101 (blocks [3,4,23,3]) from
     the same building blocks.  Conditioned weights (as in the AbsRel parity fixture) so that eval outputs are
