@@ -174,3 +174,106 @@ def trimmed_procrustes(pred, target, alpha=0.5, scales=4, batch_based=True):
     if alpha > 0:
         total = total + alpha * gradient_multiscale(p, t, mask, scales, batch_based)
     return total
+
+
+# ---------------------------------------------------------------- B8  criteria.py:839-863
+def wcel(pred_logit, gt_bins, gt, weight):
+    """Weighted cross-entropy over depth bins.  `weight` is the [C][C] matrix AFTER the
+    row normalisation the reference's constructor applies (criteria.py:846-848); a bin
+    label outside [0, C) selects an all-zero row (the one-hot comparison matches nothing),
+    and the divisor counts gt > 0 over the depth map, not the labels."""
+    C = pred_logit.shape[1]
+    logp = torch.log_softmax(pred_logit, 1).permute(0, 2, 3, 1).reshape(-1, C)
+    b = gt_bins.reshape(-1).to(torch.int64)
+    inside = (b >= 0) & (b < C)
+    rows = weight.to(torch.float32)[b.clamp(0, C - 1)] * inside.unsqueeze(1)
+    return -(rows * logp).sum() / (gt > 0).sum().to(torch.float32)
+
+
+def wcel_weight(C):
+    """modules/vnl.py:162 followed by criteria.py:846-847 (float64 on the host, like numpy)."""
+    import numpy as np
+    i = np.arange(C, dtype=np.float64)
+    w = np.exp(-0.2 * (i[None, :] - i[:, None]) ** 2)
+    return torch.from_numpy(w / w.sum(1, keepdims=True))
+
+
+# ---------------------------------------------------------------- B7  criteria.py:866-1045
+def vnl_back_project(depth, fx, fy):
+    """criteria.py:877-910: principal point = size // 2, x = (u - u0) * |d| / fx, z = d.
+    depth [B,1,H,W] -> points [B,H,W,3]."""
+    _, _, H, W = depth.shape
+    u = (torch.arange(W, dtype=torch.float32) - float(W // 2)).view(1, 1, 1, W)
+    v = (torch.arange(H, dtype=torch.float32) - float(H // 2)).view(1, 1, H, 1)
+    x = u * depth.abs() / torch.tensor([fx], dtype=torch.float32)
+    y = v * depth.abs() / torch.tensor([fy], dtype=torch.float32)
+    return torch.cat([x, y, depth], 1).permute(0, 2, 3, 1)
+
+
+def vnl_groups(pw, p123, W):
+    """criteria.py:934-953: [B, n, 3 (xyz), 3 (point)] from three linear pixel index arrays."""
+    pts = [pw[:, torch.as_tensor(p // W), torch.as_tensor(p % W), :] for p in p123]
+    return torch.stack(pts, 3)
+
+
+def vnl_filter(groups_gt, delta_cos=0.867, delta_diff=0.005, delta_z=0.0001):
+    """criteria.py:955-988 with the thresholds select_points_groups actually passes
+    (0.867 / 0.005, :996-1000 — the constructor's 0.01s are never used)."""
+    d12 = groups_gt[..., 1] - groups_gt[..., 0]
+    d13 = groups_gt[..., 2] - groups_gt[..., 0]
+    d23 = groups_gt[..., 2] - groups_gt[..., 1]
+    diff = torch.stack([d12, d13, d23], 3)                       # [B, n, xyz, 3 diffs]
+    B, n = diff.shape[:2]
+    q = diff.reshape(B * n, 3, 3).permute(0, 2, 1)               # [Bn, diff, xyz]
+    qn = q.norm(2, dim=2)
+    nm = qn.unsqueeze(2) * qn.unsqueeze(1)
+    energy = torch.bmm(q, q.permute(0, 2, 1)) / (nm + 1e-8)
+    energy = energy.reshape(B * n, 9)
+    mask_cos = (((energy > delta_cos) | (energy < -delta_cos)).sum(1) > 3).view(B, n)
+    mask_pad = (groups_gt[:, :, 2, :] > delta_z).sum(2) == 3
+    near = [(diff[:, :, c, :].abs() < delta_diff).sum(2) > 0 for c in range(3)]
+    ignore = (near[0] & near[1] & near[2]) | mask_cos
+    return mask_pad & ~ignore
+
+
+def vnl(gt_depth, pred_depth, p123, fx, fy, select=True):
+    """Virtual-normal loss on GIVEN sample indices (the reference draws them from the global
+    numpy RNG, criteria.py:912-932; p123 = three arrays of linear pixel indices).
+
+    Reproduced on purpose: `pw_groups_pred[pw_groups_pred[:, :, 2, :] == 0] = 0.0001`
+    (criteria.py:1004) indexes the first THREE dims [B, n, xyz] with a [B, n, point] mask, so a
+    predicted point j with z == 0 overwrites coordinate j (x, y or z) of all three points."""
+    W = gt_depth.shape[-1]
+    g_gt = vnl_groups(vnl_back_project(gt_depth, fx, fy), p123, W)
+    g_dt = vnl_groups(vnl_back_project(pred_depth, fx, fy), p123, W)
+    keep = vnl_filter(g_gt)
+    zero = g_dt[:, :, 2, :] == 0                                 # [B, n, point]
+    g_dt = torch.where(zero.unsqueeze(3), torch.full_like(g_dt, 0.0001), g_dt)
+    gt, dt = g_gt[keep], g_dt[keep]                              # [M, xyz, point]
+    n_gt = torch.cross(gt[..., 1] - gt[..., 0], gt[..., 2] - gt[..., 0], dim=1)
+    n_dt = torch.cross(dt[..., 1] - dt[..., 0], dt[..., 2] - dt[..., 0], dim=1)
+    l_gt = n_gt.norm(2, dim=1, keepdim=True)
+    l_dt = n_dt.norm(2, dim=1, keepdim=True)
+    l_gt = l_gt + (l_gt == 0).to(torch.float32) * 0.01
+    l_dt = l_dt + (l_dt == 0).to(torch.float32) * 0.01
+    loss = (n_gt / l_gt - n_dt / l_dt).abs().sum(1)
+    if select:
+        loss = torch.sort(loss)[0][int(loss.numel() * 0.25):]
+    return loss.mean()
+
+
+def vnl_select_index(H, W, sample_ratio=0.15):
+    """criteria.py:912-932: the exact sequence of draws from the GLOBAL numpy RNG."""
+    import numpy as np
+    num = H * W
+    out = []
+    for _ in range(3):
+        p = np.random.choice(num, int(num * sample_ratio), replace=True)
+        np.random.shuffle(p)
+        out.append(p)
+    return out
+
+
+def model_loss(pred_depth, pred_logit, depth_bins, depth_gt, weight, p123, fx, fy, diff_loss_weight):
+    """criteria.py:1047-1062."""
+    return wcel(pred_logit, depth_bins, depth_gt, weight) + diff_loss_weight * vnl(depth_gt, pred_depth, p123, fx, fy)

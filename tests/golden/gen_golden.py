@@ -111,6 +111,74 @@ def gen_losses(criteria):
     print("losses.npz", len(out), "arrays")
 
 
+def gen_vnl(criteria):
+    """G3: VNL_Loss on 2x1x48x64 with the sampled indices stored; WCEL_Loss / ModelLoss on 2x150x24x32.
+
+    criteria.py:924-930 uses ``np.int``, removed from numpy >= 1.24 (this image has 2.2): the alias is restored
+    HERE, in the generator's process, before the call; the reference file is untouched.  VNL_Loss draws its
+    sample indices from the global numpy RNG, so the stream is seeded and the very same draw is recorded by
+    calling the reference's own select_index() under the same seed."""
+    if not hasattr(np, "int"):
+        np.int = int
+    out = {}
+    Hh, Ww, fx = 48, 64, 60.0
+    pred, gt = depth_pair(31, (2, 1, Hh, Ww))
+    gt[:, :, :4] = 0.0                                   # "padding" rows: mask_pad must reject them
+    pred = pred.clone()
+    pred[0, 0, 5:9, 7:23] = 0.0                          # exact zeros: the z == 0 overwrite at criteria.py:1004
+    vn = criteria.VNL_Loss(focal_x=fx, focal_y=fx, input_size=(Hh, Ww))
+    np.random.seed(1234)
+    p123 = vn.select_index()
+    out["g3_p123"] = np.stack([p123["p%d_y" % i] * Ww + p123["p%d_x" % i] for i in (1, 2, 3)]).astype(np.int32)
+    out["g3_pred"], out["g3_gt"], out["g3_fx"] = _np(pred), _np(gt), np.float32(fx)
+    for select in (True, False):
+        np.random.seed(1234)
+        l, g = _loss_and_grad(lambda p: vn(gt, p, select=select), pred)
+        out["g3_vnl_%d" % select], out["g3_vnl_%d_grad" % select] = l, g
+    # WCEL / ModelLoss at the reference's 150 bins (modules/vnl.py:160-163 builds these fields)
+    C, h, w = 150, 24, 32
+    dmin, dmax = 0.01, 1.7
+    interval = (np.log10(dmax) - np.log10(dmin)) / C
+    args = types.SimpleNamespace(
+        dec_out_c=C, focal_x=30.0, focal_y=30.0, crop_size=(h, w), diff_loss_weight=6,
+        wce_loss_weight=[[np.exp(-0.2 * (i - j) ** 2) for i in range(C)] for j in np.arange(C)])
+    border = np.array([np.log10(dmin) + interval * (i + 0.5) for i in range(C)])
+    logit = W.normal(32, "logit", (2, C, h, w), std=2.0)        # regenerated by the tests, not stored
+    _, dgt = depth_pair(33, (2, 1, h, w))
+    dgt = dgt * 1.6
+    dgt[:, :, :, :3] = -1.0                              # invalid side padding, label C + 1 (vnl.py:209-216)
+    d = dgt.clamp(dmin, dmax)
+    bins = ((torch.log10(d) - np.log10(dmin)) / interval).to(torch.int)
+    bins[dgt < 0] = C + 1
+    bins[bins == C] = C - 1
+    out["g3_logit_seed"], out["g3_dgt"], out["g3_bins"] = np.int32(32), _np(dgt), _np(bins)
+    out["g3_border"] = border.astype(np.float32)
+    wl = criteria.WCEL_Loss(args)
+    l, g = _loss_and_grad(lambda x: wl(x, bins, dgt), logit)
+    # the full gradient is 0.9 MB of noise-like floats: keep a strided sample plus sums over each axis group
+    out["g3_wcel"], out["g3_wcel_grad_sample"] = l, g[:, ::7, ::3, ::5].copy()
+    out["g3_wcel_grad_csum"], out["g3_wcel_grad_psum"] = g.sum((2, 3)), g.sum(1)
+    out["g3_wcel_grad_abs"] = np.abs(g).sum((2, 3))
+    # ModelLoss: depth = 10 ** sum(softmax * border) (modules/vnl.py:219-230), differentiated through to the logits
+    args.wce_loss_weight = [[np.exp(-0.2 * (i - j) ** 2) for i in range(C)] for j in np.arange(C)]
+    ml = criteria.ModelLoss(args)
+    np.random.seed(99)
+    p123 = ml.virtual_normal_loss.select_index()
+    out["g3_model_p123"] = np.stack([p123["p%d_y" % i] * w + p123["p%d_x" % i] for i in (1, 2, 3)]).astype(np.int32)
+    bt = torch.from_numpy(border.astype(np.float32))
+
+    def model(x):
+        depth = 10 ** (torch.softmax(x, 1).permute(0, 2, 3, 1) * bt).sum(3, dtype=torch.float32, keepdim=True)
+        return ml(depth.permute(0, 3, 1, 2), x, bins, dgt)
+    np.random.seed(99)
+    l, g = _loss_and_grad(model, logit)
+    out["g3_model"], out["g3_model_grad_sample"] = l, g[:, ::7, ::3, ::5].copy()
+    out["g3_model_grad_abs"] = np.abs(g).sum((2, 3))
+    np.savez_compressed(os.path.join(HERE, "vnl.npz"), **out)
+    print("vnl.npz", len(out), "arrays; vnl", float(out["g3_vnl_1"]), float(out["g3_vnl_0"]), "wcel",
+          float(out["g3_wcel"]), "model", float(out["g3_model"]))
+
+
 def gen_metrics(metrics):
     pred, tgt = depth_pair(13, (4, 1, 48, 64))
     mc = metrics.MetricComputation(["absrel", "rmse", "delta1", "delta2", "delta3", "log10"])
@@ -219,6 +287,7 @@ def main():
     torch.set_num_threads(8)
     criteria, metrics, FCRN = _import_reference()
     gen_losses(criteria)
+    gen_vnl(criteria)
     gen_metrics(metrics)
     gen_upproj(FCRN)
     gen_fcrn(criteria, metrics, FCRN)

@@ -162,3 +162,57 @@ def test_fcrn50_conditioned_eval(golden):
     got = M.compute(y, tgt)
     for k in M.NAMES:
         _close(got[k], g["eval_" + k], rtol=1e-4)
+
+
+# ---------------------------------------------------------------- G3: VNL_Loss, WCEL_Loss, ModelLoss
+@pytest.mark.parametrize("select", [True, False])
+def test_vnl(golden, select):
+    g = golden("vnl")
+    fx = float(g["g3_fx"])
+    p123 = [g["g3_p123"][i].astype(np.int64) for i in range(3)]
+    l, gr = _lg(lambda p: L.vnl(_t(g["g3_gt"]), p, p123, fx, fx, select=select), _t(g["g3_pred"]))
+    _close(l, g["g3_vnl_%d" % select])
+    _close(gr, g["g3_vnl_%d_grad" % select], rtol=1e-4, atol=1e-7)
+    assert np.abs(g["g3_vnl_%d_grad" % select]).sum() > 0
+
+
+def test_vnl_sampling_stream(golden):
+    """The sample indices are part of the result: same seed -> the reference's own draw."""
+    g = golden("vnl")
+    np.random.seed(1234)
+    p = L.vnl_select_index(48, 64)
+    assert all(np.array_equal(p[i], g["g3_p123"][i]) for i in range(3))
+    np.random.seed(99)
+    p = L.vnl_select_index(24, 32)
+    assert all(np.array_equal(p[i], g["g3_model_p123"][i]) for i in range(3))
+
+
+def _g3_logit(g):
+    return W.normal(int(g["g3_logit_seed"]), "logit", (2, 150, 24, 32), std=2.0)
+
+
+def test_wcel(golden):
+    g = golden("vnl")
+    bins, dgt = _t(g["g3_bins"]), _t(g["g3_dgt"])
+    assert int((bins > 149).sum()) > 0            # invalid labels are exercised
+    l, gr = _lg(lambda x: L.wcel(x, bins, dgt, L.wcel_weight(150)), _g3_logit(g))
+    _close(l, g["g3_wcel"])
+    gr = gr.numpy()
+    _close(gr[:, ::7, ::3, ::5], g["g3_wcel_grad_sample"], rtol=1e-4, atol=1e-9)
+    _close(gr.sum((2, 3)), g["g3_wcel_grad_csum"], rtol=1e-4, atol=1e-7)
+    _close(gr.sum(1), g["g3_wcel_grad_psum"], rtol=1e-4, atol=1e-7)
+    _close(np.abs(gr).sum((2, 3)), g["g3_wcel_grad_abs"], rtol=1e-4, atol=1e-7)
+
+
+def test_model_loss(golden):
+    g = golden("vnl")
+    bins, dgt, border = _t(g["g3_bins"]), _t(g["g3_dgt"]), _t(g["g3_border"])
+    p123 = [g["g3_model_p123"][i].astype(np.int64) for i in range(3)]
+
+    def model(x):
+        depth = 10 ** (torch.softmax(x, 1).permute(0, 2, 3, 1) * border).sum(3, keepdim=True)
+        return L.model_loss(depth.permute(0, 3, 1, 2), x, bins, dgt, L.wcel_weight(150), p123, 30.0, 30.0, 6)
+    l, gr = _lg(model, _g3_logit(g))
+    _close(l, g["g3_model"])
+    _close(gr.numpy()[:, ::7, ::3, ::5], g["g3_model_grad_sample"], rtol=2e-4, atol=1e-8)
+    _close(np.abs(gr.numpy()).sum((2, 3)), g["g3_model_grad_abs"], rtol=2e-4, atol=1e-7)
