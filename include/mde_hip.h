@@ -250,6 +250,41 @@ int mde_procrustes_bwd(const float* pred, const float* target, int N, int H, int
 /* compute_scale_and_shift alone (criteria.py:154-176): scale[N], shift[N]. */
 int mde_scale_and_shift(const float* pred, const float* target, int N, int H, int W, void* ws, float* scale,
                         float* shift, void* stream);
+/* ---- The VNL configuration's criteria (reference criteria.py:839-1062, modules/vnl.py:202-230) ----
+ * WCEL_Loss (criteria.py:839-863): logit [N][C][HW] fp32 (NCHW), bins [N][HW] int32 labels (a label outside
+ * [0, C) contributes nothing, like the reference's one-hot comparison), gt [N][HW] depth (only gt > 0 is
+ * counted, for the divisor), weight [C][C] = the matrix AFTER the constructor's row normalisation.
+ * loss = -sum_px sum_c weight[bin][c] * log_softmax(logit)[c] / #{gt > 0}.  lse: caller-owned [N][HW] scratch
+ * fwd fills (log-sum-exp per pixel) and bwd reads.  ws >= mde_wcel_ws_bytes(C). */
+size_t mde_wcel_ws_bytes(int C);
+int mde_wcel_fwd(const float* logit, const int32_t* bins, const float* gt, const float* weight, int N, int C,
+                 int64_t HW, void* ws, float* lse, float* loss, void* stream);
+int mde_wcel_bwd(const float* logit, const int32_t* bins, const float* weight, int N, int C, int64_t HW,
+                 const void* ws, const float* lse, const float* gscale, float* grad, void* stream);
+/* bins_to_depth (modules/vnl.py:219-230): depth[n][p] = 10 ** sum_c prob[n][c][p] * border[c]; bwd fills
+ * gprob [N][C][HW] from gdepth [N][HW] and the depth fwd produced. */
+int mde_bins_to_depth_fwd(const float* prob, const float* border, int N, int C, int64_t HW, float* depth,
+                          void* stream);
+int mde_bins_to_depth_bwd(const float* depth, const float* gdepth, const float* border, int N, int C,
+                          int64_t HW, float* gprob, void* stream);
+/* depth_to_bins (modules/vnl.py:202-217): bins = trunc((log10(clamp(depth)) - depth_min_log) / interval),
+ * C + 1 where depth < 0, C -> C - 1; depth is rewritten IN PLACE (clamped; -1 where it was negative), as the
+ * reference does. */
+int mde_depth_to_bins(float* depth, int64_t n, float depth_min, float depth_max, float depth_min_log,
+                      float interval, int C, int32_t* bins, void* stream);
+/* VNL_Loss (criteria.py:866-1045).  gt, pred: [B][H][W] fp32 depth.  p123: DEVICE int32 [3][n] linear pixel
+ * indices (y * W + x) of the three points of each of the n triples, drawn by the host exactly as
+ * criteria.py:912-932 does and shared by every image of the batch; a triple with an index outside [0, H*W)
+ * is rejected.  Back-projection with principal point (W/2, H/2) (integer division), the reference's
+ * collinear / near / invalid-depth filter (thresholds 0.867, 0.005, 1e-4), |n_gt - n_pred|_1 of the unit
+ * normals; select != 0 drops the int(0.25 * M) smallest of the M surviving values before the mean
+ * (M == 0 -> NaN, like the reference).  bwd zero-fills grad [B][H][W] and scatters with fp32 atomics.
+ * ws >= mde_vnl_ws_bytes(B, n), carried from fwd to bwd. */
+size_t mde_vnl_ws_bytes(int B, int n);
+int mde_vnl_fwd(const float* gt, const float* pred, const int32_t* p123, int B, int H, int W, int n, float fx,
+                float fy, int select, void* ws, float* loss, void* stream);
+int mde_vnl_bwd(const float* gt, const float* pred, const int32_t* p123, int B, int H, int W, int n, float fx,
+                float fy, const void* ws, const float* gscale, float* grad, void* stream);
 /* Depth metrics (metrics.py:58-109): out[6] = absrel, 'rmse' (= mean sqrt((p-t)^2/t), sic),
  * delta1, delta2, delta3, log10.  ws >= mde_metrics_ws_bytes(). */
 size_t mde_metrics_ws_bytes(void);

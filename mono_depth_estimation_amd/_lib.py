@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MDE_LIB_PATH") or os.path.join(_HERE, "libmde_hip.so")   # override: diagnostic builds only
-ABI_VERSION = 3
+ABI_VERSION = 4
 MAX_TAPS = 32
 
 
@@ -86,6 +86,15 @@ SIGNATURES = {
     "mde_procrustes_fwd": (_I, [_P, _P, _I, _I, _I, _F, _I, _I, _P, _P, _P, _P, _P]),
     "mde_procrustes_bwd": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "mde_scale_and_shift": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P]),
+    "mde_wcel_ws_bytes": (_Z, [_I]),
+    "mde_wcel_fwd": (_I, [_P, _P, _P, _P, _I, _I, _L, _P, _P, _P, _P]),
+    "mde_wcel_bwd": (_I, [_P, _P, _P, _I, _I, _L, _P, _P, _P, _P, _P]),
+    "mde_bins_to_depth_fwd": (_I, [_P, _P, _I, _I, _L, _P, _P]),
+    "mde_bins_to_depth_bwd": (_I, [_P, _P, _P, _I, _I, _L, _P, _P]),
+    "mde_depth_to_bins": (_I, [_P, _L, _F, _F, _F, _F, _I, _P, _P]),
+    "mde_vnl_ws_bytes": (_Z, [_I, _I]),
+    "mde_vnl_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _F, _F, _I, _P, _P, _P]),
+    "mde_vnl_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _F, _F, _P, _P, _P, _P]),
     "mde_metrics_ws_bytes": (_Z, []),
     "mde_depth_metrics": (_I, [_P, _P, _L, _P, _P, _P]),
     "mde_adam_step": (_I, [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _F, _I, _P]),

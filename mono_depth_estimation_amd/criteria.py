@@ -12,7 +12,16 @@ kernels in csrc/losses.hip; no CPU fallback):
       L1 term (its sort-and-slice trims nothing) and only the batch-based reduction is well-formed for the
       data terms; every mask is target > 0.
   TrimmedProcrustesLoss(alpha, scales, reduction)(prediction, target)   criteria.py:335-363 (+ :135-152)
+  WCEL_Loss(args)(pred_logit, gt_bins, gt)             criteria.py:839-863
+  VNL_Loss(focal_x, focal_y, input_size, ...)(gt_depth, pred_depth, select=True)   criteria.py:866-1045
+      the triples are drawn on the host from the GLOBAL numpy RNG with the reference's exact sequence of
+      calls (select_index), so a seeded run samples the same pixels as the reference.
+  ModelLoss(args)(pred_depth, pred_logit, depth_bins, depth_gt)   criteria.py:1047-1062
+  bins_to_depth(depth_bin, depth_bin_border), depth_to_bins(depth, depth_min, depth_max, dec_out_c)
+      modules/vnl.py:202-230 (methods of the reference's VNLModule; free functions here, kernels in
+      csrc/vnl_losses.hip)
 """
+import numpy as np
 import torch
 import torch.nn as nn
 
@@ -268,3 +277,183 @@ class TrimmedProcrustesLoss(nn.Module):
         loss, pn = _ProcrustesFunction.apply(prediction, target, self.alpha if self.alpha > 0 else 0.0, self.scales, True)
         self.prediction_ssi = pn.detach()
         return loss
+
+
+# ------------------------------------------------------------------------------ VNL configuration (csrc/vnl_losses.hip)
+class _WcelFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logit, bins, gt, weight):
+        ctx.in_dtype = logit.dtype
+        x = logit.contiguous().float()
+        N, C = x.shape[0], x.shape[1]
+        HW = x.numel() // (N * C)
+        if bins.numel() != N * HW or gt.numel() != N * HW:
+            raise ValueError("WCEL_Loss: logits %s need %d labels and depths, got %d and %d"
+                             % (tuple(logit.shape), N * HW, bins.numel(), gt.numel()))
+        if tuple(weight.shape) != (C, C):
+            raise ValueError("WCEL_Loss: weight %s for %d bins" % (tuple(weight.shape), C))
+        b = bins.to(device=x.device, dtype=torch.int32).contiguous()
+        g = gt.to(device=x.device, dtype=torch.float32).contiguous()
+        ws = ops.wcel_ws(C, x.device)
+        lse = torch.empty(N * HW, device=x.device)
+        loss = torch.empty(1, device=x.device)
+        ops.wcel_fwd(x, b, g, weight, N, C, HW, ws, lse, loss)
+        ctx.save_for_backward(x, b, weight, ws, lse)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, gout):
+        x, b, weight, ws, lse = ctx.saved_tensors
+        N, C = x.shape[0], x.shape[1]
+        grad = torch.empty_like(x)
+        ops.wcel_bwd(x, b, weight, N, C, x.numel() // (N * C), ws, lse, gout.contiguous().float().reshape(1), grad)
+        return grad.to(ctx.in_dtype), None, None, None
+
+
+class WCEL_Loss(nn.Module):
+    """criteria.py:839-863.  `args` carries dec_out_c and wce_loss_weight (a [C][C] list or array, row-normalised
+    here exactly as the reference's constructor does, in float64)."""
+
+    def __init__(self, args):
+        super().__init__()
+        self.args = args
+        w = np.asarray(self.args.wce_loss_weight, dtype=np.float64)
+        w = w / np.sum(w, 1, keepdims=True)
+        self.weight = torch.from_numpy(w)
+
+    def forward(self, pred_logit, gt_bins, gt):
+        _need_gpu(pred_logit, "WCEL_Loss")
+        if pred_logit.shape[1] != self.args.dec_out_c:
+            raise ValueError("WCEL_Loss: %d logit channels, dec_out_c = %d" % (pred_logit.shape[1], self.args.dec_out_c))
+        self.weight = self.weight.to(device=pred_logit.device, dtype=torch.float).contiguous()
+        return _WcelFunction.apply(pred_logit, gt_bins, gt, self.weight)
+
+
+class _VnlFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, gt, pred, p123, fx, fy, select):
+        ctx.in_dtype = pred.dtype
+        B, _, H, W = pred.shape
+        p = pred.contiguous().float()
+        g = gt.to(device=p.device, dtype=torch.float32).contiguous()
+        n = p123.shape[1]
+        ws = ops.vnl_ws(B, n, p.device)
+        loss = torch.empty(1, device=p.device)
+        ops.vnl_fwd(g, p, p123, B, H, W, n, fx, fy, select, ws, loss)
+        ctx.save_for_backward(g, p, p123, ws)
+        ctx.cfg = (fx, fy)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, gout):
+        g, p, p123, ws = ctx.saved_tensors
+        B, _, H, W = p.shape
+        grad = torch.empty_like(p)
+        ops.vnl_bwd(g, p, p123, B, H, W, p123.shape[1], ctx.cfg[0], ctx.cfg[1], ws,
+                    gout.contiguous().float().reshape(1), grad)
+        return None, grad.to(ctx.in_dtype), None, None, None, None
+
+
+class VNL_Loss(nn.Module):
+    """criteria.py:866-1045.  As in the reference, the filter thresholds that actually apply are the ones
+    select_points_groups hard-codes (0.867 / 0.005; the delta_cos / delta_diff_* constructor arguments are stored
+    and never used) plus delta_z; unlike the reference, tensors follow the prediction's device instead of being
+    pinned to cuda:0, and the ground truth receives no gradient."""
+
+    def __init__(self, focal_x, focal_y, input_size, delta_cos=0.867, delta_diff_x=0.01, delta_diff_y=0.01,
+                 delta_diff_z=0.01, delta_z=0.0001, sample_ratio=0.15):
+        super().__init__()
+        if delta_z != 0.0001:
+            raise NotImplementedError("VNL_Loss: the HIP path fixes delta_z = 1e-4 (the reference's only call site)")
+        self.fx, self.fy = float(focal_x), float(focal_y)
+        self.input_size = (int(input_size[0]), int(input_size[1]))
+        self.delta_cos, self.delta_z, self.sample_ratio = delta_cos, delta_z, sample_ratio
+        self.delta_diff_x, self.delta_diff_y, self.delta_diff_z = delta_diff_x, delta_diff_y, delta_diff_z
+
+    def select_index(self):
+        """The reference's draw, call for call (criteria.py:912-932): three `choice(num, int(num * ratio))` with
+        replacement, each followed by a `shuffle`, all on the global numpy RNG."""
+        H, W = self.input_size
+        num = W * H
+        out = {}
+        for i in (1, 2, 3):
+            p = np.random.choice(num, int(num * self.sample_ratio), replace=True)
+            np.random.shuffle(p)
+            out["p%d_x" % i] = p % W
+            out["p%d_y" % i] = (p / W).astype(int)
+        return out
+
+    def forward(self, gt_depth, pred_depth, select=True):
+        _need_gpu(pred_depth, "VNL_Loss")
+        if pred_depth.ndim != 4 or pred_depth.shape[1] != 1 or tuple(pred_depth.shape[2:]) != self.input_size:
+            raise ValueError("VNL_Loss: prediction %s, expected [B, 1, %d, %d]" % ((tuple(pred_depth.shape),) + self.input_size))
+        if gt_depth.shape != pred_depth.shape:
+            raise ValueError("VNL_Loss: ground truth %s vs prediction %s" % (tuple(gt_depth.shape), tuple(pred_depth.shape)))
+        s = self.select_index()
+        W = self.input_size[1]
+        lin = np.stack([s["p%d_y" % i] * W + s["p%d_x" % i] for i in (1, 2, 3)]).astype(np.int32)
+        if lin.shape[1] == 0:
+            raise ValueError("VNL_Loss: input_size %s samples no triples" % (self.input_size,))
+        p123 = torch.from_numpy(lin).to(pred_depth.device, non_blocking=True)
+        return _VnlFunction.apply(gt_depth, pred_depth, p123, self.fx, self.fy, bool(select))
+
+
+class ModelLoss(nn.Module):
+    """criteria.py:1047-1062: WCEL + diff_loss_weight * VNL."""
+
+    def __init__(self, args):
+        super().__init__()
+        self.args = args
+        self.weight_cross_entropy_loss = WCEL_Loss(args)
+        self.virtual_normal_loss = VNL_Loss(focal_x=args.focal_x, focal_y=args.focal_y, input_size=args.crop_size)
+
+    def forward(self, pred_depth, pred_logit, depth_bins, depth_gt):
+        loss_metric = self.weight_cross_entropy_loss(pred_logit, depth_bins, depth_gt)
+        loss_normal = self.virtual_normal_loss(depth_gt, pred_depth)
+        return loss_metric + self.args.diff_loss_weight * loss_normal
+
+
+class _BinsToDepthFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, prob, border):
+        ctx.in_dtype = prob.dtype
+        x = prob.contiguous().float()
+        N, C = x.shape[0], x.shape[1]
+        HW = x.numel() // (N * C)
+        depth = torch.empty((N, 1) + tuple(x.shape[2:]), device=x.device)
+        ops.bins_to_depth_fwd(x, border, N, C, HW, depth)
+        ctx.save_for_backward(depth, border)
+        ctx.shape = tuple(x.shape)
+        return depth
+
+    @staticmethod
+    def backward(ctx, gdepth):
+        depth, border = ctx.saved_tensors
+        N, C = ctx.shape[0], ctx.shape[1]
+        gprob = torch.empty(ctx.shape, device=depth.device)
+        ops.bins_to_depth_bwd(depth, gdepth.contiguous().float(), border, N, C, depth.numel() // N, gprob)
+        return gprob.to(ctx.in_dtype), None
+
+
+def bins_to_depth(depth_bin, depth_bin_border):
+    """modules/vnl.py:219-230: [b, c, h, w] bin probabilities -> [b, 1, h, w] depth = 10 ** sum_c p_c * border_c
+    (fp32 result).  depth_bin_border: the C log10 bin centres (array or tensor)."""
+    _need_gpu(depth_bin, "bins_to_depth")
+    border = torch.as_tensor(np.asarray(depth_bin_border.cpu() if torch.is_tensor(depth_bin_border) else depth_bin_border),
+                             dtype=torch.float32).to(depth_bin.device).contiguous()
+    if depth_bin.ndim != 4 or border.numel() != depth_bin.shape[1]:
+        raise ValueError("bins_to_depth: %s probabilities, %d borders" % (tuple(depth_bin.shape), border.numel()))
+    return _BinsToDepthFunction.apply(depth_bin, border)
+
+
+def depth_to_bins(depth, depth_min, depth_max, dec_out_c):
+    """modules/vnl.py:202-217.  Returns int32 bins shaped like `depth`; like the reference it also rewrites `depth`
+    IN PLACE (clamped to [depth_min, depth_max]; -1 where it was negative = invalid padding, label dec_out_c + 1)."""
+    _need_gpu(depth, "depth_to_bins")
+    if depth.dtype != torch.float32 or not depth.is_contiguous():
+        raise ValueError("depth_to_bins: a contiguous fp32 depth map is rewritten in place")
+    dmin_log = np.log10(depth_min)
+    interval = (np.log10(depth_max) - dmin_log) / dec_out_c
+    bins = torch.empty(depth.shape, dtype=torch.int32, device=depth.device)
+    ops.depth_to_bins(depth, float(depth_min), float(depth_max), float(dmin_log), float(interval), int(dec_out_c), bins)
+    return bins

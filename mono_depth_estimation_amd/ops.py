@@ -400,6 +400,49 @@ def scale_and_shift(pred, target, N, H, W, ws, scale, shift):
           "mde_scale_and_shift")
 
 
+# ------------------------------------------------------------------------------ VNL configuration criteria
+def wcel_ws(C, device="cuda"):
+    return torch.zeros((_lib.load().mde_wcel_ws_bytes(C) + 7) // 8, dtype=torch.float64, device=device)
+
+
+def wcel_fwd(logit, bins, gt, weight, N, C, HW, ws, lse, loss):
+    check(_lib.load().mde_wcel_fwd(_p(logit), _p(bins), _p(gt), _p(weight), N, C, HW, _p(ws), _p(lse), _p(loss), _stream()),
+          "mde_wcel_fwd")
+
+
+def wcel_bwd(logit, bins, weight, N, C, HW, ws, lse, gscale, grad):
+    check(_lib.load().mde_wcel_bwd(_p(logit), _p(bins), _p(weight), N, C, HW, _p(ws), _p(lse), _p(gscale), _p(grad),
+                                   _stream()), "mde_wcel_bwd")
+
+
+def bins_to_depth_fwd(prob, border, N, C, HW, depth):
+    check(_lib.load().mde_bins_to_depth_fwd(_p(prob), _p(border), N, C, HW, _p(depth), _stream()), "mde_bins_to_depth_fwd")
+
+
+def bins_to_depth_bwd(depth, gdepth, border, N, C, HW, gprob):
+    check(_lib.load().mde_bins_to_depth_bwd(_p(depth), _p(gdepth), _p(border), N, C, HW, _p(gprob), _stream()),
+          "mde_bins_to_depth_bwd")
+
+
+def depth_to_bins(depth, depth_min, depth_max, depth_min_log, interval, C, bins):
+    check(_lib.load().mde_depth_to_bins(_p(depth), depth.numel(), depth_min, depth_max, depth_min_log, interval, C, _p(bins),
+                                        _stream()), "mde_depth_to_bins")
+
+
+def vnl_ws(B, n, device="cuda"):
+    return torch.zeros((_lib.load().mde_vnl_ws_bytes(B, n) + 7) // 8, dtype=torch.float64, device=device)
+
+
+def vnl_fwd(gt, pred, p123, B, H, W, n, fx, fy, select, ws, loss):
+    check(_lib.load().mde_vnl_fwd(_p(gt), _p(pred), _p(p123), B, H, W, n, fx, fy, int(select), _p(ws), _p(loss), _stream()),
+          "mde_vnl_fwd")
+
+
+def vnl_bwd(gt, pred, p123, B, H, W, n, fx, fy, ws, gscale, grad):
+    check(_lib.load().mde_vnl_bwd(_p(gt), _p(pred), _p(p123), B, H, W, n, fx, fy, _p(ws), _p(gscale), _p(grad), _stream()),
+          "mde_vnl_bwd")
+
+
 def metrics_ws(device="cuda"):
     return torch.zeros((_lib.load().mde_metrics_ws_bytes() + 7) // 8, dtype=torch.float64, device=device)
 

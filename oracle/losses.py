@@ -277,3 +277,26 @@ def vnl_select_index(H, W, sample_ratio=0.15):
 def model_loss(pred_depth, pred_logit, depth_bins, depth_gt, weight, p123, fx, fy, diff_loss_weight):
     """criteria.py:1047-1062."""
     return wcel(pred_logit, depth_bins, depth_gt, weight) + diff_loss_weight * vnl(depth_gt, pred_depth, p123, fx, fy)
+
+
+# ---------------------------------------------------------------- B8 companion  modules/vnl.py:202-230
+def bins_to_depth(depth_bin, border):
+    """[b, c, h, w] probabilities -> [b, 1, h, w]: 10 ** sum_c p_c * border_c."""
+    d = (depth_bin.permute(0, 2, 3, 1) * border.to(torch.float32)).sum(3, dtype=torch.float32, keepdim=True)
+    return (10 ** d).permute(0, 3, 1, 2)
+
+
+def depth_to_bins(depth, depth_min, depth_max, C):
+    """Returns (bins int32, rewritten depth) — the reference mutates `depth` in place (clamp; invalid -> -1)."""
+    import numpy as np
+    depth = depth.clone()
+    invalid = depth < 0.
+    depth[depth < depth_min] = depth_min
+    depth[depth > depth_max] = depth_max
+    dmin_log = np.log10(depth_min)
+    interval = (np.log10(depth_max) - dmin_log) / C
+    bins = ((torch.log10(depth) - dmin_log) / interval).to(torch.int)
+    bins[invalid] = C + 1
+    bins[bins == C] = C - 1
+    depth[invalid] = -1.0
+    return bins, depth
