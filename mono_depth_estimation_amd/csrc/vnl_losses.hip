@@ -102,16 +102,199 @@ __global__ __launch_bounds__(NT) void wcel_bwd_k(const float* __restrict__ logit
     for (int c = 0; c < C; ++c) g[(int64_t)c * HW] = -k * (wr[c] - expf(x[(int64_t)c * HW] - l) * rs);
 }
 
+// ---- the production WCEL path: weight table in LDS (C <= 192: 150 x 150 x 4 B = 90 KB), persistent 1024-thread
+// workgroups, V pixels per thread as one b32/b128 access per channel, the channel walk in chunks of U so that U
+// loads are in flight per lane, ONE walk over the logits (running max / rescaled sum per chunk).  The per-lane
+// weight row lookup is an LDS read instead of a 64-address global gather.
+constexpr int WNT = 1024;
+constexpr int WCEL_LDS_MAX_C = 192;
+
+template <int V> struct PixVec;
+template <> struct PixVec<1> { typedef float T; };
+template <> struct PixVec<4> { typedef f32x4_t T; };
+template <int V> __device__ __forceinline__ float pv_get(const typename PixVec<V>::T& v, int i);
+template <> __device__ __forceinline__ float pv_get<1>(const float& v, int) { return v; }
+template <> __device__ __forceinline__ float pv_get<4>(const f32x4_t& v, int i) { return v[i]; }
+template <int V> __device__ __forceinline__ void pv_set(typename PixVec<V>::T& v, int i, float x);
+template <> __device__ __forceinline__ void pv_set<1>(float& v, int, float x) { v = x; }
+template <> __device__ __forceinline__ void pv_set<4>(f32x4_t& v, int i, float x) { v[i] = x; }
+
+__device__ __forceinline__ double wblock_sum_d(double v, double* sh) {   // WNT threads; result in thread 0
+    const double r = mde_wave_sum_d(v);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = r;
+    __syncthreads();
+    double t = 0.0;
+    if (threadIdx.x == 0)
+        for (int i = 0; i < WNT / 64; ++i) t += sh[i];
+    __syncthreads();
+    return t;
+}
+
+template <int V, int U>
+__global__ __launch_bounds__(WNT) void wcel_fwd_lds_k(const float* __restrict__ logit, const int* __restrict__ bins,
+                                                      const float* __restrict__ gt, const float* __restrict__ weight,
+                                                      const float* __restrict__ rowsum, int C, int64_t HW, int64_t total,
+                                                      float* __restrict__ lse, WcelHead* h) {
+    typedef typename PixVec<V>::T vec_t;
+    extern __shared__ __attribute__((aligned(16))) float wl[];   // [C][C]
+    __shared__ double sh[WNT / 64];
+    for (int i = threadIdx.x; i < C * C; i += WNT) wl[i] = weight[i];
+    __syncthreads();
+    double part = 0.0, val = 0.0;
+    for (int64_t base = ((int64_t)blockIdx.x * WNT + threadIdx.x) * V; base < total; base += (int64_t)gridDim.x * WNT * V) {
+        const int64_t n = base / HW, p = base - n * HW;          // HW % V == 0: the V pixels share an image
+        const float* x = logit + n * C * HW + p;
+        int b[V];
+        const float* wr[V];
+        float m[V], s[V], a[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            b[j] = bins[base + j];
+            wr[j] = wl + ((unsigned)b[j] < (unsigned)C ? b[j] : 0) * C;
+            m[j] = -__builtin_inff();
+            s[j] = a[j] = 0.f;
+        }
+        int c = 0;
+        for (; c + U <= C; c += U) {
+            vec_t v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) v[u] = *(const vec_t*)(x + (int64_t)(c + u) * HW);
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                float cm = pv_get<V>(v[0], j);
+#pragma unroll
+                for (int u = 1; u < U; ++u) cm = fmaxf(cm, pv_get<V>(v[u], j));
+                const float mn = fmaxf(m[j], cm);
+                float acc = s[j] * __expf(m[j] - mn);
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const float xv = pv_get<V>(v[u], j);
+                    acc += __expf(xv - mn);
+                    a[j] += wr[j][c + u] * xv;
+                }
+                s[j] = acc;
+                m[j] = mn;
+            }
+        }
+        for (; c < C; ++c) {
+            const vec_t v = *(const vec_t*)(x + (int64_t)c * HW);
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                const float xv = pv_get<V>(v, j);
+                const float mn = fmaxf(m[j], xv);
+                s[j] = s[j] * __expf(m[j] - mn) + __expf(xv - mn);
+                m[j] = mn;
+                a[j] += wr[j][c] * xv;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            const float l = m[j] + logf(s[j]);
+            lse[base + j] = l;
+            if ((unsigned)b[j] < (unsigned)C) part += (double)(a[j] - l * rowsum[b[j]]);
+            val += gt[base + j] > 0.f ? 1.0 : 0.0;
+        }
+    }
+    const double ps = wblock_sum_d(part, sh);
+    const double vs = wblock_sum_d(val, sh);
+    if (threadIdx.x == 0) {
+        if (ps != 0.0) atomicAdd(&h->sum, ps);
+        if (vs != 0.0) atomicAdd(&h->valid, vs);
+    }
+}
+
+template <int V, int U>
+__global__ __launch_bounds__(WNT) void wcel_bwd_lds_k(const float* __restrict__ logit, const int* __restrict__ bins,
+                                                      const float* __restrict__ weight, const float* __restrict__ rowsum,
+                                                      int C, int64_t HW, int64_t total, const float* __restrict__ lse,
+                                                      const WcelHead* __restrict__ h, const float* __restrict__ gscale,
+                                                      float* __restrict__ grad) {
+    typedef typename PixVec<V>::T vec_t;
+    extern __shared__ __attribute__((aligned(16))) float wl[];   // [C][C] then one all-zero row
+    for (int i = threadIdx.x; i < C * C + C; i += WNT) wl[i] = i < C * C ? weight[i] : 0.f;
+    __syncthreads();
+    const float k = -(gscale ? *gscale : 1.f) / (float)h->valid;
+    for (int64_t base = ((int64_t)blockIdx.x * WNT + threadIdx.x) * V; base < total; base += (int64_t)gridDim.x * WNT * V) {
+        const int64_t n = base / HW, p = base - n * HW;
+        const float* x = logit + n * C * HW + p;
+        float* g = grad + n * C * HW + p;
+        const float* wr[V];
+        float l[V], rs[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            const int b = bins[base + j];
+            const bool inside = (unsigned)b < (unsigned)C;
+            wr[j] = wl + (inside ? b : C) * C;                  // an outside label reads the zero row ...
+            rs[j] = inside ? rowsum[b] : 0.f;                   // ... and has no softmax term: gradient 0
+            l[j] = lse[base + j];
+        }
+        int c = 0;
+        for (; c + U <= C; c += U) {
+            vec_t v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) v[u] = *(const vec_t*)(x + (int64_t)(c + u) * HW);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                vec_t o;
+#pragma unroll
+                for (int j = 0; j < V; ++j) pv_set<V>(o, j, k * (wr[j][c + u] - __expf(pv_get<V>(v[u], j) - l[j]) * rs[j]));
+                *(vec_t*)(g + (int64_t)(c + u) * HW) = o;
+            }
+        }
+        for (; c < C; ++c) {
+            const vec_t v = *(const vec_t*)(x + (int64_t)c * HW);
+            vec_t o;
+#pragma unroll
+            for (int j = 0; j < V; ++j) pv_set<V>(o, j, k * (wr[j][c] - __expf(pv_get<V>(v, j) - l[j]) * rs[j]));
+            *(vec_t*)(g + (int64_t)c * HW) = o;
+        }
+    }
+}
+
+template <typename K>
+int wcel_lds_attr(K kernel, size_t smem, const char* what) {
+    return mde_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             (int)smem), what);
+}
+
+int wcel_grid(int64_t total, int V) {
+    int cus = 256;
+    mde_device_cu_count(&cus);
+    const int64_t chunks = (total / V + WNT - 1) / WNT;
+    return (int)(chunks < cus ? (chunks < 1 ? 1 : chunks) : cus);
+}
+
 // =================================================================================== bin mapping
+template <int V, int U>
 __global__ __launch_bounds__(NT) void bins_to_depth_fwd_k(const float* __restrict__ prob, const float* __restrict__ border,
                                                           int C, int64_t HW, int64_t total, float* __restrict__ depth) {
-    const int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x;
+    typedef typename PixVec<V>::T vec_t;
+    const int64_t i = ((int64_t)blockIdx.x * NT + threadIdx.x) * V;
     if (i >= total) return;
     const int64_t n = i / HW, p = i - n * HW;
     const float* x = prob + n * C * HW + p;
-    float s = 0.f;
-    for (int c = 0; c < C; ++c) s += x[(int64_t)c * HW] * border[c];
-    depth[i] = exp10f(s);
+    float s[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) s[j] = 0.f;
+    int c = 0;
+    for (; c + U <= C; c += U) {
+        vec_t v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = *(const vec_t*)(x + (int64_t)(c + u) * HW);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int j = 0; j < V; ++j) s[j] += pv_get<V>(v[u], j) * border[c + u];
+    }
+    for (; c < C; ++c) {
+        const vec_t v = *(const vec_t*)(x + (int64_t)c * HW);
+#pragma unroll
+        for (int j = 0; j < V; ++j) s[j] += pv_get<V>(v, j) * border[c];
+    }
+    vec_t o;
+#pragma unroll
+    for (int j = 0; j < V; ++j) pv_set<V>(o, j, exp10f(s[j]));
+    *(vec_t*)(depth + i) = o;
 }
 
 // d depth / d prob[c] = depth * ln 10 * border[c]
@@ -421,8 +604,20 @@ extern "C" int mde_wcel_fwd(const float* logit, const int32_t* bins, const float
     const int64_t total = (int64_t)N * HW;
     wcel_init_k<<<mde_cdiv(C, 64), 64, 0, st>>>(h, weight, C, rowsum);
     MDE_LAUNCH_CHECK("wcel_init_k");
-    wcel_fwd_k<<<mde_cdiv(total, NT), NT, 0, st>>>(logit, bins, gt, weight, rowsum, C, HW, total, lse, h);
-    MDE_LAUNCH_CHECK("wcel_fwd_k");
+    if (C <= WCEL_LDS_MAX_C) {
+        const size_t smem = (size_t)C * C * sizeof(float);
+        if (HW % 4 == 0 && ((uintptr_t)logit & 15) == 0) {
+            if (int rc = wcel_lds_attr(&wcel_fwd_lds_k<4, 4>, smem, "hipFuncSetAttribute(wcel_fwd_lds_k)")) return rc;
+            wcel_fwd_lds_k<4, 4><<<wcel_grid(total, 4), WNT, smem, st>>>(logit, bins, gt, weight, rowsum, C, HW, total, lse, h);
+        } else {
+            if (int rc = wcel_lds_attr(&wcel_fwd_lds_k<1, 8>, smem, "hipFuncSetAttribute(wcel_fwd_lds_k)")) return rc;
+            wcel_fwd_lds_k<1, 8><<<wcel_grid(total, 1), WNT, smem, st>>>(logit, bins, gt, weight, rowsum, C, HW, total, lse, h);
+        }
+        MDE_LAUNCH_CHECK("wcel_fwd_lds_k");
+    } else {
+        wcel_fwd_k<<<mde_cdiv(total, NT), NT, 0, st>>>(logit, bins, gt, weight, rowsum, C, HW, total, lse, h);
+        MDE_LAUNCH_CHECK("wcel_fwd_k");
+    }
     wcel_finalize_k<<<1, 1, 0, st>>>(h, loss);
     MDE_LAUNCH_CHECK("wcel_finalize_k");
     return MDE_OK;
@@ -434,9 +629,24 @@ extern "C" int mde_wcel_bwd(const float* logit, const int32_t* bins, const float
     MDE_REQUIRE(N > 0 && C > 0 && HW > 0 && C <= 4096, "mde_wcel_bwd: bad shape N=%d C=%d HW=%lld", N, C, (long long)HW);
     const WcelHead* h = (const WcelHead*)ws;
     const int64_t total = (int64_t)N * HW;
-    wcel_bwd_k<<<mde_cdiv(total, NT), NT, 0, (hipStream_t)stream>>>(logit, bins, weight, (const float*)(h + 1), C, HW, total,
-                                                                    lse, h, gscale, grad);
-    MDE_LAUNCH_CHECK("wcel_bwd_k");
+    hipStream_t st = (hipStream_t)stream;
+    const float* rowsum = (const float*)(h + 1);
+    if (C <= WCEL_LDS_MAX_C) {
+        const size_t smem = ((size_t)C * C + C) * sizeof(float);
+        if (HW % 4 == 0 && (((uintptr_t)logit | (uintptr_t)grad) & 15) == 0) {
+            if (int rc = wcel_lds_attr(&wcel_bwd_lds_k<4, 4>, smem, "hipFuncSetAttribute(wcel_bwd_lds_k)")) return rc;
+            wcel_bwd_lds_k<4, 4><<<wcel_grid(total, 4), WNT, smem, st>>>(logit, bins, weight, rowsum, C, HW, total, lse, h,
+                                                                         gscale, grad);
+        } else {
+            if (int rc = wcel_lds_attr(&wcel_bwd_lds_k<1, 8>, smem, "hipFuncSetAttribute(wcel_bwd_lds_k)")) return rc;
+            wcel_bwd_lds_k<1, 8><<<wcel_grid(total, 1), WNT, smem, st>>>(logit, bins, weight, rowsum, C, HW, total, lse, h,
+                                                                         gscale, grad);
+        }
+        MDE_LAUNCH_CHECK("wcel_bwd_lds_k");
+    } else {
+        wcel_bwd_k<<<mde_cdiv(total, NT), NT, 0, st>>>(logit, bins, weight, rowsum, C, HW, total, lse, h, gscale, grad);
+        MDE_LAUNCH_CHECK("wcel_bwd_k");
+    }
     return MDE_OK;
 }
 
@@ -445,7 +655,10 @@ extern "C" int mde_bins_to_depth_fwd(const float* prob, const float* border, int
     MDE_REQUIRE(prob && border && depth, "mde_bins_to_depth_fwd: null pointer");
     MDE_REQUIRE(N > 0 && C > 0 && HW > 0, "mde_bins_to_depth_fwd: bad shape N=%d C=%d HW=%lld", N, C, (long long)HW);
     const int64_t total = (int64_t)N * HW;
-    bins_to_depth_fwd_k<<<mde_cdiv(total, NT), NT, 0, (hipStream_t)stream>>>(prob, border, C, HW, total, depth);
+    if (HW % 4 == 0 && (((uintptr_t)prob | (uintptr_t)depth) & 15) == 0)
+        bins_to_depth_fwd_k<4, 4><<<mde_cdiv(total / 4, NT), NT, 0, (hipStream_t)stream>>>(prob, border, C, HW, total, depth);
+    else
+        bins_to_depth_fwd_k<1, 8><<<mde_cdiv(total, NT), NT, 0, (hipStream_t)stream>>>(prob, border, C, HW, total, depth);
     MDE_LAUNCH_CHECK("bins_to_depth_fwd_k");
     return MDE_OK;
 }
