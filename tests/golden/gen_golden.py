@@ -179,6 +179,65 @@ def gen_vnl(criteria):
           float(out["g3_wcel"]), "model", float(out["g3_model"]))
 
 
+def _reference_stdepth_loss(criteria, loss, single_layer):
+    """The reference's composite criterion is a closure built by BaseModule.setup_criterion
+    (modules/base_module.py:124-208).  That file cannot be imported here (top-level pytorch_lightning, wandb,
+    cv2-backed datasets, and modules/__init__ runs a torch.hub download), so the ONE method is lifted out of the
+    reference file with `ast` at generation time and executed unchanged in a namespace holding exactly the names
+    it uses (torch, F, criteria, and stdepth_utils' depth_sort / composite_layers / dssim2d, all imported from
+    the reference).  Nothing of it is stored in this repo."""
+    import ast
+    import torch.nn.functional as F
+    import stdepth_utils
+    src = open(os.path.join(REF, "modules", "base_module.py")).read()
+    cls = next(n for n in ast.parse(src).body if isinstance(n, ast.ClassDef) and n.name == "BaseModule")
+    fn = next(n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name == "setup_criterion")
+    ns = {"torch": torch, "F": F, "criteria": criteria, "depth_sort": stdepth_utils.depth_sort,
+          "composite_layers": stdepth_utils.composite_layers, "dssim2d": stdepth_utils.dssim2d}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), "base_module.py:setup_criterion", "exec"), ns)
+    me = types.SimpleNamespace(single_layer=single_layer, method=types.SimpleNamespace(
+        loss=loss, variance_focus=0.85, depth_loss_weight=10.0, comp_loss_weight=2.0, fbdiv_loss_weight=0.2,
+        ssim_loss_weight=2.0))
+    return ns["setup_criterion"](me)
+
+
+def stdepth_batch(seed, C, shape=(2, 20, 28)):
+    """pred / targ [N, C, H, W] in roughly [-0.1, 1.1], rgba with ~30 % transparent pixels, depth channels with holes."""
+    N, H, Wd = shape
+    pred = W.uniform(seed, "pred", (N, C, H, Wd), -0.1, 1.1)
+    targ = W.uniform(seed, "targ", (N, C, H, Wd), 0.0, 1.0)
+    rgba = W.uniform(seed, "rgba", (N, 4, H, Wd), 0.0, 1.0)
+    rgba[:, 3] = rgba[:, 3].masked_fill(W.uniform(seed, "hole", (N, H, Wd)) < 0.3, 0.0)
+    d = slice(8, 10) if C == 10 else slice(16, 20)
+    targ[:, d] = targ[:, d].masked_fill(W.uniform(seed, "dhole", targ[:, d].shape) < 0.2, 0.0)
+    pred[:, d] = pred[:, d].abs() + 0.05             # silog takes log(pred)
+    return pred, targ, rgba
+
+
+STDEPTH_CASES = [("mae+composite", True), ("silma", True), ("silms+fbdivergence", True), ("mse", True),
+                 ("mae+composite+ssim", True), ("allssim+colorssim", True), ("silma+mse+fbdivergence", False)]
+
+
+def gen_stdepth(criteria):
+    """G6: the composite criterion (reference defaults: laina 'mae+composite', bts 'silma'; weights 10 / 2 / 0.2 / 2)."""
+    out = {}
+    for C in (10, 20):
+        pred, targ, rgba = stdepth_batch(61 + C, C)
+        out["c%d_pred" % C], out["c%d_targ" % C], out["c%d_rgba" % C] = _np(pred), _np(targ), _np(rgba)
+    for i, (loss, single) in enumerate(STDEPTH_CASES):
+        C = 10 if single else 20
+        fn = _reference_stdepth_loss(criteria, loss, single)
+        pred, targ, rgba = [torch.from_numpy(out["c%d_%s" % (C, k)]) for k in ("pred", "targ", "rgba")]
+        p = pred.clone().requires_grad_(True)
+        total, full, terms = fn(p, targ, rgba, return_composited=True, return_loss_dict=True)
+        total.backward()
+        out["k%d_loss" % i], out["k%d_grad" % i], out["k%d_full" % i] = _np(total), _np(p.grad), _np(full)
+        out["k%d_terms" % i] = np.array([float(v) for v in terms.values()], dtype=np.float32)
+        out["k%d_names" % i] = np.array(list(terms.keys()))
+        print("stdepth %-24s single=%d  loss %.6f  %s" % (loss, single, float(total), {k: round(float(v), 5) for k, v in terms.items()}))
+    np.savez_compressed(os.path.join(HERE, "stdepth.npz"), **out)
+
+
 def gen_metrics(metrics):
     pred, tgt = depth_pair(13, (4, 1, 48, 64))
     mc = metrics.MetricComputation(["absrel", "rmse", "delta1", "delta2", "delta3", "log10"])
@@ -288,6 +347,7 @@ def main():
     criteria, metrics, FCRN = _import_reference()
     gen_losses(criteria)
     gen_vnl(criteria)
+    gen_stdepth(criteria)
     gen_metrics(metrics)
     gen_upproj(FCRN)
     gen_fcrn(criteria, metrics, FCRN)

@@ -216,3 +216,25 @@ def test_model_loss(golden):
     _close(l, g["g3_model"])
     _close(gr.numpy()[:, ::7, ::3, ::5], g["g3_model_grad_sample"], rtol=2e-4, atol=1e-8)
     _close(np.abs(gr.numpy()).sum((2, 3)), g["g3_model_grad_abs"], rtol=2e-4, atol=1e-7)
+
+
+# ---------------------------------------------------------------- G6: the stdepth composite criterion
+STDEPTH_CASES = [("mae+composite", True), ("silma", True), ("silms+fbdivergence", True), ("mse", True),
+                 ("mae+composite+ssim", True), ("allssim+colorssim", True), ("silma+mse+fbdivergence", False)]
+
+
+@pytest.mark.parametrize("i", range(len(STDEPTH_CASES)))
+def test_stdepth_loss(golden, i):
+    from oracle import stdepth as S
+    g = golden("stdepth")
+    loss, single = STDEPTH_CASES[i]
+    C = 10 if single else 20
+    pred, targ, rgba = [_t(g["c%d_%s" % (C, k)]) for k in ("pred", "targ", "rgba")]
+    p = pred.clone().requires_grad_(True)
+    total, full, terms = S.stdepth_loss(p, targ, rgba, loss, single)
+    total.backward()
+    assert list(terms.keys()) == [str(n) for n in g["k%d_names" % i]]
+    _close(total.detach(), g["k%d_loss" % i])
+    _close(torch.stack(list(terms.values())).detach(), g["k%d_terms" % i])
+    _close(full.detach(), g["k%d_full" % i], atol=1e-6)
+    _close(p.grad, g["k%d_grad" % i], rtol=1e-4, atol=1e-7)
