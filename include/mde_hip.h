@@ -285,6 +285,33 @@ int mde_vnl_fwd(const float* gt, const float* pred, const int32_t* p123, int B, 
                 float fy, int select, void* ws, float* loss, void* stream);
 int mde_vnl_bwd(const float* gt, const float* pred, const int32_t* p123, int B, int H, int W, int n, float fx,
                 float fy, const void* ws, const float* gscale, float* grad, void* stream);
+/* ---- The stdepth composite criterion (reference modules/base_module.py:124-208 `_loss`, stdepth_utils.py) ----
+ * pred, targ: [N][C][H][W] fp32, C = 10 (single layer: front RGBA, back RGBA, 2 depths) or 20 (3 depth-sorted RGBA
+ * layers, back RGBA, 4 depths); rgba [N][4][H][W].  terms = OR of MDE_ST_* (the reference selects them by substrings
+ * of method.loss; COMPOSITE_SSIM = 'composite' and 'ssim' both present).  The composite terms need C = 10, where the
+ * reference's own indexing is well-formed.  out[12] = total, depth_silog, color_mae, color_mse, all_mse, all_mae,
+ * all_ssim, front_ssim, back_ssim, composite_mse, composite_ssim, fb_divergence (unselected = 0).
+ * pred_full: optional [N][4][H][W] output, the clamped composite (any C); required when COMPOSITE_SSIM is set.
+ * scratch: caller-owned fp32, >= mde_stdepth_scratch_elems(...) elements, carried from fwd to bwd with ws
+ * (>= mde_stdepth_ws_bytes()); may be NULL when no SSIM term is selected. */
+#define MDE_ST_SILMA 1u
+#define MDE_ST_SILMS 2u
+#define MDE_ST_MSE 4u
+#define MDE_ST_MAE 8u
+#define MDE_ST_ALLSSIM 16u
+#define MDE_ST_COLORSSIM 32u
+#define MDE_ST_COMPOSITE 64u
+#define MDE_ST_COMPOSITE_SSIM 128u
+#define MDE_ST_FBDIV 256u
+size_t mde_stdepth_ws_bytes(void);
+size_t mde_stdepth_scratch_elems(int N, int C, int H, int W, unsigned terms);
+int mde_stdepth_fwd(const float* pred, const float* targ, const float* rgba, int N, int C, int H, int W,
+                    unsigned terms, float variance_focus, float depth_w, float comp_w, float fbdiv_w, float ssim_w,
+                    void* ws, float* scratch, float* pred_full, float* out, void* stream);
+int mde_stdepth_bwd(const float* pred, const float* targ, const float* rgba, int N, int C, int H, int W,
+                    unsigned terms, float variance_focus, float depth_w, float comp_w, float fbdiv_w, float ssim_w,
+                    const void* ws, float* scratch, const float* pred_full, const float* gscale, float* grad,
+                    void* stream);
 /* Depth metrics (metrics.py:58-109): out[6] = absrel, 'rmse' (= mean sqrt((p-t)^2/t), sic),
  * delta1, delta2, delta3, log10.  ws >= mde_metrics_ws_bytes(). */
 size_t mde_metrics_ws_bytes(void);

@@ -43,7 +43,7 @@ class WgradDesc(C.Structure):
     ]
 
 
-_P, _I, _L, _F, _Z = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
+_P, _I, _L, _F, _Z, _U = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t, C.c_uint
 
 # name -> (restype, argtypes); every symbol include/mde_hip.h declares
 SIGNATURES = {
@@ -95,6 +95,10 @@ SIGNATURES = {
     "mde_vnl_ws_bytes": (_Z, [_I, _I]),
     "mde_vnl_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _F, _F, _I, _P, _P, _P]),
     "mde_vnl_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _F, _F, _P, _P, _P, _P]),
+    "mde_stdepth_ws_bytes": (_Z, []),
+    "mde_stdepth_scratch_elems": (_Z, [_I, _I, _I, _I, _U]),
+    "mde_stdepth_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _U, _F, _F, _F, _F, _F, _P, _P, _P, _P, _P]),
+    "mde_stdepth_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _U, _F, _F, _F, _F, _F, _P, _P, _P, _P, _P, _P]),
     "mde_metrics_ws_bytes": (_Z, []),
     "mde_depth_metrics": (_I, [_P, _P, _L, _P, _P, _P]),
     "mde_adam_step": (_I, [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _F, _I, _P]),

@@ -443,6 +443,28 @@ def vnl_bwd(gt, pred, p123, B, H, W, n, fx, fy, ws, gscale, grad):
           "mde_vnl_bwd")
 
 
+# ------------------------------------------------------------------------------ stdepth composite criterion
+def stdepth_ws(device="cuda"):
+    return torch.zeros((_lib.load().mde_stdepth_ws_bytes() + 7) // 8, dtype=torch.float64, device=device)
+
+
+def stdepth_scratch(N, C, H, W, terms, device="cuda"):
+    n = _lib.load().mde_stdepth_scratch_elems(N, C, H, W, terms)
+    return torch.empty(n, dtype=torch.float32, device=device) if n else None
+
+
+def stdepth_fwd(pred, targ, rgba, N, C, H, W, terms, weights, ws, scratch, pred_full, out):
+    vf, dw, cw, fw, sw = weights
+    check(_lib.load().mde_stdepth_fwd(_p(pred), _p(targ), _p(rgba), N, C, H, W, terms, vf, dw, cw, fw, sw, _p(ws),
+                                      _p(scratch), _p(pred_full), _p(out), _stream()), "mde_stdepth_fwd")
+
+
+def stdepth_bwd(pred, targ, rgba, N, C, H, W, terms, weights, ws, scratch, pred_full, gscale, grad):
+    vf, dw, cw, fw, sw = weights
+    check(_lib.load().mde_stdepth_bwd(_p(pred), _p(targ), _p(rgba), N, C, H, W, terms, vf, dw, cw, fw, sw, _p(ws),
+                                      _p(scratch), _p(pred_full), _p(gscale), _p(grad), _stream()), "mde_stdepth_bwd")
+
+
 def metrics_ws(device="cuda"):
     return torch.zeros((_lib.load().mde_metrics_ws_bytes() + 7) // 8, dtype=torch.float64, device=device)
 
