@@ -69,27 +69,39 @@ __device__ __forceinline__ void composite(const float (*ly)[4], int L, float (&u
     un[0] = r; un[1] = g; un[2] = b; un[3] = a;
 }
 
-// the layers of pixel p in compositing order (single layer: front, back; multi: 3 layers stably sorted by their
-// depth channel 16 + i, then back)
-__device__ __forceinline__ int load_layers(const float* __restrict__ px, int64_t HW, int C, float (*ly)[4]) {
-    if (C == 10) {
+// the layers of one pixel (its CC channel values in v[]) in compositing order: single layer = front, back;
+// multi = 3 layers stably sorted by their depth channel 16 + i, then back
+template <int CC>
+__device__ __forceinline__ int load_layers(const float (&v)[CC], float (*ly)[4]) {
+    if constexpr (CC == 10) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) ly[i][c] = px[(int64_t)(4 * i + c) * HW];
+            for (int c = 0; c < 4; ++c) ly[i][c] = v[4 * i + c];
         return 2;
-    }
-    int o[3] = {0, 1, 2};
-    float d[3];
+    } else {
+        float d[3] = {v[16], v[17], v[18]};
+        float l[3][4];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) d[i] = px[(int64_t)(16 + i) * HW];
-#define ST_SWAP(i, j) if (d[o[j]] < d[o[i]]) { const int t = o[i]; o[i] = o[j]; o[j] = t; }
-    ST_SWAP(0, 1) ST_SWAP(1, 2) ST_SWAP(0, 1)          // insertion network on indices: equal keys keep their order
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) l[i][c] = v[4 * i + c];
+        // bubble network with strict compares, rows swapped together with their keys: equal keys keep their order
+#define ST_SWAP(i, j)                                                                         \
+    if (d[j] < d[i]) {                                                                        \
+        const float t = d[i]; d[i] = d[j]; d[j] = t;                                          \
+        for (int c = 0; c < 4; ++c) { const float u = l[i][c]; l[i][c] = l[j][c]; l[j][c] = u; } \
+    }
+        ST_SWAP(0, 1) ST_SWAP(1, 2) ST_SWAP(0, 1)
 #undef ST_SWAP
-    for (int i = 0; i < 3; ++i)
-        for (int c = 0; c < 4; ++c) ly[i][c] = px[(int64_t)(4 * o[i] + c) * HW];
-    for (int c = 0; c < 4; ++c) ly[3][c] = px[(int64_t)(12 + c) * HW];
-    return 4;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) ly[i][c] = l[i][c];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) ly[3][c] = v[12 + c];
+        return 4;
+    }
 }
 
 __global__ void st_init_k(StHead* h) {
@@ -100,6 +112,7 @@ __global__ void st_init_k(StHead* h) {
     if (t < 12) h->out[t] = 0.f;
 }
 
+template <int CC>
 __global__ __launch_bounds__(NT) void st_reduce_k(const float* __restrict__ pred, const float* __restrict__ targ,
                                                   const float* __restrict__ rgba, StCfg g, float* __restrict__ pred_full,
                                                   StHead* h) {
@@ -117,10 +130,16 @@ __global__ __launch_bounds__(NT) void st_reduce_k(const float* __restrict__ pred
         float a[NSUM];
 #pragma unroll
         for (int k = 0; k < NSUM; ++k) a[k] = 0.f;
+        // every channel of the pixel is loaded up front (CC is a template constant: the loops unroll and the
+        // 2*CC + 4 loads are in flight together instead of one dependent trip per channel)
+        float pv[CC], tv[CC];
+#pragma unroll
+        for (int c = 0; c < CC; ++c) { pv[c] = pp[(int64_t)c * HW]; tv[c] = tp[(int64_t)c * HW]; }
         if (m1) {
             a[0] = 1.f;
-            for (int c = 0; c < g.C; ++c) {
-                const float d = pp[(int64_t)c * HW] - tp[(int64_t)c * HW];
+#pragma unroll
+            for (int c = 0; c < CC; ++c) {
+                const float d = pv[c] - tv[c];
                 if (c < 8) { a[1] += fabsf(d); a[2] += d * d; }
                 a[3] += fabsf(d);
                 a[4] += d * d;
@@ -128,20 +147,18 @@ __global__ __launch_bounds__(NT) void st_reduce_k(const float* __restrict__ pred
             if (g.terms & T_FBDIV) {
                 float A[3], B[3], A2[3], B2[3];
 #pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    A[c] = pp[(int64_t)c * HW]; B[c] = tp[(int64_t)(4 + c) * HW];
-                    A2[c] = pp[(int64_t)(4 + c) * HW]; B2[c] = tp[(int64_t)c * HW];
-                }
+                for (int c = 0; c < 3; ++c) { A[c] = pv[c]; B[c] = tv[4 + c]; A2[c] = pv[4 + c]; B2[c] = tv[c]; }
                 const float m_1 = sqrtf(A[0] * A[0] + A[1] * A[1] + A[2] * A[2]) * sqrtf(B[0] * B[0] + B[1] * B[1] + B[2] * B[2]) + 1e-3f;
                 const float m_2 = sqrtf(A2[0] * A2[0] + A2[1] * A2[1] + A2[2] * A2[2]) * sqrtf(B2[0] * B2[0] + B2[1] * B2[1] + B2[2] * B2[2]) + 1e-3f;
                 a[12] = (A[0] * B[0] / m_1 + A[1] * B[1] / m_1 + A[2] * B[2] / m_1) +
                         (A2[0] * B2[0] / m_2 + A2[1] * B2[1] / m_2 + A2[2] * B2[2] / m_2);
             }
         }
-        for (int c = g.d0; c < g.d1; ++c) {            // the depth mask is its own (targ > 0), independent of alpha
-            const float t = tp[(int64_t)c * HW];
+#pragma unroll
+        for (int c = (CC == 10 ? 8 : 16); c < CC; ++c) {   // the depth mask is its own (targ > 0), independent of alpha
+            const float t = tv[c];
             if (t > 0.f) {
-                const float q = pp[(int64_t)c * HW], d = q - t;
+                const float q = pv[c], d = q - t;
                 a[5] += 1.f; a[6] += fabsf(d); a[7] += d * d;
                 if (t > 1e-2f) {                         // silog's own validity test inside the masked vector
                     const float dl = logf(q) - logf(t);
@@ -151,7 +168,7 @@ __global__ __launch_bounds__(NT) void st_reduce_k(const float* __restrict__ pred
         }
         if (pred_full || (g.terms & (T_COMPOSITE | T_COMPOSITE_SSIM))) {
             float ly[4][4], un[4];
-            const int L = load_layers(pp, HW, g.C, ly);
+            const int L = load_layers<CC>(pv, ly);
             composite(ly, L, un);
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
@@ -214,6 +231,7 @@ __global__ void st_finalize_k(StHead* h, StCfg g, float* out) {
 }
 
 // gfull: d loss / d pred_full from the composite SSIM term (already scaled), or null
+template <int CC>
 __global__ __launch_bounds__(NT) void st_bwd_k(const float* __restrict__ pred, const float* __restrict__ targ,
                                                const float* __restrict__ rgba, StCfg g, const StHead* __restrict__ h,
                                                const float* __restrict__ gscale, const float* __restrict__ gfull,
@@ -230,25 +248,23 @@ __global__ __launch_bounds__(NT) void st_bwd_k(const float* __restrict__ pred, c
         const float* rp = rgba + n * 4 * HW + p;
         float* gp = grad + n * g.C * HW + p;
         const bool m1 = rp[3 * HW] > 0.f;
-        float gr[MAXC];
+        float gr[CC], pv[CC], tv[CC];
 #pragma unroll
-        for (int c = 0; c < MAXC; ++c) gr[c] = 0.f;
+        for (int c = 0; c < CC; ++c) { gr[c] = 0.f; pv[c] = pp[(int64_t)c * HW]; tv[c] = tp[(int64_t)c * HW]; }
         if (m1) {
 #pragma unroll
-            for (int c = 0; c < MAXC; ++c) {
-                if (c < g.C) {
-                    const float d = pp[(int64_t)c * HW] - tp[(int64_t)c * HW];
-                    float v = k_amae * sgn(d) + k_amse * d;
-                    if (c < 8) v += k_cmae * sgn(d) + k_cmse * d;
-                    gr[c] = v;
-                }
+            for (int c = 0; c < CC; ++c) {
+                const float d = pv[c] - tv[c];
+                float v = k_amae * sgn(d) + k_amse * d;
+                if (c < 8) v += k_cmae * sgn(d) + k_cmse * d;
+                gr[c] = v;
             }
             if (k_fb != 0.f) {
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {          // (pred[:, :3], targ[:, 4:7]) and (pred[:, 4:7], targ[:, :3])
                     float A[3], B[3];
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) { A[c] = pp[(int64_t)(4 * s + c) * HW]; B[c] = tp[(int64_t)(4 * (1 - s) + c) * HW]; }
+                    for (int c = 0; c < 3; ++c) { A[c] = pv[4 * s + c]; B[c] = tv[4 * (1 - s) + c]; }
                     const float nA = sqrtf(A[0] * A[0] + A[1] * A[1] + A[2] * A[2]);
                     const float nB = sqrtf(B[0] * B[0] + B[1] * B[1] + B[2] * B[2]);
                     const float mag = nA * nB + 1e-3f;
@@ -260,20 +276,18 @@ __global__ __launch_bounds__(NT) void st_bwd_k(const float* __restrict__ pred, c
             }
         }
 #pragma unroll
-        for (int c = 0; c < MAXC; ++c) {
-            if (c >= g.d0 && c < g.d1) {
-                const float t = tp[(int64_t)c * HW];
-                if (t > 0.f) {
-                    const float q = pp[(int64_t)c * HW], d = q - t;
-                    float v = k_dmae * sgn(d) + k_dmse * d;
-                    if (t > 1e-2f) v += k_sil * ((logf(q) - logf(t)) - g.lambda * sil_mean) / q;
-                    gr[c] += v;
-                }
+        for (int c = (CC == 10 ? 8 : 16); c < CC; ++c) {
+            const float t = tv[c];
+            if (t > 0.f) {
+                const float q = pv[c], d = q - t;
+                float v = k_dmae * sgn(d) + k_dmse * d;
+                if (t > 1e-2f) v += k_sil * ((logf(q) - logf(t)) - g.lambda * sil_mean) / q;
+                gr[c] += v;
             }
         }
-        if (g.C == 10 && (k_comp != 0.f || gfull)) {
+        if (CC == 10 && (k_comp != 0.f || gfull)) {
             float ly[4][4], un[4], e[4];
-            load_layers(pp, HW, g.C, ly);
+            load_layers<CC>(pv, ly);
             composite(ly, 2, un);
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
@@ -299,8 +313,7 @@ __global__ __launch_bounds__(NT) void st_bwd_k(const float* __restrict__ pred, c
             gr[7] += ga1;
         }
 #pragma unroll
-        for (int c = 0; c < MAXC; ++c)
-            if (c < g.C) gp[(int64_t)c * HW] = gr[c];
+        for (int c = 0; c < CC; ++c) gp[(int64_t)c * HW] = gr[c];
     }
 }
 
@@ -498,7 +511,8 @@ extern "C" int mde_stdepth_fwd(const float* pred, const float* targ, const float
         abc_pred = scratch + 20 * plane;
     }
     st_init_k<<<1, 64, 0, st>>>(h);
-    st_reduce_k<<<grid_for(plane), NT, 0, st>>>(pred, targ, rgba, g, full, h);
+    if (C == 10) st_reduce_k<10><<<grid_for(plane), NT, 0, st>>>(pred, targ, rgba, g, full, h);
+    else st_reduce_k<20><<<grid_for(plane), NT, 0, st>>>(pred, targ, rgba, g, full, h);
     MDE_LAUNCH_CHECK("st_reduce_k");
     const int tiles_x = mde_cdiv(W, TW), tiles = tiles_x * mde_cdiv(H, TH);
     const Gauss gw = make_gauss();
@@ -538,7 +552,8 @@ extern "C" int mde_stdepth_bwd(const float* pred, const float* targ, const float
         gfull = gf;
         abc_pred = scratch + 20 * plane;
     }
-    st_bwd_k<<<grid_for(plane), NT, 0, st>>>(pred, targ, rgba, g, h, gscale, gfull, grad);
+    if (C == 10) st_bwd_k<10><<<grid_for(plane), NT, 0, st>>>(pred, targ, rgba, g, h, gscale, gfull, grad);
+    else st_bwd_k<20><<<grid_for(plane), NT, 0, st>>>(pred, targ, rgba, g, h, gscale, gfull, grad);
     MDE_LAUNCH_CHECK("st_bwd_k");
     if (needs_ssim_pred(terms)) {
         ssim_bwd_k<<<dim3(tiles, C, N), NT, 0, st>>>(pred, targ, abc_pred, plane * C, C, H, W, tiles_x, gw, &h->k_ssim_all,
