@@ -517,3 +517,41 @@ def test_state_dict_round_trip(setup):
     assert hip._store.storage_is_current()
     with torch.no_grad():
         assert torch.equal(hip(rgb.cuda()), y0)
+
+
+def test_laina_default_step_stdepth_criterion():
+    """What the reference's FCRNModule trains with by default: `FCRN.ResNet(output_size, out_channels=10)`
+    (laina.py:15) under the composite criterion 'mae+composite' (laina.py:71, base_module.py:124-208) and an Adam
+    step.  Train-mode loss and its per-term dict equal the oracle's on the same weights; every parameter gets a
+    finite gradient; the sigmoid output feeds the compositing directly."""
+    import types
+    from oracle import stdepth as OS
+    from mono_depth_estimation_amd import stdepth
+    from mono_depth_estimation_amd.network import FCRN
+    size = (96, 128)
+    ora = ofcrn.FCRNOracle(50, size, out_channels=10)
+    W.fcrn_conditioned_state(ora, 77)
+    rgb, _ = W.synthetic_batch(77, 2, *size)
+    targ = W.uniform(77, "targ", (2, 10) + size, 0.0, 1.0)
+    targ[:, 8:] = targ[:, 8:].masked_fill(W.uniform(77, "dh", (2, 2) + size) < 0.2, 0.0)
+    rgba = W.uniform(77, "rgba", (2, 4) + size, 0.0, 1.0)
+    rgba[:, 3] = rgba[:, 3].masked_fill(W.uniform(77, "ah", (2,) + size) < 0.3, 0.0)
+    net = FCRN.ResNet(layers=50, output_size=size, out_channels=10, pretrained=False)
+    net.load_state_dict(ora.state_dict())
+    net = net.cuda().train()
+    ora.train()
+    method = types.SimpleNamespace(loss="mae+composite", variance_focus=0.85, depth_loss_weight=10.0, comp_loss_weight=2.0,
+                                   fbdiv_loss_weight=0.2, ssim_loss_weight=2.0)
+    crit = stdepth.setup_criterion(method, single_layer=True)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-4)
+    loss, terms = crit(net(rgb.cuda()), targ.cuda(), rgba.cuda(), return_loss_dict=True)
+    loss.backward()
+    with torch.no_grad():
+        ref, _, rterms = OS.stdepth_loss(ora(rgb), targ, rgba, "mae+composite", True)
+    assert abs(float(loss.detach()) - float(ref)) <= 2e-3 * abs(float(ref)), (float(loss.detach()), float(ref))
+    for k in rterms:
+        assert abs(float(terms[k]) - float(rterms[k])) <= 3e-3 * abs(float(rterms[k])) + 1e-5, k
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters())
+    opt.step()
+    l2, = crit(net(rgb.cuda()), targ.cuda(), rgba.cuda())
+    assert float(l2.detach()) < float(loss.detach())
