@@ -327,6 +327,15 @@ int mde_depth_metrics(const float* pred, const float* target, int64_t n, void* w
 int mde_adam_step(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, float lr,
                   float beta1, float beta2, float eps, float weight_decay, float grad_scale, int step,
                   void* stream);
+/* torch.optim.AdamW (modules/bts.py:139-152: eps 1e-3, weight_decay 1e-2 / 0): same contract as mde_adam_step, the
+ * decay is decoupled (p *= 1 - lr * weight_decay before the Adam update; the moments never see it). */
+int mde_adamw_step(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, float lr,
+                   float beta1, float beta2, float eps, float weight_decay, float grad_scale, int step,
+                   void* stream);
+/* torch.optim.SGD with momentum (modules/vnl.py:289-326: momentum 0.9, weight_decay 5e-4; dampening 0, no Nesterov):
+ * g' = grad_scale * g + weight_decay * p; buf = momentum * buf + g'; p -= lr * buf.  buf starts at zero. */
+int mde_sgd_step(float* p, const float* g, float* buf, void* p_bf16, int64_t n, float lr, float momentum,
+                 float weight_decay, float grad_scale, void* stream);
 /* bf16 cast of a flat fp32 range (weight shadow refresh after load_state_dict). */
 int mde_cast_bf16(const float* src, void* dst, int64_t n, void* stream);
 /* dst[i][t][o] = bf16(src[o][t][i])  — the dgrad ("transposed") weight packing. */

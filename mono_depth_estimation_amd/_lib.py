@@ -102,6 +102,8 @@ SIGNATURES = {
     "mde_metrics_ws_bytes": (_Z, []),
     "mde_depth_metrics": (_I, [_P, _P, _L, _P, _P, _P]),
     "mde_adam_step": (_I, [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _F, _I, _P]),
+    "mde_adamw_step": (_I, [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _F, _I, _P]),
+    "mde_sgd_step": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _P]),
     "mde_cast_bf16": (_I, [_P, _P, _L, _P]),
     "mde_pack_wt": (_I, [_P, _P, _I, _I, _I, _P]),
     "mde_pack_wt_batch": (_I, [_P, _P, _P, _I, _L, _P]),

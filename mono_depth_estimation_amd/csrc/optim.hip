@@ -9,11 +9,15 @@ namespace {
 
 constexpr int NT = 256;
 
+// DEC = false: torch.optim.Adam (L2: the decay joins the gradient); DEC = true: torch.optim.AdamW (the parameter is
+// first scaled by 1 - lr * wd, the moments never see the decay)
+template <bool DEC>
 __global__ __launch_bounds__(NT) void adam_k(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                              float* __restrict__ v, bf16_t* __restrict__ pb, int64_t n, float lr,
                                              float b1, float b2, float eps, float wd, float gs, float bc1, float bc2s) {
     // bc1 = 1 - b1^t ; bc2s = sqrt(1 - b2^t)
     const float step = lr / bc1;
+    const float keep = DEC ? 1.f - lr * wd : 1.f, l2 = DEC ? 0.f : wd;
     for (int64_t i = ((int64_t)blockIdx.x * NT + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * NT * 4) {
         if (i + 4 <= n) {
             f32x4_t pp = *reinterpret_cast<f32x4_t*>(p + i);
@@ -21,7 +25,8 @@ __global__ __launch_bounds__(NT) void adam_k(float* __restrict__ p, const float*
             f32x4_t mm = *reinterpret_cast<f32x4_t*>(m + i), vv = *reinterpret_cast<f32x4_t*>(v + i);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float ge = gg[e] * gs + wd * pp[e];
+                if (DEC) pp[e] *= keep;
+                const float ge = gg[e] * gs + l2 * pp[e];
                 mm[e] = b1 * mm[e] + (1.f - b1) * ge;
                 vv[e] = b2 * vv[e] + (1.f - b2) * ge * ge;
                 pp[e] -= step * mm[e] / (sqrtf(vv[e]) / bc2s + eps);
@@ -37,10 +42,42 @@ __global__ __launch_bounds__(NT) void adam_k(float* __restrict__ p, const float*
             }
         } else {
             for (int64_t j = i; j < n; ++j) {
-                const float ge = g[j] * gs + wd * p[j];
+                if (DEC) p[j] *= keep;
+                const float ge = g[j] * gs + l2 * p[j];
                 m[j] = b1 * m[j] + (1.f - b1) * ge;
                 v[j] = b2 * v[j] + (1.f - b2) * ge * ge;
                 p[j] -= step * m[j] / (sqrtf(v[j]) / bc2s + eps);
+                if (pb) pb[j] = (bf16_t)p[j];
+            }
+        }
+    }
+}
+
+// torch.optim.SGD with momentum (dampening 0, no Nesterov): g += wd * p; buf = mu * buf + g; p -= lr * buf.
+// A zero-initialised buf makes the first step buf = g, as torch does.
+__global__ __launch_bounds__(NT) void sgd_k(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
+                                            bf16_t* __restrict__ pb, int64_t n, float lr, float mu, float wd, float gs) {
+    for (int64_t i = ((int64_t)blockIdx.x * NT + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * NT * 4) {
+        if (i + 4 <= n) {
+            f32x4_t pp = *reinterpret_cast<f32x4_t*>(p + i), bb = *reinterpret_cast<f32x4_t*>(buf + i);
+            const f32x4_t gg = *reinterpret_cast<const f32x4_t*>(g + i);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                bb[e] = mu * bb[e] + (gg[e] * gs + wd * pp[e]);
+                pp[e] -= lr * bb[e];
+            }
+            *reinterpret_cast<f32x4_t*>(p + i) = pp;
+            *reinterpret_cast<f32x4_t*>(buf + i) = bb;
+            if (pb) {
+                bf16x4_t o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (bf16_t)pp[e];
+                *reinterpret_cast<bf16x4_t*>(pb + i) = o;
+            }
+        } else {
+            for (int64_t j = i; j < n; ++j) {
+                buf[j] = mu * buf[j] + (g[j] * gs + wd * p[j]);
+                p[j] -= lr * buf[j];
                 if (pb) pb[j] = (bf16_t)p[j];
             }
         }
@@ -122,9 +159,33 @@ extern "C" int mde_adam_step(float* p, const float* g, float* m, float* v, void*
                 "mde_adam_step: ranges must be 16-byte aligned");
     const float bc1 = 1.f - powf(beta1, (float)step);
     const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
-    adam_k<<<grid_for4(n), NT, 0, (hipStream_t)stream>>>(p, g, m, v, (bf16_t*)p_bf16, n, lr, beta1, beta2, eps,
-                                                        weight_decay, grad_scale, bc1, bc2s);
+    adam_k<false><<<grid_for4(n), NT, 0, (hipStream_t)stream>>>(p, g, m, v, (bf16_t*)p_bf16, n, lr, beta1, beta2, eps,
+                                                               weight_decay, grad_scale, bc1, bc2s);
     MDE_LAUNCH_CHECK("adam_k");
+    return MDE_OK;
+}
+
+extern "C" int mde_adamw_step(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, float lr, float beta1,
+                              float beta2, float eps, float weight_decay, float grad_scale, int step, void* stream) {
+    MDE_REQUIRE(p && g && m && v && n > 0 && step >= 1, "mde_adamw_step: bad argument");
+    MDE_REQUIRE(((uintptr_t)p % 16) == 0 && ((uintptr_t)g % 16) == 0 && ((uintptr_t)m % 16) == 0 && ((uintptr_t)v % 16) == 0 &&
+                    ((uintptr_t)p_bf16 % 8) == 0,
+                "mde_adamw_step: ranges must be 16-byte aligned");
+    const float bc1 = 1.f - powf(beta1, (float)step);
+    const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
+    adam_k<true><<<grid_for4(n), NT, 0, (hipStream_t)stream>>>(p, g, m, v, (bf16_t*)p_bf16, n, lr, beta1, beta2, eps,
+                                                              weight_decay, grad_scale, bc1, bc2s);
+    MDE_LAUNCH_CHECK("adam_k<AdamW>");
+    return MDE_OK;
+}
+
+extern "C" int mde_sgd_step(float* p, const float* g, float* buf, void* p_bf16, int64_t n, float lr, float momentum,
+                            float weight_decay, float grad_scale, void* stream) {
+    MDE_REQUIRE(p && g && buf && n > 0, "mde_sgd_step: bad argument");
+    MDE_REQUIRE(((uintptr_t)p % 16) == 0 && ((uintptr_t)g % 16) == 0 && ((uintptr_t)buf % 16) == 0 && ((uintptr_t)p_bf16 % 8) == 0,
+                "mde_sgd_step: ranges must be 16-byte aligned");
+    sgd_k<<<grid_for4(n), NT, 0, (hipStream_t)stream>>>(p, g, buf, (bf16_t*)p_bf16, n, lr, momentum, weight_decay, grad_scale);
+    MDE_LAUNCH_CHECK("sgd_k");
     return MDE_OK;
 }
 

@@ -164,6 +164,7 @@ class ParamStore:
         self.convs = {}           # id(first weight) -> Conv (shared packings)
         self.packed_version = -1
         self.adam_state = None
+        self.sgd_state = None
         self.step_count = 0
         self._flatten_parameters()
 
@@ -347,19 +348,34 @@ class ParamStore:
             ops.pack_wt_batch(self.P, self.WD, jobs, nblocks)
 
     # fused Adam over the two flat ranges (encoder 1x LR, decoder 10x LR: modules/laina.py:51-57)
-    def adam_step(self, lr_encoder, lr_decoder, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, grad_scale=1.0):
+    def adam_step(self, lr_encoder, lr_decoder, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, grad_scale=1.0,
+                  decoupled=False):
+        """decoupled=True: torch.optim.AdamW (modules/bts.py:139-152), weight_decay a scalar or an (encoder, decoder)
+        pair as BTS configures it (1e-2 / 0)."""
         if self.adam_state is None:
             self.adam_state = (torch.zeros_like(self.P), torch.zeros_like(self.P))
         mom, var = self.adam_state
         self.step_count += 1
         e, n = self.encoder_numel, self.P.numel()
         G = self.grad_buffer()
-        ops.adam_step(self.P, G, mom, var, self.Pb, e, lr_encoder, betas[0], betas[1], eps, weight_decay, grad_scale,
-                      self.step_count)
-        ops.adam_step(self.P[e:], G[e:], mom[e:], var[e:], self.Pb[e:], n - e, lr_decoder, betas[0], betas[1], eps,
-                      weight_decay, grad_scale, self.step_count)
+        wd = weight_decay if isinstance(weight_decay, (tuple, list)) else (weight_decay, weight_decay)
+        step = ops.adamw_step if decoupled else ops.adam_step
+        step(self.P, G, mom, var, self.Pb, e, lr_encoder, betas[0], betas[1], eps, wd[0], grad_scale, self.step_count)
+        step(self.P[e:], G[e:], mom[e:], var[e:], self.Pb[e:], n - e, lr_decoder, betas[0], betas[1], eps, wd[1],
+             grad_scale, self.step_count)
         self.repack()
         self.packed_version = self.params_version()   # shadow + packings are current (the kernels bump no version counter)
+
+    # fused SGD with momentum over the same two ranges (modules/vnl.py:289-326: momentum 0.9, weight_decay 5e-4)
+    def sgd_step(self, lr_encoder, lr_decoder, momentum=0.9, weight_decay=0.0, grad_scale=1.0):
+        if self.sgd_state is None:
+            self.sgd_state = torch.zeros_like(self.P)
+        e, n = self.encoder_numel, self.P.numel()
+        G, buf = self.grad_buffer(), self.sgd_state
+        ops.sgd_step(self.P, G, buf, self.Pb, e, lr_encoder, momentum, weight_decay, grad_scale)
+        ops.sgd_step(self.P[e:], G[e:], buf[e:], self.Pb[e:], n - e, lr_decoder, momentum, weight_decay, grad_scale)
+        self.repack()
+        self.packed_version = self.params_version()
 
 
 class FCRNEngine:

@@ -475,6 +475,16 @@ def depth_metrics(pred, target, ws, out):
 
 
 # ------------------------------------------------------------------------------ optimiser plumbing
+def adamw_step(p, g, m, v, p_bf16, n, lr, beta1, beta2, eps, weight_decay, grad_scale, step):
+    check(_lib.load().mde_adamw_step(_p(p), _p(g), _p(m), _p(v), _p(p_bf16), n, lr, beta1, beta2, eps, weight_decay,
+                                     grad_scale, step, _stream()), "mde_adamw_step")
+
+
+def sgd_step(p, g, buf, p_bf16, n, lr, momentum, weight_decay, grad_scale):
+    check(_lib.load().mde_sgd_step(_p(p), _p(g), _p(buf), _p(p_bf16), n, lr, momentum, weight_decay, grad_scale, _stream()),
+          "mde_sgd_step")
+
+
 def adam_step(p, g, m, v, p_bf16, n, lr, beta1, beta2, eps, weight_decay, grad_scale, step):
     check(_lib.load().mde_adam_step(_p(p), _p(g), _p(m), _p(v), _p(p_bf16), n, lr, beta1, beta2, eps, weight_decay,
                                     grad_scale, step, _stream()), "mde_adam_step")

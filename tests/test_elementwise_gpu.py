@@ -387,6 +387,31 @@ def test_adam_matches_torch():
     assert torch.equal(pb.cpu(), pd.cpu().to(torch.bfloat16))
 
 
+def test_adamw_and_sgd_match_torch():
+    """The other optimiser configurations of SURVEY §8 row O: AdamW eps 1e-3 wd 1e-2 (bts.py:139-152) and SGD momentum
+    0.9 wd 5e-4 (vnl.py:289-326), three steps each against torch.optim on the CPU."""
+    from mono_depth_estimation_amd import ops
+    n = 100003
+    p0 = W.normal(15, "p", (n,))
+    gs = [W.normal(15, "g%d" % i, (n,), 0.5) for i in range(3)]
+    pa, ps = torch.nn.Parameter(p0.clone()), torch.nn.Parameter(p0.clone())
+    adamw = torch.optim.AdamW([pa], lr=1e-3, betas=(0.9, 0.999), eps=1e-3, weight_decay=1e-2)
+    sgd = torch.optim.SGD([ps], lr=1e-2, momentum=0.9, weight_decay=5e-4)
+    da, m, v = p0.clone().cuda(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    ds, buf = p0.clone().cuda(), torch.zeros(n, device="cuda")
+    ba, bs = torch.empty(n, dtype=torch.bfloat16, device="cuda"), torch.empty(n, dtype=torch.bfloat16, device="cuda")
+    for step, g in enumerate(gs, 1):
+        pa.grad, ps.grad = g.clone(), g.clone()
+        adamw.step()
+        sgd.step()
+        ops.adamw_step(da, (4.0 * g).cuda(), m, v, ba, n, 1e-3, 0.9, 0.999, 1e-3, 1e-2, 0.25, step)
+        ops.sgd_step(ds, (4.0 * g).cuda(), buf, bs, n, 1e-2, 0.9, 5e-4, 0.25)
+    torch.cuda.synchronize()
+    assert torch.allclose(da.cpu(), pa.detach(), rtol=1e-5, atol=1e-7)
+    assert torch.allclose(ds.cpu(), ps.detach(), rtol=1e-5, atol=1e-7)
+    assert torch.equal(ba.cpu(), da.cpu().to(torch.bfloat16)) and torch.equal(bs.cpu(), ds.cpu().to(torch.bfloat16))
+
+
 def test_cast_and_pack():
     from mono_depth_estimation_amd import ops
     O, T, I = 70, 9, 130

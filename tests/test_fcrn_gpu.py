@@ -555,3 +555,40 @@ def test_laina_default_step_stdepth_criterion():
     opt.step()
     l2, = crit(net(rgb.cuda()), targ.cuda(), rgba.cuda())
     assert float(l2.detach()) < float(loss.detach())
+
+
+def test_fused_adamw_and_sgd_steps_on_the_store():
+    """ParamStore.adam_step(decoupled=True) / sgd_step against torch.optim.AdamW / SGD applied to the same module
+    gradients (two-group learning rates, the BTS / VNL hyper-parameters)."""
+    from mono_depth_estimation_amd import criteria
+    from mono_depth_estimation_amd.network import FCRN
+    size = (64, 96)
+    rgb, tgt = W.synthetic_batch(31, 2, *size)
+    for kind in ("adamw", "sgd"):
+        torch.manual_seed(0)
+        net = FCRN.ResNet(layers=50, output_size=size, out_channels=1, pretrained=False).cuda().train()
+        loss = criteria.silog_loss(0.85)(net(rgb.cuda()), tgt.cuda())
+        loss.backward()
+        names = [n for n, _ in net.named_parameters()]
+        before = {n: p.detach().clone() for n, p in net.named_parameters()}
+        grads = {n: p.grad.detach().clone() for n, p in net.named_parameters()}
+        enc = {id(p) for p in net.get_1x_lr_params()}
+        ref = {n: torch.nn.Parameter(before[n].clone()) for n in names}
+        g_enc = [ref[n] for n, p in net.named_parameters() if id(p) in enc]
+        g_dec = [ref[n] for n, p in net.named_parameters() if id(p) not in enc]
+        if kind == "adamw":
+            opt = torch.optim.AdamW([{"params": g_enc, "lr": 1e-4, "weight_decay": 1e-2},
+                                     {"params": g_dec, "lr": 1e-3, "weight_decay": 0.0}], eps=1e-3)
+        else:
+            opt = torch.optim.SGD([{"params": g_enc, "lr": 1e-3}, {"params": g_dec, "lr": 1e-2}], momentum=0.9, weight_decay=5e-4)
+        for n in names:
+            ref[n].grad = grads[n].clone()
+        opt.step()
+        if kind == "adamw":
+            net._store.adam_step(1e-4, 1e-3, eps=1e-3, weight_decay=(1e-2, 0.0), decoupled=True)
+        else:
+            net._store.sgd_step(1e-3, 1e-2, momentum=0.9, weight_decay=5e-4)
+        for n, p in net.named_parameters():
+            assert torch.allclose(p.detach(), ref[n].detach(), rtol=1e-5, atol=1e-7), (kind, n)
+        y = net(rgb.cuda())                      # the convs see the updated weights (shadow + packings refreshed)
+        assert bool(torch.isfinite(y).all())
