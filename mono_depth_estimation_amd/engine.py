@@ -195,8 +195,15 @@ class ParamStore:
                 conv_bn(blk.downsample[0], blk.downsample[1])
         self.n_encoder_entries = len(plist)
         conv_bn(m.conv2, m.bn2)
+        kind = getattr(m.upSample, "kind", "upproj")
         for name in ("layer1", "layer2", "layer3", "layer4"):
             up = getattr(m.upSample, name)
+            if kind == "upconv":
+                conv_bn(up.conv, up.batchnorm)
+                continue
+            if kind == "deconv":
+                conv_bn(getattr(up, "deconv%d" % m.upSample.kernel_size), up.batchnorm)
+                continue
             ub, bb = up.upper_branch, up.bottom_branch
             plist.append(("w", [ub.conv1.weight, bb.conv.weight]))          # fused [2C][25][Cin]
             plist.append(("g", [ub.batchnorm1.weight, bb.batchnorm.weight]))
@@ -441,7 +448,14 @@ class FCRNEngine:
         self.layers.append(L)
         x = L.out
         for name in ("layer1", "layer2", "layer3", "layer4"):
-            L = UpProjLayer(self, x, getattr(m.upSample, name))
+            mod = getattr(m.upSample, name)
+            kind = getattr(m.upSample, "kind", "upproj")
+            if kind == "upproj":
+                L = UpProjLayer(self, x, mod)
+            elif kind == "upconv":
+                L = UpConvLayer(self, x, mod)
+            else:
+                L = DeConvLayer(self, x, mod, m.upSample.kernel_size)
             self.layers.append(L)
             x = L.out
         self.feat = x                                   # [N][H/2][W/2][64] for the standard net
@@ -697,4 +711,93 @@ class UpProjLayer:
         self.eng.wgrad(self.wdesc, x.t, yg, self.w55.dw)
         self.ddesc.accumulate = int(x.gw)
         ops.conv_gemm(self.ddesc, yg, self.w55.wd, x.g)
+        x.gw = True
+
+
+class UpConvLayer:
+    """reference network/FCRN.py:91-110 (`UpConv.upconv_module`): unpool -> 5x5 conv -> BN -> ReLU, the zero-stuffed
+    tensor never materialised: the 5x5 runs as four output phases over x (a quarter of the dense taps)."""
+
+    def __init__(self, eng, x, mod):
+        self.eng, self.x, self.mod = eng, x, mod
+        dev, N, h, w, Cin = eng.dev, x.N, x.H, x.W, x.C
+        C = Cin // 2
+        self.w = eng._conv([mod.conv.weight])
+        self.site = eng._site([mod.batchnorm])
+        self.y = Act(dev, N, 2 * h, 2 * w, C)          # pre-BN
+        self.out = Act(dev, N, 2 * h, 2 * w, C)
+        self.fdescs = ops.upproj_fwd_descs(N, h, w, x.ld, Cin, x.nbytes, C, C)
+        self.ddesc = ops.upproj_dgrad_desc(N, h, w, x.ld, Cin, C, C, self.y.nbytes)
+        self.wdesc = ops.upproj_wgrad_desc(N, h, w, x.ld, Cin, x.nbytes, C, C, self.y.nbytes, eng._ksplit(x.M, C, Cin, 25))
+
+    def first_param_offset(self):
+        return self.eng.store.p_off[id(self.mod.conv.weight)]
+
+    def reset_grad_flags(self):
+        self.y.gw = self.out.gw = False
+
+    def fwd(self, train):
+        x, y, s = self.x, self.y, self.site
+        for d in self.fdescs:
+            ops.conv_gemm(d, x.t, self.w.wf, y.t, s.part if train else None)
+        s.finalize(y.M, train)
+        ops.bn_apply(y.t, y.ld, s.scale, s.shift, self.out.t, self.out.ld, y.M, y.C, True)
+
+    def bwd(self):
+        x, y = self.x, self.y
+        self.site.backward(self.out.g, self.out, y, True, y.g, mask_from_x=True)
+        self.eng.wgrad(self.wdesc, x.t, y.g, self.w.dw)
+        self.ddesc.accumulate = int(x.gw)
+        ops.conv_gemm(self.ddesc, y.g, self.w.wd, x.g)
+        x.gw = True
+
+
+class DeConvLayer:
+    """reference network/FCRN.py:68-88 (`DeConv.convt`): ConvTranspose2d(k, stride 2, pad (k-1)//2, output_padding
+    k%2, no bias) -> BN -> ReLU.  A transposed convolution IS the input gradient of the strided convolution with the
+    same weight tensor [Cin][Cout][k][k] read as that convolution's [O][I][kh][kw]: the forward pass runs the
+    conv kernel's stride-2 output phases with the transposed packing, the input gradient is the plain strided
+    forward convolution of d(out), and the weight gradient is that convolution's weight gradient with the roles of
+    activation and output gradient exchanged."""
+
+    def __init__(self, eng, x, mod, k):
+        self.eng, self.x, self.mod, self.k = eng, x, mod, k
+        dev, N, h, w, Cin = eng.dev, x.N, x.H, x.W, x.C
+        C = Cin // 2
+        pad = (k - 1) // 2
+        assert ops.out_size(2 * h, k, 2, pad) == h and ops.out_size(2 * w, k, 2, pad) == w
+        self.convt = getattr(mod, "deconv%d" % k)
+        self.w = eng._conv([self.convt.weight])          # O = Cin (of the ConvTranspose), I = C
+        self.site = eng._site([mod.batchnorm])
+        self.y = Act(dev, N, 2 * h, 2 * w, C)          # pre-BN
+        self.out = Act(dev, N, 2 * h, 2 * w, C)
+        # forward: "dgrad" of the virtual conv  y-shaped [2h][2w][C] -> x-shaped [h][w][Cin]
+        self.fdescs, self.fzero = ops.dgrad_descs(N, 2 * h, 2 * w, self.y.ld, C, h, w, x.ld, Cin, x.nbytes, k, 2, pad)
+        # input gradient: the virtual conv's forward over d(y)
+        self.ddesc = ops.fwd_desc(N, 2 * h, 2 * w, self.y.ld, C, self.y.nbytes, k, 2, pad, Cin, x.ld)
+        self.wdesc = ops.conv_wgrad_desc(N, 2 * h, 2 * w, self.y.ld, C, self.y.nbytes, h, w, x.ld, Cin, x.nbytes, k, 2, pad,
+                                         eng._ksplit(x.M, Cin, C, k * k))
+
+    def first_param_offset(self):
+        return self.eng.store.p_off[id(self.convt.weight)]
+
+    def reset_grad_flags(self):
+        self.y.gw = self.out.gw = False
+
+    def fwd(self, train):
+        x, y, s = self.x, self.y, self.site
+        if self.fzero:
+            y.t.zero_()
+        for d in self.fdescs:
+            d.accumulate = 0
+            ops.conv_gemm(d, x.t, self.w.wd, y.t, s.part if train else None)
+        s.finalize(y.M, train)
+        ops.bn_apply(y.t, y.ld, s.scale, s.shift, self.out.t, self.out.ld, y.M, y.C, True)
+
+    def bwd(self):
+        x, y = self.x, self.y
+        self.site.backward(self.out.g, self.out, y, True, y.g, mask_from_x=True)
+        self.eng.wgrad(self.wdesc, x.t, y.g, self.w.dw)
+        self.ddesc.accumulate = int(x.gw)
+        ops.conv_gemm(self.ddesc, y.g, self.w.wf, x.g)
         x.gw = True

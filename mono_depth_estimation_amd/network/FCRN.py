@@ -45,6 +45,14 @@ class _Container(nn.Module):
                            "mono_depth_estimation_amd.network.FCRN.ResNet instead" % type(self).__name__)
 
 
+class _Seq(nn.Sequential):
+    """nn.Sequential as a parameter container (same child names -> same state_dict keys); never run by torch."""
+
+    def forward(self, *a, **k):
+        raise RuntimeError("this Sequential is a parameter container of the HIP FCRN path; call the parent "
+                           "mono_depth_estimation_amd.network.FCRN.ResNet instead")
+
+
 class Bottleneck(_Container):
     """torchvision Bottleneck (v1.5: stride on conv2) — names as torchvision's."""
     expansion = 4
@@ -86,8 +94,59 @@ class Decoder(_Container):
     names = ['deconv2', 'deconv3', 'upconv', 'upproj']
 
 
+class DeConv(Decoder):
+    """reference FCRN.py:68-88: four x {ConvTranspose2d(k, 2, (k-1)//2, k%2, bias=False) -> BN -> ReLU}."""
+    kind = "deconv"
+
+    def __init__(self, in_channels, kernel_size):
+        assert kernel_size >= 2, "kernel_size out of range: {}".format(kernel_size)
+        super().__init__()
+        if kernel_size > 5:
+            raise NotImplementedError("HIP deconv decoder: kernel_size <= 5 (%d taps per launch)" % (kernel_size ** 2))
+        self.kernel_size = kernel_size
+
+        def convt(in_channels):
+            stride = 2
+            padding = (kernel_size - 1) // 2
+            output_padding = kernel_size % 2
+            assert -2 - 2 * padding + kernel_size + output_padding == 0, "deconv parameters incorrect"
+            module_name = "deconv{}".format(kernel_size)
+            return _Seq(collections.OrderedDict([
+                (module_name, nn.ConvTranspose2d(in_channels, in_channels // 2, kernel_size, stride, padding,
+                                                 output_padding, bias=False)),
+                ('batchnorm', nn.BatchNorm2d(in_channels // 2)),
+                ('relu', nn.ReLU(inplace=True)),
+            ]))
+
+        self.layer1 = convt(in_channels)
+        self.layer2 = convt(in_channels // 2)
+        self.layer3 = convt(in_channels // (2 ** 2))
+        self.layer4 = convt(in_channels // (2 ** 3))
+
+
+class UpConv(Decoder):
+    """reference FCRN.py:91-110: four x {unpool -> 5x5 conv -> BN -> ReLU}."""
+    kind = "upconv"
+
+    def upconv_module(self, in_channels):
+        return _Seq(collections.OrderedDict([
+            ('unpool', Unpool(in_channels)),
+            ('conv', nn.Conv2d(in_channels, in_channels // 2, kernel_size=5, stride=1, padding=2, bias=False)),
+            ('batchnorm', nn.BatchNorm2d(in_channels // 2)),
+            ('relu', nn.ReLU()),
+        ]))
+
+    def __init__(self, in_channels):
+        super().__init__()
+        self.layer1 = self.upconv_module(in_channels)
+        self.layer2 = self.upconv_module(in_channels // 2)
+        self.layer3 = self.upconv_module(in_channels // 4)
+        self.layer4 = self.upconv_module(in_channels // 8)
+
+
 class UpProj(Decoder):
     """reference FCRN.py:167-205."""
+    kind = "upproj"
 
     class UpProjModule(_Container):
         def __init__(self, in_channels):
@@ -116,12 +175,17 @@ class UpProj(Decoder):
 
 
 def choose_decoder(decoder, in_channels):
-    """reference FCRN.py:282-294.  Only the reference's default ('upproj', the one
-    modules/laina.py uses) has HIP kernels; the alternatives are SURVEY.md §8f row N4."""
+    """reference FCRN.py:282-294.  'upproj' (the reference's default, the one modules/laina.py uses), 'upconv' and
+    'deconvK' run on the same conv kernels; the pixel-shuffle 'fasterupproj' variant has no HIP path."""
+    if decoder[:6] == 'deconv':
+        assert len(decoder) == 7
+        return DeConv(in_channels, int(decoder[6]))
     if decoder == "upproj":
         return UpProj(in_channels)
-    if decoder[:6] == 'deconv' or decoder in ("upconv", "fasterupproj"):
-        raise NotImplementedError("decoder '%s' has no HIP path yet (only 'upproj')" % decoder)
+    if decoder == "upconv":
+        return UpConv(in_channels)
+    if decoder == "fasterupproj":
+        raise NotImplementedError("decoder 'fasterupproj' has no HIP path (upproj / upconv / deconvK do)")
     assert False, "invalid option for decoder: {}".format(decoder)
 
 

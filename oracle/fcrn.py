@@ -154,9 +154,63 @@ class UpProj(nn.Module):
         return self.layer4(self.layer3(self.layer2(self.layer1(x))))
 
 
+class _Unpool(nn.Module):
+    def forward(self, x):
+        return unpool2x(x)
+
+
+class UpConv(nn.Module):
+    """FCRN.py:91-110: four x {unpool -> 5x5 conv -> BN -> ReLU}, channels halving."""
+
+    def __init__(self, cin):
+        super().__init__()
+        for i in range(4):
+            c = cin // (2 ** i)
+            setattr(self, "layer%d" % (i + 1), nn.Sequential(OrderedDict([
+                ("unpool", _Unpool()),
+                ("conv", nn.Conv2d(c, c // 2, 5, padding=2, bias=False)),
+                ("batchnorm", nn.BatchNorm2d(c // 2)),
+                ("relu", nn.ReLU()),
+            ])))
+
+    def forward(self, x):
+        return self.layer4(self.layer3(self.layer2(self.layer1(x))))
+
+
+class DeConv(nn.Module):
+    """FCRN.py:68-88: four x {ConvTranspose2d(k, stride 2, pad (k-1)//2, output_padding k%2) -> BN -> ReLU}."""
+
+    def __init__(self, cin, k):
+        super().__init__()
+        for i in range(4):
+            c = cin // (2 ** i)
+            setattr(self, "layer%d" % (i + 1), nn.Sequential(OrderedDict([
+                ("deconv%d" % k, nn.ConvTranspose2d(c, c // 2, k, 2, (k - 1) // 2, k % 2, bias=False)),
+                ("batchnorm", nn.BatchNorm2d(c // 2)),
+                ("relu", nn.ReLU(inplace=True)),
+            ])))
+
+    def forward(self, x):
+        return self.layer4(self.layer3(self.layer2(self.layer1(x))))
+
+
+def make_decoder(decoder, cin):
+    """FCRN.py:282-294 (the Faster* pixel-shuffle variants are not restated)."""
+    if decoder[:6] == "deconv":
+        return DeConv(cin, int(decoder[6]))
+    if decoder == "upproj":
+        return UpProj(cin)
+    if decoder == "upconv":
+        return UpConv(cin)
+    raise ValueError(decoder)
+
+
 def he_init_(m):
-    """FCRN.py:14-28: N(0, sqrt(2 / (kh*kw*Cout))) for convs, BN -> (1, 0)."""
-    if isinstance(m, nn.Conv2d):
+    """FCRN.py:14-28: N(0, sqrt(2 / (kh*kw*Cout))) for convs (ConvTranspose: Cin), BN -> (1, 0)."""
+    if isinstance(m, nn.ConvTranspose2d):
+        fan = m.kernel_size[0] * m.kernel_size[1] * m.in_channels
+        m.weight.data.normal_(0, math.sqrt(2.0 / fan))
+    elif isinstance(m, nn.Conv2d):
         fan = m.kernel_size[0] * m.kernel_size[1] * m.out_channels
         m.weight.data.normal_(0, math.sqrt(2.0 / fan))
         if m.bias is not None:
@@ -167,9 +221,9 @@ def he_init_(m):
 
 
 class FCRNOracle(nn.Module):
-    """FCRN.ResNet restated (decoder='upproj' only). Returns sigmoid(depth map)."""
+    """FCRN.ResNet restated (decoders upproj / upconv / deconvK). Returns sigmoid(depth map)."""
 
-    def __init__(self, layers=50, output_size=(228, 304), in_channels=3, out_channels=20):
+    def __init__(self, layers=50, output_size=(228, 304), in_channels=3, out_channels=20, decoder="upproj"):
         super().__init__()
         t = ResNetTrunk(layers, in_channels)
         for name in ("conv1", "bn1", "relu", "maxpool", "layer1", "layer2", "layer3", "layer4"):
@@ -178,7 +232,7 @@ class FCRNOracle(nn.Module):
         self.output_size = tuple(output_size)
         self.conv2 = nn.Conv2d(nch, nch // 2, 1, bias=False)
         self.bn2 = nn.BatchNorm2d(nch // 2)
-        self.upSample = UpProj(nch // 2)
+        self.upSample = make_decoder(decoder, nch // 2)
         self.conv3 = nn.Conv2d(nch // 32, out_channels, 3, padding=1, bias=False)
         for m in (self.conv2, self.bn2, self.upSample, self.conv3):
             m.apply(he_init_)

@@ -315,6 +315,36 @@ def gen_fcrn(criteria, metrics, FCRN):
           "keys", int(out["n_state_keys"]), "params", int(out["n_params"]))
 
 
+def gen_fcrn_decoders(criteria, metrics, FCRN):
+    """G5c: the reference network with its other decoders (FCRN.py:68-110: deconv2, deconv3, upconv) on the
+    conditioned state, 2x3x64x96: eval output + metrics, train-mode SILog, per-parameter gradient norms."""
+    size = (64, 96)
+    out = {}
+    for dec in ("upconv", "deconv2", "deconv3"):
+        ref = FCRN.ResNet(layers=50, decoder=dec, output_size=size, in_channels=3, out_channels=1, pretrained=False)
+        W.fcrn_conditioned_state(ref, 8)
+        rgb, tgt = W.synthetic_batch(8, 2, *size)
+        W.calibrate_running_stats(ref, rgb)
+        ref.eval()
+        with torch.no_grad():
+            y = ref(rgb)
+        out[dec + "_eval_out"] = _np(y)
+        for n, v in zip(metrics.MetricComputation(["absrel", "rmse", "delta1"]).names,
+                        metrics.MetricComputation(["absrel", "rmse", "delta1"]).compute(y, tgt)):
+            out[dec + "_eval_" + n] = _np(v)
+        ref.train()
+        loss = criteria.silog_loss(0.85)(ref(rgb), tgt)
+        loss.backward()
+        out[dec + "_train_silog"] = _np(loss)
+        out[dec + "_names"] = np.array([k for k, _ in ref.named_parameters()])
+        out[dec + "_grad_norm"] = np.array([float(p.grad.double().norm()) for _, p in ref.named_parameters()])
+        out[dec + "_state_keys"] = np.array(list(ref.state_dict().keys()))
+        print("fcrn_decoders %-8s absrel %.6f train_silog %.5f params %d range %.3f..%.3f" % (
+            dec, float(out[dec + "_eval_absrel"]), float(loss), sum(p.numel() for p in ref.parameters()),
+            float(y.min()), float(y.max())))
+    np.savez_compressed(os.path.join(HERE, "fcrn_decoders.npz"), **out)
+
+
 def gen_fcrn_conditioned(criteria, metrics, FCRN):
     """G5b: the same reference network on the well-conditioned state (oracle/weights.py:
     fcrn_conditioned_state) — the fixture on which the 1e-4 AbsRel bound is asserted."""
@@ -352,6 +382,7 @@ def main():
     gen_upproj(FCRN)
     gen_fcrn(criteria, metrics, FCRN)
     gen_fcrn_conditioned(criteria, metrics, FCRN)
+    gen_fcrn_decoders(criteria, metrics, FCRN)
 
 
 if __name__ == "__main__":

@@ -238,3 +238,27 @@ def test_stdepth_loss(golden, i):
     _close(torch.stack(list(terms.values())).detach(), g["k%d_terms" % i])
     _close(full.detach(), g["k%d_full" % i], atol=1e-6)
     _close(p.grad, g["k%d_grad" % i], rtol=1e-4, atol=1e-7)
+
+
+# ---------------------------------------------------------------- G5c: the other decoders (FCRN.py:68-110)
+@pytest.mark.parametrize("dec", ["upconv", "deconv2", "deconv3"])
+def test_fcrn50_other_decoders(golden, dec):
+    g = golden("fcrn_decoders")
+    net = ofcrn.FCRNOracle(layers=50, output_size=(64, 96), out_channels=1, decoder=dec)
+    assert list(net.state_dict().keys()) == [str(k) for k in g[dec + "_state_keys"]]
+    W.fcrn_conditioned_state(net, 8)
+    rgb, tgt = W.synthetic_batch(8, 2, 64, 96)
+    W.calibrate_running_stats(net, rgb)
+    net.eval()
+    with torch.no_grad():
+        y = net(rgb)
+    _close(y, g[dec + "_eval_out"], rtol=1e-4, atol=2e-5)
+    got = M.compute(y, tgt)
+    for k in ("absrel", "rmse", "delta1"):
+        _close(got[k], g[dec + "_eval_" + k], rtol=1e-4)
+    net.train()
+    loss = L.silog(net(rgb), tgt)
+    loss.backward()
+    _close(loss.detach(), g[dec + "_train_silog"], rtol=1e-4)
+    gn = np.array([float(p.grad.double().norm()) for _, p in net.named_parameters()])
+    assert np.allclose(gn, g[dec + "_grad_norm"], rtol=2e-3, atol=1e-6), np.abs(gn / g[dec + "_grad_norm"] - 1).max()
