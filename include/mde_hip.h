@@ -185,6 +185,11 @@ int mde_bn_bwd_apply2(const void* dout, int ldd, const void* xa, int ldxa, const
 int mde_maxpool_fwd(const void* x, void* out, uint8_t* idx, int N, int H, int W, int C, void* stream);
 int mde_maxpool_bwd(const void* dout, const uint8_t* idx, void* dx, int N, int H, int W, int C,
                     void* stream);
+/* nn.PixelShuffle(2) on NHWC bf16 (FCRN.py:236,245): dst[n][2y+a][2x+b][c] = src[n][y][x][4c+2a+b]; src has 4C
+ * channels at pixel stride ld_src, dst C channels at ld_dst (multiples of 8).  inverse != 0 writes src from dst
+ * (the gradient of the forward permutation). */
+int mde_pixel_shuffle2(void* src, int ld_src, void* dst, int ld_dst, int N, int h, int w, int C, int inverse,
+                       void* stream);
 /* Bilinear resize align_corners=True followed by sigmoid (FCRN.py:341,369-371).
  * x: fp32 [N][H][W][C] -> out fp32 NCHW [N][C][OH][OW] (the module's return tensor). */
 int mde_upsample_sigmoid_fwd(const float* x, float* out, int N, int H, int W, int C, int OH, int OW,

@@ -66,6 +66,7 @@ SIGNATURES = {
     "mde_bn_bwd_apply2": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _L, _I, _P, _I, _P, _I, _P]),
     "mde_bn_bwd_finalize": (_I, [_P, _L, _I, _P, _P, _P, _P, _P, _P]),
     "mde_bn_bwd_apply": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P, _I, _I, _P, _I, _P]),
+    "mde_pixel_shuffle2": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
     "mde_maxpool_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "mde_maxpool_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "mde_upsample_sigmoid_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),

@@ -192,6 +192,63 @@ int grid_for(int64_t total) {
 
 }  // namespace
 
+// nn.PixelShuffle(2) on NHWC bf16 (reference FCRN.py:236,245 — the FasterUpProj decoder):
+//   dst[n][2y+a][2x+b][c] = src[n][y][x][4c + 2a + b],  src has 4C channels (pixel stride ld_src), dst C (ld_dst).
+// A thread moves 32 source channels (64 B) = 8 destination channels at each of the 4 sub-pixels (16 B each).
+// INV: the same permutation read the other way (gradient of the forward: src is written from dst).
+template <bool INV>
+__global__ __launch_bounds__(256) void pixel_shuffle_k(bf16_t* __restrict__ src, int ld_src, bf16_t* __restrict__ dst,
+                                                       int ld_dst, int64_t pixels, int h, int w, int C) {
+    const int groups = C / 8;
+    const int64_t total = pixels * groups;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t pix = i / groups;
+        const int gq = (int)(i - pix * groups);
+        const int x = (int)(pix % w);
+        const int64_t ny = pix / w;                 // n * h + y
+        const int y = (int)(ny % h);
+        const int64_t n = ny / h;
+        bf16_t* sp = src + pix * ld_src + gq * 32;
+        bf16_t* dp = dst + ((n * 2 * h + 2 * y) * (int64_t)(2 * w) + 2 * x) * ld_dst + gq * 8;
+        bf16x8_t v[4], o[4];
+        if (!INV) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const bf16x8_t*>(sp + 8 * q);
+#pragma unroll
+            for (int ab = 0; ab < 4; ++ab)
+#pragma unroll
+                for (int c = 0; c < 8; ++c) o[ab][c] = v[(4 * c + ab) >> 3][(4 * c + ab) & 7];
+#pragma unroll
+            for (int ab = 0; ab < 4; ++ab)
+                *reinterpret_cast<bf16x8_t*>(dp + ((int64_t)(ab >> 1) * 2 * w + (ab & 1)) * ld_dst) = o[ab];
+        } else {
+#pragma unroll
+            for (int ab = 0; ab < 4; ++ab)
+                o[ab] = *reinterpret_cast<const bf16x8_t*>(dp + ((int64_t)(ab >> 1) * 2 * w + (ab & 1)) * ld_dst);
+#pragma unroll
+            for (int ab = 0; ab < 4; ++ab)
+#pragma unroll
+                for (int c = 0; c < 8; ++c) v[(4 * c + ab) >> 3][(4 * c + ab) & 7] = o[ab][c];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) *reinterpret_cast<bf16x8_t*>(sp + 8 * q) = v[q];
+        }
+    }
+}
+
+extern "C" int mde_pixel_shuffle2(void* src, int ld_src, void* dst, int ld_dst, int N, int h, int w, int C, int inverse,
+                                  void* stream) {
+    MDE_REQUIRE(src && dst && N > 0 && h > 0 && w > 0 && C > 0, "mde_pixel_shuffle2: bad argument");
+    MDE_REQUIRE(C % 8 == 0 && ld_src % 8 == 0 && ld_dst % 8 == 0 && ld_src >= 4 * C && ld_dst >= C &&
+                    ((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 16) == 0,
+                "mde_pixel_shuffle2: C=%d, ld_src=%d, ld_dst=%d must be multiples of 8 with 16-byte aligned bases", C, ld_src, ld_dst);
+    const int64_t pixels = (int64_t)N * h * w, total = pixels * (C / 8);
+    const int grid = (int)((total + 255) / 256 > 65536 ? 65536 : (total + 255) / 256);
+    if (inverse) pixel_shuffle_k<true><<<grid, 256, 0, (hipStream_t)stream>>>((bf16_t*)src, ld_src, (bf16_t*)dst, ld_dst, pixels, h, w, C);
+    else pixel_shuffle_k<false><<<grid, 256, 0, (hipStream_t)stream>>>((bf16_t*)src, ld_src, (bf16_t*)dst, ld_dst, pixels, h, w, C);
+    MDE_LAUNCH_CHECK("pixel_shuffle_k");
+    return MDE_OK;
+}
+
 extern "C" int mde_maxpool_fwd(const void* x, void* out, uint8_t* idx, int N, int H, int W, int C, void* stream) {
     MDE_REQUIRE(x && out && idx && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "mde_maxpool_fwd: bad argument (C %% 8 == 0)");
     MDE_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)out % 16) == 0 && ((uintptr_t)idx % 8) == 0, "mde_maxpool_fwd: alignment");

@@ -204,6 +204,14 @@ class ParamStore:
             if kind == "deconv":
                 conv_bn(getattr(up, "deconv%d" % m.upSample.kernel_size), up.batchnorm)
                 continue
+            if kind == "fasterupproj":
+                for fu in (up.upper_branch.faster_upconv, up.bottom_branch):
+                    for cn in ("conv1_", "conv2_", "conv3_", "conv4_"):
+                        seq = getattr(fu, cn)
+                        conv_bn(seq.conv1, seq.bn1)
+                        plist.append(("b", [seq.conv1.bias]))
+                conv_bn(up.upper_branch.conv, up.upper_branch.batchnorm)
+                continue
             ub, bb = up.upper_branch, up.bottom_branch
             plist.append(("w", [ub.conv1.weight, bb.conv.weight]))          # fused [2C][25][Cin]
             plist.append(("g", [ub.batchnorm1.weight, bb.batchnorm.weight]))
@@ -452,6 +460,8 @@ class FCRNEngine:
             kind = getattr(m.upSample, "kind", "upproj")
             if kind == "upproj":
                 L = UpProjLayer(self, x, mod)
+            elif kind == "fasterupproj":
+                L = FasterUpProjLayer(self, x, mod)
             elif kind == "upconv":
                 L = UpConvLayer(self, x, mod)
             else:
@@ -801,3 +811,100 @@ class DeConvLayer:
         self.ddesc.accumulate = int(x.gw)
         ops.conv_gemm(self.ddesc, y.g, self.w.wf, x.g)
         x.gw = True
+
+
+# (pad_top, pad_left, kh, kw) of faster_upconv's conv1_ .. conv4_ (FCRN.py:214-239: F.pad(x, (l, r, t, b)) + Conv2d)
+_FASTER_GEOMETRY = ((1, 1, 3, 3), (0, 1, 2, 3), (1, 0, 3, 2), (0, 0, 2, 2))
+
+
+class _BiasedConvBN:
+    """One of faster_upconv's four {Conv2d WITH bias -> BatchNorm2d} units writing a channel slice.  In training
+    mode the bias cancels in the normalisation (its gradient is exactly zero and stays zero in the flat buffer); it
+    only moves the running mean, and in eval mode it joins the shift."""
+
+    def __init__(self, eng, x, seq, geo, y, yb):
+        pt, pl, kh, kw = geo
+        self.eng, self.x, self.y, self.yb = eng, x, y, yb            # y: pre-BN slice, yb: post-BN slice
+        self.conv = eng._conv([seq.conv1.weight])
+        self.site = eng._site([seq.bn1])
+        self.bias = eng.P[eng.p_off[id(seq.conv1.bias)]:eng.p_off[id(seq.conv1.bias)] + y.C]
+        taps = [(i - pt, j - pl, i * kw + j) for i in range(kh) for j in range(kw)]
+        N, H, W, C = x.N, x.H, x.W, y.C
+        self.fdesc = ops.taps_fwd_desc(N, H, W, x.ld, x.C, x.nbytes, taps, kh * kw, C, y.ld)
+        self.ddesc = ops.taps_dgrad_desc(N, H, W, x.ld, x.C, y.ld, C, y.nbytes, taps, kh * kw)
+        self.wdesc = ops.taps_wgrad_desc(N, H, W, x.ld, x.C, x.nbytes, y.ld, C, y.nbytes, taps, kh * kw,
+                                         eng._ksplit(x.M, C, x.C, kh * kw))
+
+    def fwd(self, train, relu):
+        s, y = self.site, self.y
+        ops.conv_gemm(self.fdesc, self.x.t, self.conv.wf, y.t, s.part if train else None)
+        s.finalize(y.M, train)
+        with torch.no_grad():
+            if train:
+                mom = s.bn.momentum if s.bn.momentum is not None else 0.1
+                s.rmean.add_(self.bias, alpha=mom)           # running mean of (conv + bias)
+            else:
+                s.shift.addcmul_(s.scale, self.bias)
+        ops.bn_apply(y.t, y.ld, s.scale, s.shift, self.yb.t, self.yb.ld, y.M, y.C, relu)
+
+    def bwd(self, relu):
+        x, y, yb = self.x, self.y, self.yb
+        self.site.backward(yb.g, yb, y, relu, y.g, mask_from_x=relu)
+        self.eng.wgrad(self.wdesc, y.g, x.t, self.conv.dw)
+        self.ddesc.accumulate = int(x.gw)
+        ops.conv_gemm(self.ddesc, y.g, self.conv.wd, x.g)
+        x.gw = True
+
+
+class FasterUpProjLayer:
+    """reference network/FCRN.py:206-281 (`FasterUpProj.FasterUpProjModule`): per branch four convs (3x3, 2x3, 3x2,
+    2x2 with asymmetric zero padding, biased) + BN each, concatenated and pixel-shuffled to 2x resolution; upper
+    branch -> ReLU -> 3x3 conv -> BN, joined with the bottom branch and ReLU.  The eight convs write channel slices
+    of ONE [N][h][w][8C] tensor (the `cat` never exists separately), BN + ReLU run before the shuffle (a pure
+    permutation commutes with them), and the shuffle is one 64-byte-per-thread permutation kernel."""
+
+    def __init__(self, eng, x, mod):
+        self.eng, self.x, self.mod = eng, x, mod
+        dev, N, h, w, Cin = eng.dev, x.N, x.H, x.W, x.C
+        C = Cin // 2
+        self.C = C
+        self.Y = Act(dev, N, h, w, 8 * C)               # pre-BN outputs of the 8 convs: upper 4, bottom 4
+        self.T = Act(dev, N, h, w, 8 * C)               # post-BN (upper: + ReLU), still un-shuffled
+        self.units = []
+        for bi, fu in enumerate((mod.upper_branch.faster_upconv, mod.bottom_branch)):
+            for ci, cn in enumerate(("conv1_", "conv2_", "conv3_", "conv4_")):
+                c0 = (4 * bi + ci) * C
+                self.units.append(_BiasedConvBN(eng, x, getattr(fu, cn), _FASTER_GEOMETRY[ci], self.Y.slice(c0, C),
+                                                self.T.slice(c0, C)))
+        self.a1 = Act(dev, N, 2 * h, 2 * w, C)          # relu(shuffle(upper))
+        self.r = Act(dev, N, 2 * h, 2 * w, C)           # shuffle(bottom)
+        ub = mod.upper_branch
+        self.c2 = ConvBN(eng, self.a1, eng._conv([ub.conv.weight]), eng._site([ub.batchnorm]), 3, 1, 1, True, res=self.r)
+        self.out = self.c2.out
+
+    def first_param_offset(self):
+        return self.eng.store.p_off[id(self.mod.upper_branch.faster_upconv.conv1_.conv1.weight)]
+
+    def reset_grad_flags(self):
+        self.Y.gw = self.T.gw = self.a1.gw = self.r.gw = False
+        self.c2.reset_grad_flags()
+
+    def _shuffle(self, inverse):
+        T, C, x = self.T, self.C, self.x
+        for half, dst in ((0, self.a1), (1, self.r)):
+            src = (T.g if inverse else T.t)[..., half * 4 * C:(half + 1) * 4 * C]
+            ops.pixel_shuffle2(src, T.ld, dst.g if inverse else dst.t, dst.ld, x.N, x.H, x.W, C, inverse)
+
+    def fwd(self, train):
+        for i, u in enumerate(self.units):
+            u.fwd(train, relu=i < 4)
+        self._shuffle(False)
+        self.c2.fwd(train)
+
+    def bwd(self):
+        c2 = self.c2
+        c2.bn_bwd(dres_to=self.r)                       # d(out) -> d(c2.c), and the masked gradient to the bottom branch
+        c2.conv_bwd()                                   # -> d(a1), dW(conv)
+        self._shuffle(True)                             # d(a1), d(r) -> d(T)
+        for i, u in enumerate(self.units):
+            u.bwd(relu=i < 4)

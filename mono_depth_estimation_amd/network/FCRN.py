@@ -174,9 +174,45 @@ class UpProj(Decoder):
         self.layer4 = self.UpProjModule(in_channels // 8)
 
 
+class FasterUpProj(Decoder):
+    """reference FCRN.py:206-281 (pixel-shuffle formulation; its own weights, not UpProj's)."""
+    kind = "fasterupproj"
+
+    class faster_upconv(_Container):
+        def __init__(self, in_channel):
+            super().__init__()
+            for name, ks in (("conv1_", 3), ("conv2_", (2, 3)), ("conv3_", (3, 2)), ("conv4_", 2)):
+                setattr(self, name, _Seq(collections.OrderedDict([
+                    ('conv1', nn.Conv2d(in_channel, in_channel // 2, kernel_size=ks)),
+                    ('bn1', nn.BatchNorm2d(in_channel // 2)),
+                ])))
+            self.ps = nn.PixelShuffle(2)
+            self.relu = nn.ReLU(inplace=True)
+
+    class FasterUpProjModule(_Container):
+        def __init__(self, in_channels):
+            super().__init__()
+            out_channels = in_channels // 2
+            self.upper_branch = _Seq(collections.OrderedDict([
+                ('faster_upconv', FasterUpProj.faster_upconv(in_channels)),
+                ('relu', nn.ReLU(inplace=True)),
+                ('conv', nn.Conv2d(out_channels, out_channels, kernel_size=3, stride=1, padding=1, bias=False)),
+                ('batchnorm', nn.BatchNorm2d(out_channels)),
+            ]))
+            self.bottom_branch = FasterUpProj.faster_upconv(in_channels)
+            self.relu = nn.ReLU(inplace=True)
+
+    def __init__(self, in_channel):
+        super().__init__()
+        self.layer1 = self.FasterUpProjModule(in_channel)
+        self.layer2 = self.FasterUpProjModule(in_channel // 2)
+        self.layer3 = self.FasterUpProjModule(in_channel // 4)
+        self.layer4 = self.FasterUpProjModule(in_channel // 8)
+
+
 def choose_decoder(decoder, in_channels):
-    """reference FCRN.py:282-294.  'upproj' (the reference's default, the one modules/laina.py uses), 'upconv' and
-    'deconvK' run on the same conv kernels; the pixel-shuffle 'fasterupproj' variant has no HIP path."""
+    """reference FCRN.py:282-294: every option runs on the same conv kernels ('upproj' is the reference's default,
+    the one modules/laina.py uses)."""
     if decoder[:6] == 'deconv':
         assert len(decoder) == 7
         return DeConv(in_channels, int(decoder[6]))
@@ -185,7 +221,7 @@ def choose_decoder(decoder, in_channels):
     if decoder == "upconv":
         return UpConv(in_channels)
     if decoder == "fasterupproj":
-        raise NotImplementedError("decoder 'fasterupproj' has no HIP path (upproj / upconv / deconvK do)")
+        return FasterUpProj(in_channels)
     assert False, "invalid option for decoder: {}".format(decoder)
 
 

@@ -58,6 +58,23 @@ def fwd_desc(N, H, W, ld_in, Cin, in_bytes, k, stride, pad, Cout, ld_out, dil=1)
                      ncols=Cout)
 
 
+def taps_fwd_desc(N, H, W, ld_in, Cin, in_bytes, taps, ntaps_total, Cout, ld_out):
+    """Stride-1 same-size conv given as an explicit tap list [(dy, dx, weight tap)] (asymmetric padding, non-square
+    kernels: FCRN.py:236-239).  Weights [Cout][ntaps_total][Cin]."""
+    return conv_desc(N, H, W, ld_in, Cin, in_bytes, H, W, 1, 1, taps, ntaps_total, H, W, ld_out, ncols=Cout)
+
+
+def taps_dgrad_desc(N, H, W, ld_dx, Cin, ld_dy, Cout, dy_bytes, taps, ntaps_total, accumulate=False):
+    """Input gradient of taps_fwd_desc's conv: the mirrored taps over dY with the transposed weights."""
+    return conv_desc(N, H, W, ld_dy, Cout, dy_bytes, H, W, 1, 1, [(-dy, -dx, t) for dy, dx, t in taps], ntaps_total, H, W,
+                     ld_dx, ncols=Cin, accumulate=accumulate)
+
+
+def taps_wgrad_desc(N, H, W, ld_x, Cin, x_bytes, ld_dy, Cout, dy_bytes, taps, ntaps_total, ksplit):
+    """dW[Cout][ntaps_total][Cin] of taps_fwd_desc's conv: direct = dY, gathered = x."""
+    return wgrad_desc(N, H, W, ld_dy, Cout, dy_bytes, H, W, ld_x, Cin, x_bytes, 1, 1, taps, ntaps_total, False, ksplit)
+
+
 def dgrad_descs(N, H, W, ld_dx, Cin, OH, OW, ld_dy, Cout, dy_bytes, k, stride, pad, dil=1, accumulate=False):
     """Conv2d input gradient as 1 (stride 1) or stride^2 output-phase launches over
     dY [N][OH][OW][ld_dy] with the transposed weights [Cin][k*k][Cout].
@@ -295,6 +312,11 @@ def bn_bwd_apply(dout, ldd, out, ldo, x, ldx, smean, srstd, coef, M, C_, relu, d
 
 
 # ------------------------------------------------------------------------------ pool / resize
+def pixel_shuffle2(src, ld_src, dst, ld_dst, N, h, w, C_, inverse=False):
+    check(_lib.load().mde_pixel_shuffle2(_p(src), ld_src, _p(dst), ld_dst, N, h, w, C_, int(inverse), _stream()),
+          "mde_pixel_shuffle2")
+
+
 def maxpool_fwd(x, out, idx, N, H, W, C_):
     check(_lib.load().mde_maxpool_fwd(_p(x), _p(out), _p(idx), N, H, W, C_, _stream()), "mde_maxpool_fwd")
 

@@ -194,8 +194,53 @@ class DeConv(nn.Module):
         return self.layer4(self.layer3(self.layer2(self.layer1(x))))
 
 
+class FasterUpconv(nn.Module):
+    """FCRN.py:209-246: four biased convs on differently zero-padded copies of x, BN each, cat, PixelShuffle(2)."""
+
+    def __init__(self, cin):
+        super().__init__()
+        for name, ks in (("conv1_", 3), ("conv2_", (2, 3)), ("conv3_", (3, 2)), ("conv4_", 2)):
+            setattr(self, name, nn.Sequential(OrderedDict([("conv1", nn.Conv2d(cin, cin // 2, ks)),
+                                                           ("bn1", nn.BatchNorm2d(cin // 2))])))
+        self.ps = nn.PixelShuffle(2)
+        self.relu = nn.ReLU(inplace=True)
+
+    def forward(self, x):
+        xs = [self.conv1_(F.pad(x, (1, 1, 1, 1))), self.conv2_(F.pad(x, (1, 1, 0, 1))),
+              self.conv3_(F.pad(x, (0, 1, 1, 1))), self.conv4_(F.pad(x, (0, 1, 0, 1)))]
+        return self.ps(torch.cat(xs, 1))
+
+
+class FasterUpProjModule(nn.Module):
+    """FCRN.py:248-269."""
+
+    def __init__(self, cin):
+        super().__init__()
+        c = cin // 2
+        self.upper_branch = nn.Sequential(OrderedDict([
+            ("faster_upconv", FasterUpconv(cin)), ("relu", nn.ReLU(inplace=True)),
+            ("conv", nn.Conv2d(c, c, 3, padding=1, bias=False)), ("batchnorm", nn.BatchNorm2d(c))]))
+        self.bottom_branch = FasterUpconv(cin)
+        self.relu = nn.ReLU(inplace=True)
+
+    def forward(self, x):
+        return self.relu(self.upper_branch(x) + self.bottom_branch(x))
+
+
+class FasterUpProj(nn.Module):
+    def __init__(self, cin):
+        super().__init__()
+        for i in range(4):
+            setattr(self, "layer%d" % (i + 1), FasterUpProjModule(cin // (2 ** i)))
+
+    def forward(self, x):
+        return self.layer4(self.layer3(self.layer2(self.layer1(x))))
+
+
 def make_decoder(decoder, cin):
-    """FCRN.py:282-294 (the Faster* pixel-shuffle variants are not restated)."""
+    """FCRN.py:282-294."""
+    if decoder == "fasterupproj":
+        return FasterUpProj(cin)
     if decoder[:6] == "deconv":
         return DeConv(cin, int(decoder[6]))
     if decoder == "upproj":
@@ -221,7 +266,7 @@ def he_init_(m):
 
 
 class FCRNOracle(nn.Module):
-    """FCRN.ResNet restated (decoders upproj / upconv / deconvK). Returns sigmoid(depth map)."""
+    """FCRN.ResNet restated (decoders upproj / upconv / deconvK / fasterupproj). Returns sigmoid(depth map)."""
 
     def __init__(self, layers=50, output_size=(228, 304), in_channels=3, out_channels=20, decoder="upproj"):
         super().__init__()

@@ -320,7 +320,7 @@ def gen_fcrn_decoders(criteria, metrics, FCRN):
     conditioned state, 2x3x64x96: eval output + metrics, train-mode SILog, per-parameter gradient norms."""
     size = (64, 96)
     out = {}
-    for dec in ("upconv", "deconv2", "deconv3"):
+    for dec in ("upconv", "deconv2", "deconv3", "fasterupproj"):
         ref = FCRN.ResNet(layers=50, decoder=dec, output_size=size, in_channels=3, out_channels=1, pretrained=False)
         W.fcrn_conditioned_state(ref, 8)
         rgb, tgt = W.synthetic_batch(8, 2, *size)

@@ -594,11 +594,13 @@ def test_fused_adamw_and_sgd_steps_on_the_store():
         assert bool(torch.isfinite(y).all())
 
 
-@pytest.mark.parametrize("dec", ["upconv", "deconv2", "deconv3"])
+@pytest.mark.parametrize("dec", ["upconv", "deconv2", "deconv3", "fasterupproj"])
 def test_other_decoders_against_the_reference(golden, dec):
     """reference FCRN.py:68-110 (`decoder='upconv' | 'deconv2' | 'deconv3'`): same state_dict keys as the reference,
     eval output / AbsRel against the reference's own output on the conditioned fixture, train-mode SILog and
-    per-parameter gradient norms against the reference's.  AbsRel bound 3e-4 here: 12 K pixels instead of the 24 K
+    per-parameter gradient norms against the reference's ('fasterupproj': its undamped two-branch joins triple the
+    bf16 noise of this fixture — mean |Δ| 4.9e-3 — while every layer alone is within the usual bounds,
+    test_decoder_layers_teacher_forced).  AbsRel bound 3e-4 here: 12 K pixels instead of the 24 K
     of the 96x128 north-star fixture, and the fixture's damping of the joining BNs only exists in 'upproj'
     (measured 0.3 / 1.4 / 1.2 e-4 for upconv / deconv2 / deconv3; mean |Δoutput| 1.6e-3 = bf16 noise)."""
     from mono_depth_estimation_amd import criteria, metrics
@@ -616,11 +618,12 @@ def test_other_decoders_against_the_reference(golden, dec):
     with torch.no_grad():
         y = net(rgb.cuda())
     d = (y.cpu() - torch.from_numpy(g[dec + "_eval_out"])).abs()
-    assert d.max() <= 2e-2 and d.mean() <= 3e-3, (float(d.max()), float(d.mean()))
+    k = 2.0 if dec == "fasterupproj" else 1.0
+    assert d.max() <= k * 2e-2 and d.mean() <= k * 3e-3, (float(d.max()), float(d.mean()))
     a = float(metrics.MetricComputation(["absrel"]).compute(y, tgt.cuda())[0])
     print("decoder %s: max|d| %.2e mean|d| %.2e dAbsRel %.2e" % (dec, float(d.max()), float(d.mean()),
                                                                  abs(a - float(g[dec + "_eval_absrel"]))))
-    assert abs(a - float(g[dec + "_eval_absrel"])) <= 3e-4, (a, float(g[dec + "_eval_absrel"]))
+    assert abs(a - float(g[dec + "_eval_absrel"])) <= k * 3e-4, (a, float(g[dec + "_eval_absrel"]))
     net.train()
     loss = criteria.silog_loss(0.85)(net(rgb.cuda()), tgt.cuda())
     loss.backward()
@@ -632,3 +635,73 @@ def test_other_decoders_against_the_reference(golden, dec):
     assert np.median(rel) <= 2e-2 and rel.max() <= 0.15, (float(np.median(rel)), float(rel.max()))
     with pytest.raises(RuntimeError):
         net.upSample.layer1(torch.zeros(1, 1024, 2, 3).cuda())        # containers never compute
+
+
+@pytest.mark.parametrize("dec", ["upconv", "deconv2", "deconv3", "fasterupproj"])
+def test_decoder_layers_teacher_forced(dec):
+    """Each decoder layer of the other decoders alone: fed the (bf16-emulating) oracle's input activation and output
+    gradient, compared on its output, input gradient and every parameter gradient (relative L2)."""
+    from mono_depth_estimation_amd.network import FCRN
+    size = (64, 96)
+    ora = ofcrn.FCRNOracle(50, size, out_channels=1, decoder=dec)
+    sd = W.fcrn_fixture_state(ora, 21)
+    rgb, tgt = W.synthetic_batch(21, 2, *size)
+    hip = FCRN.ResNet(layers=50, decoder=dec, output_size=size, out_channels=1, pretrained=False)
+    hip.load_state_dict(sd)
+    hip = hip.cuda().train()
+    rnd = lambda mod, inp, out: out.to(torch.bfloat16).float()
+    for name, mod in ora.named_modules():
+        if isinstance(mod, (torch.nn.Conv2d, torch.nn.ConvTranspose2d)):
+            if name not in ("conv1", "conv3"):
+                mod.weight.data = mod.weight.data.to(torch.bfloat16).float()
+            if name != "conv3":
+                mod.register_forward_hook(rnd)
+        elif isinstance(mod, torch.nn.ReLU) or name == "bn2" or (name.startswith("upSample.") and name.endswith("bn1")):
+            mod.register_forward_hook(rnd)
+    ora.train()
+    ins, outs = {}, {}
+    for i in (1, 2, 3, 4):
+        m = getattr(ora.upSample, "layer%d" % i)
+        m.register_forward_pre_hook(lambda mod, inp, i=i: ins.__setitem__(i, inp[0]))
+
+        def post(mod, inp, out, i=i):
+            out = out.to(torch.bfloat16).float()
+            out.retain_grad()
+            outs[i] = out
+            return out
+        m.register_forward_hook(post)
+    y = ora(rgb)
+    for t in ins.values():
+        t.retain_grad()
+    OL.silog(y, tgt).backward()
+    with torch.no_grad():
+        hip(rgb.cuda())
+    eng = next(iter(hip._engines.values()))
+    hp = dict(hip.named_parameters())
+    dev = lambda t: t.detach().permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).cuda()
+    report = []
+    for i, L in zip((1, 2, 3, 4), eng.layers[-4:]):
+        L.x.t.copy_(dev(ins[i]))
+        L.fwd(True)
+        e_f = _rel(_nchw(L.out.t), outs[i].detach())
+        eng.store.G.zero_()
+        L.reset_grad_flags()
+        L.x.gw = False
+        L.out.g.copy_(dev(outs[i].grad))
+        L.bwd()
+        e_b = _rel(_nchw(L.x.g), ins[i].grad)
+        prefix = "upSample.layer%d." % i
+        op = {k: q for k, q in ora.named_parameters() if k.startswith(prefix)}
+        # a conv bias in front of a train-mode BN has an exactly zero gradient (autograd leaves rounding dust there)
+        biases = [k for k in op if k.endswith("conv1.bias")]
+        for k in biases:
+            assert float(hp[k]._mde_grad.abs().max()) == 0.0
+            assert float(op[k].grad.abs().max()) <= 1e-2 * float(op[k[:-4] + "weight"].grad.abs().max())
+        errs = {k: _rel(hp[k]._mde_grad.cpu(), q.grad) for k, q in op.items() if k not in biases}
+        worst = max(errs, key=errs.get)
+        report.append((i, e_f, e_b, errs[worst], worst))
+    torch.cuda.synchronize()
+    for r in report:
+        print("%s layer%d fwd %.3e  dx %.3e  dW %.3e (%s)" % ((dec,) + r))
+    for i, e_f, e_b, e_w, worst in report:
+        assert e_f <= 1e-2 and e_b <= 1e-1 and e_w <= 1e-1, (dec, i, e_f, e_b, e_w, worst)
