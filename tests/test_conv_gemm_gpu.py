@@ -146,3 +146,34 @@ def test_conv_rejects_bad_args():
     d = ops.fwd_desc(1, 4, 4, 48, 48, x.numel() * 2, 1, 1, 0, 64, 64)
     with pytest.raises(_lib.MdeError, match="multiple of 64"):
         ops.conv_gemm(d, x, w, out)
+
+
+@pytest.mark.parametrize("N,H,Wd,Cin,Cout,dil", [
+    (2, 30, 40, 256, 128, 3), (1, 30, 40, 256, 128, 6), (1, 30, 40, 256, 128, 12), (1, 30, 40, 256, 128, 18),
+    (1, 30, 40, 256, 128, 24),                # the reference's atrous stack (Bts.py:62-63,196-205: 256 -> 128 at 1/8 scale)
+    (2, 17, 23, 128, 128, 2),                 # VNL's FTB blocks (VNL.py:336-339)
+])
+def test_atrous_conv_fwd_dgrad_wgrad(N, H, Wd, Cin, Cout, dil):
+    """Dilated 3x3 convolution (padding = dilation) is only a different tap table for the same kernels: forward,
+    input gradient and weight gradient against torch's dilated conv2d."""
+    from mono_depth_estimation_amd import ops
+    x = _bf(W.normal(6, "x", (N, Cin, H, Wd)))
+    w = _bf(W.normal(6, "w", (Cout, Cin, 3, 3), std=(2.0 / (9 * Cin)) ** 0.5))
+    xi, wi = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    ref = F.conv2d(xi, wi, padding=dil, dilation=dil)
+    dy = _bf(W.normal(6, "dy", tuple(ref.shape)))
+    ref.backward(dy)
+    xd, dyd = _nhwc(x), _nhwc(dy)
+    out = torch.empty(N, H, Wd, Cout, dtype=torch.bfloat16, device="cuda")
+    ops.conv_gemm(ops.fwd_desc(N, H, Wd, Cin, Cin, xd.numel() * 2, 3, 1, dil, Cout, Cout, dil=dil), xd, _pack_fwd(w), out)
+    dx = torch.empty(N, H, Wd, Cin, dtype=torch.bfloat16, device="cuda")
+    descs, zero = ops.dgrad_descs(N, H, Wd, Cin, Cin, H, Wd, Cout, Cout, dyd.numel() * 2, 3, 1, dil, dil=dil)
+    assert len(descs) == 1 and not zero
+    ops.conv_gemm(descs[0], dyd, _pack_dgrad(w), dx)
+    dw = torch.zeros(Cout, 9, Cin, device="cuda")
+    ops.conv_wgrad(ops.conv_wgrad_desc(N, H, Wd, Cin, Cin, xd.numel() * 2, H, Wd, Cout, Cout, dyd.numel() * 2, 3, 1, dil, 2,
+                                       dil=dil), dyd, xd, dw)
+    torch.cuda.synchronize()
+    _assert_close(_nchw(out), ref.detach(), "atrous fwd d=%d" % dil)
+    _assert_close(_nchw(dx), xi.grad, "atrous dgrad d=%d" % dil)
+    _assert_close(dw.cpu(), wi.grad.permute(0, 2, 3, 1).reshape(Cout, 9, Cin), "atrous wgrad d=%d" % dil)

@@ -17,11 +17,12 @@ def main():
     dev = "cuda"
     torch.manual_seed(0)
     x = torch.randn(N, H, W, Cin, device=dev).to(torch.bfloat16)
-    pad = k // 2
+    dil = int(os.environ.get("MB_DIL", "1"))          # atrous: padding = dilation * (k // 2)
+    pad = dil * (k // 2)
     if kind == "fwd":
         w = (torch.randn(Cout, k * k, Cin, device=dev) * 0.05).to(torch.bfloat16)
         out = torch.empty(N, H, W, Cout, dtype=torch.bfloat16, device=dev)
-        d = ops.fwd_desc(N, H, W, Cin, Cin, x.numel() * 2, k, 1, pad, Cout, Cout)
+        d = ops.fwd_desc(N, H, W, Cin, Cin, x.numel() * 2, k, 1, pad, Cout, Cout, dil=dil)
         stats = ops.new_stat_buffer(Cout) if os.environ.get("MB_STATS") else None   # BN partial sums in the epilogue
         fn = lambda: ops.conv_gemm(d, x, w, out, stats)
         flops = 2.0 * N * H * W * Cout * k * k * Cin
@@ -33,7 +34,7 @@ def main():
         ks = int(os.environ["MB_KS"]) if os.environ.get("MB_KS") else ops.choose_ksplit(
             N * H * W, rt, ct, k * k, tile_elems=(Cout // rt) * (Cin // ct), wg_per_cu=min(8, 160 * 1024 // (256 * (Cout // rt + Cin // ct) + 512)))
         print("ksplit", ks, end="  ")
-        d = ops.conv_wgrad_desc(N, H, W, Cin, Cin, x.numel() * 2, H, W, Cout, Cout, dy.numel() * 2, k, 1, pad, ks)
+        d = ops.conv_wgrad_desc(N, H, W, Cin, Cin, x.numel() * 2, H, W, Cout, Cout, dy.numel() * 2, k, 1, pad, ks, dil=dil)
         fn = lambda: ops.conv_wgrad(d, dy, x, dw)
         flops = 2.0 * N * H * W * Cout * k * k * Cin
     for _ in range(3):
