@@ -273,6 +273,7 @@ class ParamStore:
             self.nbt[i] = int(bn.num_batches_tracked)
             bn.num_batches_tracked.data = self.nbt[i]
         self.params = [p for p in m.parameters()]
+        self._g_base, self._g2_base = self._uses(self.G), None      # storage use counts with no outside views
 
     def attach_grads(self):
         """Make the .grad of every Parameter that requires grad the matching view of the flat gradient buffer
@@ -299,18 +300,43 @@ class ParamStore:
                 return self.G2 if self._in(p.grad, self.G2) else self.G
         return self.G
 
+    @staticmethod
+    def _uses(buf):
+        """Number of live tensors sharing buf's storage (every view counts), or None if torch does not tell."""
+        try:
+            return torch._C._storage_Use_Count(buf.untyped_storage()._cdata)
+        except Exception:
+            return None
+
     def begin_autograd_backward(self):
-        """Pick and zero the buffer this backward writes: the one that does NOT hold the live .grad tensors, so that
-        autograd can add the returned views onto them (accumulation) or adopt them without a copy (.grad is None)."""
+        """Pick and zero the buffer this backward writes: one that holds neither the live .grad tensors (so that
+        autograd can add the returned views onto them — accumulation — or adopt them without a copy when .grad is
+        None) nor views somebody else still owns: the gradients torch.autograd.grad() returned from an earlier
+        backward are views of a flat buffer too, and zeroing it under them would silently change those tensors.
+        The storage's use count says whether such views exist; a buffer still referenced is left to its owners."""
         held = None
         for p in self.params:
             if p.requires_grad and p.grad is not None:
                 held = p.grad
                 break
-        target = self.G
-        if held is not None and self._in(held, self.G):
-            if self.G2 is None:
-                self.G2 = torch.zeros_like(self.G)
+
+        def free(buf, base):
+            if buf is None or (held is not None and self._in(held, buf)):
+                return False
+            u = self._uses(buf)
+            return u is not None and u <= base
+        if self._g_base is None:                      # no use counts: the old rule (and backward returns copies)
+            target = self.G
+            if held is not None and self._in(held, self.G):
+                if self.G2 is None:
+                    self.G2 = torch.zeros_like(self.G)
+                target = self.G2
+        elif free(self.G, self._g_base):
+            target = self.G
+        else:
+            if not free(self.G2, self._g2_base):
+                self.G2 = torch.zeros_like(self.G)  # the previous G2 (if any) lives on with whoever references it
+                self._g2_base = self._uses(self.G2)
             target = self.G2
         target.zero_()
         self.Gcur = target

@@ -248,6 +248,8 @@ class _FCRNFunction(torch.autograd.Function):
         finally:
             st.Gcur = st.G                       # the direct (non-autograd) path always accumulates into G
         grads = tuple(st.grad_view(p, buf) if need else None for p, need in zip(eng.params, ctx.needs_input_grad[3:]))
+        if st._g_base is None:                   # torch cannot tell who still views the flat buffers: hand out copies
+            grads = tuple(g.clone() if g is not None else None for g in grads)
         return (None, None, None) + grads
 
 
