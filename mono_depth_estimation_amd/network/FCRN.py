@@ -236,11 +236,20 @@ class _FCRNFunction(torch.autograd.Function):
     def forward(ctx, x, engine, train, *params):
         ctx.engine = engine
         y = engine.forward(x, train)
+        engine.forward_serial = ctx.serial = getattr(engine, "forward_serial", 0) + 1
         return y.clone()
 
     @staticmethod
     def backward(ctx, dy):
         eng = ctx.engine
+        if ctx.serial != eng.forward_serial:
+            # the launch plan of one input shape owns ONE set of activation buffers: a later forward of the same shape
+            # has replaced what this backward needs.  Refuse instead of returning gradients of the wrong activations.
+            raise RuntimeError(
+                "mono_depth_estimation_amd FCRN: backward() of a forward pass whose activations were overwritten by a "
+                "later forward of the same input shape (forward #%d, latest #%d).  Run forward and backward in pairs "
+                "(gradient accumulation over micro-batches does), or keep a second module copy for the interleaved "
+                "pass." % (ctx.serial, eng.forward_serial))
         st = eng.store
         buf = st.begin_autograd_backward()
         try:

@@ -799,3 +799,23 @@ def test_autograd_grad_results_are_not_overwritten():
     (net(x) * dy).sum().backward()
     same_direction([p.grad for p in ps], 2.0)
     net._store.adam_step(1e-4, 1e-3)
+
+
+def test_backward_after_a_later_forward_is_refused():
+    """One launch plan per input shape owns one set of activations: fwd, fwd, bwd(first) would differentiate the
+    wrong activations.  It raises; fwd/bwd pairs, other shapes and no-grad evaluation passes of ANOTHER shape between
+    a forward and its backward are fine."""
+    from mono_depth_estimation_amd.network import FCRN
+    size = (64, 96)
+    net = FCRN.ResNet(layers=50, output_size=size, out_channels=1, pretrained=False).cuda().train()
+    x1, x2 = torch.rand(2, 3, *size, device="cuda"), torch.rand(2, 3, *size, device="cuda")
+    y1 = net(x1)
+    y2 = net(x2)
+    y2.sum().backward()                                  # the latest forward: fine
+    with pytest.raises(RuntimeError, match="overwritten by a later forward"):
+        y1.sum().backward()
+    y1 = net(x1)
+    with torch.no_grad():
+        net(torch.rand(1, 3, *size, device="cuda"))      # another shape = another plan
+    y1.sum().backward()
+    assert all(torch.isfinite(p.grad).all() for p in net.parameters())
