@@ -356,6 +356,16 @@ typedef struct mde_pack_job {
 } mde_pack_job;
 int mde_pack_wt_batch(const float* src, void* dst, const mde_pack_job* jobs, int njobs, int64_t nblocks,
                       void* stream);
+/* Detecting parameter writes torch's version counters do not see (`.data` writes, collectives into detached views):
+ * mde_param_fingerprint folds the raw words of the flat fp32 range into a 64-bit position-weighted sum and records in
+ * `state` (DEVICE, >= mde_param_fingerprint_state_bytes(), zero-initialised once) whether it differs from the previous
+ * call's; mde_refresh_if_changed then re-derives the bf16 shadow and the transposed packings ON DEVICE only if it did
+ * (no host synchronisation: the kernels read the flag and return).  Cost when nothing changed: one read of the range. */
+size_t mde_param_fingerprint_state_bytes(void);
+int mde_param_fingerprint(const float* p, int64_t n, void* state, void* stream);
+int mde_refresh_if_changed(const float* src, void* shadow, void* packed, const mde_pack_job* jobs, int njobs,
+                           int64_t nblocks, int64_t n, const void* state, void* stream);
+
 /* fp32 NCHW -> bf16 NHWC (and back) layout changes at the module boundary. */
 int mde_nchw_to_nhwc_bf16(const float* src, void* dst, int N, int C, int H, int W, void* stream);
 int mde_nhwc_bf16_to_nchw(const void* src, float* dst, int N, int C, int H, int W, void* stream);

@@ -106,6 +106,9 @@ SIGNATURES = {
     "mde_adamw_step": (_I, [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _F, _I, _P]),
     "mde_sgd_step": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _P]),
     "mde_cast_bf16": (_I, [_P, _P, _L, _P]),
+    "mde_param_fingerprint_state_bytes": (_Z, []),
+    "mde_param_fingerprint": (_I, [_P, _L, _P, _P]),
+    "mde_refresh_if_changed": (_I, [_P, _P, _P, _P, _I, _L, _L, _P, _P]),
     "mde_pack_wt": (_I, [_P, _P, _I, _I, _I, _P]),
     "mde_pack_wt_batch": (_I, [_P, _P, _P, _I, _L, _P]),
     "mde_nchw_to_nhwc_bf16": (_I, [_P, _P, _I, _I, _I, _I, _P]),

@@ -84,7 +84,9 @@ __global__ __launch_bounds__(NT) void sgd_k(float* __restrict__ p, const float* 
     }
 }
 
-__global__ __launch_bounds__(NT) void cast_k(const float* __restrict__ src, bf16_t* __restrict__ dst, int64_t n) {
+__global__ __launch_bounds__(NT) void cast_k(const float* __restrict__ src, bf16_t* __restrict__ dst, int64_t n,
+                                             const uint32_t* __restrict__ gate) {
+    if (gate && *gate == 0u) return;                 // gated form: the fingerprint found the masters unchanged
     for (int64_t i = ((int64_t)blockIdx.x * NT + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * NT * 4) {
         if (i + 4 <= n) {
             const f32x4_t s = *reinterpret_cast<const f32x4_t*>(src + i);
@@ -116,8 +118,9 @@ __global__ void pack_wt_k(const float* __restrict__ src, bf16_t* __restrict__ ds
 
 // one launch for many weights: block b belongs to the last job whose first_block <= b
 __global__ void pack_wt_batch_k(const float* __restrict__ src, bf16_t* __restrict__ dst,
-                                const mde_pack_job* __restrict__ jobs, int njobs) {
+                                const mde_pack_job* __restrict__ jobs, int njobs, const uint32_t* __restrict__ gate) {
     __shared__ float tile[32][33];
+    if (gate && *gate == 0u) return;
     int lo = 0, hi = njobs - 1;                      // uniform binary search (the table is L2-resident)
     while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
@@ -141,6 +144,39 @@ __global__ void pack_wt_batch_k(const float* __restrict__ src, bf16_t* __restric
         const int i = i0 + r, o = o0 + threadIdx.x;
         if (i < I && o < O) d[((size_t)i * T + t) * O + o] = (bf16_t)tile[threadIdx.x][r];
     }
+}
+
+// Position-weighted 64-bit sum of the raw words of a flat fp32 range: any in-place change of a parameter that torch's
+// version counters do not see (writes through `.data`, collectives into detached views) changes it.
+struct FpState { unsigned long long acc, last; uint32_t changed, pad; };
+
+__global__ __launch_bounds__(NT) void fingerprint_k(const uint32_t* __restrict__ w, int64_t n, FpState* st) {
+    __shared__ unsigned long long sh[NT / 64];
+    unsigned long long a = 0ull;
+    for (int64_t i = ((int64_t)blockIdx.x * NT + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * NT * 4) {
+        if (i + 4 <= n) {
+            const i32x4_t v = *reinterpret_cast<const i32x4_t*>(w + i);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a += (unsigned long long)(uint32_t)v[e] * (unsigned long long)(2 * (i + e) + 1);
+        } else {
+            for (int64_t j = i; j < n; ++j) a += (unsigned long long)w[j] * (unsigned long long)(2 * j + 1);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long t = 0ull;
+        for (int k = 0; k < NT / 64; ++k) t += sh[k];
+        atomicAdd(&st->acc, t);
+    }
+}
+
+__global__ void fingerprint_finish_k(FpState* st) {
+    st->changed = st->acc != st->last ? 1u : 0u;
+    st->last = st->acc;
+    st->acc = 0ull;
 }
 
 int grid_for4(int64_t n) {
@@ -192,15 +228,39 @@ extern "C" int mde_sgd_step(float* p, const float* g, float* buf, void* p_bf16, 
 extern "C" int mde_cast_bf16(const float* src, void* dst, int64_t n, void* stream) {
     MDE_REQUIRE(src && dst && n > 0, "mde_cast_bf16: bad argument");
     MDE_REQUIRE(((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 8) == 0, "mde_cast_bf16: alignment");
-    cast_k<<<grid_for4(n), NT, 0, (hipStream_t)stream>>>(src, (bf16_t*)dst, n);
+    cast_k<<<grid_for4(n), NT, 0, (hipStream_t)stream>>>(src, (bf16_t*)dst, n, nullptr);
     MDE_LAUNCH_CHECK("cast_k");
+    return MDE_OK;
+}
+
+extern "C" size_t mde_param_fingerprint_state_bytes(void) { return sizeof(FpState); }
+
+extern "C" int mde_param_fingerprint(const float* p, int64_t n, void* state, void* stream) {
+    MDE_REQUIRE(p && state && n > 0 && ((uintptr_t)p % 16) == 0, "mde_param_fingerprint: bad argument");
+    fingerprint_k<<<grid_for4(n), NT, 0, (hipStream_t)stream>>>(reinterpret_cast<const uint32_t*>(p), n, (FpState*)state);
+    fingerprint_finish_k<<<1, 1, 0, (hipStream_t)stream>>>((FpState*)state);
+    MDE_LAUNCH_CHECK("fingerprint_k");
+    return MDE_OK;
+}
+
+extern "C" int mde_refresh_if_changed(const float* src, void* shadow, void* packed, const mde_pack_job* jobs, int njobs,
+                                      int64_t nblocks, int64_t n, const void* state, void* stream) {
+    MDE_REQUIRE(src && shadow && state && n > 0, "mde_refresh_if_changed: bad argument");
+    MDE_REQUIRE(((uintptr_t)src % 16) == 0 && ((uintptr_t)shadow % 8) == 0, "mde_refresh_if_changed: alignment");
+    const uint32_t* gate = &((const FpState*)state)->changed;
+    cast_k<<<grid_for4(n), NT, 0, (hipStream_t)stream>>>(src, (bf16_t*)shadow, n, gate);
+    if (packed && jobs && njobs > 0 && nblocks > 0) {
+        MDE_REQUIRE(nblocks < (1ll << 31), "mde_refresh_if_changed: grid too large");
+        pack_wt_batch_k<<<dim3((unsigned)nblocks), dim3(32, 8), 0, (hipStream_t)stream>>>(src, (bf16_t*)packed, jobs, njobs, gate);
+    }
+    MDE_LAUNCH_CHECK("mde_refresh_if_changed");
     return MDE_OK;
 }
 
 extern "C" int mde_pack_wt_batch(const float* src, void* dst, const mde_pack_job* jobs, int njobs, int64_t nblocks,
                                  void* stream) {
     MDE_REQUIRE(src && dst && jobs && njobs > 0 && nblocks > 0 && nblocks < (1ll << 31), "mde_pack_wt_batch: bad argument");
-    pack_wt_batch_k<<<dim3((unsigned)nblocks), dim3(32, 8), 0, (hipStream_t)stream>>>(src, (bf16_t*)dst, jobs, njobs);
+    pack_wt_batch_k<<<dim3((unsigned)nblocks), dim3(32, 8), 0, (hipStream_t)stream>>>(src, (bf16_t*)dst, jobs, njobs, nullptr);
     MDE_LAUNCH_CHECK("pack_wt_batch_k");
     return MDE_OK;
 }

@@ -165,6 +165,7 @@ class ParamStore:
         self.packed_version = -1
         self.adam_state = None
         self.sgd_state = None
+        self._fp_state, self._fp_valid = None, False     # device fingerprint of P (refresh_weights(check_data=True))
         self.step_count = 0
         self._flatten_parameters()
 
@@ -371,20 +372,37 @@ class ParamStore:
         version counter, not P's (``p.data = view`` keeps the parameter's own counter): P._version never moves."""
         return sum(p._version for p in self.params) + self.P._version
 
-    def refresh_weights(self, force=False):
-        """bf16 shadow + transposed packings follow the fp32 masters (after any in-place update)."""
+    def refresh_weights(self, force=False, check_data=False):
+        """bf16 shadow + transposed packings follow the fp32 masters (after any in-place update).
+        check_data (the nn.Module path): also catch writes torch's version counters do not record — `p.data.mul_()`,
+        the reference's own `weights_init` (`m.weight.data.normal_`), a collective into `p.data`: a device-side
+        fingerprint of the flat masters gates the same two kernels, without a host synchronisation (one extra read
+        of the 254 MB range per forward, ~0.07 ms)."""
         v = self.params_version()
         if force or v != self.packed_version:
             ops.cast_bf16(self.P, self.Pb)
             self.repack()
             self.packed_version = v
+            self._fp_valid = False
+        elif check_data:
+            if self._fp_state is None:
+                self._fp_state = ops.fingerprint_state(self.dev)
+            ops.param_fingerprint(self.P, self._fp_state)
+            if self._fp_valid:
+                jobs, nblocks = self._jobs()
+                ops.refresh_if_changed(self.P, self.Pb, self.WD if jobs is not None else None, jobs,
+                                       jobs.shape[0] if jobs is not None else 0, nblocks, self._fp_state)
+            self._fp_valid = True          # (a first call only records the fingerprint: the shadows are known fresh)
 
-    def repack(self):
-        """Transposed ("dgrad") packings of every conv weight that needs one, in a single launch."""
+    def _jobs(self):
         if self._pack_jobs is None:
             todo = sorted((c.off, c.O, c.T, c.I) for c in self.convs.values() if c.wd is not None)
             self._pack_jobs = ops.pack_jobs(todo, self.dev) if todo else (None, 0)
-        jobs, nblocks = self._pack_jobs
+        return self._pack_jobs
+
+    def repack(self):
+        """Transposed ("dgrad") packings of every conv weight that needs one, in a single launch."""
+        jobs, nblocks = self._jobs()
         if jobs is not None:
             ops.pack_wt_batch(self.P, self.WD, jobs, nblocks)
 
@@ -406,6 +424,7 @@ class ParamStore:
              grad_scale, self.step_count)
         self.repack()
         self.packed_version = self.params_version()   # shadow + packings are current (the kernels bump no version counter)
+        self._fp_valid = False
 
     # fused SGD with momentum over the same two ranges (modules/vnl.py:289-326: momentum 0.9, weight_decay 5e-4)
     def sgd_step(self, lr_encoder, lr_decoder, momentum=0.9, weight_decay=0.0, grad_scale=1.0):
@@ -417,6 +436,7 @@ class ParamStore:
         ops.sgd_step(self.P[e:], G[e:], buf[e:], self.Pb[e:], n - e, lr_decoder, momentum, weight_decay, grad_scale)
         self.repack()
         self.packed_version = self.params_version()
+        self._fp_valid = False
 
 
 class FCRNEngine:
@@ -502,9 +522,9 @@ class FCRNEngine:
         self.y = torch.empty(N, Co, self.OH, self.OW, device=dev)
 
     # ------------------------------------------------------------------ execution
-    def forward(self, x, train):
+    def forward(self, x, train, check_data=False):
         assert x.shape == (self.N, 3, self.H, self.W) and x.dtype == torch.float32 and x.is_contiguous()
-        self.store.refresh_weights()
+        self.store.refresh_weights(check_data=check_data)
         self.x = x
         s = self.stem_site
         ops.stem_conv_fwd(x, self.stem_w.w32, self.stem_c.t, s.part if train else None)

@@ -235,7 +235,7 @@ class _FCRNFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, engine, train, *params):
         ctx.engine = engine
-        y = engine.forward(x, train)
+        y = engine.forward(x, train, check_data=True)
         engine.forward_serial = ctx.serial = getattr(engine, "forward_serial", 0) + 1
         return y.clone()
 

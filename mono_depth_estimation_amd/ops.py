@@ -497,6 +497,19 @@ def depth_metrics(pred, target, ws, out):
 
 
 # ------------------------------------------------------------------------------ optimiser plumbing
+def fingerprint_state(device="cuda"):
+    return torch.zeros((_lib.load().mde_param_fingerprint_state_bytes() + 7) // 8, dtype=torch.int64, device=device)
+
+
+def param_fingerprint(p, state):
+    check(_lib.load().mde_param_fingerprint(_p(p), p.numel(), _p(state), _stream()), "mde_param_fingerprint")
+
+
+def refresh_if_changed(src, shadow, packed, jobs, njobs, nblocks, state):
+    check(_lib.load().mde_refresh_if_changed(_p(src), _p(shadow), _p(packed), _p(jobs), njobs, nblocks, src.numel(), _p(state),
+                                             _stream()), "mde_refresh_if_changed")
+
+
 def adamw_step(p, g, m, v, p_bf16, n, lr, beta1, beta2, eps, weight_decay, grad_scale, step):
     check(_lib.load().mde_adamw_step(_p(p), _p(g), _p(m), _p(v), _p(p_bf16), n, lr, beta1, beta2, eps, weight_decay,
                                      grad_scale, step, _stream()), "mde_adamw_step")

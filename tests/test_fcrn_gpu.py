@@ -819,3 +819,34 @@ def test_backward_after_a_later_forward_is_refused():
         net(torch.rand(1, 3, *size, device="cuda"))      # another shape = another plan
     y1.sum().backward()
     assert all(torch.isfinite(p.grad).all() for p in net.parameters())
+
+
+def test_data_writes_reach_the_kernels():
+    """Writes torch's version counters do not record (`p.data.mul_()`, the reference's `weights_init` style
+    `m.weight.data.normal_()`): the module path fingerprints the flat masters on the device and re-derives the bf16
+    shadow and the transposed packings when they changed — forward (shadow) and backward (transposed packing) alike."""
+    from mono_depth_estimation_amd.network import FCRN
+    size = (64, 96)
+    net = FCRN.ResNet(layers=50, output_size=size, out_channels=1, pretrained=False).cuda().eval()
+    x = torch.rand(2, 3, *size, device="cuda")
+    with torch.no_grad():
+        y0 = net(x)
+        y0b = net(x)
+        assert torch.equal(y0, y0b)
+        v = net._store.params_version()
+        net.conv3.weight.data.mul_(0.5)                       # invisible to _version
+        net.layer3[1].conv2.weight.data.normal_(0, 0.02)      # a trunk conv: forward shadow AND dgrad packing
+        assert net._store.params_version() == v
+        y1 = net(x)
+        net._store.refresh_weights(force=True)
+        y2 = net(x)
+    assert not torch.equal(y1, y0) and torch.equal(y1, y2)
+    net.train()
+    w = net.layer3[1].conv2.weight
+    g_ref = torch.autograd.grad(net(x).sum(), [net.conv1.weight])[0].clone()
+    w.data.neg_()                                             # flips the sign of everything flowing back through it
+    g_new = torch.autograd.grad(net(x).sum(), [net.conv1.weight])[0].clone()
+    net._store.refresh_weights(force=True)
+    g_chk = torch.autograd.grad(net(x).sum(), [net.conv1.weight])[0].clone()
+    cos = lambda a, b: float((a * b).sum() / (a.norm() * b.norm()))
+    assert cos(g_new, g_chk) >= 0.98 and cos(g_new, g_ref) < 0.9, (cos(g_new, g_chk), cos(g_new, g_ref))
