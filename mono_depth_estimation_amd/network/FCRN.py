@@ -367,9 +367,16 @@ class ResNet(nn.Module):
             self._store = st = ParamStore(self, x.device)
             self._engines.clear()
         key = tuple(x.shape)
-        eng = self._engines.get(key)
+        eng = self._engines.pop(key, None)
         if eng is None:
-            eng = self._engines[key] = FCRNEngine(self, st, x.shape[0], x.shape[2], x.shape[3])
+            # a launch plan owns every activation buffer of its shape (GBs at training batch sizes): keep the most
+            # recently used few ($MDE_MAX_PLANS, default 4), e.g. train + validation shapes; a plan that still has a
+            # backward pending stays alive through the autograd graph that references it.
+            cap = max(1, int(os.environ.get("MDE_MAX_PLANS", "4")))
+            while len(self._engines) >= cap:
+                self._engines.pop(next(iter(self._engines)))
+            eng = FCRNEngine(self, st, x.shape[0], x.shape[2], x.shape[3])
+        self._engines[key] = eng                     # (re)insert as the most recent
         return eng
 
     def forward(self, x):
