@@ -188,3 +188,26 @@ def test_depth_to_bins():
     assert int((diff & ~edge).sum()) == 0 and int(diff.sum()) <= 2
     assert int((bh.cpu() - bo).abs().max()) <= 1
     assert int((bh == C + 1).sum()) == int((depth < 0).sum()) and int(bh[bh <= C].max()) == C - 1
+
+
+def test_wcel_and_bin_mapping_full_size():
+    """BASELINE config 5's map size (150 bins at 480 x 640): WCEL value and gradient against the oracle, and the
+    round trip depth -> bins -> one-hot probabilities -> depth lands inside the bin it started from."""
+    from mono_depth_estimation_amd import criteria
+    C, H, Wd, dmin, dmax = 150, 480, 640, 0.01, 10.0
+    logit = W.normal(50, "x", (1, C, H, Wd), std=2.0)
+    gt = W.uniform(50, "g", (1, 1, H, Wd), -0.5, 11.0)
+    bins = criteria.depth_to_bins(gt.clone().cuda(), dmin, dmax, C)
+    crit = criteria.WCEL_Loss(_args(C, (H, Wd)))
+    lo, go = _lg(lambda x: OL.wcel(x, bins.cpu(), gt, OL.wcel_weight(C)), logit)
+    lh, gh = _lg(lambda x: crit(x, bins, gt.cuda()), logit.cuda())
+    _close(lh, lo, 2e-5, 1e-6, "wcel loss 480x640")
+    _close(gh, go, 1e-4, 1e-10, "wcel grad 480x640")
+    interval = (np.log10(dmax) - np.log10(dmin)) / C
+    border = np.log10(dmin) + interval * (np.arange(C) + 0.5)
+    valid = (bins < C).squeeze(1)
+    onehot = torch.nn.functional.one_hot(bins.clamp(0, C - 1).long().squeeze(1), C).permute(0, 3, 1, 2).float().contiguous()
+    centre = criteria.bins_to_depth(onehot, border)
+    d = gt.cuda().clamp(dmin, dmax)
+    ratio = (torch.log10(centre) - torch.log10(d)).abs().squeeze(1)[valid]
+    assert float(ratio.max()) <= 0.5 * interval * (1 + 1e-3)
