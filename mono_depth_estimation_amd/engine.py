@@ -205,6 +205,12 @@ class ParamStore:
             if kind == "deconv":
                 conv_bn(getattr(up, "deconv%d" % m.upSample.kernel_size), up.batchnorm)
                 continue
+            if kind == "fasterupconv":
+                for cn in ("conv1_", "conv2_", "conv3_", "conv4_"):
+                    seq = getattr(up, cn)
+                    conv_bn(seq.conv1, seq.bn1)
+                    plist.append(("b", [seq.conv1.bias]))
+                continue
             if kind == "fasterupproj":
                 for fu in (up.upper_branch.faster_upconv, up.bottom_branch):
                     for cn in ("conv1_", "conv2_", "conv3_", "conv4_"):
@@ -508,6 +514,8 @@ class FCRNEngine:
                 L = UpProjLayer(self, x, mod)
             elif kind == "fasterupproj":
                 L = FasterUpProjLayer(self, x, mod)
+            elif kind == "fasterupconv":
+                L = FasterUpConvLayer(self, x, mod)
             elif kind == "upconv":
                 L = UpConvLayer(self, x, mod)
             else:
@@ -954,3 +962,35 @@ class FasterUpProjLayer:
         self._shuffle(True)                             # d(a1), d(r) -> d(T)
         for i, u in enumerate(self.units):
             u.bwd(relu=i < 4)
+
+
+class FasterUpConvLayer:
+    """reference network/FCRN.py:113-164 (`FasterUpConv.faster_upconv_module`): the four biased convs + BN, the
+    pixel shuffle, ReLU — one branch of FasterUpProjLayer without the 3x3 and the join."""
+
+    def __init__(self, eng, x, mod):
+        self.eng, self.x, self.mod = eng, x, mod
+        dev, N, h, w, Cin = eng.dev, x.N, x.H, x.W, x.C
+        C = Cin // 2
+        self.C = C
+        self.Y = Act(dev, N, h, w, 4 * C)
+        self.T = Act(dev, N, h, w, 4 * C)
+        self.units = [_BiasedConvBN(eng, x, getattr(mod, cn), _FASTER_GEOMETRY[ci], self.Y.slice(ci * C, C), self.T.slice(ci * C, C))
+                      for ci, cn in enumerate(("conv1_", "conv2_", "conv3_", "conv4_"))]
+        self.out = Act(dev, N, 2 * h, 2 * w, C)
+
+    def first_param_offset(self):
+        return self.eng.store.p_off[id(self.mod.conv1_.conv1.weight)]
+
+    def reset_grad_flags(self):
+        self.Y.gw = self.T.gw = self.out.gw = False
+
+    def fwd(self, train):
+        for u in self.units:
+            u.fwd(train, relu=True)
+        ops.pixel_shuffle2(self.T.t, self.T.ld, self.out.t, self.out.ld, self.x.N, self.x.H, self.x.W, self.C)
+
+    def bwd(self):
+        ops.pixel_shuffle2(self.T.g, self.T.ld, self.out.g, self.out.ld, self.x.N, self.x.H, self.x.W, self.C, inverse=True)
+        for u in self.units:
+            u.bwd(relu=True)

@@ -174,6 +174,30 @@ class UpProj(Decoder):
         self.layer4 = self.UpProjModule(in_channels // 8)
 
 
+class FasterUpConv(Decoder):
+    """reference FCRN.py:113-164 (pixel-shuffle formulation of UpConv; its own weights).  The reference defines the
+    class but its choose_decoder never returns it; here `decoder='fasterupconv'` selects it."""
+    kind = "fasterupconv"
+
+    class faster_upconv_module(_Container):
+        def __init__(self, in_channel):
+            super().__init__()
+            for name, ks in (("conv1_", 3), ("conv2_", (2, 3)), ("conv3_", (3, 2)), ("conv4_", 2)):
+                setattr(self, name, _Seq(collections.OrderedDict([
+                    ('conv1', nn.Conv2d(in_channel, in_channel // 2, kernel_size=ks)),
+                    ('bn1', nn.BatchNorm2d(in_channel // 2)),
+                ])))
+            self.ps = nn.PixelShuffle(2)
+            self.relu = nn.ReLU(inplace=True)
+
+    def __init__(self, in_channel):
+        super().__init__()
+        self.layer1 = self.faster_upconv_module(in_channel)
+        self.layer2 = self.faster_upconv_module(in_channel // 2)
+        self.layer3 = self.faster_upconv_module(in_channel // 4)
+        self.layer4 = self.faster_upconv_module(in_channel // 8)
+
+
 class FasterUpProj(Decoder):
     """reference FCRN.py:206-281 (pixel-shuffle formulation; its own weights, not UpProj's)."""
     kind = "fasterupproj"
@@ -222,6 +246,8 @@ def choose_decoder(decoder, in_channels):
         return UpConv(in_channels)
     if decoder == "fasterupproj":
         return FasterUpProj(in_channels)
+    if decoder == "fasterupconv":          # (not offered by the reference's choose_decoder; the class is, FCRN.py:113)
+        return FasterUpConv(in_channels)
     assert False, "invalid option for decoder: {}".format(decoder)
 
 

@@ -197,18 +197,20 @@ class DeConv(nn.Module):
 class FasterUpconv(nn.Module):
     """FCRN.py:209-246: four biased convs on differently zero-padded copies of x, BN each, cat, PixelShuffle(2)."""
 
-    def __init__(self, cin):
+    def __init__(self, cin, with_relu=False):
         super().__init__()
         for name, ks in (("conv1_", 3), ("conv2_", (2, 3)), ("conv3_", (3, 2)), ("conv4_", 2)):
             setattr(self, name, nn.Sequential(OrderedDict([("conv1", nn.Conv2d(cin, cin // 2, ks)),
                                                            ("bn1", nn.BatchNorm2d(cin // 2))])))
         self.ps = nn.PixelShuffle(2)
         self.relu = nn.ReLU(inplace=True)
+        self.with_relu = with_relu       # FasterUpConv's module applies it (FCRN.py:160), FasterUpProj's does not (:245)
 
     def forward(self, x):
         xs = [self.conv1_(F.pad(x, (1, 1, 1, 1))), self.conv2_(F.pad(x, (1, 1, 0, 1))),
               self.conv3_(F.pad(x, (0, 1, 1, 1))), self.conv4_(F.pad(x, (0, 1, 0, 1)))]
-        return self.ps(torch.cat(xs, 1))
+        y = self.ps(torch.cat(xs, 1))
+        return self.relu(y) if self.with_relu else y
 
 
 class FasterUpProjModule(nn.Module):
@@ -237,8 +239,22 @@ class FasterUpProj(nn.Module):
         return self.layer4(self.layer3(self.layer2(self.layer1(x))))
 
 
+class FasterUpConv(nn.Module):
+    """FCRN.py:113-164: four x faster_upconv_module (the four convs + BN, shuffle, ReLU)."""
+
+    def __init__(self, cin):
+        super().__init__()
+        for i in range(4):
+            setattr(self, "layer%d" % (i + 1), FasterUpconv(cin // (2 ** i), with_relu=True))
+
+    def forward(self, x):
+        return self.layer4(self.layer3(self.layer2(self.layer1(x))))
+
+
 def make_decoder(decoder, cin):
-    """FCRN.py:282-294."""
+    """FCRN.py:282-294 (+ 'fasterupconv' for the class the reference defines at :113 but never selects)."""
+    if decoder == "fasterupconv":
+        return FasterUpConv(cin)
     if decoder == "fasterupproj":
         return FasterUpProj(cin)
     if decoder[:6] == "deconv":

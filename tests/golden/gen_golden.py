@@ -320,8 +320,12 @@ def gen_fcrn_decoders(criteria, metrics, FCRN):
     conditioned state, 2x3x64x96: eval output + metrics, train-mode SILog, per-parameter gradient norms."""
     size = (64, 96)
     out = {}
-    for dec in ("upconv", "deconv2", "deconv3", "fasterupproj"):
-        ref = FCRN.ResNet(layers=50, decoder=dec, output_size=size, in_channels=3, out_channels=1, pretrained=False)
+    for dec in ("upconv", "deconv2", "deconv3", "fasterupproj", "fasterupconv"):
+        if dec == "fasterupconv":     # the reference's choose_decoder never returns this class (FCRN.py:113, :282-294)
+            ref = FCRN.ResNet(layers=50, decoder="upconv", output_size=size, in_channels=3, out_channels=1, pretrained=False)
+            ref.upSample = FCRN.FasterUpConv(1024)
+        else:
+            ref = FCRN.ResNet(layers=50, decoder=dec, output_size=size, in_channels=3, out_channels=1, pretrained=False)
         W.fcrn_conditioned_state(ref, 8)
         rgb, tgt = W.synthetic_batch(8, 2, *size)
         W.calibrate_running_stats(ref, rgb)

@@ -595,7 +595,7 @@ def test_fused_adamw_and_sgd_steps_on_the_store():
         assert bool(torch.isfinite(y).all())
 
 
-@pytest.mark.parametrize("dec", ["upconv", "deconv2", "deconv3", "fasterupproj"])
+@pytest.mark.parametrize("dec", ["upconv", "deconv2", "deconv3", "fasterupproj", "fasterupconv"])
 def test_other_decoders_against_the_reference(golden, dec):
     """reference FCRN.py:68-110 (`decoder='upconv' | 'deconv2' | 'deconv3'`): same state_dict keys as the reference,
     eval output / AbsRel against the reference's own output on the conditioned fixture, train-mode SILog and
@@ -638,7 +638,7 @@ def test_other_decoders_against_the_reference(golden, dec):
         net.upSample.layer1(torch.zeros(1, 1024, 2, 3).cuda())        # containers never compute
 
 
-@pytest.mark.parametrize("dec", ["upconv", "deconv2", "deconv3", "fasterupproj"])
+@pytest.mark.parametrize("dec", ["upconv", "deconv2", "deconv3", "fasterupproj", "fasterupconv"])
 def test_decoder_layers_teacher_forced(dec):
     """Each decoder layer of the other decoders alone: fed the (bf16-emulating) oracle's input activation and output
     gradient, compared on its output, input gradient and every parameter gradient (relative L2)."""

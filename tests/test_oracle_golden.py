@@ -241,7 +241,7 @@ def test_stdepth_loss(golden, i):
 
 
 # ---------------------------------------------------------------- G5c: the other decoders (FCRN.py:68-110)
-@pytest.mark.parametrize("dec", ["upconv", "deconv2", "deconv3", "fasterupproj"])
+@pytest.mark.parametrize("dec", ["upconv", "deconv2", "deconv3", "fasterupproj", "fasterupconv"])
 def test_fcrn50_other_decoders(golden, dec):
     g = golden("fcrn_decoders")
     net = ofcrn.FCRNOracle(layers=50, output_size=(64, 96), out_channels=1, decoder=dec)
