@@ -55,12 +55,8 @@ def _param_groups(module):
     return [list(module.get_1x_lr_params()), list(module.get_10x_lr_params())]
 
 
-def _oihw(flat, off, p):
-    n = p.numel()
-    if p.dim() == 4:
-        O, I, kh, kw = p.shape
-        return flat[off:off + n].view(O, kh, kw, I).permute(0, 3, 1, 2)
-    return flat[off:off + n].view(p.shape)
+def _oihw(store, flat, p):
+    return store.view_of(flat, p)
 
 
 def adam_state_dict(module, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
@@ -74,10 +70,9 @@ def adam_state_dict(module, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
     for gi, params in enumerate(groups):
         ids = []
         for p in params:
-            off = store.p_off[id(p)]
             state[idx] = {"step": torch.tensor(float(store.step_count)),
-                          "exp_avg": _oihw(mom, off, p).detach().to("cpu").contiguous().clone(),
-                          "exp_avg_sq": _oihw(var, off, p).detach().to("cpu").contiguous().clone()}
+                          "exp_avg": _oihw(store, mom, p).detach().to("cpu").contiguous().clone(),
+                          "exp_avg_sq": _oihw(store, var, p).detach().to("cpu").contiguous().clone()}
             ids.append(idx)
             idx += 1
         pg.append({"lr": lr * (1 if gi == 0 else 10), "betas": tuple(betas), "eps": eps, "weight_decay": weight_decay,
@@ -106,9 +101,8 @@ def load_adam_state_dict(module, sd):
                 continue
             if tuple(st["exp_avg"].shape) != tuple(p.shape):
                 raise ValueError("optimizer state %d has shape %s, parameter %s" % (i, tuple(st["exp_avg"].shape), tuple(p.shape)))
-            off = store.p_off[id(p)]
-            _oihw(mom, off, p).copy_(st["exp_avg"].to(mom.device))
-            _oihw(var, off, p).copy_(st["exp_avg_sq"].to(var.device))
+            _oihw(store, mom, p).copy_(st["exp_avg"].to(mom.device))
+            _oihw(store, var, p).copy_(st["exp_avg_sq"].to(var.device))
             steps.add(int(st["step"]))
     if len(steps) > 1:
         raise ValueError("optimizer state carries different step counts per parameter: %s" % sorted(steps))

@@ -187,11 +187,10 @@ class ParamStore:
 
         conv_bn(m.conv1, m.bn1)
         for _, blk in self._blocks():
-            if not hasattr(blk, "conv3"):
-                raise NotImplementedError("HIP engine supports bottleneck trunks (layers 50/101/152) only")
             conv_bn(blk.conv1, blk.bn1)
             conv_bn(blk.conv2, blk.bn2)
-            conv_bn(blk.conv3, blk.bn3)
+            if hasattr(blk, "conv3"):
+                conv_bn(blk.conv3, blk.bn3)
             if blk.downsample is not None:
                 conv_bn(blk.downsample[0], blk.downsample[1])
         self.n_encoder_entries = len(plist)
@@ -228,12 +227,29 @@ class ParamStore:
             conv_bn(ub.conv2, ub.batchnorm2)
         plist.append(("w", [m.conv3.weight]))
 
+        # Storage shape of every parameter.  The GEMM kernels take channel counts that are multiples of 64; the
+        # decoders of the ResNet-18/34 variants end in 32- and 16-channel layers (FCRN.py:329-349 with
+        # num_channels = 512), so such tensors are stored zero-padded to 64 channels ([Op][kh][kw][Ip], BN vectors
+        # [Cp]) and the Parameter is the strided view of the real entries.  Padded entries stay exactly zero: their
+        # activations, gradients and Adam moments are all zero.  Nothing is padded for the 50/101/152 networks.
+        pad64 = lambda c: (c + 63) // 64 * 64
+        no_pad = {id(m.conv1.weight): (False, False), id(m.conv3.weight): (False, True)}   # (pad O, pad I)
+        self.sdims = {}
+        for _, ts in plist:
+            for t in ts:
+                if t.dim() == 4:
+                    po, pi = no_pad.get(id(t), (True, True))
+                    O, I, kh, kw = t.shape
+                    self.sdims[id(t)] = (pad64(O) if po else O, kh, kw, pad64(I) if pi else I)
+                else:
+                    self.sdims[id(t)] = (pad64(t.numel()),)
+        snumel = lambda t: int(torch.Size(self.sdims[id(t)]).numel())
         offs, size = [], 0
         for i, (_, ts) in enumerate(plist):
             if i == self.n_encoder_entries:
                 self.encoder_numel = size
             offs.append(size)
-            size = _round_up(size + sum(t.numel() for t in ts))
+            size = _round_up(size + sum(snumel(t) for t in ts))
         self.P = torch.zeros(size, dtype=torch.float32, device=dev)
         self.G = torch.zeros(size, dtype=torch.float32, device=dev)
         self.G2 = None                    # second gradient buffer, only for the autograd path (see begin_autograd_backward)
@@ -245,23 +261,17 @@ class ParamStore:
         for (kind, ts), off in zip(plist, offs):
             o = off
             for t in ts:
-                n = t.numel()
-                if t.dim() == 4:
-                    O, I, kh, kw = t.shape
-                    view = self.P[o:o + n].view(O, kh, kw, I).permute(0, 3, 1, 2)     # OIHW view of OHWI storage
-                    gview = self.G[o:o + n].view(O, kh, kw, I).permute(0, 3, 1, 2)
-                else:
-                    view, gview = self.P[o:o + n].view(t.shape), self.G[o:o + n].view(t.shape)
+                self.p_off[id(t)] = o
+                view, gview = self.view_of(self.P, t), self.view_of(self.G, t)       # OIHW view of OHWI storage
                 with torch.no_grad():
                     view.copy_(t.detach().to(dev))
                 t.data = view
                 t._mde_grad = gview
-                self.p_off[id(t)] = o
-                o += n
+                o += snumel(t)
         bsize, boffs = 0, []
         for ts in blist:
             boffs.append(bsize)
-            bsize = _round_up(bsize + sum(t.numel() for t in ts))
+            bsize = _round_up(bsize + sum(pad64(t.numel()) for t in ts))
         self.B = torch.zeros(bsize, dtype=torch.float32, device=dev)
         self.b_off = {}
         for ts, off in zip(blist, boffs):
@@ -272,7 +282,7 @@ class ParamStore:
                 view.copy_(t.detach().to(dev))
                 t.data = view
                 self.b_off[id(t)] = o
-                o += n
+                o += pad64(n)
         # one shared int64 counter vector for every BN's num_batches_tracked
         bns = [mod for mod in m.modules() if isinstance(mod, torch.nn.BatchNorm2d)]
         self.nbt = torch.zeros(len(bns), dtype=torch.int64, device=dev)
@@ -349,13 +359,18 @@ class ParamStore:
         self.Gcur = target
         return target
 
-    def grad_view(self, p, buf):
-        """A FRESH tensor (nobody else references it: autograd may adopt it as .grad) viewing p's slice of buf."""
-        off, n = self.p_off[id(p)], p.numel()
+    def view_of(self, flat, p):
+        """p's entries inside a flat buffer laid out like P (its storage may be zero-padded to 64 channels)."""
+        off, sd = self.p_off[id(p)], self.sdims[id(p)]
+        n = int(torch.Size(sd).numel())
         if p.dim() == 4:
             O, I, kh, kw = p.shape
-            return buf[off:off + n].view(O, kh, kw, I).permute(0, 3, 1, 2)
-        return buf[off:off + n].view(p.shape)
+            return flat[off:off + n].view(sd)[:O, :, :, :I].permute(0, 3, 1, 2)
+        return flat[off:off + p.numel()].view(p.shape)
+
+    def grad_view(self, p, buf):
+        """A FRESH tensor (nobody else references it: autograd may adopt it as .grad) viewing p's slice of buf."""
+        return self.view_of(buf, p)
 
     def storage_is_current(self):
         p = self.m.conv1.weight
@@ -365,8 +380,8 @@ class ParamStore:
         t0 = weights[0]
         c = self.convs.get(id(t0))
         if c is None:
-            O = sum(t.shape[0] for t in weights)
-            _, I, kh, kw = t0.shape
+            O = sum(self.sdims[id(t)][0] for t in weights)            # storage (possibly padded) channel counts
+            _, kh, kw, I = self.sdims[id(t0)]
             c = Conv(self, self.p_off[id(t0)], O, kh * kw, I, need_dgrad)
             self.convs[id(t0)] = c
             self._pack_jobs = None
@@ -473,7 +488,7 @@ class FCRNEngine:
 
     def _site(self, bns):
         g0, b0, rm0, rv0 = bns[0].weight, bns[0].bias, bns[0].running_mean, bns[0].running_var
-        C = sum(b.num_features for b in bns)
+        C = sum(self.store.sdims[id(b.weight)][0] for b in bns)     # storage (possibly padded) channel count
         po, pb = self.p_off[id(g0)], self.p_off[id(b0)]
         bo, bv = self.b_off[id(rm0)], self.b_off[id(rv0)]
         return BNSite(self, C, self.P[po:po + C], self.P[pb:pb + C], po, pb,
@@ -500,7 +515,7 @@ class FCRNEngine:
         self.pool_idx = torch.empty(N, H4, W4, 64, dtype=torch.uint8, device=dev)
         x = self.pool
         for _, blk in self._blocks():
-            L = Bottleneck(self, x, blk)
+            L = Bottleneck(self, x, blk) if hasattr(blk, "conv3") else BasicBlock(self, x, blk)
             self.layers.append(L)
             x = L.out
         L = ConvBN(self, x, self._conv([m.conv2.weight]), self._site([m.bn2]), 1, 1, 0, relu=False)
@@ -723,6 +738,50 @@ class Bottleneck:
         self.a.bwd()
 
 
+class BasicBlock:
+    """torchvision BasicBlock (resnet18 / 34, reference network/FCRN.py:305 with layers <= 34): 3x3(stride) -> BN -> ReLU
+    -> 3x3 -> BN -> (+ identity or 1x1/stride shortcut-BN) -> ReLU."""
+
+    def __init__(self, eng, x, blk):
+        self.x, self.eng, self.blk = x, eng, blk
+        s = blk.conv1.stride[0]
+        self.a = ConvBN(eng, x, eng._conv([blk.conv1.weight]), eng._site([blk.bn1]), 3, s, 1, True)
+        self.ds = None
+        if blk.downsample is not None:
+            self.ds = ConvBN(eng, x, eng._conv([blk.downsample[0].weight]), eng._site([blk.downsample[1]]), 1,
+                             blk.downsample[0].stride[0], 0, False, has_out=False)
+            self.c = ConvBN(eng, self.a.out, eng._conv([blk.conv2.weight]), eng._site([blk.bn2]), 3, 1, 1, True,
+                            res=self.ds.c, res_site=self.ds.site)
+        else:
+            self.c = ConvBN(eng, self.a.out, eng._conv([blk.conv2.weight]), eng._site([blk.bn2]), 3, 1, 1, True, res=x)
+        self.out = self.c.out
+
+    def first_param_offset(self):
+        return self.eng.store.p_off[id(self.blk.conv1.weight)]
+
+    def reset_grad_flags(self):
+        for u in (self.a, self.c, self.ds):
+            if u is not None:
+                u.reset_grad_flags()
+
+    def fwd(self, train):
+        self.a.fwd(train)
+        if self.ds is not None:
+            self.ds.conv_fwd(train)
+        self.c.fwd(train)
+
+    def bwd(self):
+        c, ds = self.c, self.ds
+        if ds is None:
+            c.bn_bwd(dres_to=self.x)
+        else:
+            bn_join_backward(c.site, ds.site, c.out.g, c.out, c.c, ds.c, c.c.g, ds.c.g, c.bits)
+            c.c.gw = ds.c.gw = True
+            ds.conv_bwd()
+        c.conv_bwd()
+        self.a.bwd()
+
+
 class UpProjLayer:
     """reference network/FCRN.py:170-198 without the zero-stuffed tensor: both 5x5 branches as
     one 4-phase GEMM into y55 [N][2h][2w][2C]; upper half -> BN -> ReLU -> 3x3 -> BN, joined
@@ -731,9 +790,9 @@ class UpProjLayer:
     def __init__(self, eng, x, mod):
         self.eng, self.x, self.mod = eng, x, mod
         dev, N, h, w, Cin = eng.dev, x.N, x.H, x.W, x.C
-        C = Cin // 2
         ub, bb = mod.upper_branch, mod.bottom_branch
         self.w55 = eng._conv([ub.conv1.weight, bb.conv.weight])
+        C = self.w55.O // 2                               # (storage channels: Cin // 2, or 64 where that is smaller)
         self.site55 = eng._site([ub.batchnorm1, bb.batchnorm])
         self.site_u, self.site_b = self.site55.half(eng, 0), self.site55.half(eng, 1)
         self.y55 = Act(dev, N, 2 * h, 2 * w, 2 * C)

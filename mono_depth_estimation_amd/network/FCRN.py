@@ -72,10 +72,30 @@ class Bottleneck(_Container):
             self.downsample = nn.Sequential(nn.Conv2d(cin, cout, 1, stride=stride, bias=False), nn.BatchNorm2d(cout))
 
 
-_BLOCKS = {50: [3, 4, 6, 3], 101: [3, 4, 23, 3], 152: [3, 8, 36, 3]}
+class BasicBlock(_Container):
+    """torchvision BasicBlock (resnet18 / resnet34) — names as torchvision's."""
+    expansion = 1
+
+    def __init__(self, cin, width, stride=1, project=False):
+        super().__init__()
+        self.conv1 = nn.Conv2d(cin, width, 3, stride=stride, padding=1, bias=False)
+        self.bn1 = nn.BatchNorm2d(width)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = nn.Conv2d(width, width, 3, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(width)
+        self.downsample = None
+        if project:
+            self.downsample = nn.Sequential(nn.Conv2d(cin, width, 1, stride=stride, bias=False), nn.BatchNorm2d(width))
 
 
-def _stage(cin, width, n, stride):
+_BLOCKS = {18: [2, 2, 2, 2], 34: [3, 4, 6, 3], 50: [3, 4, 6, 3], 101: [3, 4, 23, 3], 152: [3, 8, 36, 3]}
+
+
+def _stage(cin, width, n, stride, basic=False):
+    if basic:
+        mods = [BasicBlock(cin, width, stride, project=(stride != 1 or cin != width))]
+        mods += [BasicBlock(width, width) for _ in range(1, n)]
+        return nn.Sequential(*mods)
     mods = [Bottleneck(cin, width, stride, project=True)]
     mods += [Bottleneck(width * 4, width) for _ in range(1, n)]
     return nn.Sequential(*mods)
@@ -293,8 +313,6 @@ class ResNet(nn.Module):
                  out_channels=20, pretrained=True):
         if layers not in [18, 34, 50, 101, 152]:
             raise RuntimeError('Only 18, 34, 50, 101, and 152 layer model are defined for ResNet. Got {}'.format(layers))
-        if layers not in _BLOCKS:
-            raise NotImplementedError("HIP FCRN path implements the bottleneck trunks (50/101/152); got %d" % layers)
         if in_channels != 3:
             raise NotImplementedError("HIP FCRN stem kernel takes 3-channel images (got in_channels=%d)" % in_channels)
         super(ResNet, self).__init__()
@@ -304,16 +322,18 @@ class ResNet(nn.Module):
         self.output_size = tuple(output_size)
         self.relu = nn.ReLU(inplace=True)
         self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
-        self.layer1 = _stage(64, 64, n[0], 1)
-        self.layer2 = _stage(256, 128, n[1], 2)
-        self.layer3 = _stage(512, 256, n[2], 2)
-        self.layer4 = _stage(1024, 512, n[3], 2)
+        basic = layers <= 34
+        e = 1 if basic else 4
+        self.layer1 = _stage(64, 64, n[0], 1, basic)
+        self.layer2 = _stage(64 * e, 128, n[1], 2, basic)
+        self.layer3 = _stage(128 * e, 256, n[2], 2, basic)
+        self.layer4 = _stage(256 * e, 512, n[3], 2, basic)
         # torchvision's default init of the trunk (pretrained=False): He fan-out normal, BN (1, 0)
         for m in (self.conv1, self.layer1, self.layer2, self.layer3, self.layer4):
             for mod in m.modules():
                 if isinstance(mod, nn.Conv2d):
                     nn.init.kaiming_normal_(mod.weight, mode='fan_out', nonlinearity='relu')
-        num_channels = 2048
+        num_channels = 512 if basic else 2048           # reference FCRN.py:329-332
         self.conv2 = nn.Conv2d(num_channels, num_channels // 2, kernel_size=1, bias=False)
         self.bn2 = nn.BatchNorm2d(num_channels // 2)
         self.upSample = choose_decoder(decoder, num_channels // 2)

@@ -89,7 +89,7 @@ def calibrate_running_stats(model, x):
         m.momentum = o
 
 
-def fcrn_conditioned_state(model, seed):
+def fcrn_conditioned_state(model, seed, basic=False):
     """A WELL-CONDITIONED deterministic state for end-to-end precision parity: the last BN of
     every residual branch has gamma x0.05 (the "zero-init residual" regime) and the decoder's
     joining BNs gamma x0.3.  With plain He-init (fcrn_fixture_state) the 50-layer net amplifies
@@ -103,8 +103,8 @@ def fcrn_conditioned_state(model, seed):
         if sd[k].ndim == 4:
             sd[k] = sd[k].to(torch.bfloat16).to(torch.float32)
     for k in sd:
-        if k.endswith("bn3.weight"):
-            sd[k] = sd[k] * 0.05
+        if k.endswith("bn3.weight") or (basic and k.startswith("layer") and k.endswith("bn2.weight")):
+            sd[k] = sd[k] * 0.05            # (basic: the BasicBlock trunks' residual branches end in bn2)
         elif "upper_branch.batchnorm2.weight" in k or "bottom_branch.batchnorm.weight" in k:
             sd[k] = sd[k] * 0.3
     sd["conv3.weight"] = (sd["conv3.weight"] * 0.05).to(torch.bfloat16).to(torch.float32)

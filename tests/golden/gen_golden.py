@@ -349,6 +349,37 @@ def gen_fcrn_decoders(criteria, metrics, FCRN):
     np.savez_compressed(os.path.join(HERE, "fcrn_decoders.npz"), **out)
 
 
+def gen_fcrn_basic_trunks(criteria, metrics, FCRN):
+    """G5d: the reference network on the BasicBlock trunks (`layers=18 / 34`, FCRN.py:297-332: num_channels = 512, so
+    the UpProj decoder runs 256 -> 16 channels), 2x3x64x96: eval output + metrics, train SILog, gradient norms."""
+    size = (64, 96)
+    out = {}
+    for layers in (18, 34):
+        tag = "r%d" % layers
+        ref = FCRN.ResNet(layers=layers, decoder="upproj", output_size=size, in_channels=3, out_channels=1, pretrained=False)
+        W.fcrn_conditioned_state(ref, 10 + layers, basic=True)
+        rgb, tgt = W.synthetic_batch(10 + layers, 2, *size)
+        W.calibrate_running_stats(ref, rgb)
+        ref.eval()
+        with torch.no_grad():
+            y = ref(rgb)
+        out[tag + "_eval_out"] = _np(y)
+        mc = metrics.MetricComputation(["absrel", "rmse", "delta1"])
+        for n, v in zip(mc.names, mc.compute(y, tgt)):
+            out[tag + "_eval_" + n] = _np(v)
+        ref.train()
+        loss = criteria.silog_loss(0.85)(ref(rgb), tgt)
+        loss.backward()
+        out[tag + "_train_silog"] = _np(loss)
+        out[tag + "_names"] = np.array([k for k, _ in ref.named_parameters()])
+        out[tag + "_grad_norm"] = np.array([float(p.grad.double().norm()) for _, p in ref.named_parameters()])
+        out[tag + "_state_keys"] = np.array(list(ref.state_dict().keys()))
+        print("fcrn_basic_trunks resnet%d absrel %.6f train_silog %.5f params %d keys %d range %.3f..%.3f" % (
+            layers, float(out[tag + "_eval_absrel"]), float(loss), sum(p.numel() for p in ref.parameters()),
+            len(ref.state_dict()), float(y.min()), float(y.max())))
+    np.savez_compressed(os.path.join(HERE, "fcrn_basic_trunks.npz"), **out)
+
+
 def gen_fcrn_conditioned(criteria, metrics, FCRN):
     """G5b: the same reference network on the well-conditioned state (oracle/weights.py:
     fcrn_conditioned_state) — the fixture on which the 1e-4 AbsRel bound is asserted."""
@@ -387,6 +418,7 @@ def main():
     gen_fcrn(criteria, metrics, FCRN)
     gen_fcrn_conditioned(criteria, metrics, FCRN)
     gen_fcrn_decoders(criteria, metrics, FCRN)
+    gen_fcrn_basic_trunks(criteria, metrics, FCRN)
 
 
 if __name__ == "__main__":

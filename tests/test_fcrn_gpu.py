@@ -638,16 +638,18 @@ def test_other_decoders_against_the_reference(golden, dec):
         net.upSample.layer1(torch.zeros(1, 1024, 2, 3).cuda())        # containers never compute
 
 
-@pytest.mark.parametrize("dec", ["upconv", "deconv2", "deconv3", "fasterupproj", "fasterupconv"])
-def test_decoder_layers_teacher_forced(dec):
-    """Each decoder layer of the other decoders alone: fed the (bf16-emulating) oracle's input activation and output
-    gradient, compared on its output, input gradient and every parameter gradient (relative L2)."""
+@pytest.mark.parametrize("dec,layers", [("upconv", 50), ("deconv2", 50), ("deconv3", 50), ("fasterupproj", 50),
+                                        ("fasterupconv", 50), ("upproj", 18)])
+def test_decoder_layers_teacher_forced(dec, layers):
+    """Each decoder layer of the other decoders (and of the zero-padded 32/16-channel UpProj tail of ResNet-18) alone:
+    fed the (bf16-emulating) oracle's input activation and output gradient, compared on its output, input gradient and
+    every parameter gradient (relative L2); padded channels must come out exactly zero."""
     from mono_depth_estimation_amd.network import FCRN
     size = (64, 96)
-    ora = ofcrn.FCRNOracle(50, size, out_channels=1, decoder=dec)
+    ora = ofcrn.FCRNOracle(layers, size, out_channels=1, decoder=dec)
     sd = W.fcrn_fixture_state(ora, 21)
     rgb, tgt = W.synthetic_batch(21, 2, *size)
-    hip = FCRN.ResNet(layers=50, decoder=dec, output_size=size, out_channels=1, pretrained=False)
+    hip = FCRN.ResNet(layers=layers, decoder=dec, output_size=size, out_channels=1, pretrained=False)
     hip.load_state_dict(sd)
     hip = hip.cuda().train()
     rnd = lambda mod, inp, out: out.to(torch.bfloat16).float()
@@ -659,6 +661,8 @@ def test_decoder_layers_teacher_forced(dec):
                 mod.register_forward_hook(rnd)
         elif isinstance(mod, torch.nn.ReLU) or name == "bn2" or (name.startswith("upSample.") and name.endswith("bn1")):
             mod.register_forward_hook(rnd)
+        elif isinstance(mod, ofcrn.UpProjModule):
+            pass                                              # (its output is rounded by the layer hook below)
     ora.train()
     ins, outs = {}, {}
     for i in (1, 2, 3, 4):
@@ -682,15 +686,20 @@ def test_decoder_layers_teacher_forced(dec):
     dev = lambda t: t.detach().permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).cuda()
     report = []
     for i, L in zip((1, 2, 3, 4), eng.layers[-4:]):
-        L.x.t.copy_(dev(ins[i]))
+        ci, co = ins[i].shape[1], outs[i].shape[1]            # real channels; the engine's tensors may be padded to 64
+        L.x.t.zero_()
+        L.x.t[..., :ci].copy_(dev(ins[i]))
         L.fwd(True)
-        e_f = _rel(_nchw(L.out.t), outs[i].detach())
+        e_f = _rel(_nchw(L.out.t[..., :co]), outs[i].detach())
+        assert float(L.out.t[..., co:].float().abs().max() if L.out.C > co else 0.0) == 0.0
         eng.store.G.zero_()
         L.reset_grad_flags()
         L.x.gw = False
-        L.out.g.copy_(dev(outs[i].grad))
+        L.out.g.zero_()
+        L.out.g[..., :co].copy_(dev(outs[i].grad))
         L.bwd()
-        e_b = _rel(_nchw(L.x.g), ins[i].grad)
+        e_b = _rel(_nchw(L.x.g[..., :ci]), ins[i].grad)
+        assert float(L.x.g[..., ci:].float().abs().max() if L.x.C > ci else 0.0) == 0.0
         prefix = "upSample.layer%d." % i
         op = {k: q for k, q in ora.named_parameters() if k.startswith(prefix)}
         # a conv bias in front of a train-mode BN has an exactly zero gradient (autograd leaves rounding dust there)
@@ -703,7 +712,7 @@ def test_decoder_layers_teacher_forced(dec):
         report.append((i, e_f, e_b, errs[worst], worst))
     torch.cuda.synchronize()
     for r in report:
-        print("%s layer%d fwd %.3e  dx %.3e  dW %.3e (%s)" % ((dec,) + r))
+        print("%s/%d layer%d fwd %.3e  dx %.3e  dW %.3e (%s)" % ((dec, layers) + r))
     for i, e_f, e_b, e_w, worst in report:
         assert e_f <= 1e-2 and e_b <= 1e-1 and e_w <= 1e-1, (dec, i, e_f, e_b, e_w, worst)
 
@@ -861,3 +870,58 @@ def test_launch_plans_are_bounded():
         again = net(torch.rand(1, 3, 64, 64, device="cuda"))               # evicted and rebuilt
     assert len(net._engines) <= 4 and all(o.shape == (1, 1, 32, 32) for o in outs + [again])
     assert (1, 3, 64, 64) in net._engines and (1, 3, 96, 64) not in net._engines
+
+
+@pytest.mark.parametrize("layers", [18, 34])
+def test_basic_block_trunks_against_the_reference(golden, layers):
+    """reference FCRN.py:297-332 with `layers=18 / 34`: BasicBlock trunk, num_channels = 512, so the UpProj decoder
+    runs 256 -> 128 -> 64 -> 32 -> 16 channels.  The 32- and 16-channel tensors are stored zero-padded to 64 channels
+    (the GEMM kernels' granularity); the Parameters are the strided views of the real entries, so state_dict keys and
+    shapes are the reference's.  Eval output / AbsRel, train SILog and gradient norms against the reference; the
+    padding stays exactly zero through a fused Adam step."""
+    from mono_depth_estimation_amd import criteria, metrics
+    from mono_depth_estimation_amd.network import FCRN
+    g, tag, size = golden("fcrn_basic_trunks"), "r%d" % layers, (64, 96)
+    ora = ofcrn.FCRNOracle(layers, size, out_channels=1)
+    W.fcrn_conditioned_state(ora, 10 + layers, basic=True)
+    rgb, tgt = W.synthetic_batch(10 + layers, 2, *size)
+    W.calibrate_running_stats(ora, rgb)
+    net = FCRN.ResNet(layers=layers, output_size=size, out_channels=1, pretrained=False)
+    assert list(net.state_dict().keys()) == [str(k) for k in g[tag + "_state_keys"]]
+    net.load_state_dict(ora.state_dict())
+    net = net.cuda().eval()
+    assert all(tuple(v.shape) == tuple(o.shape) for v, o in zip(net.state_dict().values(), ora.state_dict().values()))
+    assert all(torch.equal(v.cpu(), o) for v, o in zip(net.state_dict().values(), ora.state_dict().values()))
+    with torch.no_grad():
+        y = net(rgb.cuda())
+    d = (y.cpu() - torch.from_numpy(g[tag + "_eval_out"])).abs()
+    a = float(metrics.MetricComputation(["absrel"]).compute(y, tgt.cuda())[0])
+    print("resnet%d: max|d| %.2e mean|d| %.2e dAbsRel %.2e" % (layers, float(d.max()), float(d.mean()), abs(a - float(g[tag + "_eval_absrel"]))))
+    assert d.max() <= 2e-2 and d.mean() <= 3e-3 and abs(a - float(g[tag + "_eval_absrel"])) <= 1e-4
+    net.train()
+    loss = criteria.silog_loss(0.85)(net(rgb.cuda()), tgt.cuda())
+    loss.backward()
+    ref = float(g[tag + "_train_silog"])
+    assert abs(float(loss.detach()) - ref) <= 1e-3 * abs(ref), (float(loss.detach()), ref)
+    names = [str(k) for k in g[tag + "_names"]]
+    gn = {n: float(p.grad.double().norm()) for n, p in net.named_parameters()}
+    rel = np.array([abs(gn[n] / r - 1.0) for n, r in zip(names, g[tag + "_grad_norm"]) if r > 1e-8])
+    assert np.median(rel) <= 3e-2 and rel.max() <= 0.2, (float(np.median(rel)), float(rel.max()))
+    # the padded layers sit next to the loss, where bf16 noise is smallest: their gradients against the fp32 oracle's
+    ora.train()
+    OL.silog(ora(rgb), tgt).backward()
+    og = dict(ora.named_parameters())
+    for n, p in net.named_parameters():
+        if n.startswith(("upSample.layer4.", "upSample.layer3.", "conv3.")) and p.dim() == 4:
+            a, b = p.grad.cpu().flatten(), og[n].grad.flatten()
+            c = float((a * b).sum() / (a.norm() * b.norm()))
+            # (direction only: the per-layer accuracy of these layers is test_decoder_layers_teacher_forced[upproj-18])
+            assert c >= (0.97 if n.startswith("conv3.") else 0.85), (n, c)
+    st = net._store
+    real = torch.zeros_like(st.P, dtype=torch.bool)
+    for p in net.parameters():
+        st.view_of(real, p).fill_(True)
+    assert int((~real).sum()) > 0                                  # this network does have padded storage
+    st.adam_step(1e-4, 1e-3)
+    assert float(st.P[~real].abs().max()) == 0.0 and float(st.G[~real].abs().max()) == 0.0
+    assert bool(torch.isfinite(net(rgb.cuda())).all())

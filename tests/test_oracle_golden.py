@@ -262,3 +262,27 @@ def test_fcrn50_other_decoders(golden, dec):
     _close(loss.detach(), g[dec + "_train_silog"], rtol=1e-4)
     gn = np.array([float(p.grad.double().norm()) for _, p in net.named_parameters()])
     assert np.allclose(gn, g[dec + "_grad_norm"], rtol=2e-3, atol=1e-6), np.abs(gn / g[dec + "_grad_norm"] - 1).max()
+
+
+# ---------------------------------------------------------------- G5d: BasicBlock trunks (layers = 18 / 34)
+@pytest.mark.parametrize("layers", [18, 34])
+def test_fcrn_basic_trunks(golden, layers):
+    g, tag = golden("fcrn_basic_trunks"), "r%d" % layers
+    net = ofcrn.FCRNOracle(layers=layers, output_size=(64, 96), out_channels=1)
+    assert list(net.state_dict().keys()) == [str(k) for k in g[tag + "_state_keys"]]
+    W.fcrn_conditioned_state(net, 10 + layers, basic=True)
+    rgb, tgt = W.synthetic_batch(10 + layers, 2, 64, 96)
+    W.calibrate_running_stats(net, rgb)
+    net.eval()
+    with torch.no_grad():
+        y = net(rgb)
+    _close(y, g[tag + "_eval_out"], rtol=1e-4, atol=2e-5)
+    got = M.compute(y, tgt)
+    for k in ("absrel", "rmse", "delta1"):
+        _close(got[k], g[tag + "_eval_" + k], rtol=1e-4)
+    net.train()
+    loss = L.silog(net(rgb), tgt)
+    loss.backward()
+    _close(loss.detach(), g[tag + "_train_silog"], rtol=1e-4)
+    gn = np.array([float(p.grad.double().norm()) for _, p in net.named_parameters()])
+    assert np.allclose(gn, g[tag + "_grad_norm"], rtol=2e-3, atol=1e-6), np.abs(gn / g[tag + "_grad_norm"] - 1).max()
