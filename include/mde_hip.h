@@ -368,6 +368,9 @@ int mde_refresh_if_changed(const float* src, void* shadow, void* packed, const m
 
 /* fp32 NCHW -> bf16 NHWC (and back) layout changes at the module boundary. */
 int mde_nchw_to_nhwc_bf16(const float* src, void* dst, int N, int C, int H, int W, void* stream);
+/* The same into [N][H][W][Cpad], channels [C, Cpad) zero: the input of the generic stem (FCRN.py:307-313,
+ * in_channels != 3), whose 7x7/2 conv runs on the GEMM kernel with the input channels padded to 64. */
+int mde_nchw_to_nhwc_bf16_pad(const float* src, void* dst, int N, int C, int H, int W, int Cpad, void* stream);
 int mde_nhwc_bf16_to_nchw(const void* src, float* dst, int N, int C, int H, int W, void* stream);
 
 #ifdef __cplusplus

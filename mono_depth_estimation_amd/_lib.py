@@ -112,6 +112,7 @@ SIGNATURES = {
     "mde_pack_wt": (_I, [_P, _P, _I, _I, _I, _P]),
     "mde_pack_wt_batch": (_I, [_P, _P, _P, _I, _L, _P]),
     "mde_nchw_to_nhwc_bf16": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "mde_nchw_to_nhwc_bf16_pad": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "mde_nhwc_bf16_to_nchw": (_I, [_P, _P, _I, _I, _I, _I, _P]),
 }
 

@@ -173,6 +173,18 @@ __global__ __launch_bounds__(NT) void nchw2nhwc_k(const float* __restrict__ src,
         dst[i] = (bf16_t)src[(n * C + c) * (int64_t)H * W + hw];
     }
 }
+// the same into a wider pixel stride: channels [C, Cpad) are written as zeros (generic-stem input, in_channels != 3)
+__global__ __launch_bounds__(NT) void nchw2nhwc_pad_k(const float* __restrict__ src, bf16_t* __restrict__ dst, int N, int C,
+                                                      int H, int W, int Cpad) {
+    const int64_t total = (int64_t)N * H * W * Cpad;
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
+        const int c = (int)(i % Cpad);
+        const int64_t p = i / Cpad;
+        const int64_t hw = p % ((int64_t)H * W);
+        const int64_t n = p / ((int64_t)H * W);
+        dst[i] = c < C ? (bf16_t)src[(n * C + c) * (int64_t)H * W + hw] : (bf16_t)0.f;
+    }
+}
 __global__ __launch_bounds__(NT) void nhwc2nchw_k(const bf16_t* __restrict__ src, float* __restrict__ dst, int N, int C,
                                                   int H, int W) {
     const int64_t total = (int64_t)N * H * W * C;
@@ -296,6 +308,13 @@ extern "C" int mde_nchw_to_nhwc_bf16(const float* src, void* dst, int N, int C, 
     MDE_REQUIRE(src && dst && N > 0 && C > 0 && H > 0 && W > 0, "mde_nchw_to_nhwc_bf16: bad argument");
     nchw2nhwc_k<<<grid_for((int64_t)N * C * H * W), NT, 0, (hipStream_t)stream>>>(src, (bf16_t*)dst, N, C, H, W);
     MDE_LAUNCH_CHECK("nchw2nhwc_k");
+    return MDE_OK;
+}
+
+extern "C" int mde_nchw_to_nhwc_bf16_pad(const float* src, void* dst, int N, int C, int H, int W, int Cpad, void* stream) {
+    MDE_REQUIRE(src && dst && N > 0 && C > 0 && H > 0 && W > 0 && Cpad >= C, "mde_nchw_to_nhwc_bf16_pad: bad argument");
+    nchw2nhwc_pad_k<<<grid_for((int64_t)N * Cpad * H * W), NT, 0, (hipStream_t)stream>>>(src, (bf16_t*)dst, N, C, H, W, Cpad);
+    MDE_LAUNCH_CHECK("nchw2nhwc_pad_k");
     return MDE_OK;
 }
 

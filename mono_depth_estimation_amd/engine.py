@@ -233,7 +233,9 @@ class ParamStore:
         # [Cp]) and the Parameter is the strided view of the real entries.  Padded entries stay exactly zero: their
         # activations, gradients and Adam moments are all zero.  Nothing is padded for the 50/101/152 networks.
         pad64 = lambda c: (c + 63) // 64 * 64
-        no_pad = {id(m.conv1.weight): (False, False), id(m.conv3.weight): (False, True)}   # (pad O, pad I)
+        # (pad O, pad I): the 3-channel stem and the head have their own kernels; a stem for in_channels != 3 runs
+        # on the GEMM kernel with its input channels padded
+        no_pad = {id(m.conv1.weight): (False, m.conv1.in_channels != 3), id(m.conv3.weight): (False, True)}
         self.sdims = {}
         for _, ts in plist:
             for t in ts:
@@ -508,6 +510,21 @@ class FCRNEngine:
         H2, W2 = ops.out_size(H, 7, 2, 3), ops.out_size(W, 7, 2, 3)
         self.stem_w = self._conv([m.conv1.weight], need_dgrad=False)
         self.stem_c = Act(dev, N, H2, W2, 64)
+        self.cin = m.conv1.in_channels
+        if self.cin != 3:
+            # reference FCRN.py:307-313: a fresh 7x7/2 conv for in_channels != 3.  No special kernel: the image goes
+            # to NHWC bf16 with its channels zero-padded to the stored weight's 64, the 49 taps run as two launches
+            # of the GEMM kernel (32 + 17, the second accumulating), BN statistics by the stand-alone reduction.
+            Cp = self.stem_w.I
+            self.xin = Act(dev, N, H, W, Cp)
+            taps = [(i - 3, j - 3, i * 7 + j) for i in range(7) for j in range(7)]
+            self.stem_fd, self.stem_wd = [], []
+            ks = self._ksplit(N * H2 * W2, 64, Cp, 32)
+            for part, acc in ((taps[:32], False), (taps[32:], True)):
+                self.stem_fd.append(ops.conv_desc(N, H, W, Cp, Cp, self.xin.nbytes, H2, W2, 2, 2, part, 49, H2, W2, 64,
+                                                  ncols=64, accumulate=acc))
+                self.stem_wd.append(ops.wgrad_desc(N, H2, W2, 64, 64, self.stem_c.nbytes, H, W, Cp, Cp, self.xin.nbytes,
+                                                   2, 2, part, 49, False, ks))
         self.stem_a = Act(dev, N, H2, W2, 64)
         self.stem_site = self._site([m.bn1])
         H4, W4 = ops.out_size(H2, 3, 2, 1), ops.out_size(W2, 3, 2, 1)
@@ -546,11 +563,18 @@ class FCRNEngine:
 
     # ------------------------------------------------------------------ execution
     def forward(self, x, train, check_data=False):
-        assert x.shape == (self.N, 3, self.H, self.W) and x.dtype == torch.float32 and x.is_contiguous()
+        assert x.shape == (self.N, self.cin, self.H, self.W) and x.dtype == torch.float32 and x.is_contiguous()
         self.store.refresh_weights(check_data=check_data)
         self.x = x
         s = self.stem_site
-        ops.stem_conv_fwd(x, self.stem_w.w32, self.stem_c.t, s.part if train else None)
+        if self.cin == 3:
+            ops.stem_conv_fwd(x, self.stem_w.w32, self.stem_c.t, s.part if train else None)
+        else:
+            ops.nchw_to_nhwc_bf16_pad(x, self.xin.t, self.xin.C)
+            for d in self.stem_fd:
+                ops.conv_gemm(d, self.xin.t, self.stem_w.wf, self.stem_c.t)
+            if train:
+                ops.bn_stats(self.stem_c.t, self.stem_c.M, 64, 64, s.part)
         s.finalize(self.stem_c.M, train)
         ops.bn_apply(self.stem_c.t, 64, s.scale, s.shift, self.stem_a.t, 64, self.stem_c.M, 64, True)
         ops.maxpool_fwd(self.stem_a.t, self.pool.t, self.pool_idx, self.N, self.stem_a.H, self.stem_a.W, 64)
@@ -613,7 +637,11 @@ class FCRNEngine:
         ops.maxpool_bwd(self.pool.g, self.pool_idx, self.stem_a.g, self.N, self.stem_a.H, self.stem_a.W, 64)
         s = self.stem_site
         s.backward(self.stem_a.g, self.stem_a, self.stem_c, True, self.stem_c.g, mask_from_x=True)
-        ops.stem_conv_wgrad(self.x, self.stem_c.g, self.stem_w.dw)
+        if self.cin == 3:
+            ops.stem_conv_wgrad(self.x, self.stem_c.g, self.stem_w.dw)
+        else:
+            for d in self.stem_wd:
+                self.wgrad(d, self.stem_c.g, self.xin.t, self.stem_w.dw)
         self.join_side()
         if on_progress is not None:
             on_progress(0)

@@ -339,6 +339,11 @@ def nchw_to_nhwc_bf16(src, dst):
     check(_lib.load().mde_nchw_to_nhwc_bf16(_p(src), _p(dst), N, C_, H, W, _stream()), "mde_nchw_to_nhwc_bf16")
 
 
+def nchw_to_nhwc_bf16_pad(src, dst, Cpad):
+    N, C_, H, W = src.shape
+    check(_lib.load().mde_nchw_to_nhwc_bf16_pad(_p(src), _p(dst), N, C_, H, W, Cpad, _stream()), "mde_nchw_to_nhwc_bf16_pad")
+
+
 def nhwc_bf16_to_nchw(src, dst):
     N, C_, H, W = dst.shape
     check(_lib.load().mde_nhwc_bf16_to_nchw(_p(src), _p(dst), N, C_, H, W, _stream()), "mde_nhwc_bf16_to_nchw")

@@ -380,6 +380,35 @@ def gen_fcrn_basic_trunks(criteria, metrics, FCRN):
     np.savez_compressed(os.path.join(HERE, "fcrn_basic_trunks.npz"), **out)
 
 
+def gen_fcrn_in_channels(criteria, metrics, FCRN):
+    """G5e: `in_channels != 3` (FCRN.py:307-313: a fresh conv1 / bn1), here 4 (RGB-D) and 1, ResNet-50, 2xCx64x96."""
+    size = (64, 96)
+    out = {}
+    for cin in (4, 1):
+        tag = "c%d" % cin
+        ref = FCRN.ResNet(layers=50, decoder="upproj", output_size=size, in_channels=cin, out_channels=1, pretrained=False)
+        W.fcrn_conditioned_state(ref, 40 + cin)
+        x = W.uniform(40 + cin, "x", (2, cin) + size)
+        _, tgt = W.synthetic_batch(40 + cin, 2, *size)
+        W.calibrate_running_stats(ref, x)
+        ref.eval()
+        with torch.no_grad():
+            y = ref(x)
+        out[tag + "_eval_out"] = _np(y)
+        mc = metrics.MetricComputation(["absrel", "rmse", "delta1"])
+        for n, v in zip(mc.names, mc.compute(y, tgt)):
+            out[tag + "_eval_" + n] = _np(v)
+        ref.train()
+        loss = criteria.silog_loss(0.85)(ref(x), tgt)
+        loss.backward()
+        out[tag + "_train_silog"] = _np(loss)
+        out[tag + "_conv1_grad"] = _np(ref.conv1.weight.grad)
+        out[tag + "_grad_norm"] = np.array([float(p.grad.double().norm()) for _, p in ref.named_parameters()])
+        print("fcrn_in_channels %d absrel %.6f train_silog %.5f range %.3f..%.3f" % (
+            cin, float(out[tag + "_eval_absrel"]), float(loss), float(y.min()), float(y.max())))
+    np.savez_compressed(os.path.join(HERE, "fcrn_in_channels.npz"), **out)
+
+
 def gen_fcrn_conditioned(criteria, metrics, FCRN):
     """G5b: the same reference network on the well-conditioned state (oracle/weights.py:
     fcrn_conditioned_state) — the fixture on which the 1e-4 AbsRel bound is asserted."""
@@ -419,6 +448,7 @@ def main():
     gen_fcrn_conditioned(criteria, metrics, FCRN)
     gen_fcrn_decoders(criteria, metrics, FCRN)
     gen_fcrn_basic_trunks(criteria, metrics, FCRN)
+    gen_fcrn_in_channels(criteria, metrics, FCRN)
 
 
 if __name__ == "__main__":

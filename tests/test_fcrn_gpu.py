@@ -925,3 +925,39 @@ def test_basic_block_trunks_against_the_reference(golden, layers):
     st.adam_step(1e-4, 1e-3)
     assert float(st.P[~real].abs().max()) == 0.0 and float(st.G[~real].abs().max()) == 0.0
     assert bool(torch.isfinite(net(rgb.cuda())).all())
+
+
+@pytest.mark.parametrize("cin", [4, 1])
+def test_in_channels_other_than_3(golden, cin):
+    """reference FCRN.py:307-313: `in_channels != 3` gives the network a fresh 7x7/2 stem.  Here it runs on the GEMM
+    kernel (channels zero-padded to 64, 49 taps in two launches); eval output / AbsRel, train SILog and the stem's
+    weight gradient against the reference.  The image itself is rounded to bf16 on this path (the 3-channel stem kernel
+    splits it into hi + lo instead), which shows as ~1.5e-4 in AbsRel on this 12 K-pixel fixture: bound 3e-4."""
+    from mono_depth_estimation_amd import criteria, metrics
+    from mono_depth_estimation_amd.network import FCRN
+    g, tag, size = golden("fcrn_in_channels"), "c%d" % cin, (64, 96)
+    ora = ofcrn.FCRNOracle(50, size, in_channels=cin, out_channels=1)
+    W.fcrn_conditioned_state(ora, 40 + cin)
+    x = W.uniform(40 + cin, "x", (2, cin) + size)
+    _, tgt = W.synthetic_batch(40 + cin, 2, *size)
+    W.calibrate_running_stats(ora, x)
+    net = FCRN.ResNet(layers=50, output_size=size, in_channels=cin, out_channels=1, pretrained=False)
+    assert tuple(net.conv1.weight.shape) == (64, cin, 7, 7)
+    net.load_state_dict(ora.state_dict())
+    net = net.cuda().eval()
+    with torch.no_grad():
+        y = net(x.cuda())
+    d = (y.cpu() - torch.from_numpy(g[tag + "_eval_out"])).abs()
+    a = float(metrics.MetricComputation(["absrel"]).compute(y, tgt.cuda())[0])
+    print("in_channels %d: max|d| %.2e mean|d| %.2e dAbsRel %.2e" % (cin, float(d.max()), float(d.mean()), abs(a - float(g[tag + "_eval_absrel"]))))
+    assert d.max() <= 2e-2 and d.mean() <= 3e-3 and abs(a - float(g[tag + "_eval_absrel"])) <= 3e-4
+    net.train()
+    loss = criteria.silog_loss(0.85)(net(x.cuda()), tgt.cuda())
+    loss.backward()
+    ref = float(g[tag + "_train_silog"])
+    assert abs(float(loss.detach()) - ref) <= 1e-3 * abs(ref)
+    gw, rw = net.conv1.weight.grad.cpu().flatten(), torch.from_numpy(g[tag + "_conv1_grad"]).flatten()
+    c = float((gw * rw).sum() / (gw.norm() * rw.norm()))
+    assert tuple(net.conv1.weight.grad.shape) == (64, cin, 7, 7) and c >= 0.85 and abs(float(gw.norm() / rw.norm()) - 1) <= 0.2, c
+    with pytest.raises(ValueError):
+        net(torch.rand(1, 3, *size, device="cuda"))

@@ -286,3 +286,24 @@ def test_fcrn_basic_trunks(golden, layers):
     _close(loss.detach(), g[tag + "_train_silog"], rtol=1e-4)
     gn = np.array([float(p.grad.double().norm()) for _, p in net.named_parameters()])
     assert np.allclose(gn, g[tag + "_grad_norm"], rtol=2e-3, atol=1e-6), np.abs(gn / g[tag + "_grad_norm"] - 1).max()
+
+
+# ---------------------------------------------------------------- G5e: in_channels != 3
+@pytest.mark.parametrize("cin", [4, 1])
+def test_fcrn_in_channels(golden, cin):
+    g, tag = golden("fcrn_in_channels"), "c%d" % cin
+    net = ofcrn.FCRNOracle(layers=50, output_size=(64, 96), in_channels=cin, out_channels=1)
+    W.fcrn_conditioned_state(net, 40 + cin)
+    x = W.uniform(40 + cin, "x", (2, cin, 64, 96))
+    _, tgt = W.synthetic_batch(40 + cin, 2, 64, 96)
+    W.calibrate_running_stats(net, x)
+    net.eval()
+    with torch.no_grad():
+        y = net(x)
+    _close(y, g[tag + "_eval_out"], rtol=1e-4, atol=2e-5)
+    _close(M.compute(y, tgt)["absrel"], g[tag + "_eval_absrel"], rtol=1e-4)
+    net.train()
+    loss = L.silog(net(x), tgt)
+    loss.backward()
+    _close(loss.detach(), g[tag + "_train_silog"], rtol=1e-4)
+    _close(net.conv1.weight.grad, g[tag + "_conv1_grad"], rtol=2e-3, atol=2e-3 * float(np.abs(g[tag + "_conv1_grad"]).max()))
