@@ -317,8 +317,9 @@ int mde_stdepth_bwd(const float* pred, const float* targ, const float* rgba, int
                     unsigned terms, float variance_focus, float depth_w, float comp_w, float fbdiv_w, float ssim_w,
                     const void* ws, float* scratch, const float* pred_full, const float* gscale, float* grad,
                     void* stream);
-/* Depth metrics (metrics.py:58-109): out[6] = absrel, 'rmse' (= mean sqrt((p-t)^2/t), sic),
- * delta1, delta2, delta3, log10.  ws >= mde_metrics_ws_bytes(). */
+/* Depth metrics (metrics.py:58-123) over target > 0 with pred clamped at 1e-7: out[10] = absrel, 'rmse' (= mean
+ * sqrt((p-t)^2/t), sic), delta1, delta2, delta3, log10, mae, mse, msle (= mean (log1p p - log1p t)^2, the
+ * torchmetrics definitions the reference maps those names to), sqrel.  ws >= mde_metrics_ws_bytes(). */
 size_t mde_metrics_ws_bytes(void);
 int mde_depth_metrics(const float* pred, const float* target, int64_t n, void* ws, float* out,
                       void* stream);

@@ -79,12 +79,15 @@ __global__ __launch_bounds__(NT) void silog_bwd_k(const float* __restrict__ est,
     }
 }
 
-struct MetricWs { double s[7]; };  // absrel, rmse(sic), d1, d2, d3, log10, count
+struct MetricWs { double s[11]; };  // absrel, rmse(sic), d1, d2, d3, log10, mae, mse, msle, sqrel, count
 
 __global__ __launch_bounds__(NT) void metrics_reduce_k(const float* __restrict__ pred, const float* __restrict__ tgt,
                                                        int64_t n, MetricWs* ws) {
-    float a[7] = {0, 0, 0, 0, 0, 0, 0};
-    double acc[7] = {0, 0, 0, 0, 0, 0, 0};
+    constexpr int K = 11;
+    float a[K];
+    double acc[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) { a[k] = 0.f; acc[k] = 0.0; }
     int run = 0;
     for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
         const float t = tgt[i];
@@ -92,28 +95,33 @@ __global__ __launch_bounds__(NT) void metrics_reduce_k(const float* __restrict__
             const float p = fmaxf(pred[i], 1e-7f);
             const float diff = p - t;
             const float ratio = fmaxf(p / t, t / p);
+            const float dl = log1pf(p) - log1pf(t);
             a[0] += fabsf(diff) / t;
             a[1] += sqrtf(diff * diff / t);
             a[2] += ratio < 1.25f ? 1.f : 0.f;
             a[3] += ratio < 1.25f * 1.25f ? 1.f : 0.f;
             a[4] += ratio < 1.25f * 1.25f * 1.25f ? 1.f : 0.f;
             a[5] += fabsf(log10f(p) - log10f(t));
-            a[6] += 1.f;
+            a[6] += fabsf(diff);              // torchmetrics mean_absolute_error (metrics.py:118)
+            a[7] += diff * diff;              // mean_squared_error (:121)
+            a[8] += dl * dl;                  // mean_squared_log_error (:120): (log1p p - log1p t)^2
+            a[9] += diff * diff / t;          // RelativeSquareError (:100-103)
+            a[10] += 1.f;
         }
         if (++run == 64) {
 #pragma unroll
-            for (int k = 0; k < 7; ++k) { acc[k] += a[k]; a[k] = 0.f; }
+            for (int k = 0; k < K; ++k) { acc[k] += a[k]; a[k] = 0.f; }
             run = 0;
         }
     }
 #pragma unroll
-    for (int k = 0; k < 7; ++k) acc[k] += a[k];
-    block_atomic_add<7>(acc, ws->s);
+    for (int k = 0; k < K; ++k) acc[k] += a[k];
+    block_atomic_add<K>(acc, ws->s);
 }
 
 __global__ void metrics_finalize_k(const MetricWs* ws, float* out) {
     const int k = threadIdx.x;
-    if (k < 6) out[k] = (float)(ws->s[k] / ws->s[6]);
+    if (k < 10) out[k] = (float)(ws->s[k] / ws->s[10]);
 }
 
 // ------------------------------------------------------------------ masked pointwise losses (criteria.py:67-133)

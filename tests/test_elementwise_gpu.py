@@ -362,11 +362,30 @@ def test_metrics_golden(golden):
     from mono_depth_estimation_amd import ops
     g = golden("metrics")
     pred, tgt = torch.from_numpy(g["pred"]).cuda(), torch.from_numpy(g["tgt"]).cuda()
-    ws, out = ops.metrics_ws(), torch.empty(6, device="cuda")
+    ws, out = ops.metrics_ws(), torch.empty(len(OM.NAMES), device="cuda")
     ops.depth_metrics(pred, tgt, ws, out)
     got = out.cpu().numpy()
+    ora = OM.compute(torch.from_numpy(g["pred"]), torch.from_numpy(g["tgt"]))
     for i, k in enumerate(OM.NAMES):
-        assert np.allclose(got[i], g[k], rtol=1e-5), k
+        if k in OM.PINNED:
+            assert np.allclose(got[i], g[k], rtol=1e-5), k              # the reference's own value
+        assert np.allclose(got[i], float(ora[k]), rtol=2e-5), k        # mae / mse / msle: by definition (oracle)
+
+
+def test_metric_computation_accepts_the_reference_default_names():
+    """train.py:67 asks for ['delta1', 'delta2', 'delta3', 'mse', 'mae', 'log10', 'rmse', 'ssim'] by default: all but
+    'ssim' (a torchmetrics CPU call in the reference, metrics.py:63,123) are computed in the one device pass."""
+    from mono_depth_estimation_amd import metrics
+    pred, tgt = W.uniform(3, "p", (2, 1, 40, 56), 0.0, 1.2).cuda(), W.uniform(3, "t", (2, 1, 40, 56), -0.2, 1.0).cuda()
+    names = ['delta1', 'delta2', 'delta3', 'mse', 'mae', 'log10', 'rmse', 'msle', 'sqrel', 'absrel']
+    mc = metrics.MetricComputation(names)
+    vals = mc.compute(pred, tgt)
+    ora = OM.compute(pred.cpu(), tgt.cpu())
+    for n, v in zip(names, vals):
+        assert np.allclose(float(v), float(ora[n]), rtol=2e-5), n
+    assert np.allclose(float(mc.avg("mae")), float(ora["mae"]), rtol=2e-5)
+    with pytest.raises(NotImplementedError):
+        metrics.MetricComputation(["ssim"])
 
 
 # ------------------------------------------------------------------------------------ optimiser plumbing

@@ -82,7 +82,7 @@ def test_eval_absrel_parity_conditioned(golden):
         y = hip(x)
     ref = torch.from_numpy(g["eval_out"])
     diff = (y.cpu() - ref).abs()
-    mc = metrics.MetricComputation(list(metrics.NAMES))
+    mc = metrics.MetricComputation(["absrel", "rmse", "delta1", "delta2", "delta3", "log10"])
     vals = {k: float(v) for k, v in zip(mc.names, mc.compute(y, t))}
     print("conditioned eval: max|diff| %.3e mean %.3e; " % (diff.max(), diff.mean()) +
           ", ".join("d%s %.2e" % (k, vals[k] - float(g["eval_" + k])) for k in mc.names))
