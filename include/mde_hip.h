@@ -291,10 +291,11 @@ int mde_vnl_fwd(const float* gt, const float* pred, const int32_t* p123, int B, 
 int mde_vnl_bwd(const float* gt, const float* pred, const int32_t* p123, int B, int H, int W, int n, float fx,
                 float fy, const void* ws, const float* gscale, float* grad, void* stream);
 /* ---- The stdepth composite criterion (reference modules/base_module.py:124-208 `_loss`, stdepth_utils.py) ----
- * pred, targ: [N][C][H][W] fp32, C = 10 (single layer: front RGBA, back RGBA, 2 depths) or 20 (3 depth-sorted RGBA
- * layers, back RGBA, 4 depths); rgba [N][4][H][W].  terms = OR of MDE_ST_* (the reference selects them by substrings
- * of method.loss; COMPOSITE_SSIM = 'composite' and 'ssim' both present).  The composite terms need C = 10, where the
- * reference's own indexing is well-formed.  out[12] = total, depth_silog, color_mae, color_mse, all_mse, all_mae,
+ * pred, targ: [N][C][H][W] fp32, C = 10 or 20; single_layer != 0 is the reference's default layout (front RGBA, back
+ * RGBA, depths in channels 8:10, whatever C is: laina's default is 20 output channels with single_layer), 0 the
+ * multi-layer one (C = 20: 3 depth-sorted RGBA layers, back RGBA, depths 16:20); rgba [N][4][H][W].  terms = OR of MDE_ST_* (the reference selects them by substrings
+ * of method.loss; COMPOSITE_SSIM = 'composite' and 'ssim' both present).  The composite terms need single_layer, where
+ * the reference's own indexing is well-formed.  out[12] = total, depth_silog, color_mae, color_mse, all_mse, all_mae,
  * all_ssim, front_ssim, back_ssim, composite_mse, composite_ssim, fb_divergence (unselected = 0).
  * pred_full: optional [N][4][H][W] output, the clamped composite (any C); required when COMPOSITE_SSIM is set.
  * scratch: caller-owned fp32, >= mde_stdepth_scratch_elems(...) elements, carried from fwd to bwd with ws
@@ -311,10 +312,10 @@ int mde_vnl_bwd(const float* gt, const float* pred, const int32_t* p123, int B, 
 size_t mde_stdepth_ws_bytes(void);
 size_t mde_stdepth_scratch_elems(int N, int C, int H, int W, unsigned terms);
 int mde_stdepth_fwd(const float* pred, const float* targ, const float* rgba, int N, int C, int H, int W,
-                    unsigned terms, float variance_focus, float depth_w, float comp_w, float fbdiv_w, float ssim_w,
+                    int single_layer, unsigned terms, float variance_focus, float depth_w, float comp_w, float fbdiv_w, float ssim_w,
                     void* ws, float* scratch, float* pred_full, float* out, void* stream);
 int mde_stdepth_bwd(const float* pred, const float* targ, const float* rgba, int N, int C, int H, int W,
-                    unsigned terms, float variance_focus, float depth_w, float comp_w, float fbdiv_w, float ssim_w,
+                    int single_layer, unsigned terms, float variance_focus, float depth_w, float comp_w, float fbdiv_w, float ssim_w,
                     const void* ws, float* scratch, const float* pred_full, const float* gscale, float* grad,
                     void* stream);
 /* Depth metrics (metrics.py:58-123) over target > 0 with pred clamped at 1e-7: out[10] = absrel, 'rmse' (= mean

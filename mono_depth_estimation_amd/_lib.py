@@ -98,8 +98,8 @@ SIGNATURES = {
     "mde_vnl_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _F, _F, _P, _P, _P, _P]),
     "mde_stdepth_ws_bytes": (_Z, []),
     "mde_stdepth_scratch_elems": (_Z, [_I, _I, _I, _I, _U]),
-    "mde_stdepth_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _U, _F, _F, _F, _F, _F, _P, _P, _P, _P, _P]),
-    "mde_stdepth_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _U, _F, _F, _F, _F, _F, _P, _P, _P, _P, _P, _P]),
+    "mde_stdepth_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _U, _F, _F, _F, _F, _F, _P, _P, _P, _P, _P]),
+    "mde_stdepth_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _U, _F, _F, _F, _F, _F, _P, _P, _P, _P, _P, _P]),
     "mde_metrics_ws_bytes": (_Z, []),
     "mde_depth_metrics": (_I, [_P, _P, _L, _P, _P, _P]),
     "mde_adam_step": (_I, [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _F, _I, _P]),

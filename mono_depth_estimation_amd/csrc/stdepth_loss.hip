@@ -71,9 +71,9 @@ __device__ __forceinline__ void composite(const float (*ly)[4], int L, float (&u
 
 // the layers of one pixel (its CC channel values in v[]) in compositing order: single layer = front, back;
 // multi = 3 layers stably sorted by their depth channel 16 + i, then back
-template <int CC>
+template <int CC, bool SINGLE>
 __device__ __forceinline__ int load_layers(const float (&v)[CC], float (*ly)[4]) {
-    if constexpr (CC == 10) {
+    if constexpr (SINGLE) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -112,7 +112,9 @@ __global__ void st_init_k(StHead* h) {
     if (t < 12) h->out[t] = 0.f;
 }
 
-template <int CC>
+// CC: channels of pred / targ; SINGLE: the reference's `single_layer` (depth channels 8:10 and two compositing layers,
+// whatever CC is — the laina module's default is out_channels = 20 with single_layer = True), else 16:20 and 3 + 1 layers
+template <int CC, bool SINGLE>
 __global__ __launch_bounds__(NT) void st_reduce_k(const float* __restrict__ pred, const float* __restrict__ targ,
                                                   const float* __restrict__ rgba, StCfg g, float* __restrict__ pred_full,
                                                   StHead* h) {
@@ -155,7 +157,7 @@ __global__ __launch_bounds__(NT) void st_reduce_k(const float* __restrict__ pred
             }
         }
 #pragma unroll
-        for (int c = (CC == 10 ? 8 : 16); c < CC; ++c) {   // the depth mask is its own (targ > 0), independent of alpha
+        for (int c = (SINGLE ? 8 : 16); c < (SINGLE ? 10 : 20); ++c) {   // the depth mask is its own (targ > 0), independent of alpha
             const float t = tv[c];
             if (t > 0.f) {
                 const float q = pv[c], d = q - t;
@@ -168,7 +170,7 @@ __global__ __launch_bounds__(NT) void st_reduce_k(const float* __restrict__ pred
         }
         if (pred_full || (g.terms & (T_COMPOSITE | T_COMPOSITE_SSIM))) {
             float ly[4][4], un[4];
-            const int L = load_layers<CC>(pv, ly);
+            const int L = load_layers<CC, SINGLE>(pv, ly);
             composite(ly, L, un);
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
@@ -231,7 +233,7 @@ __global__ void st_finalize_k(StHead* h, StCfg g, float* out) {
 }
 
 // gfull: d loss / d pred_full from the composite SSIM term (already scaled), or null
-template <int CC>
+template <int CC, bool SINGLE>
 __global__ __launch_bounds__(NT) void st_bwd_k(const float* __restrict__ pred, const float* __restrict__ targ,
                                                const float* __restrict__ rgba, StCfg g, const StHead* __restrict__ h,
                                                const float* __restrict__ gscale, const float* __restrict__ gfull,
@@ -276,7 +278,7 @@ __global__ __launch_bounds__(NT) void st_bwd_k(const float* __restrict__ pred, c
             }
         }
 #pragma unroll
-        for (int c = (CC == 10 ? 8 : 16); c < CC; ++c) {
+        for (int c = (SINGLE ? 8 : 16); c < (SINGLE ? 10 : 20); ++c) {
             const float t = tv[c];
             if (t > 0.f) {
                 const float q = pv[c], d = q - t;
@@ -285,9 +287,9 @@ __global__ __launch_bounds__(NT) void st_bwd_k(const float* __restrict__ pred, c
                 gr[c] += v;
             }
         }
-        if (CC == 10 && (k_comp != 0.f || gfull)) {
+        if (SINGLE && (k_comp != 0.f || gfull)) {
             float ly[4][4], un[4], e[4];
-            load_layers<CC>(pv, ly);
+            load_layers<CC, SINGLE>(pv, ly);
             composite(ly, 2, un);
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
@@ -464,13 +466,14 @@ Gauss make_gauss() {
 
 unsigned needs_ssim_pred(unsigned t) { return t & (T_ALLSSIM | T_COLORSSIM); }
 
-int st_check(const char* fn, const void* pred, const void* targ, const void* rgba, int N, int C, int H, int W, unsigned terms,
-             const void* ws, const void* scratch) {
+int st_check(const char* fn, const void* pred, const void* targ, const void* rgba, int N, int C, int H, int W, int single,
+             unsigned terms, const void* ws, const void* scratch) {
     MDE_REQUIRE(pred && targ && rgba && ws, "%s: null pointer", fn);
     MDE_REQUIRE(N > 0 && H > 0 && W > 0 && (C == 10 || C == 20), "%s: bad shape N=%d C=%d H=%d W=%d (C is 10 or 20)", fn, N, C, H, W);
+    MDE_REQUIRE(single || C == 20, "%s: the multi-layer layout needs C = 20", fn);
     MDE_REQUIRE(terms != 0 && terms < 512u, "%s: bad term mask %u", fn, terms);
-    MDE_REQUIRE(!(terms & (T_COMPOSITE | T_COMPOSITE_SSIM)) || C == 10,
-                "%s: the composite terms are only well-formed single-layer (C = 10), as in the reference", fn);
+    MDE_REQUIRE(!(terms & (T_COMPOSITE | T_COMPOSITE_SSIM)) || single,
+                "%s: the composite terms are only well-formed single-layer, as in the reference", fn);
     MDE_REQUIRE(!(terms & T_COMPOSITE_SSIM) || (terms & T_COMPOSITE), "%s: composite_ssim without composite", fn);
     MDE_REQUIRE(!(terms & (T_ALLSSIM | T_COLORSSIM | T_COMPOSITE_SSIM)) || scratch, "%s: the SSIM terms need scratch", fn);
     return MDE_OK;
@@ -494,13 +497,13 @@ extern "C" size_t mde_stdepth_scratch_elems(int N, int C, int H, int W, unsigned
 }
 
 extern "C" int mde_stdepth_fwd(const float* pred, const float* targ, const float* rgba, int N, int C, int H, int W,
-                               unsigned terms, float variance_focus, float depth_w, float comp_w, float fbdiv_w,
+                               int single_layer, unsigned terms, float variance_focus, float depth_w, float comp_w, float fbdiv_w,
                                float ssim_w, void* ws, float* scratch, float* pred_full, float* out, void* stream) {
-    if (int rc = st_check("mde_stdepth_fwd", pred, targ, rgba, N, C, H, W, terms, ws, scratch)) return rc;
+    if (int rc = st_check("mde_stdepth_fwd", pred, targ, rgba, N, C, H, W, single_layer, terms, ws, scratch)) return rc;
     MDE_REQUIRE(out, "mde_stdepth_fwd: null out");
     hipStream_t st = (hipStream_t)stream;
     StHead* h = (StHead*)ws;
-    const StCfg g = {N, C, H, W, C == 10 ? 8 : 16, C == 10 ? 10 : 20, terms, variance_focus, depth_w, comp_w, fbdiv_w, ssim_w};
+    const StCfg g = {N, C, H, W, single_layer ? 8 : 16, single_layer ? 10 : 20, terms, variance_focus, depth_w, comp_w, fbdiv_w, ssim_w};
     const int64_t plane = (int64_t)N * H * W;
     float* full = pred_full;
     float* abc_comp = nullptr;
@@ -511,8 +514,9 @@ extern "C" int mde_stdepth_fwd(const float* pred, const float* targ, const float
         abc_pred = scratch + 20 * plane;
     }
     st_init_k<<<1, 64, 0, st>>>(h);
-    if (C == 10) st_reduce_k<10><<<grid_for(plane), NT, 0, st>>>(pred, targ, rgba, g, full, h);
-    else st_reduce_k<20><<<grid_for(plane), NT, 0, st>>>(pred, targ, rgba, g, full, h);
+    if (C == 10) st_reduce_k<10, true><<<grid_for(plane), NT, 0, st>>>(pred, targ, rgba, g, full, h);
+    else if (single_layer) st_reduce_k<20, true><<<grid_for(plane), NT, 0, st>>>(pred, targ, rgba, g, full, h);
+    else st_reduce_k<20, false><<<grid_for(plane), NT, 0, st>>>(pred, targ, rgba, g, full, h);
     MDE_LAUNCH_CHECK("st_reduce_k");
     const int tiles_x = mde_cdiv(W, TW), tiles = tiles_x * mde_cdiv(H, TH);
     const Gauss gw = make_gauss();
@@ -530,14 +534,14 @@ extern "C" int mde_stdepth_fwd(const float* pred, const float* targ, const float
 }
 
 extern "C" int mde_stdepth_bwd(const float* pred, const float* targ, const float* rgba, int N, int C, int H, int W,
-                               unsigned terms, float variance_focus, float depth_w, float comp_w, float fbdiv_w,
+                               int single_layer, unsigned terms, float variance_focus, float depth_w, float comp_w, float fbdiv_w,
                                float ssim_w, const void* ws, float* scratch, const float* pred_full, const float* gscale,
                                float* grad, void* stream) {
-    if (int rc = st_check("mde_stdepth_bwd", pred, targ, rgba, N, C, H, W, terms, ws, scratch)) return rc;
+    if (int rc = st_check("mde_stdepth_bwd", pred, targ, rgba, N, C, H, W, single_layer, terms, ws, scratch)) return rc;
     MDE_REQUIRE(grad, "mde_stdepth_bwd: null grad");
     hipStream_t st = (hipStream_t)stream;
     const StHead* h = (const StHead*)ws;
-    const StCfg g = {N, C, H, W, C == 10 ? 8 : 16, C == 10 ? 10 : 20, terms, variance_focus, depth_w, comp_w, fbdiv_w, ssim_w};
+    const StCfg g = {N, C, H, W, single_layer ? 8 : 16, single_layer ? 10 : 20, terms, variance_focus, depth_w, comp_w, fbdiv_w, ssim_w};
     const int64_t plane = (int64_t)N * H * W;
     const int tiles_x = mde_cdiv(W, TW), tiles = tiles_x * mde_cdiv(H, TH);
     const Gauss gw = make_gauss();
@@ -552,8 +556,9 @@ extern "C" int mde_stdepth_bwd(const float* pred, const float* targ, const float
         gfull = gf;
         abc_pred = scratch + 20 * plane;
     }
-    if (C == 10) st_bwd_k<10><<<grid_for(plane), NT, 0, st>>>(pred, targ, rgba, g, h, gscale, gfull, grad);
-    else st_bwd_k<20><<<grid_for(plane), NT, 0, st>>>(pred, targ, rgba, g, h, gscale, gfull, grad);
+    if (C == 10) st_bwd_k<10, true><<<grid_for(plane), NT, 0, st>>>(pred, targ, rgba, g, h, gscale, gfull, grad);
+    else if (single_layer) st_bwd_k<20, true><<<grid_for(plane), NT, 0, st>>>(pred, targ, rgba, g, h, gscale, gfull, grad);
+    else st_bwd_k<20, false><<<grid_for(plane), NT, 0, st>>>(pred, targ, rgba, g, h, gscale, gfull, grad);
     MDE_LAUNCH_CHECK("st_bwd_k");
     if (needs_ssim_pred(terms)) {
         ssim_bwd_k<<<dim3(tiles, C, N), NT, 0, st>>>(pred, targ, abc_pred, plane * C, C, H, W, tiles_x, gw, &h->k_ssim_all,

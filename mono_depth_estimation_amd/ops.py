@@ -480,15 +480,15 @@ def stdepth_scratch(N, C, H, W, terms, device="cuda"):
     return torch.empty(n, dtype=torch.float32, device=device) if n else None
 
 
-def stdepth_fwd(pred, targ, rgba, N, C, H, W, terms, weights, ws, scratch, pred_full, out):
+def stdepth_fwd(pred, targ, rgba, N, C, H, W, single, terms, weights, ws, scratch, pred_full, out):
     vf, dw, cw, fw, sw = weights
-    check(_lib.load().mde_stdepth_fwd(_p(pred), _p(targ), _p(rgba), N, C, H, W, terms, vf, dw, cw, fw, sw, _p(ws),
+    check(_lib.load().mde_stdepth_fwd(_p(pred), _p(targ), _p(rgba), N, C, H, W, int(single), terms, vf, dw, cw, fw, sw, _p(ws),
                                       _p(scratch), _p(pred_full), _p(out), _stream()), "mde_stdepth_fwd")
 
 
-def stdepth_bwd(pred, targ, rgba, N, C, H, W, terms, weights, ws, scratch, pred_full, gscale, grad):
+def stdepth_bwd(pred, targ, rgba, N, C, H, W, single, terms, weights, ws, scratch, pred_full, gscale, grad):
     vf, dw, cw, fw, sw = weights
-    check(_lib.load().mde_stdepth_bwd(_p(pred), _p(targ), _p(rgba), N, C, H, W, terms, vf, dw, cw, fw, sw, _p(ws),
+    check(_lib.load().mde_stdepth_bwd(_p(pred), _p(targ), _p(rgba), N, C, H, W, int(single), terms, vf, dw, cw, fw, sw, _p(ws),
                                       _p(scratch), _p(pred_full), _p(gscale), _p(grad), _stream()), "mde_stdepth_bwd")
 
 

@@ -201,21 +201,23 @@ def _reference_stdepth_loss(criteria, loss, single_layer):
     return ns["setup_criterion"](me)
 
 
-def stdepth_batch(seed, C, shape=(2, 20, 28)):
+def stdepth_batch(seed, C, shape=(2, 20, 28), single=None):
     """pred / targ [N, C, H, W] in roughly [-0.1, 1.1], rgba with ~30 % transparent pixels, depth channels with holes."""
     N, H, Wd = shape
     pred = W.uniform(seed, "pred", (N, C, H, Wd), -0.1, 1.1)
     targ = W.uniform(seed, "targ", (N, C, H, Wd), 0.0, 1.0)
     rgba = W.uniform(seed, "rgba", (N, 4, H, Wd), 0.0, 1.0)
     rgba[:, 3] = rgba[:, 3].masked_fill(W.uniform(seed, "hole", (N, H, Wd)) < 0.3, 0.0)
-    d = slice(8, 10) if C == 10 else slice(16, 20)
+    single = (C == 10) if single is None else single
+    d = slice(8, 10) if single else slice(16, 20)
     targ[:, d] = targ[:, d].masked_fill(W.uniform(seed, "dhole", targ[:, d].shape) < 0.2, 0.0)
     pred[:, d] = pred[:, d].abs() + 0.05             # silog takes log(pred)
     return pred, targ, rgba
 
 
 STDEPTH_CASES = [("mae+composite", True), ("silma", True), ("silms+fbdivergence", True), ("mse", True),
-                 ("mae+composite+ssim", True), ("allssim+colorssim", True), ("silma+mse+fbdivergence", False)]
+                 ("mae+composite+ssim", True), ("allssim+colorssim", True), ("silma+mse+fbdivergence", False),
+                 ("mae+composite", True, 20), ("silma+allssim+composite+ssim", True, 20)]   # laina's default: 20 channels, single_layer
 
 
 def gen_stdepth(criteria):
@@ -224,10 +226,14 @@ def gen_stdepth(criteria):
     for C in (10, 20):
         pred, targ, rgba = stdepth_batch(61 + C, C)
         out["c%d_pred" % C], out["c%d_targ" % C], out["c%d_rgba" % C] = _np(pred), _np(targ), _np(rgba)
-    for i, (loss, single) in enumerate(STDEPTH_CASES):
-        C = 10 if single else 20
+    pred, targ, rgba = stdepth_batch(90, 20, single=True)      # 20 channels in the single-layer layout (laina's default)
+    out["c20s_pred"], out["c20s_targ"], out["c20s_rgba"] = _np(pred), _np(targ), _np(rgba)
+    for i, case in enumerate(STDEPTH_CASES):
+        loss, single = case[:2]
+        C = case[2] if len(case) > 2 else (10 if single else 20)
         fn = _reference_stdepth_loss(criteria, loss, single)
-        pred, targ, rgba = [torch.from_numpy(out["c%d_%s" % (C, k)]) for k in ("pred", "targ", "rgba")]
+        key = "c20s" if (single and C == 20) else "c%d" % C
+        pred, targ, rgba = [torch.from_numpy(out["%s_%s" % (key, k)]) for k in ("pred", "targ", "rgba")]
         p = pred.clone().requires_grad_(True)
         total, full, terms = fn(p, targ, rgba, return_composited=True, return_loss_dict=True)
         total.backward()

@@ -220,16 +220,18 @@ def test_model_loss(golden):
 
 # ---------------------------------------------------------------- G6: the stdepth composite criterion
 STDEPTH_CASES = [("mae+composite", True), ("silma", True), ("silms+fbdivergence", True), ("mse", True),
-                 ("mae+composite+ssim", True), ("allssim+colorssim", True), ("silma+mse+fbdivergence", False)]
+                 ("mae+composite+ssim", True), ("allssim+colorssim", True), ("silma+mse+fbdivergence", False),
+                 ("mae+composite", True, 20), ("silma+allssim+composite+ssim", True, 20)]   # laina's default: 20 channels, single_layer
 
 
 @pytest.mark.parametrize("i", range(len(STDEPTH_CASES)))
 def test_stdepth_loss(golden, i):
     from oracle import stdepth as S
     g = golden("stdepth")
-    loss, single = STDEPTH_CASES[i]
-    C = 10 if single else 20
-    pred, targ, rgba = [_t(g["c%d_%s" % (C, k)]) for k in ("pred", "targ", "rgba")]
+    loss, single = STDEPTH_CASES[i][:2]
+    C = STDEPTH_CASES[i][2] if len(STDEPTH_CASES[i]) > 2 else (10 if single else 20)
+    key = "c20s" if (single and C == 20) else "c%d" % C
+    pred, targ, rgba = [_t(g["%s_%s" % (key, k)]) for k in ("pred", "targ", "rgba")]
     p = pred.clone().requires_grad_(True)
     total, full, terms = S.stdepth_loss(p, targ, rgba, loss, single)
     total.backward()

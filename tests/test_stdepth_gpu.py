@@ -15,7 +15,8 @@ from oracle import weights as W
 pytestmark = pytest.mark.gpu
 
 CASES = [("mae+composite", True), ("silma", True), ("silms+fbdivergence", True), ("mse", True),
-         ("mae+composite+ssim", True), ("allssim+colorssim", True), ("silma+mse+fbdivergence", False)]
+         ("mae+composite+ssim", True), ("allssim+colorssim", True), ("silma+mse+fbdivergence", False),
+                 ("mae+composite", True, 20), ("silma+allssim+composite+ssim", True, 20)]   # laina's default: 20 channels, single_layer
 
 
 def _method(loss):
@@ -35,12 +36,13 @@ def _close(got, ref, rtol, atol, what):
     assert bad == 0, "%s: %d/%d outside tolerance, max err %.4g" % (what, bad, ref.numel(), err.max().item())
 
 
-def _batch(seed, C, N, H, Wd):
+def _batch(seed, C, N, H, Wd, single=None):
     pred = W.uniform(seed, "pred", (N, C, H, Wd), -0.1, 1.1)
     targ = W.uniform(seed, "targ", (N, C, H, Wd), 0.0, 1.0)
     rgba = W.uniform(seed, "rgba", (N, 4, H, Wd), 0.0, 1.0)
     rgba[:, 3] = rgba[:, 3].masked_fill(W.uniform(seed, "hole", (N, H, Wd)) < 0.3, 0.0)
-    d = slice(8, 10) if C == 10 else slice(16, 20)
+    single = (C == 10) if single is None else single
+    d = slice(8, 10) if single else slice(16, 20)
     targ[:, d] = targ[:, d].masked_fill(W.uniform(seed, "dhole", targ[:, d].shape) < 0.2, 0.0)
     pred[:, d] = pred[:, d].abs() + 0.05
     return pred, targ, rgba
@@ -50,9 +52,10 @@ def _batch(seed, C, N, H, Wd):
 def test_stdepth_golden(golden, i):
     from mono_depth_estimation_amd import stdepth
     g = golden("stdepth")
-    loss, single = CASES[i]
-    C = 10 if single else 20
-    pred, targ, rgba = [_t(g["c%d_%s" % (C, k)]).cuda() for k in ("pred", "targ", "rgba")]
+    loss, single = CASES[i][:2]
+    C = CASES[i][2] if len(CASES[i]) > 2 else (10 if single else 20)
+    key = "c20s" if (single and C == 20) else "c%d" % C
+    pred, targ, rgba = [_t(g["%s_%s" % (key, k)]).cuda() for k in ("pred", "targ", "rgba")]
     crit = stdepth.setup_criterion(_method(loss), single_layer=single)
     p = pred.clone().requires_grad_(True)
     total, full, terms = crit(p, targ, rgba, return_composited=True, return_loss_dict=True)
@@ -117,8 +120,10 @@ def test_stdepth_rejects():
     pred, targ, rgba = [x.cuda() for x in _batch(91, 20, 1, 8, 8)]
     with pytest.raises(ValueError):
         stdepth.setup_criterion(_method("mae+composite"), False)(pred, targ, rgba)
+    l20, = stdepth.setup_criterion(_method("mae"), True)(pred, targ, rgba)      # 20 channels, single-layer layout: fine
+    assert bool(torch.isfinite(l20))
     with pytest.raises(ValueError):
-        stdepth.setup_criterion(_method("mae"), True)(pred, targ, rgba)
+        stdepth.setup_criterion(_method("mae"), True)(pred[:, :12], targ[:, :12], rgba)
     with pytest.raises(ValueError):
         stdepth.setup_criterion(_method("nothing"), False)(pred, targ, rgba)
     with pytest.raises(RuntimeError):
