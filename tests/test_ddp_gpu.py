@@ -20,23 +20,23 @@ pytestmark = pytest.mark.gpu
 SIZE = (64, 96)
 
 
-def _fresh(rank, state):
+def _fresh(rank, state, layers=50):
     from mono_depth_estimation_amd import criteria
     from mono_depth_estimation_amd.network import FCRN
     torch.manual_seed(100 + rank)
     x = torch.rand(2, 3, *SIZE, device="cuda")
     t = torch.rand(2, 1, *SIZE, device="cuda") * 0.9 + 0.05
-    net = FCRN.ResNet(layers=50, output_size=SIZE, out_channels=1, pretrained=False)
+    net = FCRN.ResNet(layers=layers, output_size=SIZE, out_channels=1, pretrained=False)
     net.load_state_dict(state)
     return net.cuda().train(), x, t, criteria.silog_loss(0.85)
 
 
-def _worker(rank, world, path, port, out):
+def _worker(rank, world, path, port, out, layers=50):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(0)
     state = torch.load(path)
-    net, x, t, crit = _fresh(rank, state)                      # each rank's own gradient, averaged by hand
+    net, x, t, crit = _fresh(rank, state, layers)              # each rank's own gradient, averaged by hand
     crit(net(x), t).backward()
     mine = {n: p.grad.detach().clone() for n, p in net.named_parameters()}
     want = {}
@@ -44,7 +44,7 @@ def _worker(rank, world, path, port, out):
         gg = g.contiguous().clone()
         dist.all_reduce(gg)
         want[n] = gg / world
-    net2, x, t, crit = _fresh(rank, state)                     # the same through DistributedDataParallel
+    net2, x, t, crit = _fresh(rank, state, layers)             # the same through DistributedDataParallel
     ddp = torch.nn.parallel.DistributedDataParallel(net2, device_ids=[0])
     crit(ddp(x), t).backward()
     rel = sorted(float((p.grad - want[n]).abs().max() / (want[n].abs().max() + 1e-20)) for n, p in net2.named_parameters())
@@ -55,12 +55,13 @@ def _worker(rank, world, path, port, out):
     dist.destroy_process_group()
 
 
-def test_ddp_averages_gradients(tmp_path):
-    ora = ofcrn.FCRNOracle(50, SIZE, out_channels=1)
-    W.fcrn_conditioned_state(ora, 51)
+@pytest.mark.parametrize("layers", [50, 18])      # 18: some Parameters are strided views of zero-padded storage
+def test_ddp_averages_gradients(tmp_path, layers):
+    ora = ofcrn.FCRNOracle(layers, SIZE, out_channels=1)
+    W.fcrn_conditioned_state(ora, 51, basic=layers <= 34)
     path, out = str(tmp_path / "state.pt"), str(tmp_path / "out.pt")
     torch.save(ora.state_dict(), path)
-    mp.spawn(_worker, args=(2, path, 29571, out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, path, 29571 + layers, out, layers), nprocs=2, join=True)
     r = torch.load(out)
     print(r)
     assert r["local_median"] > 0.3, "ranks' gradients too similar for the test to mean anything"
