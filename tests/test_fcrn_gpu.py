@@ -961,3 +961,36 @@ def test_in_channels_other_than_3(golden, cin):
     assert tuple(net.conv1.weight.grad.shape) == (64, cin, 7, 7) and c >= 0.85 and abs(float(gw.norm() / rw.norm()) - 1) <= 0.2, c
     with pytest.raises(ValueError):
         net(torch.rand(1, 3, *size, device="cuda"))
+
+
+def test_checkpoint_bridge_with_padded_parameters(tmp_path):
+    """The checkpoint / optimizer-state bridge on ResNet-18, whose decoder tail parameters are strided views of
+    zero-padded storage: state_dict round trip, Adam moments out in the parameters' own shapes and back in."""
+    from mono_depth_estimation_amd import checkpoint, criteria
+    from mono_depth_estimation_amd.network import FCRN
+    size = (64, 96)
+    torch.manual_seed(0)
+    hip = FCRN.ResNet(layers=18, output_size=size, out_channels=1, pretrained=False).cuda().train()
+    x, t = torch.rand(2, 3, *size, device="cuda"), torch.rand(2, 1, *size, device="cuda") * 0.9 + 0.05
+    criteria.silog_loss(0.85)(hip(x), t).backward()
+    grads = {n: p.grad.detach().clone() for n, p in hip.named_parameters()}
+    hip._store.adam_step(1e-4, 1e-3)
+    osd = checkpoint.adam_state_dict(hip, 1e-4)
+    params = [p for g in checkpoint._param_groups(hip) for p in g]
+    names = {id(p): n for n, p in hip.named_parameters()}
+    tail = [i for i, p in enumerate(params) if names[id(p)].startswith(("upSample.layer4.", "conv3."))]
+    assert tail
+    for i in tail:
+        g = grads[names[id(params[i])]].cpu()
+        assert osd["state"][i]["exp_avg"].shape == params[i].shape
+        assert torch.allclose(osd["state"][i]["exp_avg"], 0.1 * g, rtol=1e-5, atol=1e-12), names[id(params[i])]
+    path = str(tmp_path / "r18.ckpt")
+    checkpoint.save_checkpoint(hip, path, epoch=1, global_step=1, optimizer_states=[osd])
+    other = FCRN.ResNet(layers=18, output_size=size, out_channels=1, pretrained=False).cuda().train()
+    ck = checkpoint.load_checkpoint(other, path)
+    other(x)
+    checkpoint.load_adam_state_dict(other, ck["optimizer_states"][0])
+    for a, b in zip(hip._store.adam_state, other._store.adam_state):
+        assert torch.equal(a, b)
+    assert torch.equal(other._store.P, hip._store.P)
+    assert all(torch.equal(a, b) and a.shape == b.shape for a, b in zip(hip.parameters(), other.parameters()))
