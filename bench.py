@@ -35,15 +35,45 @@ def synthetic(n, seed, device):
     return rgb, depth.masked_fill(hole, 0.0)
 
 
+TRAFFIC_FILE = os.path.join("profiles", "r02_hbm_traffic.json")
+TRAFFIC_SOURCES = ("conv_gemm.hip", "conv_wgrad.hip", "mde_common.h")
+
+
+def kernel_source_hash():
+    """sha256 over the sources of the two GEMM kernels: the traffic figures in profiles/ are only quoted for the
+    kernels they were collected on (tools/hbm_traffic.py stores this hash next to them)."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in TRAFFIC_SOURCES:
+        with open(os.path.join(ROOT, "mono_depth_estimation_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def measured_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the rocprofv3 PMC passes committed under profiles/
-    (counters cannot be read from inside the process; collection + gfx950 FETCH_SIZE x2
-    correction are documented in that file).  None when the file is absent."""
+    """(HBM bytes per launch of `kernel`, provenance note) from the rocprofv3 PMC passes committed under profiles/
+    (counters cannot be read from inside the process; collection + the gfx950 FETCH_SIZE x2 correction are
+    documented in that file).  (None, why) when the file is absent or was collected on other kernel sources."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")) as f:
-            return round(json.load(f)[kernel]["hbm_bytes_per_launch"])
-    except (OSError, KeyError, ValueError):
-        return None
+        with open(os.path.join(ROOT, TRAFFIC_FILE)) as f:
+            j = json.load(f)
+        if j.get("_source_hash") != kernel_source_hash():
+            return None, "%s was collected on kernel sources %s, the build is %s: stale, not quoted" % (
+                TRAFFIC_FILE, j.get("_source_hash"), kernel_source_hash())
+        return round(j[kernel]["hbm_bytes_per_launch"]), "%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, sources %s)" % (
+            TRAFFIC_FILE, j["_source_hash"])
+    except (OSError, KeyError, ValueError) as e:
+        return None, "no traffic file (%s)" % type(e).__name__
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def host_cores():
@@ -61,8 +91,8 @@ def host_cores():
 
 def cpu_baseline(threads):
     """The CPU oracle (a port of the reference's fp32 torch.nn path, pinned to the reference by
-    tests/golden) on the host cores: FCRN-50 480x640, batch 2, 1 warm-up + 2 timed steps of
-    forward + SILog + backward + Adam."""
+    tests/golden) on the host cores, as SURVEY.md section 8d specifies: FCRN-50 480x640, batch 4,
+    1 warm-up + 3 timed steps of forward + SILog + backward + Adam, median images/sec."""
     from oracle import fcrn as ofcrn
     from oracle import losses as OL
     torch.set_num_threads(threads)
@@ -71,10 +101,10 @@ def cpu_baseline(threads):
     net.conv3.weight.data.mul_(0.05)
     opt = torch.optim.Adam([{"params": net.get_1x_lr_params(), "lr": 1e-4},
                             {"params": net.get_10x_lr_params(), "lr": 1e-3}], lr=1e-4)
-    n = 2
+    n = 4
     rgb, tgt = synthetic(n, 1234, "cpu")
     times = []
-    for i in range(3):
+    for i in range(4):
         t0 = time.perf_counter()
         opt.zero_grad()
         loss = OL.silog(net(rgb), tgt)
@@ -82,8 +112,10 @@ def cpu_baseline(threads):
         opt.step()
         if i:
             times.append(time.perf_counter() - t0)
-    return {"value": round(n / (sum(times) / len(times)), 4), "unit": "images/sec", "cores": threads, "kind": "port",
-            "sample": "oracle FCRN-50 fp32 480x640, batch %d, 1 warm-up + %d timed train steps (fwd+SILog+bwd+Adam)" % (n, len(times))}
+    med = sorted(times)[len(times) // 2]
+    return {"value": round(n / med, 4), "unit": "images/sec", "cores": threads, "kind": "port", "cpu_model": cpu_model(),
+            "sample": "oracle FCRN-50 fp32 480x640, batch %d, 1 warm-up + %d timed train steps (fwd+SILog+bwd+Adam), median"
+                      % (n, len(times))}
 
 
 def main():
@@ -91,7 +123,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=BATCH, help="images per GPU")
+    ap.add_argument("--batch", type=int, default=BATCH, help="images per GPU (weak scaling) / global batch (strong scaling)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: --batch images on EVERY GPU; strong: --batch images split over the GPUs (SURVEY 8e)")
+    ap.add_argument("--grad-dtype", choices=("bf16", "fp32"), default=os.environ.get("MDE_DP_GRAD_DTYPE", "bf16"),
+                    help="wire format of the gradient all-reduce buckets (N > 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-launch-timing", action="store_true")
     ap.add_argument("--per-shape", action="store_true", help="print a per-shape table of the GEMM launches to stderr")
@@ -105,6 +141,10 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
         args.gpus = world
+    if args.scaling == "strong":
+        if args.batch % world:
+            sys.exit("bench.py --scaling strong: global batch %d is not divisible by %d GPUs" % (args.batch, world))
+        args.batch //= world                                  # from here on: images per GPU
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
@@ -128,7 +168,7 @@ def main():
         dist.broadcast(store.P, 0)
         dist.broadcast(store.B, 0)
     reducer = dp.FlatGradReducer(store.G, eng.grad_boundaries(), target_bytes=int(os.environ.get("MDE_DP_BUCKET_MB", "64")) << 20,
-                                 extra_streams=[eng.side])
+                                 extra_streams=[eng.side], wire_dtype=torch.bfloat16 if args.grad_dtype == "bf16" else None)
     ws, loss = ops.silog_ws(dev), torch.empty(1, device=dev)
     dy = torch.empty(args.batch, 1, H, W, device=dev)
     lr = 1e-4
@@ -182,10 +222,10 @@ def main():
         out = {
             "metric": "training images/sec, FCRN 640x480 bf16", "value": round(ips, 2), "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "FCRN ResNet-50 + UpProj (reference network/FCRN.py), %dx3x480x640 per GPU -> 1x480x640 "
                                    "depth, train step = fwd + SILog(0.85) + bwd + Adam(lr, 10*lr)%s" % (
-                                       args.batch, " + flat-gradient all-reduce (RCCL)" if world > 1 else ""),
+                                       args.batch, " + flat-gradient all-reduce (RCCL, %s buckets)" % args.grad_dtype if world > 1 else ""),
                        "global_batch": args.batch * world, "per_gpu_batch": args.batch, "parallelism": "dp%d" % world,
                        "final_loss": round(final_loss, 5)},
             "step_mfma_frac": round(ips * ALGO_GFLOP_PER_IMAGE / 1e3 / (world * PEAK_BF16_TFLOPS), 4),
@@ -202,10 +242,11 @@ def main():
             summ = timer.summary()
             n, fl, sec = summ.get("conv_gemm_nt", (0, 0.0, 1.0))
             ach = fl / sec / 1e12 if n else 0.0
+            traffic, traffic_src = measured_traffic("conv_gemm_nt")
             out["roofline"] = {
                 "bound": "mfma", "kernel": "conv_gemm_nt (implicit-GEMM conv fwd/dgrad/up-projection, bf16 MFMA)",
                 "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
-                "traffic": measured_traffic("conv_gemm_nt"), "launches": n, "avg_launch_us": round(1e6 * sec / max(n, 1), 2),
+                "traffic": traffic, "traffic_source": traffic_src, "launches": n, "avg_launch_us": round(1e6 * sec / max(n, 1), 2),
                 "avg_launch_gflop": round(fl / max(n, 1) / 1e9, 3),
                 "share_of_step_time": round(sec / timed_launch_steps / (dt / args.steps), 4),
                 "timed_launch_steps": timed_launch_steps,

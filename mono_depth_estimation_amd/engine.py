@@ -407,6 +407,8 @@ class ParamStore:
             self.repack()
             self.packed_version = v
             self._fp_valid = False
+            if check_data:
+                self._record_fingerprint()     # the shadows are fresh NOW: a .data write before the next forward must show
         elif check_data:
             if self._fp_state is None:
                 self._fp_state = ops.fingerprint_state(self.dev)
@@ -416,6 +418,13 @@ class ParamStore:
                 ops.refresh_if_changed(self.P, self.Pb, self.WD if jobs is not None else None, jobs,
                                        jobs.shape[0] if jobs is not None else 0, nblocks, self._fp_state)
             self._fp_valid = True          # (a first call only records the fingerprint: the shadows are known fresh)
+
+    def _record_fingerprint(self):
+        """Fingerprint of the masters the shadows were just derived from (module path only: one 254 MB read)."""
+        if self._fp_state is None:
+            self._fp_state = ops.fingerprint_state(self.dev)
+        ops.param_fingerprint(self.P, self._fp_state)
+        self._fp_valid = True
 
     def _jobs(self):
         if self._pack_jobs is None:
@@ -429,6 +438,42 @@ class ParamStore:
         if jobs is not None:
             ops.pack_wt_batch(self.P, self.WD, jobs, nblocks)
 
+    def _step_ranges(self):
+        """Contiguous flat ranges the fused optimiser steps may touch: [(begin, end, is_decoder)].  Parameters with
+        requires_grad=False are left out (torch.optim skips them: the reference's get_*_lr_params filter on
+        requires_grad, laina.py:51-57) — the engine's backward writes a gradient for every parameter, frozen or
+        not, and a fused step over the whole range used to move frozen weights.  All trainable: the two ranges."""
+        key = tuple(p.requires_grad for p in self.params)
+        if getattr(self, "_ranges_key", None) != key:
+            e, n = self.encoder_numel, self.P.numel()
+            if all(key):
+                self._ranges = [(0, e, False), (e, n, True)]
+            else:
+                spans = sorted((self.p_off[id(p)], self.p_off[id(p)] + int(torch.Size(self.sdims[id(p)]).numel()),
+                                p.requires_grad) for p in self.params)
+                runs = []
+                for b, en, live in spans:
+                    dec = b >= e
+                    if live and runs and runs[-1][3] and runs[-1][2] == dec:
+                        runs[-1][1] = en                   # extend the current run over the alignment gap
+                    elif live:
+                        runs.append([b, en, dec, True])
+                    elif runs:
+                        runs[-1][3] = False                # a frozen tensor ends the run
+                self._ranges = [(b, en, dec) for b, en, dec, _ in runs]
+            self._ranges_key = key
+        return self._ranges
+
+    def _sync_external_grads(self, G):
+        """Gradients torch holds OUTSIDE the flat buffer G must be copied in before a fused step reads G:
+        AccumulateGrad clones a returned gradient view when its strides do not match the parameter's (the
+        zero-padded ResNet-18/34 decoder weights), and gradient accumulation / zero_grad(set_to_none=False) / DDP
+        then act on the clone, not on G."""
+        with torch.no_grad():
+            for p in self.params:
+                if p.requires_grad and p.grad is not None and not self._in(p.grad, G):
+                    self.view_of(G, p).copy_(p.grad)
+
     # fused Adam over the two flat ranges (encoder 1x LR, decoder 10x LR: modules/laina.py:51-57)
     def adam_step(self, lr_encoder, lr_decoder, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, grad_scale=1.0,
                   decoupled=False):
@@ -438,28 +483,32 @@ class ParamStore:
             self.adam_state = (torch.zeros_like(self.P), torch.zeros_like(self.P))
         mom, var = self.adam_state
         self.step_count += 1
-        e, n = self.encoder_numel, self.P.numel()
         G = self.grad_buffer()
+        self._sync_external_grads(G)
         wd = weight_decay if isinstance(weight_decay, (tuple, list)) else (weight_decay, weight_decay)
         step = ops.adamw_step if decoupled else ops.adam_step
-        step(self.P, G, mom, var, self.Pb, e, lr_encoder, betas[0], betas[1], eps, wd[0], grad_scale, self.step_count)
-        step(self.P[e:], G[e:], mom[e:], var[e:], self.Pb[e:], n - e, lr_decoder, betas[0], betas[1], eps, wd[1],
-             grad_scale, self.step_count)
+        for b, en, dec in self._step_ranges():
+            step(self.P[b:en], G[b:en], mom[b:en], var[b:en], self.Pb[b:en], en - b, lr_decoder if dec else lr_encoder,
+                 betas[0], betas[1], eps, wd[1] if dec else wd[0], grad_scale, self.step_count)
+        self._after_fused_step()
+
+    def _after_fused_step(self):
         self.repack()
         self.packed_version = self.params_version()   # shadow + packings are current (the kernels bump no version counter)
         self._fp_valid = False
+        if self._fp_state is not None:                 # module path in use: keep the .data-write detector armed
+            self._record_fingerprint()
 
     # fused SGD with momentum over the same two ranges (modules/vnl.py:289-326: momentum 0.9, weight_decay 5e-4)
     def sgd_step(self, lr_encoder, lr_decoder, momentum=0.9, weight_decay=0.0, grad_scale=1.0):
         if self.sgd_state is None:
             self.sgd_state = torch.zeros_like(self.P)
-        e, n = self.encoder_numel, self.P.numel()
         G, buf = self.grad_buffer(), self.sgd_state
-        ops.sgd_step(self.P, G, buf, self.Pb, e, lr_encoder, momentum, weight_decay, grad_scale)
-        ops.sgd_step(self.P[e:], G[e:], buf[e:], self.Pb[e:], n - e, lr_decoder, momentum, weight_decay, grad_scale)
-        self.repack()
-        self.packed_version = self.params_version()
-        self._fp_valid = False
+        self._sync_external_grads(G)
+        for b, en, dec in self._step_ranges():
+            ops.sgd_step(self.P[b:en], G[b:en], buf[b:en], self.Pb[b:en], en - b, lr_decoder if dec else lr_encoder, momentum,
+                         weight_decay, grad_scale)
+        self._after_fused_step()
 
 
 class FCRNEngine:

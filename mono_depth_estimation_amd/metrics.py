@@ -14,45 +14,6 @@ from . import ops
 NAMES = ("absrel", "rmse", "delta1", "delta2", "delta3", "log10", "mae", "mse", "msle", "sqrel")
 
 
-class MetricLogger(object):
-    """reference metrics.py:11-45: forwards every metric of a step to the LightningModule's `log` (`module` is anything
-    with that method), keeping running averages in a MetricComputation."""
-
-    def __init__(self, metrics, module):
-        self.context = module
-        self.computer = MetricComputation(metrics)
-
-    def log_train(self, pred, target, loss):
-        values = self.computer.compute(pred, target)
-        result = {"loss": loss}
-        self.context.log("loss", loss)
-        for name, value in zip(self.computer.names, values):
-            self.context.log("train_{}".format(name), value, logger=True, on_epoch=True)
-            self.context.log("train_{}(AVG)".format(name), self.computer.avg(name), logger=False, prog_bar=True)
-            result[name] = value
-        return result
-
-    def log_val(self, pred, target, prefix=''):
-        values = self.computer.compute(pred, target)
-        result = {}
-        for name, value in zip(self.computer.names, values):
-            self.context.log("val_{}{}".format(prefix, name), value, logger=True, on_epoch=True)
-            self.context.log("val_{}{}(AVG)".format(prefix, name), self.computer.avg(name), logger=False, prog_bar=True)
-            result['{}{}'.format(prefix, name)] = value
-        return result
-
-    def log_test(self, pred, target):
-        values = self.computer.compute(pred, target)
-        result = {}
-        for name, value in zip(self.computer.names, values):
-            self.context.log("{}".format(name), value, on_step=True, on_epoch=True)
-            result[name] = value
-        return result
-
-    def reset(self):
-        self.computer.reset()
-
-
 class MetricComputation(object):
     """Same interface as the reference class: names, compute(pred, target), avg(metric), reset()."""
 

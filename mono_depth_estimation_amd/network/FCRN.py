@@ -280,7 +280,7 @@ class _FCRNFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, engine, train, *params):
-        ctx.engine = engine
+        ctx.engine, ctx.train = engine, train
         y = engine.forward(x, train, check_data=True)
         engine.forward_serial = ctx.serial = getattr(engine, "forward_serial", 0) + 1
         return y.clone()
@@ -288,6 +288,16 @@ class _FCRNFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         eng = ctx.engine
+        if not ctx.train:
+            # the backward plan is the TRAINING-mode one (batch statistics, the ReLU masks a train-mode forward wrote);
+            # after an eval-mode forward those buffers hold another step's values or nothing at all
+            raise RuntimeError(
+                "mono_depth_estimation_amd FCRN: backward() through a forward pass run in eval() mode is not supported "
+                "(BatchNorm backward with running statistics has no kernel here); call .train() before the forward "
+                "pass whose gradients you need, or wrap evaluation in torch.no_grad().")
+        if ctx.needs_input_grad[0]:
+            raise RuntimeError("mono_depth_estimation_amd FCRN: the gradient with respect to the input image is not "
+                               "computed (the stem has no input-gradient kernel); detach the input.")
         if ctx.serial != eng.forward_serial:
             # the launch plan of one input shape owns ONE set of activation buffers: a later forward of the same shape
             # has replaced what this backward needs.  Refuse instead of returning gradients of the wrong activations.

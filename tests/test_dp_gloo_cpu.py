@@ -36,6 +36,19 @@ def _worker(rank, world, port, q):
     red.ready(0)
     red.finish()
     ok = ok and torch.equal(g, torch.full((n,), float(sum(range(world)))))
+    # bf16 wire format (half the bytes on the links): small integers survive the round trip exactly
+    g = torch.arange(n, dtype=torch.float32).remainder(64.0) * (rank + 1)
+    red = dp.FlatGradReducer(g, bounds, target_bytes=8192, wire_dtype=torch.bfloat16)
+    for off in reversed(bounds):
+        red.ready(off)
+    red.finish()
+    ok = ok and torch.equal(g, torch.arange(n, dtype=torch.float32).remainder(64.0) * sum(r + 1 for r in range(world)))
+    # ... and rounds like bf16 does when they do not
+    g = torch.full((n,), 1.0 + 2.0 ** -10)
+    red = dp.FlatGradReducer(g, bounds, target_bytes=8192, wire_dtype=torch.bfloat16)
+    red.ready(0)
+    red.finish()
+    ok = ok and torch.equal(g, torch.full((n,), float(world)))
     q.put((rank, ok, len(red.buckets)))
     dist.destroy_process_group()
 

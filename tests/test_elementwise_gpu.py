@@ -585,27 +585,3 @@ def test_pixel_shuffle2_matches_torch():
     assert float(back[..., :8].float().abs().max()) == 0.0 and float(back[..., 8 + 4 * C:].float().abs().max()) == 0.0
 
 
-def test_metric_logger_surface():
-    """reference metrics.py:11-45: MetricLogger(metrics, module) logs through the module's `log` and returns dicts."""
-    from mono_depth_estimation_amd import metrics
-
-    class Ctx:
-        def __init__(self):
-            self.calls = []
-
-        def log(self, name, value, **kw):
-            self.calls.append((name, float(value), kw))
-    ctx = Ctx()
-    ml = metrics.MetricLogger(["delta1", "mae", "rmse"], ctx)
-    pred, tgt = W.uniform(4, "p", (2, 1, 24, 32), 0.1, 1.0).cuda(), W.uniform(4, "t", (2, 1, 24, 32), -0.1, 1.0).cuda()
-    r = ml.log_train(pred, tgt, torch.tensor(1.5))
-    assert set(r) == {"loss", "delta1", "mae", "rmse"} and ctx.calls[0][:2] == ("loss", 1.5)
-    assert [c[0] for c in ctx.calls[1:3]] == ["train_delta1", "train_delta1(AVG)"] and ctx.calls[2][2] == {"logger": False, "prog_bar": True}
-    v = ml.log_val(pred, tgt, prefix="x_")
-    assert set(v) == {"x_delta1", "x_mae", "x_rmse"}
-    t = ml.log_test(pred, tgt)
-    ora = OM.compute(pred.cpu(), tgt.cpu())
-    assert all(np.allclose(float(t[k]), float(ora[k]), rtol=2e-5) for k in t)
-    assert ml.computer.count == 3
-    ml.reset()
-    assert ml.computer.count == 0

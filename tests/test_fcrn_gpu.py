@@ -994,3 +994,107 @@ def test_checkpoint_bridge_with_padded_parameters(tmp_path):
         assert torch.equal(a, b)
     assert torch.equal(other._store.P, hip._store.P)
     assert all(torch.equal(a, b) and a.shape == b.shape for a, b in zip(hip.parameters(), other.parameters()))
+
+
+def test_data_write_after_a_single_forward_is_seen():
+    """The detector of untracked `.data` writes must be armed by the very forward that refreshed the shadows (after
+    optimizer.step / load_state_dict / the first forward), not one forward later: opt.step(); p.data.copy_(ema);
+    ONE validation forward; p.data.copy_(train weights); the next forward must run on the train weights."""
+    from mono_depth_estimation_amd.network import FCRN
+    size = (64, 96)
+    net = FCRN.ResNet(layers=50, output_size=size, out_channels=1, pretrained=False).cuda().eval()
+    x = torch.rand(2, 3, *size, device="cuda")
+    with torch.no_grad():
+        y0 = net(x)                                           # first forward: versioned refresh branch
+        net.conv3.weight.data.mul_(0.5)                       # invisible to _version, right after ONE forward
+        y1 = net(x)
+        net._store.refresh_weights(force=True)
+        y2 = net(x)
+        assert not torch.equal(y1, y0) and torch.equal(y1, y2)
+        net.conv3.weight.mul_(1.0)                            # a versioned write (as optimizer.step does) ...
+        y3 = net(x)                                           # ... one forward ...
+        net.conv3.weight.data.mul_(2.0)                       # ... then an untracked one
+        y4 = net(x)
+        assert torch.equal(y3, y1) and torch.equal(y4, y0)
+    # after the fused step the detector stays armed as well
+    net.train()
+    crit_in = torch.rand(2, 1, *size, device="cuda") + 0.1
+    from mono_depth_estimation_amd import criteria
+    net.zero_grad(set_to_none=True)
+    criteria.silog_loss(0.85)(net(x), crit_in).backward()
+    net._store.adam_step(1e-4, 1e-3)
+    net.eval()
+    with torch.no_grad():
+        net.conv3.weight.data.zero_()
+        y5 = net(x)
+    assert float((y5 - 0.5).abs().max()) == 0.0               # sigmoid(0): the zeroed head reached the kernels
+
+
+def test_frozen_parameters_are_not_moved_by_the_fused_step():
+    """torch.optim skips parameters with requires_grad=False (reference laina.py:51-57 filters on it); the fused
+    flat-range steps must too, although the engine's backward writes a gradient for every parameter."""
+    from mono_depth_estimation_amd import criteria
+    from mono_depth_estimation_amd.network import FCRN
+    size = (64, 96)
+    net = FCRN.ResNet(layers=50, output_size=size, out_channels=1, pretrained=False).cuda().train()
+    x, t = torch.rand(2, 3, *size, device="cuda"), torch.rand(2, 1, *size, device="cuda") + 0.1
+    crit = criteria.silog_loss(0.85)
+    net.zero_grad(set_to_none=True)
+    crit(net(x), t).backward()
+    net._store.adam_step(1e-3, 1e-2)                           # every moment non-zero
+    for p in net.get_1x_lr_params():
+        p.requires_grad_(False)
+    net.layer2[1].bn2.weight.requires_grad_(False)
+    net.upSample.layer2.upper_branch.conv2.weight.requires_grad_(False)    # one frozen tensor inside the decoder range
+    before = {k: v.detach().clone() for k, v in net.named_parameters()}
+    for step in (net._store.adam_step, net._store.sgd_step, lambda a, b: net._store.adam_step(a, b, decoupled=True, weight_decay=1e-2)):
+        net.zero_grad(set_to_none=True)
+        crit(net(x), t).backward()
+        step(1e-3, 1e-2)
+    moved = {k for k, v in net.named_parameters() if not torch.equal(v.detach(), before[k])}
+    frozen = {k for k, v in net.named_parameters() if not v.requires_grad}
+    assert not (moved & frozen), sorted(moved & frozen)[:5]
+    assert "conv2.weight" in moved and "upSample.layer2.upper_branch.conv1.weight" in moved and "conv3.weight" in moved
+    assert "upSample.layer2.upper_branch.conv2.weight" in frozen and "conv1.weight" in frozen
+
+
+def test_padded_parameters_accumulate_into_the_fused_step():
+    """ResNet-18: the decoder's 32- and 16-channel tensors are stored zero-padded, so their Parameters are non-dense
+    views and autograd keeps a CLONE of the returned gradient as .grad.  Two backwards (accumulation) and
+    zero_grad(set_to_none=False) then act on that clone; the fused step must read what torch holds."""
+    from mono_depth_estimation_amd import criteria
+    from mono_depth_estimation_amd.network import FCRN
+    size = (64, 96)
+    torch.manual_seed(3)
+    net = FCRN.ResNet(layers=18, output_size=size, out_channels=1, pretrained=False).cuda().train()
+    x, t = torch.rand(2, 3, *size, device="cuda"), torch.rand(2, 1, *size, device="cuda") + 0.1
+    crit = criteria.silog_loss(0.85)
+    names = ["upSample.layer4.upper_branch.conv2.weight", "upSample.layer4.bottom_branch.batchnorm.weight", "conv3.weight",
+             "upSample.layer1.upper_branch.conv2.weight", "layer2.0.conv1.weight"]
+    params = dict(net.named_parameters())
+    net.zero_grad(set_to_none=True)
+    crit(net(x), t).backward()
+    net.zero_grad(set_to_none=False)                            # torch zeroes ITS tensors
+    crit(net(x), t).backward()
+    crit(net(x), t).backward()                                  # .grad = g1 + g2
+    w0 = {k: params[k].detach().clone() for k in names}
+    g = {k: params[k].grad.detach().clone() for k in names}
+    net._store.adam_step(1e-3, 1e-3)
+    for k in names:
+        # first Adam step: p -= lr * g / (|g| + eps)  (bias-corrected moments of a single gradient)
+        want = w0[k] - 1e-3 * g[k] / (g[k].abs() + 1e-8)
+        assert torch.allclose(params[k].detach(), want, rtol=0, atol=2e-6), k
+    assert float(g["upSample.layer4.upper_branch.conv2.weight"].abs().max()) > 0
+
+
+def test_backward_through_an_eval_forward_is_refused():
+    from mono_depth_estimation_amd.network import FCRN
+    size = (64, 96)
+    net = FCRN.ResNet(layers=50, output_size=size, out_channels=1, pretrained=False).cuda().eval()
+    x = torch.rand(2, 3, *size, device="cuda")
+    with pytest.raises(RuntimeError, match="eval"):
+        net(x).sum().backward()
+    net.train()
+    xr = x.clone().requires_grad_(True)
+    with pytest.raises(RuntimeError, match="input image"):
+        net(xr).sum().backward()
