@@ -49,7 +49,8 @@ int mde_device_cu_count(int* out);
  * sum over taps t and channels c of   in[(gy*sy+dy[t], gx*sx+dx[t]), c] * w[col][wtap[t]][c]".
  * ---------------------------------------------------------------------------------- */
 typedef struct mde_conv_desc {
-    /* gathered operand: bf16 [N][H][W][ld_in], C contracted channels per tap (C % 64 == 0) */
+    /* gathered operand: bf16 [N][H][W][ld_in], C contracted channels per tap (C % 8 == 0; a K-step that runs past
+     * C is zero-filled by the kernel, so DenseNet's 48-channel growth or a 32-channel head need no padded storage) */
     int32_t N, H, W, ld_in, C;
     uint32_t in_bytes;          /* bytes addressable from `in` (bounds for zero-fill)       */
     /* output pixel grid of this launch: M = N*GH*GW rows */
@@ -65,6 +66,10 @@ typedef struct mde_conv_desc {
     int32_t osy, osx, ooy, oox;
     int32_t ncols;              /* output channels (GEMM columns); weight rows             */
     int32_t accumulate;         /* !=0: out += result (bf16 read-modify-write)             */
+    /* !=0: grouped convolution in block-diagonal form (ResNeXt: VNL.py:638, MiDaS' resnext101_32x8d).  C must be 64
+     * and ncols a multiple of 64: output columns [64b, 64b+64) contract with input channels [64b, 64b+64) of `in`
+     * only; w is [ncols][wtaps_total][64] with zeros outside each column's own group (mde_pack_grouped writes it). */
+    int32_t grouped;
 } mde_conv_desc;
 
 /* out[pix][col] (+)= sum_t sum_c in[src(pix,t)][c] * w[col][wtap[t]][c]
@@ -81,7 +86,7 @@ int mde_conv_gemm(const mde_conv_desc* d, const void* in, const void* w, void* o
  * other one.  The caller zeroes dw.  ksplit >= 1 splits the pixel range over workgroups. */
 typedef struct mde_wgrad_desc {
     int32_t N, GH, GW;          /* pixel grid (of the direct tensor)                        */
-    int32_t ld_d, Cd;           /* direct tensor bf16 [N][GH][GW][ld_d], Cd channels used   */
+    int32_t ld_d, Cd;           /* direct tensor bf16 [N][GH][GW][ld_d], Cd channels used (% 8 == 0) */
     int32_t H, W, ld_g, Cg;     /* gathered tensor bf16 [N][H][W][ld_g], Cg channels used   */
     uint32_t d_bytes, g_bytes;
     int32_t sy, sx, ntaps;
@@ -90,6 +95,9 @@ typedef struct mde_wgrad_desc {
     int32_t otaps_total;        /* dw is fp32 [rows][otaps_total][cols]                      */
     int32_t rows_from_gathered; /* 0: rows = direct channels, cols = gathered channels       */
     int32_t ksplit;
+    /* > 0: grouped convolution with this many channels per group (divides 64; Cd == Cg, multiples of 64): only the
+     * block-diagonal part is computed and dw is fp32 [rows][otaps_total][group_size].  0: dense. */
+    int32_t group_size;
 } mde_wgrad_desc;
 
 int mde_conv_wgrad(const mde_wgrad_desc* d, const void* direct, const void* gathered,
@@ -197,6 +205,65 @@ int mde_upsample_sigmoid_fwd(const float* x, float* out, int N, int H, int W, in
 /* dx fp32 [N][H][W][C] = d(loss)/dx given dout = d(loss)/d(out) and out (both NCHW fp32). */
 int mde_upsample_sigmoid_bwd(const float* dout, const float* out, float* dx, int N, int H, int W,
                              int C, int OH, int OW, void* stream);
+
+/* ---- Pointwise / pooling / resize ops of the VNL, MiDaS and BTS networks (NHWC bf16, own `ld` per tensor, C % 8 == 0) ----
+ * act codes: 0 none, 1 ReLU, 2 ELU (alpha 1), 3 sigmoid.
+ * out = act(x + bias[c] + r): conv bias + activation + residual add in one pass (MiDaS.py:163-229 ResidualConvUnit /
+ * FeatureFusionBlock, VNL.py:348-349 FTB_block's `out += residual; relu`, Bts.py:69-80 conv + ELU).  bias (fp32 [C]) and r
+ * may be NULL. */
+int mde_pw_fwd(const void* x, int ldx, const float* bias, const void* r, int ldr, void* out, int ldo, int64_t M, int C,
+               int act, void* stream);
+/* g = dout * act'(out) (the derivative is taken from the forward OUTPUT; out may be NULL for act 0);
+ * dx = g or dx += g (acc_x), likewise dr (the residual's gradient; may be NULL); dbias[c] += sum over rows of g (fp32,
+ * atomics; may be NULL).  dx may be NULL when only dbias / dr are wanted. */
+int mde_pw_bwd(const void* dout, int ldd, const void* out, int ldo, void* dx, int lddx, int acc_x, void* dr, int lddr,
+               int acc_r, float* dbias, int64_t M, int C, int act, void* stream);
+/* out[n][c] = scale * sum_p x[n][p][c]: nn.AdaptiveAvgPool2d(1) with scale = 1/HW (VNL.py:207,221,359,367), and the
+ * gradient of a spatial broadcast with scale = 1.  x: [N][HW][ldx]; out: bf16 [N][ldo]. */
+int mde_spatial_sum(const void* x, int ldx, int N, int64_t HW, int C, float scale, void* out, int ldo, void* stream);
+/* out[n][p][c] = scale * src[n][c] (accumulate != 0: +=): bilinear upsampling of a 1x1 map (VNL.py:225) and the gradient
+ * of the average pool (scale = 1/HW). */
+int mde_spatial_bcast(const void* src, int lds, float scale, void* out, int ldo, int N, int64_t HW, int C, int accumulate,
+                      void* stream);
+/* AFA_block's gate (VNL.py:372): out = w[n][c] * lat + top, w: bf16 [N][ldw].  Backward: dlat (+)= w * dout,
+ * dtop (+)= dout, dw[n][c] = sum_p dout * lat (bf16 [N][lddw], overwritten). */
+int mde_gate_fwd(const void* w, int ldw, const void* lat, int ldl, const void* top, int ldt, void* out, int ldo, int N,
+                 int64_t HW, int C, void* stream);
+int mde_gate_bwd(const void* dout, int ldd, const void* w, int ldw, const void* lat, int ldl, void* dlat, int lddl,
+                 int acc_lat, void* dtop, int lddt, int acc_top, void* dw, int lddw, int N, int64_t HW, int C, void* stream);
+/* F.interpolate(mode='bilinear') on NHWC bf16, ATen's source-index arithmetic for both align_corners settings
+ * (VNL.py:308,384,386 True; MiDaS.py:155-157 False, :224-227 True).  bwd is the exact transpose in gather form
+ * (deterministic); accumulate != 0 adds into dx. */
+int mde_resize_bilinear_fwd(const void* x, int ldx, void* out, int ldo, int N, int H, int W, int C, int OH, int OW,
+                            int align_corners, void* stream);
+int mde_resize_bilinear_bwd(const void* dout, int ldd, void* dx, int lddx, int N, int H, int W, int C, int OH, int OW,
+                            int align_corners, int accumulate, void* stream);
+/* Nearest x2 upsampling (Bts.py:77): out[n][2y+a][2x+b] = x[n][y][x], x is [N][H][W].  mde_sum2x2 is its gradient
+ * (scale 1) and nn.AvgPool2d(2, 2) forward (scale 0.25): dst[n][y][x] (+)= scale * sum of the 2x2 block of src
+ * [N][2H][2W]; mde_spread2x2 is the average pool's gradient: out[n][2y+a][2x+b] (+)= scale * x[n][y][x]. */
+int mde_nearest2_fwd(const void* x, int ldx, void* out, int ldo, int N, int H, int W, int C, void* stream);
+int mde_sum2x2(const void* src, int lds, void* dst, int ldd, int N, int H, int W, int C, float scale, int accumulate,
+               void* stream);
+int mde_spread2x2(const void* x, int ldx, void* out, int ldo, int N, int H, int W, int C, float scale, int accumulate,
+                  void* stream);
+/* fcn_topdown_predict (VNL.py:314-327): x = the 3x3 conv's output bf16 [N*HW][ldx] (bias not yet added);
+ * logit = x + bias, prob = softmax over channels; both fp32 NCHW [N][C][HW] (the module's two return tensors).  C <= 256.
+ * bwd: dx = dlogit + prob * (dprob - sum_c dprob * prob) as bf16 [N*HW][lddx] (channels [C, C rounded up to 8) written
+ * as zero); dbias[c] += sum_p dx (fp32, may be NULL).  dlogit or dprob may be NULL (treated as zero). */
+int mde_softmax_head_fwd(const void* x, int ldx, const float* bias, float* logit, float* prob, int N, int64_t HW, int C,
+                         void* stream);
+int mde_softmax_head_bwd(const float* dlogit, const float* dprob, const float* prob, void* dx, int lddx, float* dbias, int N,
+                         int64_t HW, int C, void* stream);
+/* out[n][c][p] = scale * act(x[n][p][c] + bias[c]), fp32 NCHW: the small-C output heads (MiDaS.py:54-56: 7 channels +
+ * sigmoid; Bts.py:202-203,273: sigmoid * max_depth).  bwd: dx bf16 [N*HW][lddx] (pad channels zero), dbias += (C <= 64). */
+int mde_to_nchw_act_fwd(const void* x, int ldx, const float* bias, float* out, int N, int64_t HW, int C, int act, float scale,
+                        void* stream);
+int mde_to_nchw_act_bwd(const float* dout, const float* out, void* dx, int lddx, float* dbias, int N, int64_t HW, int C,
+                        int act, float scale, void* stream);
+/* Block-diagonal packings of a grouped conv weight (VNL.py:638 `groups=cardinality`): src fp32 [O][T][G] (G = channels per
+ * group, O == I, O % 64 == 0, G divides 64) -> fwd bf16 [O][T][64] for mde_conv_gemm(grouped) and dgrad bf16 [O][T][64]
+ * (the transposed blocks, for the input gradient); either may be NULL. */
+int mde_pack_grouped(const float* src, void* fwd, void* dgrad, int O, int T, int G, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Losses and metrics (criteria.py / metrics.py), fp32 in, fp32/fp64 accumulation.

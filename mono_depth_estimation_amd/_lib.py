@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MDE_LIB_PATH") or os.path.join(_HERE, "libmde_hip.so")   # override: diagnostic builds only
-ABI_VERSION = 4
+ABI_VERSION = 5
 MAX_TAPS = 32
 
 
@@ -26,7 +26,7 @@ class ConvDesc(C.Structure):
         ("wtaps_total", C.c_int32),
         ("OH", C.c_int32), ("OW", C.c_int32), ("ld_out", C.c_int32),
         ("osy", C.c_int32), ("osx", C.c_int32), ("ooy", C.c_int32), ("oox", C.c_int32),
-        ("ncols", C.c_int32), ("accumulate", C.c_int32),
+        ("ncols", C.c_int32), ("accumulate", C.c_int32), ("grouped", C.c_int32),
     ]
 
 
@@ -39,7 +39,7 @@ class WgradDesc(C.Structure):
         ("d_bytes", C.c_uint32), ("g_bytes", C.c_uint32),
         ("sy", C.c_int32), ("sx", C.c_int32), ("ntaps", C.c_int32),
         ("dy", C.c_int16 * MAX_TAPS), ("dx", C.c_int16 * MAX_TAPS), ("otap", C.c_int16 * MAX_TAPS),
-        ("otaps_total", C.c_int32), ("rows_from_gathered", C.c_int32), ("ksplit", C.c_int32),
+        ("otaps_total", C.c_int32), ("rows_from_gathered", C.c_int32), ("ksplit", C.c_int32), ("group_size", C.c_int32),
     ]
 
 
@@ -71,6 +71,22 @@ SIGNATURES = {
     "mde_maxpool_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "mde_upsample_sigmoid_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "mde_upsample_sigmoid_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "mde_pw_fwd": (_I, [_P, _I, _P, _P, _I, _P, _I, _L, _I, _I, _P]),
+    "mde_pw_bwd": (_I, [_P, _I, _P, _I, _P, _I, _I, _P, _I, _I, _P, _L, _I, _I, _P]),
+    "mde_spatial_sum": (_I, [_P, _I, _I, _L, _I, _F, _P, _I, _P]),
+    "mde_spatial_bcast": (_I, [_P, _I, _F, _P, _I, _I, _L, _I, _I, _P]),
+    "mde_gate_fwd": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _L, _I, _P]),
+    "mde_gate_bwd": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _P, _I, _I, _P, _I, _I, _L, _I, _P]),
+    "mde_resize_bilinear_fwd": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "mde_resize_bilinear_bwd": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "mde_nearest2_fwd": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P]),
+    "mde_sum2x2": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _F, _I, _P]),
+    "mde_spread2x2": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _F, _I, _P]),
+    "mde_softmax_head_fwd": (_I, [_P, _I, _P, _P, _P, _I, _L, _I, _P]),
+    "mde_softmax_head_bwd": (_I, [_P, _P, _P, _P, _I, _P, _I, _L, _I, _P]),
+    "mde_to_nchw_act_fwd": (_I, [_P, _I, _P, _P, _I, _L, _I, _I, _F, _P]),
+    "mde_to_nchw_act_bwd": (_I, [_P, _P, _P, _I, _P, _I, _L, _I, _I, _F, _P]),
+    "mde_pack_grouped": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "mde_silog_ws_bytes": (_Z, []),
     "mde_silog_fwd": (_I, [_P, _P, _L, _F, _P, _P, _P]),
     "mde_silog_bwd": (_I, [_P, _P, _L, _F, _P, _P, _P, _P]),

@@ -165,10 +165,13 @@ __global__ __launch_bounds__(NT, (NT == 256 && BP * BC >= 256 * 256) ? 1 : 2) vo
 
     const int kslot8 = tid & 7;
     const int lrow = tid >> 3;           // 0..RPL-1
+    // grouped convolution (block-diagonal weights, 64-channel blocks): the column tile [n0, n0+64) contracts
+    // with the input channels [n0, n0+64) only -- the gathered operand's channel window moves with the tile
+    const int goff = d.grouped ? n0 : 0;
     int x_base[XP], x_yx[XP];
 #pragma unroll
     for (int p = 0; p < XP; ++p) {
-        x_base[p] = s_inbase[p * RPL + lrow] + kslot8 * 8;
+        x_base[p] = s_inbase[p * RPL + lrow] + goff + kslot8 * 8;
         x_yx[p] = s_yx[p * RPL + lrow];
     }
     const int wrow_len = d.wtaps_total * d.C;
@@ -200,7 +203,9 @@ __global__ __launch_bounds__(NT, (NT == 256 && BP * BC >= 256 * 256) ? 1 : 2) vo
 #pragma unroll
         for (int j = 0; j < PF; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    const int csteps = d.C / BK;
+    // C need not be a multiple of BK: the last K-step of a tap is zero-filled past C (both operands) by sending
+    // the 16-byte chunks beyond it to an out-of-range buffer offset (C % 8 == 0)
+    const int csteps = (d.C + BK - 1) / BK;
     const int nsteps = d.ntaps * csteps;
     // two register staging sets: loads are issued TWO K-steps ahead of their use, so each has
     // two full compute phases to land (the loop was global-latency-bound with one).
@@ -214,17 +219,18 @@ __global__ __launch_bounds__(NT, (NT == 256 && BP * BC >= 256 * 256) ? 1 : 2) vo
         const int woff = s_tap[MDE_MAX_TAPS + ltap] + c0;
         const int dydx = s_tap[2 * MDE_MAX_TAPS + ltap];
         const int tdy = dydx >> 16, tdx = (int)(short)(dydx & 0xFFFF);
+        const bool kin = c0 + kslot8 * 8 < d.C;
 #pragma unroll
         for (int p = 0; p < XP; ++p) {
             const int iy = (int)((uint32_t)x_yx[p] >> 16) + tdy;
             const int ix = (x_yx[p] & 0xFFFF) + tdx;
-            const bool ok = ((uint32_t)iy < (uint32_t)d.H) & ((uint32_t)ix < (uint32_t)d.W);
+            const bool ok = ((uint32_t)iy < (uint32_t)d.H) & ((uint32_t)ix < (uint32_t)d.W) & kin;
             const uint32_t off = ok ? (uint32_t)(x_base[p] + tapoff) * 2u : MDE_OOB_OFFSET;
             xr[p] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, off, 0, 0);
         }
 #pragma unroll
         for (int p = 0; p < WP; ++p)
-            wr[p] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, (uint32_t)(w_base[p] + woff) * 2u, 0, 0);
+            wr[p] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, kin ? (uint32_t)(w_base[p] + woff) * 2u : MDE_OOB_OFFSET, 0, 0);
         if (++lcs == csteps) { lcs = 0; ++ltap; }
     };
     auto stage_write = [&](int buf, const i32x4_t (&xr)[XP], const i32x4_t (&wr)[WP]) {
@@ -289,7 +295,7 @@ __global__ __launch_bounds__(NT, (NT == 256 && BP * BC >= 256 * 256) ? 1 : 2) vo
 #pragma unroll
         for (int q = 0; q < XR; ++q) {
             const int row = (wv + q * NW) * 8 + lr;
-            dx_base[q] = (uint32_t)(s_inbase[row] + k8 * 8) * 2u;
+            dx_base[q] = (uint32_t)(s_inbase[row] + goff + k8 * 8) * 2u;
             const int yx = s_yx[row];
             const int iy0 = (int)((uint32_t)yx >> 16), ix0 = yx & 0xFFFF;
             uint32_t m = 0;
@@ -303,11 +309,15 @@ __global__ __launch_bounds__(NT, (NT == 256 && BP * BC >= 256 * 256) ? 1 : 2) vo
 #pragma unroll
         for (int q = 0; q < WR; ++q) dw_base[q] = (uint32_t)((n0 + (wv + q * NW) * 8 + lr) * wrow_len + k8 * 8) * 2u;
         typedef __attribute__((address_space(3))) void* lds_ptr;
+        // K tail: this lane's chunk of a K-step lies past C once c0b >= klimb.  Its tap / weight offsets are then
+        // replaced by MDE_OOB_OFFSET: base + 2 GiB is out of range of either buffer (< 2 GiB each), the DMA writes zeros.
+        const uint32_t klimb = (uint32_t)max(d.C - k8 * 8, 0) * 2u;
         auto issue_dma = [&](int buf) {
             // per-tap offsets in bytes (LDS broadcast reads)
             const uint32_t c0b = (uint32_t)(lcs * BK) * 2u;
-            const uint32_t tapoff = (uint32_t)s_tap[ltap] * 2u + c0b;
-            const uint32_t woff = (uint32_t)s_tap[MDE_MAX_TAPS + ltap] * 2u + c0b;
+            const bool kin = c0b < klimb;
+            const uint32_t tapoff = kin ? (uint32_t)s_tap[ltap] * 2u + c0b : MDE_OOB_OFFSET;
+            const uint32_t woff = kin ? (uint32_t)s_tap[MDE_MAX_TAPS + ltap] * 2u + c0b : MDE_OOB_OFFSET;
             const uint32_t bit = 1u << ltap;
             char* xbuf = smem + buf * BUF_BYTES + wv * 1024;
 #pragma unroll
@@ -365,8 +375,9 @@ __global__ __launch_bounds__(NT, (NT == 256 && BP * BC >= 256 * 256) ? 1 : 2) vo
                 const bool more = s + DIST < nsteps;
 #endif
                 const uint32_t c0b = (uint32_t)(lcs * BK) * 2u;
-                const uint32_t tapoff = (uint32_t)s_tap[ltap] * 2u + c0b;
-                const uint32_t woff = (uint32_t)s_tap[MDE_MAX_TAPS + ltap] * 2u + c0b;
+                const bool kin = c0b < klimb;
+                const uint32_t tapoff = kin ? (uint32_t)s_tap[ltap] * 2u + c0b : MDE_OOB_OFFSET;
+                const uint32_t woff = kin ? (uint32_t)s_tap[MDE_MAX_TAPS + ltap] * 2u + c0b : MDE_OOB_OFFSET;
                 const uint32_t bitm = more ? 1u << ltap : 0u;
                 char* dbuf = smem + lbuf * BUF_BYTES + wv * 1024;
                 __builtin_amdgcn_sched_barrier(0);
@@ -674,7 +685,7 @@ int pick_and_launch(KArgs& ka, int64_t M, hipStream_t st) {
         reg = q && !strcmp(q, "reg");
     }
     const int n = ka.d.ncols;
-    if (n <= 64) {
+    if (n <= 64 || ka.d.grouped) {
         // 2-deep ring = 48 KB LDS = three workgroups per CU.  Measured alternatives, all slower on M = 2 457 600 / 614 400,
         // 64->64 3x3: 256x64 with 8 waves (423 / 423 TFLOP/s), 256x64 with 4 waves (365 / 343), 3-deep ring at two
         // workgroups per CU (443 / 456) against 487 / 576: occupancy beats prefetch depth and bigger tiles here.
@@ -741,7 +752,10 @@ int pick_and_launch(KArgs& ka, int64_t M, hipStream_t st) {
 extern "C" int mde_conv_gemm(const mde_conv_desc* d, const void* in, const void* w, void* out,
                              float* stats, void* stream) {
     MDE_REQUIRE(d && in && w && out, "mde_conv_gemm: null argument");
-    MDE_REQUIRE(d->C > 0 && d->C % BK == 0, "mde_conv_gemm: C=%d must be a positive multiple of %d", d->C, BK);
+    MDE_REQUIRE(d->C > 0 && d->C % 8 == 0, "mde_conv_gemm: C=%d must be a positive multiple of 8", d->C);
+    MDE_REQUIRE(!d->grouped || (d->C == BK && d->ncols % BK == 0),
+                "mde_conv_gemm: a grouped launch contracts %d channels per column tile and needs ncols %% %d == 0 (C=%d, ncols=%d)",
+                BK, BK, d->C, d->ncols);
     MDE_REQUIRE(d->ntaps >= 1 && d->ntaps <= MDE_MAX_TAPS, "mde_conv_gemm: ntaps=%d out of range", d->ntaps);
     MDE_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->GH > 0 && d->GW > 0 && d->ncols > 0,
                 "mde_conv_gemm: non-positive dimension");

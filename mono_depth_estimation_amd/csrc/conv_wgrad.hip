@@ -31,6 +31,7 @@ struct KArgs {
     int32_t kchunk;       // pixels per split-K slice (multiple of 64)
     int32_t nA, nB;       // tiles along rows / cols
     int32_t Crows, Ccols;
+    int32_t gsize;        // grouped convolution: channels per group (0 = dense)
     uint32_t inv_gw, inv_ghw;
 };
 
@@ -90,7 +91,8 @@ __global__ __launch_bounds__(NT, 2) void conv_wgrad_tn(const KArgs a) {
     const int tb = b % a.nB; b /= a.nB;
     const int ta = b % a.nA; b /= a.nA;
     const int ks = b;
-    const int row0 = ta * BA, col0 = tb * BB;
+    // grouped (BA == BB == 64, nB == 1): the tile on the diagonal, rows and columns are the same 64-channel window
+    const int row0 = ta * BA, col0 = a.gsize ? row0 : tb * BB;
     const int kbeg = ks * a.kchunk;
     const int kend = min(a.M, kbeg + a.kchunk);
     if (kbeg >= kend) return;
@@ -111,8 +113,9 @@ __global__ __launch_bounds__(NT, 2) void conv_wgrad_tn(const KArgs a) {
 #pragma unroll
     for (int p = 0; p < PB; ++p) b_st[p] = tile_off<BB>(b_row + p * RPP_B, b_chunk);
 
+    // (channel chunks past the tensor's channel count -- tiles of a count that is not a multiple of 64 -- read as zero)
     auto direct_off = [&](int m, int c) -> uint32_t {
-        return m < kend ? (uint32_t)(m * d.ld_d + c) * 2u : MDE_OOB_OFFSET;
+        return ((m < kend) & (c < d.Cd)) ? (uint32_t)(m * d.ld_d + c) * 2u : MDE_OOB_OFFSET;
     };
     auto gathered_off = [&](int m, int c) -> uint32_t {
         const uint32_t n = mde_fastdiv((uint32_t)m, (uint32_t)(d.GH * d.GW), a.inv_ghw);
@@ -120,7 +123,7 @@ __global__ __launch_bounds__(NT, 2) void conv_wgrad_tn(const KArgs a) {
         const uint32_t gy = mde_fastdiv(rem, (uint32_t)d.GW, a.inv_gw);
         const uint32_t gx = rem - gy * (uint32_t)d.GW;
         const int iy = (int)gy * d.sy + tdy, ix = (int)gx * d.sx + tdx;
-        const bool ok = (m < kend) & ((uint32_t)iy < (uint32_t)d.H) & ((uint32_t)ix < (uint32_t)d.W);
+        const bool ok = (m < kend) & ((uint32_t)iy < (uint32_t)d.H) & ((uint32_t)ix < (uint32_t)d.W) & (c < d.Cg);
         return ok ? (uint32_t)((((int)n * d.H + iy) * d.W + ix) * d.ld_g + c) * 2u : MDE_OOB_OFFSET;
     };
 
@@ -201,14 +204,14 @@ __global__ __launch_bounds__(NT, 2) void conv_wgrad_tn(const KArgs a) {
             for (int q = 0; q < QA; ++q) {
                 const int r = (wv + 4 * q) * RPI_A + a_lr;
                 // (an out-of-range pixel stays out of range after adding the small channel offset)
-                const uint32_t off = GA ? go[r] + (uint32_t)a_cs * 2u : direct_off(mb + r, a_cs);
+                const uint32_t off = GA ? (a_cs < d.Cg ? go[r] + (uint32_t)a_cs * 2u : MDE_OOB_OFFSET) : direct_off(mb + r, a_cs);
                 if (GA) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_g, (lds_ptr)(at + q * 4096), 16, off, 0, 0, 0);
                 else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_d, (lds_ptr)(at + q * 4096), 16, off, 0, 0, 0);
             }
 #pragma unroll
             for (int q = 0; q < QB; ++q) {
                 const int r = (wv + 4 * q) * RPI_B + b_lr;
-                const uint32_t off = GA ? direct_off(mb + r, b_cs) : go[r] + (uint32_t)b_cs * 2u;
+                const uint32_t off = GA ? direct_off(mb + r, b_cs) : (b_cs < d.Cg ? go[r] + (uint32_t)b_cs * 2u : MDE_OOB_OFFSET);
                 if (GA) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_d, (lds_ptr)(at + AT_BYTES + q * 4096), 16, off, 0, 0, 0);
                 else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_g, (lds_ptr)(at + AT_BYTES + q * 4096), 16, off, 0, 0, 0);
             }
@@ -247,7 +250,16 @@ __global__ __launch_bounds__(NT, 2) void conv_wgrad_tn(const KArgs a) {
         for (int j = 0; j < FB; ++j) {
             const int col = col0 + wb * (BB / 2) + j * 16 + (lane & 15);
             const int rbase = row0 + wa * (BA / 2) + i * 16 + (lane >> 4) * 4;
-            if (col < a.Ccols) {
+            if (a.gsize) {
+                // block-diagonal: dw is [rows][otaps_total][gsize]; keep the columns of the row's own group
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = rbase + r;
+                    const int gc = col - (row / a.gsize) * a.gsize;
+                    if (row < a.Crows && gc >= 0 && gc < a.gsize)
+                        atomicAdd(a.dw + ((size_t)row * d.otaps_total + otap) * a.gsize + gc, acc[i][j][r]);
+                }
+            } else if (col < a.Ccols) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int row = rbase + r;
@@ -287,8 +299,11 @@ inline uint32_t inv32(uint32_t dv) { return dv <= 1 ? 0xFFFFFFFFu : (uint32_t)((
 extern "C" int mde_conv_wgrad(const mde_wgrad_desc* d, const void* direct, const void* gathered,
                               float* dw, void* stream) {
     MDE_REQUIRE(d && direct && gathered && dw, "mde_conv_wgrad: null argument");
-    MDE_REQUIRE(d->Cd > 0 && d->Cg > 0 && d->Cd % 64 == 0 && d->Cg % 64 == 0,
-                "mde_conv_wgrad: channel counts (%d, %d) must be positive multiples of 64", d->Cd, d->Cg);
+    MDE_REQUIRE(d->Cd > 0 && d->Cg > 0 && d->Cd % 8 == 0 && d->Cg % 8 == 0,
+                "mde_conv_wgrad: channel counts (%d, %d) must be positive multiples of 8", d->Cd, d->Cg);
+    MDE_REQUIRE(d->group_size == 0 || (d->Cd == d->Cg && d->Cd % 64 == 0 && 64 % d->group_size == 0),
+                "mde_conv_wgrad: grouped needs equal channel counts, a multiple of 64, and a group size dividing 64 (%d, %d, %d)",
+                d->Cd, d->Cg, d->group_size);
     MDE_REQUIRE(d->ntaps >= 1 && d->ntaps <= MDE_MAX_TAPS, "mde_conv_wgrad: ntaps=%d out of range", d->ntaps);
     MDE_REQUIRE(d->N > 0 && d->GH > 0 && d->GW > 0 && d->H > 0 && d->W > 0, "mde_conv_wgrad: non-positive dimension");
     MDE_REQUIRE(d->ld_d % 8 == 0 && d->ld_g % 8 == 0 && ((uintptr_t)direct % 16) == 0 && ((uintptr_t)gathered % 16) == 0,
@@ -311,10 +326,11 @@ extern "C" int mde_conv_wgrad(const mde_wgrad_desc* d, const void* direct, const
     const bool ga = d->rows_from_gathered != 0;
     ka.Crows = ga ? d->Cg : d->Cd;
     ka.Ccols = ga ? d->Cd : d->Cg;
-    const int ba = ka.Crows % 128 == 0 ? 128 : 64;
-    const int bb = ka.Ccols % 128 == 0 ? 128 : 64;
-    ka.nA = ka.Crows / ba;
-    ka.nB = ka.Ccols / bb;
+    ka.gsize = d->group_size;
+    const int ba = (ka.Crows % 128 == 0 && !ka.gsize) ? 128 : 64;
+    const int bb = (ka.Ccols % 128 == 0 && !ka.gsize) ? 128 : 64;
+    ka.nA = mde_cdiv(ka.Crows, ba);
+    ka.nB = ka.gsize ? 1 : mde_cdiv(ka.Ccols, bb);
     int64_t chunk = (M + d->ksplit - 1) / d->ksplit;
     chunk = (chunk + BKP - 1) / BKP * BKP;
     ka.kchunk = (int32_t)chunk;

@@ -42,7 +42,18 @@ class Act:
             self.ld = parent.ld
             self.t = parent.t[..., c0:c0 + C]
         self._g = None
-        self.gw = False          # gradient already written during the current backward
+        self._gw = False         # gradient already written during the current backward (slices share their root's flag)
+
+    @property
+    def gw(self):
+        return self._gw if self.parent is None else self.parent.gw
+
+    @gw.setter
+    def gw(self, v):
+        if self.parent is None:
+            self._gw = v
+        else:
+            self.parent.gw = v
 
     @property
     def M(self):
@@ -155,13 +166,38 @@ class Conv:
         return self.store.Gcur[self.off:self.off + self.n]
 
 
-class ParamStore:
-    """Flat fp32 parameter / gradient / BN-buffer storage of one FCRN module (created once;
-    every per-shape plan shares it).  Re-points the module's Parameters and buffers at views."""
+class GroupedConv:
+    """A grouped conv parameter (reference VNL.py:638, MiDaS' resnext101_32x8d): fp32 master [O][T][G] slice of P (G input
+    channels per group) and its two block-diagonal bf16 packings [O][T][64] — forward and transposed (input gradient) —
+    in buffers of their own, rewritten by mde_pack_grouped whenever the masters change."""
+
+    def __init__(self, store, off, O, T, G):
+        self.O, self.T, self.I, self.G = O, T, 64, G
+        self.store, self.off, self.n = store, off, O * T * G
+        self.w32 = store.P[off:off + self.n]
+        self.wf = torch.zeros(O * T * 64, dtype=torch.bfloat16, device=store.dev)
+        self.wd = torch.zeros(O * T * 64, dtype=torch.bfloat16, device=store.dev)
+
+    @property
+    def dw(self):
+        return self.store.Gcur[self.off:self.off + self.n]
+
+    def pack(self):
+        ops.pack_grouped(self.w32, self.wf, self.wd, self.O, self.T, self.G)
+
+
+class FlatStore:
+    """Flat fp32 parameter / gradient / BN-buffer storage of one network module (created once; every per-shape plan
+    shares it).  Re-points the module's Parameters and buffers at views.  Subclasses say how the module's tensors
+    are laid out (`_layout`): the order (encoder range first: the two learning-rate groups every reference module
+    configures), which tensors are stored back to back as one fused GEMM operand, and the channel padding."""
+
+    pad_to = 8                    # stored channel counts are rounded up to this (the GEMM kernels take C % 8 == 0)
 
     def __init__(self, module, device):
         self.m, self.dev = module, device
         self.convs = {}           # id(first weight) -> Conv (shared packings)
+        self.grouped = []         # GroupedConv objects (their block-diagonal packings follow every weight update)
         self.packed_version = -1
         self.adam_state = None
         self.sgd_state = None
@@ -169,73 +205,22 @@ class ParamStore:
         self.step_count = 0
         self._flatten_parameters()
 
-    def _blocks(self):
-        for li in (1, 2, 3, 4):
-            for blk in getattr(self.m, "layer%d" % li):
-                yield li, blk
+    def _layout(self):
+        """-> (plist, blist, n_encoder_entries, no_pad).  plist: [(kind, [tensors])] in flat order, a fused entry lists
+        several tensors back to back; blist: [[buffers]]; no_pad: {id(weight): (pad O?, pad I?)} exceptions."""
+        raise NotImplementedError
 
     def _flatten_parameters(self):
         m, dev = self.m, self.dev
-        plist, blist = [], []     # (key, [tensors])  -- a fused entry lists several tensors back to back
-
-        def conv_bn(conv, bn):
-            plist.append(("w", [conv.weight]))
-            plist.append(("g", [bn.weight]))
-            plist.append(("b", [bn.bias]))
-            blist.append([bn.running_mean])
-            blist.append([bn.running_var])
-
-        conv_bn(m.conv1, m.bn1)
-        for _, blk in self._blocks():
-            conv_bn(blk.conv1, blk.bn1)
-            conv_bn(blk.conv2, blk.bn2)
-            if hasattr(blk, "conv3"):
-                conv_bn(blk.conv3, blk.bn3)
-            if blk.downsample is not None:
-                conv_bn(blk.downsample[0], blk.downsample[1])
-        self.n_encoder_entries = len(plist)
-        conv_bn(m.conv2, m.bn2)
-        kind = getattr(m.upSample, "kind", "upproj")
-        for name in ("layer1", "layer2", "layer3", "layer4"):
-            up = getattr(m.upSample, name)
-            if kind == "upconv":
-                conv_bn(up.conv, up.batchnorm)
-                continue
-            if kind == "deconv":
-                conv_bn(getattr(up, "deconv%d" % m.upSample.kernel_size), up.batchnorm)
-                continue
-            if kind == "fasterupconv":
-                for cn in ("conv1_", "conv2_", "conv3_", "conv4_"):
-                    seq = getattr(up, cn)
-                    conv_bn(seq.conv1, seq.bn1)
-                    plist.append(("b", [seq.conv1.bias]))
-                continue
-            if kind == "fasterupproj":
-                for fu in (up.upper_branch.faster_upconv, up.bottom_branch):
-                    for cn in ("conv1_", "conv2_", "conv3_", "conv4_"):
-                        seq = getattr(fu, cn)
-                        conv_bn(seq.conv1, seq.bn1)
-                        plist.append(("b", [seq.conv1.bias]))
-                conv_bn(up.upper_branch.conv, up.upper_branch.batchnorm)
-                continue
-            ub, bb = up.upper_branch, up.bottom_branch
-            plist.append(("w", [ub.conv1.weight, bb.conv.weight]))          # fused [2C][25][Cin]
-            plist.append(("g", [ub.batchnorm1.weight, bb.batchnorm.weight]))
-            plist.append(("b", [ub.batchnorm1.bias, bb.batchnorm.bias]))
-            blist.append([ub.batchnorm1.running_mean, bb.batchnorm.running_mean])
-            blist.append([ub.batchnorm1.running_var, bb.batchnorm.running_var])
-            conv_bn(ub.conv2, ub.batchnorm2)
-        plist.append(("w", [m.conv3.weight]))
+        plist, blist, self.n_encoder_entries, no_pad = self._layout()
+        padc = lambda c: (c + self.pad_to - 1) // self.pad_to * self.pad_to
+        pad64 = padc
 
         # Storage shape of every parameter.  The GEMM kernels take channel counts that are multiples of 64; the
         # decoders of the ResNet-18/34 variants end in 32- and 16-channel layers (FCRN.py:329-349 with
         # num_channels = 512), so such tensors are stored zero-padded to 64 channels ([Op][kh][kw][Ip], BN vectors
         # [Cp]) and the Parameter is the strided view of the real entries.  Padded entries stay exactly zero: their
         # activations, gradients and Adam moments are all zero.  Nothing is padded for the 50/101/152 networks.
-        pad64 = lambda c: (c + 63) // 64 * 64
-        # (pad O, pad I): the 3-channel stem and the head have their own kernels; a stem for in_channels != 3 runs
-        # on the GEMM kernel with its input channels padded
-        no_pad = {id(m.conv1.weight): (False, m.conv1.in_channels != 3), id(m.conv3.weight): (False, True)}
         self.sdims = {}
         for _, ts in plist:
             for t in ts:
@@ -252,6 +237,8 @@ class ParamStore:
                 self.encoder_numel = size
             offs.append(size)
             size = _round_up(size + sum(snumel(t) for t in ts))
+        if self.n_encoder_entries >= len(plist):
+            self.encoder_numel = size
         self.P = torch.zeros(size, dtype=torch.float32, device=dev)
         self.G = torch.zeros(size, dtype=torch.float32, device=dev)
         self.G2 = None                    # second gradient buffer, only for the autograd path (see begin_autograd_backward)
@@ -375,8 +362,8 @@ class ParamStore:
         return self.view_of(buf, p)
 
     def storage_is_current(self):
-        p = self.m.conv1.weight
-        return p.data_ptr() == self.P.data_ptr() + self.p_off[id(p)] * 4
+        p = self.params[0]
+        return p.data_ptr() == self.view_of(self.P, p).data_ptr()
 
     def conv(self, weights, need_dgrad=True):
         t0 = weights[0]
@@ -387,6 +374,17 @@ class ParamStore:
             c = Conv(self, self.p_off[id(t0)], O, kh * kw, I, need_dgrad)
             self.convs[id(t0)] = c
             self._pack_jobs = None
+        return c
+
+    def conv_grouped(self, w, G):
+        c = self.convs.get(id(w))
+        if c is None:
+            O, kh, kw, I = self.sdims[id(w)]
+            assert I == G and O % 64 == 0 and 64 % G == 0, (O, I, G)
+            c = GroupedConv(self, self.p_off[id(w)], O, kh * kw, G)
+            self.convs[id(w)] = c
+            self.grouped.append(c)
+            self.packed_version = -1           # its packings do not exist yet
         return c
 
     def params_version(self):
@@ -417,6 +415,8 @@ class ParamStore:
                 jobs, nblocks = self._jobs()
                 ops.refresh_if_changed(self.P, self.Pb, self.WD if jobs is not None else None, jobs,
                                        jobs.shape[0] if jobs is not None else 0, nblocks, self._fp_state)
+                for g in self.grouped:         # (not gated by the device flag: a few small launches per forward)
+                    g.pack()
             self._fp_valid = True          # (a first call only records the fingerprint: the shadows are known fresh)
 
     def _record_fingerprint(self):
@@ -428,7 +428,7 @@ class ParamStore:
 
     def _jobs(self):
         if self._pack_jobs is None:
-            todo = sorted((c.off, c.O, c.T, c.I) for c in self.convs.values() if c.wd is not None)
+            todo = sorted((c.off, c.O, c.T, c.I) for c in self.convs.values() if isinstance(c, Conv) and c.wd is not None)
             self._pack_jobs = ops.pack_jobs(todo, self.dev) if todo else (None, 0)
         return self._pack_jobs
 
@@ -437,6 +437,8 @@ class ParamStore:
         jobs, nblocks = self._jobs()
         if jobs is not None:
             ops.pack_wt_batch(self.P, self.WD, jobs, nblocks)
+        for g in self.grouped:
+            g.pack()
 
     def _step_ranges(self):
         """Contiguous flat ranges the fused optimiser steps may touch: [(begin, end, is_decoder)].  Parameters with
@@ -511,24 +513,89 @@ class ParamStore:
         self._after_fused_step()
 
 
-class FCRNEngine:
-    """Static launch plan for one (batch, height, width) input shape over a ParamStore."""
+class ParamStore(FlatStore):
+    """FlatStore of the FCRN module (network/FCRN.py): trunk, then conv2 / bn2 / decoder / conv3; each UpProj module's two
+    5x5 convs (and their BN vectors) adjacent, so they run as ONE GEMM / one BN site.  Channel counts are stored padded to
+    64 (only the ResNet-18/34 decoders have smaller ones), as the first round's kernels required."""
+
+    pad_to = 64
+
+    def _blocks(self):
+        for li in (1, 2, 3, 4):
+            for blk in getattr(self.m, "layer%d" % li):
+                yield li, blk
+
+    def _layout(self):
+        m = self.m
+        plist, blist = [], []     # (key, [tensors])  -- a fused entry lists several tensors back to back
+
+        def conv_bn(conv, bn):
+            plist.append(("w", [conv.weight]))
+            plist.append(("g", [bn.weight]))
+            plist.append(("b", [bn.bias]))
+            blist.append([bn.running_mean])
+            blist.append([bn.running_var])
+
+        conv_bn(m.conv1, m.bn1)
+        for _, blk in self._blocks():
+            conv_bn(blk.conv1, blk.bn1)
+            conv_bn(blk.conv2, blk.bn2)
+            if hasattr(blk, "conv3"):
+                conv_bn(blk.conv3, blk.bn3)
+            if blk.downsample is not None:
+                conv_bn(blk.downsample[0], blk.downsample[1])
+        n_encoder_entries = len(plist)
+        conv_bn(m.conv2, m.bn2)
+        kind = getattr(m.upSample, "kind", "upproj")
+        for name in ("layer1", "layer2", "layer3", "layer4"):
+            up = getattr(m.upSample, name)
+            if kind == "upconv":
+                conv_bn(up.conv, up.batchnorm)
+                continue
+            if kind == "deconv":
+                conv_bn(getattr(up, "deconv%d" % m.upSample.kernel_size), up.batchnorm)
+                continue
+            if kind == "fasterupconv":
+                for cn in ("conv1_", "conv2_", "conv3_", "conv4_"):
+                    seq = getattr(up, cn)
+                    conv_bn(seq.conv1, seq.bn1)
+                    plist.append(("b", [seq.conv1.bias]))
+                continue
+            if kind == "fasterupproj":
+                for fu in (up.upper_branch.faster_upconv, up.bottom_branch):
+                    for cn in ("conv1_", "conv2_", "conv3_", "conv4_"):
+                        seq = getattr(fu, cn)
+                        conv_bn(seq.conv1, seq.bn1)
+                        plist.append(("b", [seq.conv1.bias]))
+                conv_bn(up.upper_branch.conv, up.upper_branch.batchnorm)
+                continue
+            ub, bb = up.upper_branch, up.bottom_branch
+            plist.append(("w", [ub.conv1.weight, bb.conv.weight]))          # fused [2C][25][Cin]
+            plist.append(("g", [ub.batchnorm1.weight, bb.batchnorm.weight]))
+            plist.append(("b", [ub.batchnorm1.bias, bb.batchnorm.bias]))
+            blist.append([ub.batchnorm1.running_mean, bb.batchnorm.running_mean])
+            blist.append([ub.batchnorm1.running_var, bb.batchnorm.running_var])
+            conv_bn(ub.conv2, ub.batchnorm2)
+        plist.append(("w", [m.conv3.weight]))
+        # (pad O, pad I): the 3-channel stem and the head have their own kernels; a stem for in_channels != 3 runs
+        # on the GEMM kernel with its input channels padded
+        no_pad = {id(m.conv1.weight): (False, m.conv1.in_channels != 3), id(m.conv3.weight): (False, True)}
+        return plist, blist, n_encoder_entries, no_pad
+
+
+class EngineCore:
+    """What every per-shape launch plan shares: the store's flat buffers, conv / BN-site lookup, the split-K choice and the
+    (optional) weight-gradient side stream."""
 
     def __init__(self, module, store, N, H, W):
         self.m, self.store, self.N, self.H, self.W, self.dev = module, store, N, H, W, store.dev
         self.P, self.G, self.B, self.Pb = store.P, store.G, store.B, store.Pb
         self.p_off, self.b_off, self.params = store.p_off, store.b_off, store.params
-        self.out_channels = module.conv3.out_channels
-        self.OH, self.OW = module.output_size
         self.cus = torch.cuda.get_device_properties(self.dev).multi_processor_count
         # opt-in (MDE_WGRAD_STREAM=1): ~1 % faster, but per-kernel durations then include the overlap with
         # the other stream, so the roofline leg of bench.py and the rocprofv3 summaries stop describing one kernel
         self.side = torch.cuda.Stream(self.dev) if os.environ.get("MDE_WGRAD_STREAM", "0") == "1" else None
         self.side_busy = False
-        self._plan()
-
-    def _blocks(self):
-        return self.store._blocks()
 
     def attach_grads(self):
         return self.store.attach_grads()
@@ -548,8 +615,40 @@ class FCRNEngine:
     def _ksplit(self, pixels, rows, cols, ntaps):
         ba, bb = (128 if rows % 128 == 0 else 64), (128 if cols % 128 == 0 else 64)
         lds = 2 * 64 * (ba + bb) * 2 + 512           # conv_wgrad_tn's staging ring + offset table
-        return ops.choose_ksplit(pixels, rows // ba, cols // bb, ntaps, self.cus, wg_per_cu=min(8, (160 * 1024) // lds),
+        return ops.choose_ksplit(pixels, -(-rows // ba), -(-cols // bb), ntaps, self.cus, wg_per_cu=min(8, (160 * 1024) // lds),
                                  tile_elems=ba * bb)
+
+
+    def wgrad(self, desc, a, b, dw):
+        """Weight-gradient GEMM of one conv.  It only reads dY and the activation, so it can run beside the
+        input-gradient GEMM of the same layer: on a second stream its workgroups fill the CUs that the other
+        kernel's partial last round leaves idle (opt-in: MDE_WGRAD_STREAM=1; measured 32.9 -> 32.6 ms/step)."""
+        if self.side is None:
+            ops.conv_wgrad(desc, a, b, dw)
+            return
+        cur = torch.cuda.current_stream()
+        self.side.wait_stream(cur)                  # dY (and everything before it) is ready
+        with torch.cuda.stream(self.side):
+            ops.conv_wgrad(desc, a, b, dw)
+        self.side_busy = True
+
+    def join_side(self):
+        if self.side is not None and self.side_busy:
+            torch.cuda.current_stream().wait_stream(self.side)
+            self.side_busy = False
+
+
+class FCRNEngine(EngineCore):
+    """Static launch plan for one (batch, height, width) input shape over a ParamStore."""
+
+    def __init__(self, module, store, N, H, W):
+        super().__init__(module, store, N, H, W)
+        self.out_channels = module.conv3.out_channels
+        self.OH, self.OW = module.output_size
+        self._plan()
+
+    def _blocks(self):
+        return self.store._blocks()
 
     # ------------------------------------------------------------------ the plan
     def _plan(self):
@@ -643,24 +742,6 @@ class FCRNEngine:
             offs.append(L.first_param_offset())
         offs.append(self.store.p_off[id(self.m.conv3.weight)])
         return sorted(offs)
-
-    def wgrad(self, desc, a, b, dw):
-        """Weight-gradient GEMM of one conv.  It only reads dY and the activation, so it can run beside the
-        input-gradient GEMM of the same layer: on a second stream its workgroups fill the CUs that the other
-        kernel's partial last round leaves idle (opt-in: MDE_WGRAD_STREAM=1; measured 32.9 -> 32.6 ms/step)."""
-        if self.side is None:
-            ops.conv_wgrad(desc, a, b, dw)
-            return
-        cur = torch.cuda.current_stream()
-        self.side.wait_stream(cur)                  # dY (and everything before it) is ready
-        with torch.cuda.stream(self.side):
-            ops.conv_wgrad(desc, a, b, dw)
-        self.side_busy = True
-
-    def join_side(self):
-        if self.side is not None and self.side_busy:
-            torch.cuda.current_stream().wait_stream(self.side)
-            self.side_busy = False
 
     def backward(self, dy, on_progress=None, consumer_waits_side=False):
         """dy: fp32 NCHW gradient w.r.t. the output.  Adds parameter gradients into self.G.

@@ -1,0 +1,540 @@
+"""A small tape of kernel launches for the networks beside FCRN (reference network/VNL.py, MiDaS.py, Bts.py).
+
+engine.py's FCRN plan is hand-ordered; these networks are wider graphs (lateral connections, concatenations, gates),
+so their plans are TAPES: an ordered list of ops over NHWC bf16 activations (`engine.Act`: tensor, channel-slice view,
+lazily allocated gradient).  `forward` runs the tape, `backward` runs it in reverse.  Gradient convention: every
+activation has one gradient buffer; the first op that writes it in a backward pass overwrites, later ones accumulate
+(`Act.gw`), so fan-out needs no extra add kernels.  A concatenation is never executed: producers write channel slices
+of one wider tensor (pointer + pixel stride), consumers read it whole.
+
+Every op is a thin wrapper over C-ABI entry points (include/mde_hip.h); there is no torch arithmetic here.
+"""
+import os
+
+import torch
+
+from . import ops
+from .engine import Act, BNSite, EngineCore, FlatStore, bn_join_backward
+
+
+# ---------------------------------------------------------------------------------------------- parameter storage
+class NetStore(FlatStore):
+    """Generic flat storage: every parameter its own entry, the module's ENCODER parameters first (`is_encoder(name)`;
+    the reference's two learning-rate groups: vnl.py:289-326 'res' in key, midas.py:94-105 `pretrained`, bts.py:139-152
+    `encoder`), channel counts padded to 8.  `raw` names weights that keep their exact shape (grouped convs [O][G][k][k],
+    the 3-channel stem)."""
+
+    def __init__(self, module, device, is_encoder, raw=()):
+        self._is_encoder, self._raw = is_encoder, set(raw)
+        super().__init__(module, device)
+
+    def _layout(self):
+        named = list(self.m.named_parameters())
+        enc = [(n, p) for n, p in named if self._is_encoder(n)]
+        dec = [(n, p) for n, p in named if not self._is_encoder(n)]
+        plist = [("w" if p.dim() == 4 else "v", [p]) for _, p in enc + dec]
+        blist = []
+        for mod in self.m.modules():
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                blist.append([mod.running_mean])
+                blist.append([mod.running_var])
+        no_pad = {id(p): (False, False) for n, p in named if n in self._raw}
+        return plist, blist, len(enc), no_pad
+
+    def vec(self, p):
+        """fp32 view of a 1-D parameter's storage (padded length) inside P, and its offset."""
+        off, n = self.p_off[id(p)], self.sdims[id(p)][0]
+        return self.P[off:off + n], off
+
+
+# ---------------------------------------------------------------------------------------------- ops
+class Op:
+    def fwd(self, train):
+        raise NotImplementedError
+
+    def bwd(self):
+        raise NotImplementedError
+
+    def acts(self):
+        """Activations this op produces (their gradient flags are reset before a backward pass)."""
+        return ()
+
+
+def _take(x):
+    """-> accumulate flag for a write into x.g, marking it written."""
+    acc = x.gw
+    x.gw = True
+    return acc
+
+
+class Stem(Op):
+    """7x7/2 conv on the fp32 NCHW image -> BN -> ReLU -> 3x3/2 max-pool (torchvision stem; VNL.py:593-599 basic_bn_stem,
+    MiDaS.py:93-96).  The image is the graph's input: no input gradient."""
+
+    def __init__(self, eng, conv, bn, N, H, W):
+        dev = eng.dev
+        self.eng = eng
+        H2, W2 = ops.out_size(H, 7, 2, 3), ops.out_size(W, 7, 2, 3)
+        assert H % 2 == 0 and W % 2 == 0, "stem kernel: even image sizes"
+        self.w = eng._conv([conv.weight], need_dgrad=False)
+        self.site = eng._site([bn])
+        self.c, self.a = Act(dev, N, H2, W2, 64), Act(dev, N, H2, W2, 64)
+        H4, W4 = ops.out_size(H2, 3, 2, 1), ops.out_size(W2, 3, 2, 1)
+        self.out = Act(dev, N, H4, W4, 64)
+        self.idx = torch.empty(N, H4, W4, 64, dtype=torch.uint8, device=dev)
+        self.x = None
+
+    def acts(self):
+        return (self.c, self.a, self.out)
+
+    def fwd(self, train):
+        s, c, a = self.site, self.c, self.a
+        ops.stem_conv_fwd(self.x, self.w.w32, c.t, s.part if train else None)
+        s.finalize(c.M, train)
+        ops.bn_apply(c.t, 64, s.scale, s.shift, a.t, 64, c.M, 64, True)
+        ops.maxpool_fwd(a.t, self.out.t, self.idx, a.N, a.H, a.W, 64)
+
+    def bwd(self):
+        a, c = self.a, self.c
+        ops.maxpool_bwd(self.out.g, self.idx, a.g, a.N, a.H, a.W, 64)
+        self.site.backward(a.g, a, c, True, c.g, mask_from_x=True)
+        ops.stem_conv_wgrad(self.x, c.g, self.w.dw)
+
+
+class Conv(Op):
+    """A convolution (no bias, no activation): dense or grouped, any stride / dilation, writing `out` (its own tensor or a
+    channel slice of a wider one).  `site`: the BatchNorm that follows, whose batch statistics come out of this
+    launch's epilogue in training mode."""
+
+    def __init__(self, eng, x, w, k, stride=1, pad=0, dil=1, groups=1, out=None, site=None, need_dgrad=True):
+        self.eng, self.x, self.site, self.need_dgrad = eng, x, site, need_dgrad
+        store = eng.store
+        O = store.sdims[id(w)][0]
+        OH, OW = ops.out_size(x.H, k, stride, pad, dil), ops.out_size(x.W, k, stride, pad, dil)
+        self.out = out if out is not None else Act(eng.dev, x.N, OH, OW, O)
+        o = self.out
+        assert (o.N, o.H, o.W, o.C) == (x.N, OH, OW, O), ((o.N, o.H, o.W, o.C), (x.N, OH, OW, O))
+        self.own_out = out is None
+        if groups > 1:
+            G = w.shape[1]
+            assert x.C == O == G * groups, (x.C, O, G, groups)
+            self.conv = store.conv_grouped(w, G)
+            Cin = 64
+        else:
+            self.conv = store.conv([w], need_dgrad)
+            Cin = self.conv.I
+            assert x.C == Cin, "conv input has %d channels, the stored weight %d" % (x.C, Cin)
+            G = 0
+        self.fdesc = ops.fwd_desc(x.N, x.H, x.W, x.ld, Cin, x.nbytes, k, stride, pad, O, o.ld, dil=dil)
+        self.fdesc.grouped = int(groups > 1)
+        if need_dgrad:
+            # (grouped: every 64-column tile of dx contracts the matching 64-channel window of dY)
+            self.ddescs, self.dzero = ops.dgrad_descs(x.N, x.H, x.W, x.ld, x.C, OH, OW, o.ld, O if groups == 1 else 64, o.nbytes,
+                                                      k, stride, pad, dil=dil)
+            for d in self.ddescs:
+                d.grouped = int(groups > 1)
+        if groups > 1:
+            ks = ops.choose_ksplit(o.M, O // 64, 1, k * k, eng.cus, wg_per_cu=4, tile_elems=64 * 64)
+        else:
+            ks = eng._ksplit(o.M, O, Cin, k * k)
+        self.wdesc = ops.conv_wgrad_desc(x.N, x.H, x.W, x.ld, x.C, x.nbytes, OH, OW, o.ld, O, o.nbytes, k, stride, pad, ks, dil=dil)
+        self.wdesc.group_size = G
+
+    def acts(self):
+        return (self.out,) if self.own_out else ()
+
+    def fwd(self, train):
+        ops.conv_gemm(self.fdesc, self.x.t, self.conv.wf, self.out.t, self.site.part if (train and self.site is not None) else None)
+
+    def bwd(self):
+        x, o, eng = self.x, self.out, self.eng
+        og = _grad_of(o)
+        eng.wgrad(self.wdesc, og, x.t, self.conv.dw)
+        if not self.need_dgrad:
+            return
+        acc = _take(x)
+        xg = _grad_of(x)
+        if self.dzero and not acc:
+            xg.zero_()
+            acc = False
+        for d in self.ddescs:
+            d.accumulate = int(acc)
+            ops.conv_gemm(d, og, self.conv.wd, xg)
+
+
+def _grad_of(a):
+    """Gradient tensor of an activation: its own buffer, or the matching slice of its parent's."""
+    return a.g
+
+
+class BN(Op):
+    """out = act(bn(c) [+ res | + bn_r(res)]) with the batch statistics the producing Conv accumulated (training) or the
+    running ones (eval).  `bias`: the conv in front had a bias (VNL.py:336 FTB_block.conv2): under batch statistics it
+    cancels (zero gradient, only the running mean sees it); in eval mode it joins the shift."""
+
+    def __init__(self, eng, c, site, relu, out=None, res=None, res_site=None, bias=None):
+        self.eng, self.c, self.site, self.relu, self.res, self.res_site = eng, c, site, relu, res, res_site
+        self.out = out if out is not None else Act(eng.dev, c.N, c.H, c.W, c.C)
+        self.own_out = out is None
+        self.bias = eng.store.vec(bias)[0][:site.C] if bias is not None else None
+        self.bits = (torch.empty(c.M * (c.C // 8), dtype=torch.uint8, device=eng.dev) if (relu and res is not None) else None)
+        if res is not None and res_site is None and not relu:
+            raise NotImplementedError("BN + identity residual without ReLU")
+
+    def acts(self):
+        return (self.out,) if self.own_out else ()
+
+    def fwd(self, train):
+        s, c, o = self.site, self.c, self.out
+        s.finalize(c.M, train)
+        if self.res_site is not None:
+            self.res_site.finalize(self.res.M, train)
+        if self.bias is not None:
+            with torch.no_grad():
+                if train:
+                    mom = s.bn.momentum if s.bn.momentum is not None else 0.1
+                    s.rmean.add_(self.bias, alpha=mom)
+                else:
+                    s.shift.addcmul_(s.scale, self.bias)
+        if self.res is None:
+            ops.bn_apply(c.t, c.ld, s.scale, s.shift, o.t, o.ld, c.M, c.C, self.relu)
+        elif self.res_site is None:
+            ops.bn_apply(c.t, c.ld, s.scale, s.shift, o.t, o.ld, c.M, c.C, self.relu, r=self.res.t, ldr=self.res.ld,
+                         relu_bits=self.bits if train else None)
+        else:
+            rs = self.res_site
+            ops.bn_apply(c.t, c.ld, s.scale, s.shift, o.t, o.ld, c.M, c.C, self.relu, r=self.res.t, ldr=self.res.ld,
+                         rscale=rs.scale, rshift=rs.shift, relu_bits=self.bits if train else None)
+
+    def bwd(self):
+        c, o, res = self.c, self.out, self.res
+        assert not c.gw, "a pre-BN tensor has one consumer"
+        c.gw = True
+        if res is None:
+            self.site.backward(o.g, o, c, self.relu, c.g, mask_from_x=self.relu)
+        elif self.res_site is None:
+            assert not res.gw, "identity-residual gradient must be the first writer"
+            res.gw = True
+            self.site.backward(o.g, o, c, self.relu, c.g, dres=res.g, relu_bits=self.bits)
+        else:
+            assert not res.gw
+            res.gw = True
+            bn_join_backward(self.site, self.res_site, o.g, o, c, res, c.g, res.g, self.bits)
+
+
+class Pw(Op):
+    """out = act(x + bias + r): conv bias, activation and residual add in one pass (MiDaS.py:163-229, VNL.py:348-349,
+    Bts.py:69-80).  bias: a 1-D Parameter (or None); r: another activation (or None)."""
+
+    def __init__(self, eng, x, bias=None, r=None, act=None, out=None):
+        self.eng, self.x, self.r, self.act = eng, x, r, act
+        self.out = out if out is not None else Act(eng.dev, x.N, x.H, x.W, x.C)
+        self.own_out = out is None
+        self.bias, self.b_off = (None, None)
+        if bias is not None:
+            v, off = eng.store.vec(bias)
+            assert v.numel() == x.C, (v.numel(), x.C)
+            self.bias, self.b_off = v, off
+
+    def acts(self):
+        return (self.out,) if self.own_out else ()
+
+    def fwd(self, train):
+        x, r, o = self.x, self.r, self.out
+        ops.pw_fwd(x.t, x.ld, self.bias, r.t if r is not None else None, r.ld if r is not None else 0, o.t, o.ld, x.M, x.C, self.act)
+
+    def bwd(self):
+        x, r, o = self.x, self.r, self.out
+        acc_x = _take(x)
+        acc_r = _take(r) if r is not None else False
+        dbias = self.eng.store.Gcur[self.b_off:self.b_off + x.C] if self.bias is not None else None
+        ops.pw_bwd(o.g, _ldg(o), o.t, o.ld, x.g, _ldg(x), acc_x, r.g if r is not None else None, _ldg(r) if r is not None else 0,
+                   acc_r, dbias, x.M, x.C, self.act)
+
+
+def _ldg(a):
+    """Pixel stride of an activation's gradient tensor (slices share their parent's)."""
+    return a.g.stride(2) if a is not None else 0
+
+
+class Resize(Op):
+    """F.interpolate(mode='bilinear', align_corners=...) to (OH, OW)."""
+
+    def __init__(self, eng, x, OH, OW, align_corners, out=None):
+        self.x, self.align = x, align_corners
+        self.out = out if out is not None else Act(eng.dev, x.N, OH, OW, x.C)
+        self.own_out = out is None
+
+    def acts(self):
+        return (self.out,) if self.own_out else ()
+
+    def fwd(self, train):
+        x, o = self.x, self.out
+        ops.resize_bilinear_fwd(x.t, x.ld, o.t, o.ld, x.N, x.H, x.W, x.C, o.H, o.W, self.align)
+
+    def bwd(self):
+        x, o = self.x, self.out
+        acc = _take(x)
+        ops.resize_bilinear_bwd(o.g, _ldg(o), x.g, _ldg(x), x.N, x.H, x.W, x.C, o.H, o.W, self.align, acc)
+
+
+class GlobalAvgPool(Op):
+    """nn.AdaptiveAvgPool2d(1): [N][H][W][C] -> [N][1][1][C] (written into `out`, possibly a channel slice)."""
+
+    def __init__(self, eng, x, out=None):
+        self.x = x
+        self.out = out if out is not None else Act(eng.dev, x.N, 1, 1, x.C)
+        self.own_out = out is None
+
+    def acts(self):
+        return (self.out,) if self.own_out else ()
+
+    def fwd(self, train):
+        x, o = self.x, self.out
+        ops.spatial_sum(x.t, x.ld, x.N, x.H * x.W, x.C, 1.0 / (x.H * x.W), o.t, o.ld)
+
+    def bwd(self):
+        x, o = self.x, self.out
+        acc = _take(x)
+        ops.spatial_bcast(o.g, _ldg(o), 1.0 / (x.H * x.W), x.g, _ldg(x), x.N, x.H * x.W, x.C, acc)
+
+
+class Broadcast(Op):
+    """[N][1][1][C] -> [N][H][W][C]: F.interpolate of a 1x1 map (VNL.py:225)."""
+
+    def __init__(self, eng, v, out):
+        self.v, self.out = v, out
+
+    def fwd(self, train):
+        v, o = self.v, self.out
+        ops.spatial_bcast(v.t, v.ld, 1.0, o.t, o.ld, o.N, o.H * o.W, o.C)
+
+    def bwd(self):
+        v, o = self.v, self.out
+        assert not v.gw
+        v.gw = True
+        ops.spatial_sum(o.g, _ldg(o), o.N, o.H * o.W, o.C, 1.0, v.g, _ldg(v))
+
+
+class Gate(Op):
+    """AFA_block's output (VNL.py:372): out = w * lateral + top, w: [N][1][1][C]."""
+
+    def __init__(self, eng, w, lat, top):
+        self.w, self.lat, self.top = w, lat, top
+        self.out = Act(eng.dev, lat.N, lat.H, lat.W, lat.C)
+
+    def acts(self):
+        return (self.out,)
+
+    def fwd(self, train):
+        w, l, t, o = self.w, self.lat, self.top, self.out
+        ops.gate_fwd(w.t, w.ld, l.t, l.ld, t.t, t.ld, o.t, o.ld, l.N, l.H * l.W, l.C)
+
+    def bwd(self):
+        w, l, t, o = self.w, self.lat, self.top, self.out
+        assert not w.gw
+        w.gw = True
+        acc_l, acc_t = _take(l), _take(t)
+        ops.gate_bwd(o.g, _ldg(o), w.t, w.ld, l.t, l.ld, l.g, _ldg(l), acc_l, t.g, _ldg(t), acc_t, w.g, _ldg(w), l.N, l.H * l.W, l.C)
+
+
+class SoftmaxHead(Op):
+    """fcn_topdown_predict's tail (VNL.py:325-327): logits = x + bias, softmax over channels; both fp32 NCHW outputs."""
+
+    def __init__(self, eng, x, bias, C):
+        self.eng, self.x, self.C = eng, x, C
+        self.bias, self.b_off = eng.store.vec(bias)
+        self.logit = torch.empty(x.N, C, x.H, x.W, device=eng.dev)
+        self.prob = torch.empty(x.N, C, x.H, x.W, device=eng.dev)
+        self.outputs = (self.logit, self.prob)
+        self.douts = [None, None]
+
+    def fwd(self, train):
+        x = self.x
+        ops.softmax_head_fwd(x.t, x.ld, self.bias, self.logit, self.prob, x.N, x.H * x.W, self.C)
+
+    def bwd(self):
+        x = self.x
+        assert not x.gw
+        x.gw = True
+        dl, dp = self.douts
+        dbias = self.eng.store.Gcur[self.b_off:self.b_off + self.C]
+        ops.softmax_head_bwd(dl, dp, self.prob, x.g, _ldg(x), dbias, x.N, x.H * x.W, self.C)
+
+
+class ToNCHW(Op):
+    """out = scale * act(x + bias) as fp32 NCHW: the small-channel output heads (MiDaS.py:54-56, Bts.py:202-203)."""
+
+    def __init__(self, eng, x, bias, C, act, scale=1.0):
+        self.eng, self.x, self.C, self.act, self.scale = eng, x, C, act, scale
+        self.bias, self.b_off = eng.store.vec(bias) if bias is not None else (None, None)
+        self.y = torch.empty(x.N, C, x.H, x.W, device=eng.dev)
+        self.outputs = (self.y,)
+        self.douts = [None]
+
+    def fwd(self, train):
+        x = self.x
+        ops.to_nchw_act_fwd(x.t, x.ld, self.bias, self.y, x.N, x.H * x.W, self.C, self.act, self.scale)
+
+    def bwd(self):
+        x = self.x
+        assert not x.gw
+        x.gw = True
+        dbias = self.eng.store.Gcur[self.b_off:self.b_off + self.C] if self.bias is not None else None
+        ops.to_nchw_act_bwd(self.douts[0], self.y, x.g, _ldg(x), dbias, x.N, x.H * x.W, self.C, self.act, self.scale)
+
+
+# ---------------------------------------------------------------------------------------------- the tape
+class TapeEngine(EngineCore):
+    """Launch plan of one input shape: subclasses fill `self.tape` in `_plan` and name the image op (`self.stem`) and the
+    output ops (`self.heads`: ops with `.outputs` / `.douts`)."""
+
+    def __init__(self, module, store, N, H, W):
+        super().__init__(module, store, N, H, W)
+        self.tape, self.heads, self.stem, self._bufs = [], [], None, []
+        self._plan()
+        self._acts = [a for op in self.tape for a in op.acts()] + self._bufs
+
+    def add(self, op):
+        self.tape.append(op)
+        return op
+
+    def buf(self, N, H, W, C):
+        """A zero-initialised activation the plan owns (concatenation targets: producers write channel slices of it)."""
+        a = Act(self.dev, N, H, W, C)
+        a.t.zero_()
+        self._bufs.append(a)
+        return a
+
+    def forward(self, x, train, check_data=False):
+        assert x.dtype == torch.float32 and x.is_contiguous() and tuple(x.shape) == (self.N, 3, self.H, self.W), tuple(x.shape)
+        self.store.refresh_weights(check_data=check_data)
+        self.stem.x = x
+        for op in self.tape:
+            op.fwd(train)
+        if train:
+            self.store.nbt += 1
+        return tuple(t for h in self.heads for t in h.outputs)
+
+    def backward(self, douts):
+        """douts: one fp32 gradient (or None) per output tensor, in the order forward returned them.  Adds the parameter
+        gradients into store.Gcur."""
+        for a in self._acts:
+            a.gw = False
+        i = 0
+        for h in self.heads:
+            for k in range(len(h.outputs)):
+                d = douts[i]
+                h.douts[k] = d.contiguous() if d is not None else None
+                i += 1
+        for op in reversed(self.tape):
+            op.bwd()
+        self.join_side()
+
+    def grad_boundaries(self):
+        return [0, self.store.encoder_numel]
+
+
+class _TapeFunction(torch.autograd.Function):
+    """One autograd node for a whole network (see network/FCRN.py:_FCRNFunction for why backward RETURNS gradient views)."""
+
+    @staticmethod
+    def forward(ctx, x, engine, train, *params):
+        ctx.engine, ctx.train = engine, train
+        ctx.set_materialize_grads(False)          # an unused output's gradient stays None (no zero tensors of GBs)
+        ys = engine.forward(x, train, check_data=True)
+        engine.forward_serial = ctx.serial = getattr(engine, "forward_serial", 0) + 1
+        return tuple(y.clone() for y in ys)
+
+    @staticmethod
+    def backward(ctx, *douts):
+        eng = ctx.engine
+        if not ctx.train:
+            raise RuntimeError("mono_depth_estimation_amd: backward() through a forward pass run in eval() mode is not supported "
+                               "(no BatchNorm-backward kernel for running statistics); call .train() first or use torch.no_grad().")
+        if ctx.needs_input_grad[0]:
+            raise RuntimeError("mono_depth_estimation_amd: the gradient with respect to the input image is not computed; detach it.")
+        if ctx.serial != eng.forward_serial:
+            raise RuntimeError("mono_depth_estimation_amd: backward() of a forward pass whose activations were overwritten by a later "
+                               "forward of the same input shape (forward #%d, latest #%d)." % (ctx.serial, eng.forward_serial))
+        st = eng.store
+        buf = st.begin_autograd_backward()
+        try:
+            eng.backward(douts)
+        finally:
+            st.Gcur = st.G
+        grads = tuple(st.grad_view(p, buf) if need else None for p, need in zip(eng.params, ctx.needs_input_grad[3:]))
+        if st._g_base is None:
+            grads = tuple(g.clone() if g is not None else None for g in grads)
+        return (None, None, None) + grads
+
+
+class TapeModule(torch.nn.Module):
+    """nn.Module surface of a tape-run network: parameters live in the reference's submodule tree (same state_dict keys),
+    `forward` runs the HIP plan.  Subclasses set `_engine_cls` and implement `_make_store(device)`."""
+
+    _engine_cls = None
+
+    def _init_runtime(self):
+        self._engines, self._store = {}, None
+
+    def _make_store(self, device):
+        raise NotImplementedError
+
+    def _first_param(self):
+        return next(self.parameters())
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        if getattr(self, "_engines", None) is not None:
+            dev = self._first_param().device
+            self._engines, self._store = {}, None
+            if dev.type == "cuda":
+                self._store = self._make_store(dev)
+        return out
+
+    def __deepcopy__(self, memo):
+        import copy
+        with torch.no_grad():
+            for p in self.parameters():
+                memo[id(p)] = torch.nn.Parameter(p.detach().clone(), requires_grad=p.requires_grad)
+            for b in self.buffers():
+                memo[id(b)] = b.detach().clone()
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            if k not in ("_engines", "_store"):
+                new.__dict__[k] = copy.deepcopy(v, memo)
+        new._engines, new._store = {}, None
+        return new
+
+    def __getstate__(self):
+        import copy
+        if self._store is None:
+            state = dict(self.__dict__)
+            state["_engines"] = {}
+            return state
+        return copy.deepcopy(self).__dict__
+
+    def _engine(self, x):
+        if x.dim() != 4 or x.shape[1] != 3:
+            raise ValueError("expected an N x 3 x H x W image batch, got %s" % (tuple(x.shape),))
+        if not x.is_cuda:
+            raise RuntimeError("mono_depth_estimation_amd networks run on MI355X only (input is on %s); there is no CPU fallback" % x.device)
+        st = self._store
+        if st is None or st.dev != x.device or not st.storage_is_current():
+            self._store = st = self._make_store(x.device)
+            self._engines.clear()
+        key = tuple(x.shape)
+        eng = self._engines.pop(key, None)
+        if eng is None:
+            cap = max(1, int(os.environ.get("MDE_MAX_PLANS", "4")))
+            while len(self._engines) >= cap:
+                self._engines.pop(next(iter(self._engines)))
+            eng = self._engine_cls(self, st, x.shape[0], x.shape[2], x.shape[3])
+        self._engines[key] = eng
+        return eng
+
+    def _run(self, x):
+        eng = self._engine(x)
+        return _TapeFunction.apply(x.contiguous().float(), eng, self.training, *eng.params)

@@ -349,6 +349,81 @@ def nhwc_bf16_to_nchw(src, dst):
     check(_lib.load().mde_nhwc_bf16_to_nchw(_p(src), _p(dst), N, C_, H, W, _stream()), "mde_nhwc_bf16_to_nchw")
 
 
+# ------------------------------------------------------------------------------ pointwise / pooling / resize (VNL, MiDaS, BTS)
+ACT = {None: 0, "none": 0, "relu": 1, "elu": 2, "sigmoid": 3}
+
+
+def pw_fwd(x, ldx, bias, r, ldr, out, ldo, M, C_, act):
+    check(_lib.load().mde_pw_fwd(_p(x), ldx, _p(bias), _p(r), ldr, _p(out), ldo, M, C_, ACT[act], _stream()), "mde_pw_fwd")
+
+
+def pw_bwd(dout, ldd, out, ldo, dx, lddx, acc_x, dr, lddr, acc_r, dbias, M, C_, act):
+    check(_lib.load().mde_pw_bwd(_p(dout), ldd, _p(out), ldo, _p(dx), lddx, int(acc_x), _p(dr), lddr, int(acc_r), _p(dbias), M,
+                                 C_, ACT[act], _stream()), "mde_pw_bwd")
+
+
+def spatial_sum(x, ldx, N, HW, C_, scale, out, ldo):
+    check(_lib.load().mde_spatial_sum(_p(x), ldx, N, HW, C_, scale, _p(out), ldo, _stream()), "mde_spatial_sum")
+
+
+def spatial_bcast(src, lds, scale, out, ldo, N, HW, C_, accumulate=False):
+    check(_lib.load().mde_spatial_bcast(_p(src), lds, scale, _p(out), ldo, N, HW, C_, int(accumulate), _stream()),
+          "mde_spatial_bcast")
+
+
+def gate_fwd(w, ldw, lat, ldl, top, ldt, out, ldo, N, HW, C_):
+    check(_lib.load().mde_gate_fwd(_p(w), ldw, _p(lat), ldl, _p(top), ldt, _p(out), ldo, N, HW, C_, _stream()), "mde_gate_fwd")
+
+
+def gate_bwd(dout, ldd, w, ldw, lat, ldl, dlat, lddl, acc_lat, dtop, lddt, acc_top, dw, lddw, N, HW, C_):
+    check(_lib.load().mde_gate_bwd(_p(dout), ldd, _p(w), ldw, _p(lat), ldl, _p(dlat), lddl, int(acc_lat), _p(dtop), lddt,
+                                   int(acc_top), _p(dw), lddw, N, HW, C_, _stream()), "mde_gate_bwd")
+
+
+def resize_bilinear_fwd(x, ldx, out, ldo, N, H, W, C_, OH, OW, align_corners):
+    check(_lib.load().mde_resize_bilinear_fwd(_p(x), ldx, _p(out), ldo, N, H, W, C_, OH, OW, int(align_corners), _stream()),
+          "mde_resize_bilinear_fwd")
+
+
+def resize_bilinear_bwd(dout, ldd, dx, lddx, N, H, W, C_, OH, OW, align_corners, accumulate=False):
+    check(_lib.load().mde_resize_bilinear_bwd(_p(dout), ldd, _p(dx), lddx, N, H, W, C_, OH, OW, int(align_corners),
+                                              int(accumulate), _stream()), "mde_resize_bilinear_bwd")
+
+
+def nearest2_fwd(x, ldx, out, ldo, N, H, W, C_):
+    check(_lib.load().mde_nearest2_fwd(_p(x), ldx, _p(out), ldo, N, H, W, C_, _stream()), "mde_nearest2_fwd")
+
+
+def sum2x2(src, lds, dst, ldd, N, H, W, C_, scale, accumulate=False):
+    check(_lib.load().mde_sum2x2(_p(src), lds, _p(dst), ldd, N, H, W, C_, scale, int(accumulate), _stream()), "mde_sum2x2")
+
+
+def spread2x2(x, ldx, out, ldo, N, H, W, C_, scale, accumulate=False):
+    check(_lib.load().mde_spread2x2(_p(x), ldx, _p(out), ldo, N, H, W, C_, scale, int(accumulate), _stream()), "mde_spread2x2")
+
+
+def softmax_head_fwd(x, ldx, bias, logit, prob, N, HW, C_):
+    check(_lib.load().mde_softmax_head_fwd(_p(x), ldx, _p(bias), _p(logit), _p(prob), N, HW, C_, _stream()), "mde_softmax_head_fwd")
+
+
+def softmax_head_bwd(dlogit, dprob, prob, dx, lddx, dbias, N, HW, C_):
+    check(_lib.load().mde_softmax_head_bwd(_p(dlogit), _p(dprob), _p(prob), _p(dx), lddx, _p(dbias), N, HW, C_, _stream()),
+          "mde_softmax_head_bwd")
+
+
+def to_nchw_act_fwd(x, ldx, bias, out, N, HW, C_, act, scale=1.0):
+    check(_lib.load().mde_to_nchw_act_fwd(_p(x), ldx, _p(bias), _p(out), N, HW, C_, ACT[act], scale, _stream()), "mde_to_nchw_act_fwd")
+
+
+def to_nchw_act_bwd(dout, out, dx, lddx, dbias, N, HW, C_, act, scale=1.0):
+    check(_lib.load().mde_to_nchw_act_bwd(_p(dout), _p(out), _p(dx), lddx, _p(dbias), N, HW, C_, ACT[act], scale, _stream()),
+          "mde_to_nchw_act_bwd")
+
+
+def pack_grouped(src, fwd, dgrad, O, T, G):
+    check(_lib.load().mde_pack_grouped(_p(src), _p(fwd), _p(dgrad), O, T, G, _stream()), "mde_pack_grouped")
+
+
 # ------------------------------------------------------------------------------ losses / metrics
 def silog_ws(device="cuda"):
     return torch.zeros((_lib.load().mde_silog_ws_bytes() + 7) // 8, dtype=torch.float64, device=device)

@@ -110,3 +110,18 @@ def fcrn_conditioned_state(model, seed, basic=False):
     sd["conv3.weight"] = (sd["conv3.weight"] * 0.05).to(torch.bfloat16).to(torch.float32)
     model.load_state_dict(sd)
     return sd
+
+
+def net_conditioned_state(model, seed, damp=(), damp_to=0.2):
+    """Deterministic, well-conditioned state for the tape networks (VNL / MiDaS / BTS): fill_state_dict, conv weights
+    exactly bf16-representable ("identical weights" for the bf16 MFMA path and the fp32 reference alike), and the BatchNorm
+    gammas whose key contains one of `damp` scaled by `damp_to` (the last BN of each residual branch: without it a deep
+    He-initialised residual net amplifies rounding by orders of magnitude; see fcrn_conditioned_state)."""
+    sd = fill_state_dict(model, seed)
+    for k in sd:
+        if sd[k].ndim == 4:
+            sd[k] = sd[k].to(torch.bfloat16).to(torch.float32)
+        elif k.endswith(".weight") and any(d in k for d in damp):
+            sd[k] = sd[k] * damp_to
+    model.load_state_dict(sd)
+    return sd

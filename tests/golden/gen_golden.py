@@ -444,19 +444,97 @@ def gen_fcrn_conditioned(criteria, metrics, FCRN):
           "range", float(out["eval_out"].min()), float(out["eval_out"].max()))
 
 
+def _grad_norms(model):
+    names = [n for n, p in model.named_parameters() if p.grad is not None]
+    return np.array(names), np.array([float(dict(model.named_parameters())[n].grad.norm()) for n in names], dtype=np.float32)
+
+
+VNL_SIZE = (64, 96)
+
+
+def vnl_bins(depth, params):
+    """modules/vnl.py:202-217 depth_to_bins, restated (the `modules` package does not import here, see above)."""
+    C = params.dec_out_c
+    invalid = depth < 0.
+    d = depth.clamp(params.depth_min, 1.1)
+    bins = ((torch.log10(d) - params.depth_min_log) / params.depth_bin_interval).to(torch.int)
+    bins[invalid] = C + 1
+    bins[bins == C] = C - 1
+    return bins
+
+
+def gen_vnl_net(criteria):
+    """C4: the reference's own network/VNL.py (MetricDepthModel, resnext50_32x4d_body_stride16) on a deterministic,
+    well-conditioned state: eval and train outputs, criteria.ModelLoss on them (the index draw stored), gradient norms of
+    every parameter.  VNL.py only needs `import torchvision` to succeed (it touches torchvision under __main__ only)."""
+    from network import VNL
+    from oracle import nets
+    if not hasattr(np, "int"):
+        np.int = int
+    params = nets.vnl_params()
+    torch.manual_seed(0)
+    ref = VNL.MetricDepthModel(params)
+    W.net_conditioned_state(ref, 41, damp=(".bn3.",))
+    H, Wd = VNL_SIZE
+    rgb, tgt = W.synthetic_batch(41, 2, H, Wd)
+    W.calibrate_running_stats(ref, rgb)
+    border = torch.tensor(params.depth_bin_border, dtype=torch.float32)
+    to_depth = lambda prob: 10 ** (prob.permute(0, 2, 3, 1) * border).sum(3, dtype=torch.float32, keepdim=True).permute(0, 3, 1, 2)
+    out = {"keys": np.array(list(ref.state_dict().keys()))}
+    ref.eval()
+    with torch.no_grad():
+        logit, prob = ref(rgb)
+    out["eval_depth"], out["eval_logit_s"], out["eval_prob_s"] = _np(to_depth(prob)), _np(logit[:, ::5, ::4, ::4]), _np(prob[:, ::5, ::4, ::4])
+    out["eval_logit_csum"] = _np(logit.sum((2, 3)))
+    ref.train()
+    params.crop_size = (H, Wd)
+    crit = criteria.ModelLoss(params)
+    np.random.seed(77)
+    p123 = crit.virtual_normal_loss.select_index()
+    out["p123"] = np.stack([p123["p%d_y" % i] * Wd + p123["p%d_x" % i] for i in (1, 2, 3)]).astype(np.int32)
+    gt = tgt.clone()
+    gt[:, :, :, :4] = -1.0                                # invalid side padding (vnl.py:209-216)
+    bins = vnl_bins(gt.clone(), params)
+    gt_loss = gt.clone()
+    gt_loss[gt_loss < params.depth_min] = torch.where(gt_loss[gt_loss < params.depth_min] < 0, torch.tensor(-1.0), torch.tensor(params.depth_min))
+    logit, prob = ref(rgb)
+    np.random.seed(77)
+    loss = crit(to_depth(prob), logit, bins, gt_loss)
+    loss.backward()
+    out["gt"], out["bins"] = _np(gt_loss), _np(bins)
+    out["train_depth"], out["train_logit_s"], out["train_loss"] = _np(to_depth(prob)), _np(logit[:, ::5, ::4, ::4]), _np(loss)
+    out["grad_names"], out["grad_norms"] = _grad_norms(ref)
+    sd = ref.state_dict()
+    out["rm_res5"] = _np(sd["depth_model.encoder_modules.bottomup.res5.2.bn3.running_mean"])
+    out["rv_aspp"] = _np(sd["depth_model.encoder_modules.bottomup_top.globalpool_bn.running_var"])
+    np.savez_compressed(os.path.join(HERE, "vnl_net.npz"), **out)
+    print("vnl_net.npz: %d keys, %d params, eval depth range %.4f..%.4f, train loss %.5f" % (
+        len(out["keys"]), sum(p.numel() for p in ref.parameters()), out["eval_depth"].min(), out["eval_depth"].max(), float(loss)))
+
+
 def main():
     torch.set_num_threads(8)
     criteria, metrics, FCRN = _import_reference()
-    gen_losses(criteria)
-    gen_vnl(criteria)
-    gen_stdepth(criteria)
-    gen_metrics(metrics)
-    gen_upproj(FCRN)
-    gen_fcrn(criteria, metrics, FCRN)
-    gen_fcrn_conditioned(criteria, metrics, FCRN)
-    gen_fcrn_decoders(criteria, metrics, FCRN)
-    gen_fcrn_basic_trunks(criteria, metrics, FCRN)
-    gen_fcrn_in_channels(criteria, metrics, FCRN)
+    only = set(sys.argv[1:])
+    want = lambda name: not only or name in only
+    if want("losses"):
+        gen_losses(criteria)
+    if want("vnl"):
+        gen_vnl(criteria)
+    if want("stdepth"):
+        gen_stdepth(criteria)
+    if want("metrics"):
+        gen_metrics(metrics)
+    if want("upproj"):
+        gen_upproj(FCRN)
+    if want("fcrn"):
+        gen_fcrn(criteria, metrics, FCRN)
+        gen_fcrn_conditioned(criteria, metrics, FCRN)
+        gen_fcrn_decoders(criteria, metrics, FCRN)
+        gen_fcrn_basic_trunks(criteria, metrics, FCRN)
+        gen_fcrn_in_channels(criteria, metrics, FCRN)
+    if want("vnl_net"):
+        gen_vnl_net(criteria)
 
 
 if __name__ == "__main__":

@@ -34,17 +34,21 @@ def test_struct_layouts_match_header():
     """sizeof / field offsets as a C compiler lays the header's structs out."""
     from mono_depth_estimation_amd._lib import ConvDesc, WgradDesc, MAX_TAPS
     assert MAX_TAPS == 32
-    assert C.sizeof(ConvDesc) == 6 * 4 + 5 * 4 + 3 * 2 * MAX_TAPS + 4 + 3 * 4 + 4 * 4 + 2 * 4
+    assert C.sizeof(ConvDesc) == 6 * 4 + 5 * 4 + 3 * 2 * MAX_TAPS + 4 + 3 * 4 + 4 * 4 + 3 * 4
     assert ConvDesc.dy.offset == 44 and ConvDesc.wtaps_total.offset == 44 + 6 * MAX_TAPS
-    assert C.sizeof(WgradDesc) == 9 * 4 + 2 * 4 + 3 * 4 + 3 * 2 * MAX_TAPS + 3 * 4
+    assert C.sizeof(WgradDesc) == 9 * 4 + 2 * 4 + 3 * 4 + 3 * 2 * MAX_TAPS + 4 * 4
     assert WgradDesc.dy.offset == 56
 
 
 def test_argument_validation_without_a_gpu(lib):
     from mono_depth_estimation_amd import _lib, ops
-    d = ops.fwd_desc(1, 4, 4, 48, 48, 4 * 4 * 48 * 2, 1, 1, 0, 64, 64)          # C not a multiple of 64
+    d = ops.fwd_desc(1, 4, 4, 48, 44, 4 * 4 * 48 * 2, 1, 1, 0, 64, 64)          # C not a multiple of 8
     rc = lib.mde_conv_gemm(C.byref(d), C.c_void_p(16), C.c_void_p(16), C.c_void_p(16), None, None)
-    assert rc == -1 and b"multiple of 64" in lib.mde_last_error()
+    assert rc == -1 and b"multiple of 8" in lib.mde_last_error()
+    d = ops.fwd_desc(1, 4, 4, 128, 128, 4 * 4 * 128 * 2, 1, 1, 0, 128, 128)     # grouped wants C == 64 per column tile
+    d.grouped = 1
+    rc = lib.mde_conv_gemm(C.byref(d), C.c_void_p(16), C.c_void_p(16), C.c_void_p(16), None, None)
+    assert rc == -1 and b"grouped" in lib.mde_last_error()
     assert lib.mde_conv_gemm(None, None, None, None, None, None) == -1
     assert lib.mde_bn_stats(C.c_void_p(16), 10, 12, 12, C.c_void_p(16), None) == -1   # C % 8 != 0
     assert b"C=12" in lib.mde_last_error()

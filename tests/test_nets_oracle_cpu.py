@@ -1,0 +1,84 @@
+"""CPU: the functional oracles of the tape networks (oracle/nets.py) against the vectors minted from the REFERENCE's own
+network classes (tests/golden/gen_golden.py), and the HIP modules' parameter trees (state_dict keys, shapes, parameter
+counts) against the reference's.  No GPU, no libmde_hip.so compute."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import losses as L
+from oracle import nets
+from oracle import weights as W
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _golden(name):
+    return np.load(os.path.join(HERE, "golden", name + ".npz"))
+
+
+# ---------------------------------------------------------------------------------------------- VNL
+VNL_SIZE = (64, 96)
+
+
+@pytest.fixture(scope="module")
+def vnl_fixture():
+    from mono_depth_estimation_amd.network import VNL
+    params = nets.vnl_params()
+    torch.manual_seed(0)
+    mirror = VNL.MetricDepthModel(params)
+    sd = W.net_conditioned_state(mirror, 41, damp=(".bn3.",))
+    rgb, tgt = W.synthetic_batch(41, 2, *VNL_SIZE)
+    P = nets.leaf_state(sd)
+    with torch.no_grad():
+        nets.vnl_forward(P, rgb, True, momentum=1.0)          # = weights.calibrate_running_stats on the reference
+    return mirror, params, P, rgb, tgt
+
+
+def test_vnl_parameter_tree_matches_the_reference(vnl_fixture):
+    mirror, params, P, _, _ = vnl_fixture
+    g = _golden("vnl_net")
+    assert list(mirror.state_dict().keys()) == list(g["keys"])
+    assert sum(p.numel() for p in mirror.parameters()) == 71287254          # SURVEY 8c probe: 71.3 M
+    # modules/vnl.py:165-179 walks these attributes
+    dm = mirror.depth_model
+    for name in ("top", "topdown_fcn1", "topdown_fcn2", "topdown_fcn3", "topdown_fcn4", "topdown_fcn5", "topdown_predict"):
+        assert hasattr(dm.decoder_modules, name)
+    assert hasattr(dm, "encoder_modules")
+    # vnl.py:298-305: 'res' in key selects exactly the bottom-up body
+    enc = [k for k, _ in mirror.named_parameters() if 'res' in k]
+    assert enc and all(".bottomup.res" in k for k in enc)
+    assert dm.decoder_modules.top[1].eps == 0.5 and dm.encoder_modules.bottomup_top.aspp_bn1x1.momentum == 0.5
+
+
+def test_vnl_oracle_eval_matches_the_reference(vnl_fixture):
+    _, params, P, rgb, _ = vnl_fixture
+    g = _golden("vnl_net")
+    with torch.no_grad():
+        logit, prob = nets.vnl_forward(P, rgb, False)
+    depth = L.bins_to_depth(prob, torch.tensor(params.depth_bin_border, dtype=torch.float32))
+    assert np.allclose(depth.numpy(), g["eval_depth"], rtol=2e-4, atol=1e-6)
+    assert np.allclose(logit[:, ::5, ::4, ::4].numpy(), g["eval_logit_s"], rtol=1e-4, atol=2e-4)
+    assert np.allclose(prob[:, ::5, ::4, ::4].numpy(), g["eval_prob_s"], rtol=1e-3, atol=1e-7)
+    assert np.allclose(logit.sum((2, 3)).numpy(), g["eval_logit_csum"], rtol=1e-4, atol=5e-2)
+
+
+def test_vnl_oracle_train_step_matches_the_reference(vnl_fixture):
+    mirror, params, P0, rgb, _ = vnl_fixture
+    g = _golden("vnl_net")
+    P = nets.leaf_state(P0, requires_grad=True)
+    logit, prob = nets.vnl_forward(P, rgb, True)
+    border = torch.tensor(params.depth_bin_border, dtype=torch.float32)
+    depth = L.bins_to_depth(prob, border)
+    gt, bins = torch.from_numpy(g["gt"]), torch.from_numpy(g["bins"])
+    loss = L.model_loss(depth, logit, bins, gt, L.wcel_weight(150), torch.from_numpy(g["p123"]).long(), 519.0, 519.0, 6)
+    assert np.allclose(depth.detach().numpy(), g["train_depth"], rtol=2e-4, atol=1e-6)
+    assert np.allclose(float(loss), float(g["train_loss"]), rtol=2e-5)
+    loss.backward()
+    ref = dict(zip(g["grad_names"], g["grad_norms"]))
+    for k, v in ref.items():
+        got = float(P[k].grad.norm())
+        assert abs(got - v) <= 2e-3 * v + 1e-6, (k, got, v)
+    assert np.allclose(P["depth_model.encoder_modules.bottomup.res5.2.bn3.running_mean"].numpy(), g["rm_res5"], rtol=1e-4, atol=1e-6)
+    assert np.allclose(P["depth_model.encoder_modules.bottomup_top.globalpool_bn.running_var"].numpy(), g["rv_aspp"], rtol=1e-4, atol=1e-7)
