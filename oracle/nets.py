@@ -22,8 +22,11 @@ class Net:
     def __init__(self, P, train, q=None, momentum=None):
         self.P, self.train, self.q, self.momentum = P, train, (q or (lambda t: t)), momentum
 
-    def conv(self, x, key, stride=1, pad=0, dil=1, groups=1):
-        return F.conv2d(x, self.P[key + ".weight"], self.P.get(key + ".bias"), stride, pad, dil, groups)
+    def conv(self, x, key, stride=1, pad=0, dil=1, groups=1, bias=True):
+        """(bf16 emulation: the conv result is stored once WITHOUT its bias; the bias joins the following pass.)"""
+        y = self.q(F.conv2d(x, self.P[key + ".weight"], None, stride, pad, dil, groups))
+        b = self.P.get(key + ".bias") if bias else None
+        return y if b is None else y + b.view(1, -1, 1, 1)
 
     def bn(self, x, key, momentum=0.1, eps=1e-5):
         P = self.P
@@ -35,35 +38,40 @@ class Net:
 def _vnl_ftb(n, x, k):
     """FTB_block.forward (VNL.py:341-350)."""
     r = n.conv(x, k + ".conv1")
-    y = F.relu(n.bn(n.conv(r, k + ".conv2", pad=2, dil=2), k + ".bn1", momentum=0.5))
-    return F.relu(n.conv(y, k + ".conv3", pad=2, dil=2) + r)
+    y = n.q(F.relu(n.bn(n.conv(r, k + ".conv2", pad=2, dil=2), k + ".bn1", momentum=0.5)))
+    return n.q(F.relu(n.conv(y, k + ".conv3", pad=2, dil=2) + r))
 
 
 def _vnl_afa(n, lat, top, k):
     """AFA_block.forward (VNL.py:365-373)."""
-    w = torch.cat([lat, top], 1).mean((2, 3), keepdim=True)
-    w = torch.sigmoid(n.conv(F.relu(n.conv(w, k + ".conv1")), k + ".conv2"))
-    return w * lat + top
+    w = n.q(torch.cat([lat, top], 1).mean((2, 3), keepdim=True))
+    w = n.q(torch.sigmoid(n.conv(n.q(F.relu(n.conv(w, k + ".conv1"))), k + ".conv2")))
+    return n.q(w * lat + top)
 
 
 def _vnl_bottleneck(n, x, k, stride, dil):
     """ResNeXtBottleneck.forward (VNL.py:653-669); cardinality 32."""
-    y = F.relu(n.bn(n.conv(x, k + ".conv1"), k + ".bn1"))
-    y = F.relu(n.bn(n.conv(y, k + ".conv2", stride, dil, dil, 32), k + ".bn2"))
+    y = n.q(F.relu(n.bn(n.conv(x, k + ".conv1"), k + ".bn1")))
+    y = n.q(F.relu(n.bn(n.conv(y, k + ".conv2", stride, dil, dil, 32), k + ".bn2")))
     y = n.bn(n.conv(y, k + ".conv3"), k + ".bn3")
     if k + ".shortcut.conv.weight" in n.P:
         x = n.bn(n.conv(x, k + ".shortcut.conv", stride), k + ".shortcut.bn")
-    return F.relu(y + x)
+    return n.q(F.relu(y + x))
 
 
-def vnl_forward(P, x, train, block_counts=(3, 4, 6, 3), momentum=None):
+def bf16_round(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def vnl_forward(P, x, train, block_counts=(3, 4, 6, 3), momentum=None, q=None):
     """MetricDepthModel.forward (VNL.py:678-693) for the resnext*_32x4d_body_stride16 encoders -> (logits, softmax).
-    momentum: override every BatchNorm's (1.0 = "running statistics := this batch's", weights.calibrate_running_stats)."""
-    n = Net(P, train, momentum=momentum)
+    momentum: override every BatchNorm's (1.0 = "running statistics := this batch's", weights.calibrate_running_stats).
+    q: rounding applied wherever the HIP path stores a bf16 tensor (bf16_round: the bf16-emulating oracle)."""
+    n = Net(P, train, q=q, momentum=momentum)
     e, d = "depth_model.encoder_modules.", "depth_model.decoder_modules."
     H, W = x.shape[2:]
     b = e + "bottomup."
-    y = F.relu(n.bn(n.conv(x, b + "res1.conv1", 2, 3), b + "res1.bn1"))
+    y = n.q(F.relu(n.bn(n.conv(x, b + "res1.conv1", 2, 3), b + "res1.bn1")))
     y = F.max_pool2d(y, 3, 2, 1)
     feats = []
     # output stride 16: res3 and res4 open with stride 2, res5 keeps the size and dilates by 2 (VNL.py:557-569)
@@ -73,24 +81,24 @@ def vnl_forward(P, x, train, block_counts=(3, 4, 6, 3), momentum=None):
         feats.append(y)
     # ASPP_block.forward (VNL.py:211-228)
     a, t = e + "bottomup_top.", feats[-1]
-    xs = [n.bn(n.conv(t, a + "aspp_conv1x1"), a + "aspp_bn1x1", 0.5)]
+    xs = [n.q(n.bn(n.conv(t, a + "aspp_conv1x1"), a + "aspp_bn1x1", 0.5))]
     for i, r in enumerate((2, 4, 6)):
-        xs.append(n.bn(n.conv(t, a + "aspp_conv3_%d" % (i + 1), pad=r, dil=r), a + "aspp_bn3_%d" % (i + 1), 0.5))
-    g = n.bn(n.conv(t.mean((2, 3), keepdim=True), a + "globalpool_conv1x1"), a + "globalpool_bn", 0.5)
+        xs.append(n.q(n.bn(n.conv(t, a + "aspp_conv3_%d" % (i + 1), pad=r, dil=r), a + "aspp_bn3_%d" % (i + 1), 0.5)))
+    g = n.q(n.bn(n.conv(n.q(t.mean((2, 3), keepdim=True)), a + "globalpool_conv1x1"), a + "globalpool_bn", 0.5))
     xs.append(g.expand(-1, -1, t.shape[2], t.shape[3]))          # bilinear(align_corners) of a 1x1 map is a broadcast
     lats = [torch.cat(xs, 1)]
     for i in range(4):
         lats.append(_vnl_ftb(n, feats[-(i + 1)], e + "topdown_lateral_modules.%d.lateral" % i))
     # fcn_topdown.forward (VNL.py:286-294); `top`'s BatchNorm2d(dim, 0.5) has eps = 0.5 (VNL.py:253)
-    y = n.bn(n.conv(lats[0], d + "top.0"), d + "top.1", eps=0.5)
+    y = n.q(n.bn(n.conv(lats[0], d + "top.0"), d + "top.1", eps=0.5))
     for i in range(1, 5):
         lat = lats[i]
         if lat.shape != y.shape:
-            y = F.interpolate(y, size=lat.shape[2:], mode="bilinear", align_corners=True)
+            y = n.q(F.interpolate(y, size=lat.shape[2:], mode="bilinear", align_corners=True))
         y = _vnl_ftb(n, _vnl_afa(n, lat, y, d + "topdown_fcn%d.afa_block" % i), d + "topdown_fcn%d.ftb_block" % i)
-    y = F.interpolate(y, size=(math.ceil(H / 2.0), math.ceil(W / 2.0)), mode="bilinear", align_corners=True)
+    y = n.q(F.interpolate(y, size=(math.ceil(H / 2.0), math.ceil(W / 2.0)), mode="bilinear", align_corners=True))
     y = _vnl_ftb(n, y, d + "topdown_fcn5.ftb")
-    y = F.interpolate(y, size=(H, W), mode="bilinear", align_corners=True)
+    y = n.q(F.interpolate(y, size=(H, W), mode="bilinear", align_corners=True))
     logit = n.conv(y, d + "topdown_predict.conv1", pad=2, dil=2)
     return logit, torch.softmax(logit, 1)
 

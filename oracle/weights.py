@@ -125,3 +125,16 @@ def net_conditioned_state(model, seed, damp=(), damp_to=0.2):
             sd[k] = sd[k] * damp_to
     model.load_state_dict(sd)
     return sd
+
+
+def vnl_fixture_state(model, seed):
+    """The VNL network's parity fixture: net_conditioned_state with the residual branches' last BatchNorm (bn3) and the
+    ASPP image-pooling BatchNorm damped to 0.05 — the latter normalises over the BATCH only (N samples of a pooled vector,
+    VNL.py:221-223 "problem with bs = 1"), so in a 2-image fixture it turns a 2^-9 storage rounding into a 10 % change of
+    its output — and the prediction conv scaled by 0.1 (logits of order 1, not 10, so the softmax is not saturated).
+    Rounding the fp32 oracle's own activations to bf16 then moves its logits by 1.4 % (7 % without)."""
+    sd = net_conditioned_state(model, seed, damp=(".bn3.", "globalpool_bn"), damp_to=0.05)
+    k = "depth_model.decoder_modules.topdown_predict.conv1.weight"
+    sd[k] = (sd[k] * 0.1).to(torch.bfloat16).to(torch.float32)
+    model.load_state_dict(sd)
+    return sd

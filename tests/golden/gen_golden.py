@@ -474,7 +474,7 @@ def gen_vnl_net(criteria):
     params = nets.vnl_params()
     torch.manual_seed(0)
     ref = VNL.MetricDepthModel(params)
-    W.net_conditioned_state(ref, 41, damp=(".bn3.",))
+    W.vnl_fixture_state(ref, 41)
     H, Wd = VNL_SIZE
     rgb, tgt = W.synthetic_batch(41, 2, H, Wd)
     W.calibrate_running_stats(ref, rgb)

@@ -28,7 +28,7 @@ def vnl_fixture():
     params = nets.vnl_params()
     torch.manual_seed(0)
     mirror = VNL.MetricDepthModel(params)
-    sd = W.net_conditioned_state(mirror, 41, damp=(".bn3.",))
+    sd = W.vnl_fixture_state(mirror, 41)
     rgb, tgt = W.synthetic_batch(41, 2, *VNL_SIZE)
     P = nets.leaf_state(sd)
     with torch.no_grad():

@@ -4,7 +4,8 @@ tests/golden/vnl_net.npz) and against the reference's golden values directly.
 
 Tolerances (bf16 MFMA path vs fp32): eval-mode depth (bins_to_depth of the softmax) within 2 % relative L2 and AbsRel of
 that depth within 2e-3 of the reference's; train-mode ModelLoss within 2 %; parameter-gradient norms within 15 % for
-90 % of the tensors and direction cosine >= 0.9 on the decoder head (measured: see the asserts); running statistics
+90 % of the tensors (measured: 10th..90th percentile of the ratio 0.977..1.027), direction cosine >= 0.95 on decoder tensors
+(measured 0.99-0.999) and >= 0.85 in the trunk (measured 0.93-0.97); running statistics
 within 2 %."""
 import numpy as np
 import pytest
@@ -28,7 +29,7 @@ def setup():
     params = nets.vnl_params()
     torch.manual_seed(0)
     net = VNL.MetricDepthModel(params)
-    sd = W.net_conditioned_state(net, 41, damp=(".bn3.",))
+    sd = W.vnl_fixture_state(net, 41)
     rgb, tgt = W.synthetic_batch(41, 2, *SIZE)
     P = nets.leaf_state(sd)
     with torch.no_grad():
@@ -45,16 +46,25 @@ def test_vnl_eval_against_oracle_and_reference(setup, golden):
     with torch.no_grad():
         logit, prob = net(rgb.cuda())
         lo, po = nets.vnl_forward(P, rgb, False)
+        lq, pq = nets.vnl_forward(P, rgb, False, q=nets.bf16_round)      # the oracle rounding to bf16 where the HIP path stores
     assert logit.shape == (2, 150, *SIZE) and prob.shape == logit.shape and logit.dtype == torch.float32
     assert torch.allclose(prob.sum(1), torch.ones(2, *SIZE, device="cuda"), atol=1e-5)
-    depth, depth_o = L.bins_to_depth(prob.cpu(), border), L.bins_to_depth(po, border)
-    assert _rel(logit.cpu(), lo) < 3e-2, _rel(logit.cpu(), lo)
-    assert _rel(depth, depth_o) < 2e-2, _rel(depth, depth_o)
-    assert _rel(depth, torch.from_numpy(g["eval_depth"])) < 2e-2
+    depth, depth_o, depth_q = (L.bins_to_depth(p, border) for p in (prob.cpu(), po, pq))
+    # Rounding the fp32 ORACLE's own activations to bf16 moves its logits by `noise` (1.4e-2 on this fixture: 70 layers,
+    # res5 and the ASPP see 4 x 6 maps).  The HIP path must sit inside that noise, and close to the rounding oracle.
+    noise = _rel(lq, lo)
+    e_fp32, e_q = _rel(logit.cpu(), lo), _rel(logit.cpu(), lq)
+    print("VNL eval: logits HIP vs fp32 oracle %.3e, vs bf16-rounding oracle %.3e, rounding noise of the oracle %.3e" % (e_fp32, e_q, noise))
+    assert noise < 2e-2 and e_fp32 < 1.5 * noise + 5e-3, (e_fp32, noise)
+    assert e_q < 1.2 * noise + 5e-3, (e_q, noise)
+    assert _rel(depth, depth_o) < 1.5 * _rel(depth_q, depth_o) + 1e-2
+    assert _rel(depth, torch.from_numpy(g["eval_depth"])) < 1.5 * _rel(depth_q, depth_o) + 1e-2
     t = tgt.clamp(min=0)
     m = t > 0
     absrel = lambda d: float(((d - t).abs() / t.clamp(min=1e-9))[m].mean())
-    assert abs(absrel(depth) - absrel(torch.from_numpy(g["eval_depth"]))) < 2e-3
+    a_ref, a_hip, a_q = absrel(torch.from_numpy(g["eval_depth"])), absrel(depth), absrel(depth_q)
+    print("VNL eval AbsRel: reference %.5f, HIP %.5f, bf16-rounding oracle %.5f" % (a_ref, a_hip, a_q))
+    assert abs(a_hip - a_ref) < 2.0 * abs(a_q - a_ref) + 1e-3
 
 
 def test_vnl_train_step_against_oracle_and_reference(setup, golden):
@@ -71,7 +81,12 @@ def test_vnl_train_step_against_oracle_and_reference(setup, golden):
     lg, pr = logit.detach().cpu().requires_grad_(True), prob.detach().cpu().requires_grad_(True)
     loss = L.model_loss(L.bins_to_depth(pr, border), lg, bins, gt, L.wcel_weight(150), p123, 519.0, 519.0, 6)
     loss.backward()
-    assert abs(float(loss) - float(g["train_loss"])) < 2e-2 * float(g["train_loss"]), (float(loss), float(g["train_loss"]))
+    with torch.no_grad():      # what storage rounding alone does to the oracle's training-mode loss (batch statistics of 2 x 4 x 6 maps)
+        lq, pq = nets.vnl_forward(nets.leaf_state(P0), rgb, True, q=nets.bf16_round)
+        loss_q = float(L.model_loss(L.bins_to_depth(pq, border), lq, bins, gt, L.wcel_weight(150), p123, 519.0, 519.0, 6))
+    ref_loss = float(g["train_loss"])
+    print("VNL train ModelLoss: reference %.4f, HIP %.4f, bf16-rounding oracle %.4f" % (ref_loss, float(loss), loss_q))
+    assert abs(float(loss) - ref_loss) < 2.0 * abs(loss_q - ref_loss) + 5e-3 * ref_loss, (float(loss), loss_q, ref_loss)
     torch.autograd.backward([logit, prob], [lg.grad.cuda(), pr.grad.cuda()])
     # oracle gradients from the same state
     P = nets.leaf_state(P0, requires_grad=True)
@@ -86,15 +101,19 @@ def test_vnl_train_step_against_oracle_and_reference(setup, golden):
             ratios.append(float(gh.norm() / go.norm()))
             cosines[k] = float((gh * go).sum() / (gh.norm() * go.norm() + 1e-30))
     ratios = np.array(ratios)
+    print("VNL train gradient-norm ratios HIP / oracle, percentiles 1 10 50 90 99:", np.percentile(ratios, [1, 10, 50, 90, 99]))
+    print("cosines:", {k.split("modules.")[-1]: round(v, 3) for k, v in cosines.items() if "conv" in k and ("predict" in k or "fcn5" in k or "res2.0" in k or "aspp" in k)})
     assert np.mean(np.abs(ratios - 1) < 0.15) >= 0.9, np.percentile(ratios, [1, 10, 50, 90, 99])
     d = "depth_model.decoder_modules."
     for k in (d + "topdown_predict.conv1.weight", d + "topdown_predict.conv1.bias", d + "topdown_fcn5.ftb.conv3.weight",
               d + "topdown_fcn4.afa_block.conv2.weight", d + "topdown_fcn1.ftb_block.conv1.weight", d + "top.0.weight"):
-        assert cosines[k] >= 0.9, (k, cosines[k])
+        assert cosines[k] >= 0.95, (k, cosines[k])
     e = "depth_model.encoder_modules."
-    for k in (e + "bottomup_top.aspp_conv3_2.weight", e + "bottomup_top.globalpool_conv1x1.weight", e + "bottomup.res5.2.conv2.weight",
+    # (not asserted: bottomup_top.globalpool_conv1x1 -- its BatchNorm normalises over the 2 images of the batch, so its
+    #  normalised output is +-1 whatever the conv computes and the weight gradient is numerically zero on both sides)
+    for k in (e + "bottomup_top.aspp_conv3_2.weight", e + "bottomup_top.aspp_conv1x1.weight", e + "bottomup.res5.2.conv2.weight",
               e + "bottomup.res2.0.conv2.weight", e + "topdown_lateral_modules.3.lateral.conv2.weight"):
-        assert cosines[k] >= 0.7, (k, cosines[k])
+        assert cosines[k] >= 0.85, (k, cosines[k])
     # FTB's conv2 bias sits in front of a train-mode BatchNorm: its gradient is zero (up to fp32 noise in the oracle)
     kb = d + "topdown_fcn5.ftb.conv2.bias"
     assert float(named[kb].grad.abs().max()) == 0.0 and float(P[kb].grad.abs().max()) < 1e-4
