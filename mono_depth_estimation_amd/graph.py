@@ -406,6 +406,27 @@ class TapeEngine(EngineCore):
         self._bufs.append(a)
         return a
 
+    # ---- building blocks shared by the plans
+    def conv_bn(self, x, conv, bn, relu, out=None):
+        """nn.Conv2d (its own stride / padding / dilation / groups) -> nn.BatchNorm2d -> [ReLU]."""
+        k, s, p, d, g = conv.kernel_size[0], conv.stride[0], conv.padding[0], conv.dilation[0], conv.groups
+        site = self._site([bn])
+        c = self.add(Conv(self, x, conv.weight, k, s, p, d, g, site=site))
+        return self.add(BN(self, c.out, site, relu, out=out, bias=conv.bias)).out
+
+    def bottleneck(self, x, conv1, bn1, conv2, bn2, conv3, bn3, ds_conv=None, ds_bn=None):
+        """1x1 -> BN -> ReLU -> 3x3 (stride / dilation / groups) -> BN -> ReLU -> 1x1 -> BN -> (+ identity | + BN(1x1 shortcut))
+        -> ReLU: torchvision's Bottleneck v1.5 and VNL.py:618-669 alike.  The join is one pass over both BN sites."""
+        a = self.conv_bn(x, conv1, bn1, True)
+        b = self.conv_bn(a, conv2, bn2, True)
+        s3 = self._site([bn3])
+        c3 = self.add(Conv(self, b, conv3.weight, 1, site=s3)).out
+        if ds_conv is not None:
+            sd = self._site([ds_bn])
+            ds = self.add(Conv(self, x, ds_conv.weight, 1, ds_conv.stride[0], site=sd)).out
+            return self.add(BN(self, c3, s3, True, res=ds, res_site=sd)).out
+        return self.add(BN(self, c3, s3, True, res=x)).out
+
     def forward(self, x, train, check_data=False):
         assert x.dtype == torch.float32 and x.is_contiguous() and tuple(x.shape) == (self.N, 3, self.H, self.W), tuple(x.shape)
         self.store.refresh_weights(check_data=check_data)

@@ -277,26 +277,14 @@ class DepthModel(_Container):
 class VNLEngine(G.TapeEngine):
     """The tape of DepthModel.forward (VNL.py:690-693 -> lateral.forward :155-170 -> fcn_topdown.forward :286-294)."""
 
-    def _conv_bn(self, x, conv, bn, relu, out=None):
-        k, s, p, d, g = conv.kernel_size[0], conv.stride[0], conv.padding[0], conv.dilation[0], conv.groups
-        site = self._site([bn])
-        c = self.add(G.Conv(self, x, conv.weight, k, s, p, d, g, site=site))
-        return self.add(G.BN(self, c.out, site, relu, out=out, bias=conv.bias)).out
-
     def _bottleneck(self, x, blk):
-        a = self._conv_bn(x, blk.conv1, blk.bn1, True)
-        b = self._conv_bn(a, blk.conv2, blk.bn2, True)
-        s3 = self._site([blk.bn3])
-        c3 = self.add(G.Conv(self, b, blk.conv3.weight, 1, site=s3)).out
-        if blk.shortcut is not None:
-            sd = self._site([blk.shortcut.bn])
-            ds = self.add(G.Conv(self, x, blk.shortcut.conv.weight, 1, blk.shortcut.conv.stride[0], site=sd)).out
-            return self.add(G.BN(self, c3, s3, True, res=ds, res_site=sd)).out
-        return self.add(G.BN(self, c3, s3, True, res=x)).out
+        sc = blk.shortcut
+        return self.bottleneck(x, blk.conv1, blk.bn1, blk.conv2, blk.bn2, blk.conv3, blk.bn3,
+                               sc.conv if sc is not None else None, sc.bn if sc is not None else None)
 
     def _ftb(self, x, ftb):
         c1 = self.add(G.Conv(self, x, ftb.conv1.weight, 1)).out                 # also the residual
-        t = self._conv_bn(c1, ftb.conv2, ftb.bn1, True)
+        t = self.conv_bn(c1, ftb.conv2, ftb.bn1, True)
         c3 = self.add(G.Conv(self, t, ftb.conv3.weight, 3, 1, 2, 2)).out
         return self.add(G.Pw(self, c3, r=c1, act="relu")).out
 
@@ -325,18 +313,18 @@ class VNLEngine(G.TapeEngine):
         top5, aspp = feats[-1], enc.bottomup_top
         Co = aspp.dim_out
         cat = self.buf(N, top5.H, top5.W, 5 * Co)
-        self._conv_bn(top5, aspp.aspp_conv1x1, aspp.aspp_bn1x1, False, out=cat.slice(0, Co))
+        self.conv_bn(top5, aspp.aspp_conv1x1, aspp.aspp_bn1x1, False, out=cat.slice(0, Co))
         for i in range(3):
-            self._conv_bn(top5, getattr(aspp, "aspp_conv3_%d" % (i + 1)), getattr(aspp, "aspp_bn3_%d" % (i + 1)), False,
+            self.conv_bn(top5, getattr(aspp, "aspp_conv3_%d" % (i + 1)), getattr(aspp, "aspp_bn3_%d" % (i + 1)), False,
                           out=cat.slice((i + 1) * Co, Co))
         v = self.add(G.GlobalAvgPool(self, top5)).out
-        u = self._conv_bn(v, aspp.globalpool_conv1x1, aspp.globalpool_bn, False)
+        u = self.conv_bn(v, aspp.globalpool_conv1x1, aspp.globalpool_bn, False)
         self.add(G.Broadcast(self, u, cat.slice(4 * Co, Co)))
         laterals = [cat]
         for i in range(enc.num_lateral_stages):
             laterals.append(self._ftb(feats[-(i + 1)], enc.topdown_lateral_modules[i].lateral))
         # decoder (VNL.py:286-294)
-        x = self._conv_bn(laterals[0], dec.top[0], dec.top[1], False)
+        x = self.conv_bn(laterals[0], dec.top[0], dec.top[1], False)
         for i in range(1, 5):
             blk, lat = getattr(dec, "topdown_fcn%d" % i), laterals[i]
             if (lat.H, lat.W, lat.C) != (x.H, x.W, x.C):

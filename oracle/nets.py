@@ -119,6 +119,57 @@ def vnl_params(depth_max=1.1, depth_min=0.01, dec_out_c=150, encoder="resnext50_
     return p
 
 
+# ---------------------------------------------------------------------------------------------- MiDaS (network/MiDaS.py)
+def _tv_bottleneck(n, x, k, stride, groups):
+    """torchvision Bottleneck (v1.5) as MiDaS.py:93-104 wires it in; downsample present on a stage's first block."""
+    y = n.q(F.relu(n.bn(n.conv(x, k + ".conv1"), k + ".bn1")))
+    y = n.q(F.relu(n.bn(n.conv(y, k + ".conv2", stride, 1, 1, groups), k + ".bn2")))
+    y = n.bn(n.conv(y, k + ".conv3"), k + ".bn3")
+    if k + ".downsample.0.weight" in n.P:
+        x = n.bn(n.conv(x, k + ".downsample.0", stride), k + ".downsample.1")
+    return n.q(F.relu(y + x))
+
+
+def _midas_rcu(n, a, k):
+    """ResidualConvUnit.forward (MiDaS.py:188-201) on a = relu(x): the unit's first ReLU is IN PLACE, so the skip it adds
+    back is relu(x), not x."""
+    y = n.q(F.relu(n.conv(a, k + ".conv1", pad=1)))
+    return n.q(n.conv(y, k + ".conv2", pad=1) + a)
+
+
+def _midas_ffb(n, k, x0, x1=None):
+    """FeatureFusionBlock.forward (MiDaS.py:215-229)."""
+    out = x0
+    if x1 is not None:
+        out = out + _midas_rcu(n, n.q(F.relu(x1)), k + ".resConfUnit1")
+    out = _midas_rcu(n, n.q(F.relu(out)), k + ".resConfUnit2")
+    return n.q(F.interpolate(out, scale_factor=2, mode="bilinear", align_corners=True))
+
+
+def midas_forward(P, x, train, blocks=(3, 4, 23, 3), groups=32, momentum=None, q=None):
+    """MidasNet.forward (MiDaS.py:59-87) over a ResNeXt-101 32x8d trunk -> N x 7 x H x W sigmoid maps."""
+    n = Net(P, train, q=q, momentum=momentum)
+    p, s = "pretrained.", "scratch."
+    y = n.q(F.relu(n.bn(n.conv(x, p + "layer1.0", 2, 3), p + "layer1.1")))
+    y = F.max_pool2d(y, 3, 2, 1)
+    feats = []
+    for li, cnt in enumerate(blocks):
+        for i in range(cnt):
+            k = p + ("layer1.4.%d" % i if li == 0 else "layer%d.%d" % (li + 1, i))
+            y = _tv_bottleneck(n, y, k, 2 if (li > 0 and i == 0) else 1, groups)
+        feats.append(y)
+    rn = [n.conv(f, s + "layer%d_rn" % (i + 1), pad=1) for i, f in enumerate(feats)]
+    path = _midas_ffb(n, s + "refinenet4", rn[3])
+    path = _midas_ffb(n, s + "refinenet3", path, rn[2])
+    path = _midas_ffb(n, s + "refinenet2", path, rn[1])
+    path = _midas_ffb(n, s + "refinenet1", path, rn[0])
+    o = s + "output_conv."
+    y = n.q(n.conv(path, o + "0", pad=1))
+    y = n.q(F.interpolate(y, scale_factor=2, mode="bilinear", align_corners=False))
+    y = n.q(F.relu(n.conv(y, o + "2", pad=1)))
+    return torch.sigmoid(n.conv(y, o + "4"))
+
+
 def leaf_state(sd, requires_grad=False):
     """A state dict as independent fp32 leaves (parameters optionally requiring grad; buffers never)."""
     out = {}

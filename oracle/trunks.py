@@ -1,0 +1,72 @@
+"""Stand-ins for the encoder trunks the reference pulls from torchvision / torch.hub — TEST INFRASTRUCTURE ONLY.
+
+torchvision is neither under /root/reference nor in this image, and the reference pins no version of it; the
+hub repo facebookresearch/WSL-Images (MiDaS.py:110) is architecturally torchvision's resnext101_32x8d.  These classes
+restate the PUBLIC architecture definitions (module names = torchvision's, so state_dict keys match) with plain
+torch.nn layers; tests/golden/gen_golden.py hands them to the reference's own decoder / head code in place of the
+download.  Their arithmetic is torch.nn's; what is pinned by the goldens is everything the reference itself defines.
+"""
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+class _Bottleneck(nn.Module):
+    """torchvision.models.resnet.Bottleneck (v1.5: stride on the 3x3), with groups / width_per_group (ResNeXt)."""
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None, groups=1, base_width=64):
+        super().__init__()
+        width = int(planes * (base_width / 64.0)) * groups
+        self.conv1 = nn.Conv2d(inplanes, width, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(width)
+        self.conv2 = nn.Conv2d(width, width, 3, stride, 1, groups=groups, bias=False)
+        self.bn2 = nn.BatchNorm2d(width)
+        self.conv3 = nn.Conv2d(width, planes * 4, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+
+    def forward(self, x):
+        idt = x if self.downsample is None else self.downsample(x)
+        y = self.relu(self.bn1(self.conv1(x)))
+        y = self.relu(self.bn2(self.conv2(y)))
+        return self.relu(self.bn3(self.conv3(y)) + idt)
+
+
+class ResNeXt(nn.Module):
+    """torchvision.models.resnet.ResNet with Bottleneck blocks, groups and width_per_group (no avgpool / fc use)."""
+
+    def __init__(self, layers, groups, width_per_group):
+        super().__init__()
+        self.inplanes, self.groups, self.base_width = 64, groups, width_per_group
+        self.conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(3, 2, 1)
+        self.layer1 = self._make_layer(64, layers[0], 1)
+        self.layer2 = self._make_layer(128, layers[1], 2)
+        self.layer3 = self._make_layer(256, layers[2], 2)
+        self.layer4 = self._make_layer(512, layers[3], 2)
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+
+    def _make_layer(self, planes, blocks, stride):
+        ds = None
+        if stride != 1 or self.inplanes != planes * 4:
+            ds = nn.Sequential(nn.Conv2d(self.inplanes, planes * 4, 1, stride, bias=False), nn.BatchNorm2d(planes * 4))
+        mods = [_Bottleneck(self.inplanes, planes, stride, ds, self.groups, self.base_width)]
+        self.inplanes = planes * 4
+        mods += [_Bottleneck(self.inplanes, planes, groups=self.groups, base_width=self.base_width) for _ in range(1, blocks)]
+        return nn.Sequential(*mods)
+
+
+def resnext101_32x8d():
+    return ResNeXt([3, 4, 23, 3], 32, 8)
+
+
+def resnext50_32x4d():
+    return ResNeXt([3, 4, 6, 3], 32, 4)

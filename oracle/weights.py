@@ -138,3 +138,14 @@ def vnl_fixture_state(model, seed):
     sd[k] = (sd[k] * 0.1).to(torch.bfloat16).to(torch.float32)
     model.load_state_dict(sd)
     return sd
+
+
+def midas_fixture_state(model, seed):
+    """MiDaS parity fixture: net_conditioned_state with the trunk's residual branches damped (bn3 x 0.05) and the 7-channel
+    output conv scaled by 0.01 (the BN-free decoder of residual sums grows the activations; He-scale head weights saturate the
+    sigmoid completely) so the output spans 0.04..0.88.  bf16 storage then moves the fp32 oracle's output by 0.6 %."""
+    sd = net_conditioned_state(model, seed, damp=(".bn3.",), damp_to=0.05)
+    k = "scratch.output_conv.4.weight"
+    sd[k] = (sd[k] * 0.01).to(torch.bfloat16).to(torch.float32)
+    model.load_state_dict(sd)
+    return sd

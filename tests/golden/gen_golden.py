@@ -512,6 +512,41 @@ def gen_vnl_net(criteria):
         len(out["keys"]), sum(p.numel() for p in ref.parameters()), out["eval_depth"].min(), out["eval_depth"].max(), float(loss)))
 
 
+MIDAS_SIZE = (64, 96)
+
+
+def gen_midas_net(criteria):
+    """C3: the reference's own network/MiDaS.py (MidasNet: _make_scratch, FeatureFusionBlock, ResidualConvUnit, Interpolate,
+    output_conv, forward).  Its trunk comes from torch.hub (MiDaS.py:110, never executed): the one function that would
+    download it is replaced by the local resnext101_32x8d stand-in (oracle/trunks.py), wired through the reference's own
+    _make_resnet_backbone.  Loss: criteria.MidasLoss(0.5, 'ssimse') on channel 0."""
+    from network import MiDaS
+    from oracle import trunks
+    MiDaS._make_pretrained_resnext101_wsl = lambda use_pretrained: MiDaS._make_resnet_backbone(trunks.resnext101_32x8d())
+    torch.manual_seed(0)
+    ref = MiDaS.MidasNet(features=256)
+    W.midas_fixture_state(ref, 43)
+    H, Wd = MIDAS_SIZE
+    rgb, tgt = W.synthetic_batch(43, 2, H, Wd)
+    W.calibrate_running_stats(ref, rgb)
+    out = {"keys": np.array(list(ref.state_dict().keys()))}
+    ref.eval()
+    with torch.no_grad():
+        y = ref(rgb)
+    out["eval_out"] = _np(y)
+    ref.train()
+    y = ref(rgb)
+    loss = criteria.MidasLoss(alpha=0.5, loss="ssimse")(y[:, :1], tgt)
+    loss.backward()
+    out["train_out"], out["train_loss"] = _np(y), _np(loss)
+    out["grad_names"], out["grad_norms"] = _grad_norms(ref)
+    sd = ref.state_dict()
+    out["rm_l4"] = _np(sd["pretrained.layer4.2.bn3.running_mean"])
+    np.savez_compressed(os.path.join(HERE, "midas_net.npz"), **out)
+    print("midas_net.npz: %d keys, %d params, eval range %.4f..%.4f, train loss %.5f" % (
+        len(out["keys"]), sum(p.numel() for p in ref.parameters()), out["eval_out"].min(), out["eval_out"].max(), float(loss)))
+
+
 def main():
     torch.set_num_threads(8)
     criteria, metrics, FCRN = _import_reference()
@@ -535,6 +570,8 @@ def main():
         gen_fcrn_in_channels(criteria, metrics, FCRN)
     if want("vnl_net"):
         gen_vnl_net(criteria)
+    if want("midas_net"):
+        gen_midas_net(criteria)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,90 @@
+"""BASELINE.json configurations 4 and 5 at their full per-GPU sizes, as size-independent properties (the CPU oracle cannot
+run these in seconds): finite outputs of the right shape, softmax rows summing to one, eval-mode batch invariance (an
+image's prediction does not depend on its batch neighbours), a training step through the drop-in criterion with finite
+gradients for every parameter, and a loss that falls over a few optimiser steps."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import nets
+
+pytestmark = pytest.mark.gpu
+
+
+def _data(n, h, w, seed):
+    g = torch.Generator(device="cuda")
+    g.manual_seed(seed)
+    rgb = torch.rand(n, 3, h, w, generator=g, device="cuda")
+    depth = 0.05 + 0.95 * torch.rand(n, 1, h, w, generator=g, device="cuda")
+    return rgb, depth.masked_fill(torch.rand(n, 1, h, w, generator=g, device="cuda") < 0.1, 0.0)
+
+
+def test_config5_vnl_16x3x480x640_with_model_loss():
+    """VNL resnext50 stride 16, 150 bins, 16 images per GPU at 480 x 640, ModelLoss = WCEL + 6 VNL."""
+    from mono_depth_estimation_amd import criteria
+    from mono_depth_estimation_amd.network import VNL
+    params = nets.vnl_params()
+    params.crop_size = (480, 640)
+    torch.manual_seed(1)
+    net = VNL.MetricDepthModel(params).cuda()
+    with torch.no_grad():
+        net.depth_model.decoder_modules.topdown_predict.conv1.weight.mul_(0.1)
+    x, gt = _data(16, 480, 640, 5)
+    net.eval()
+    with torch.no_grad():
+        logit, prob = net(x)
+        assert logit.shape == (16, 150, 480, 640) and torch.isfinite(logit).all()
+        assert torch.allclose(prob.sum(1), torch.ones_like(prob[:, 0]), atol=1e-4)
+        l2, _ = net(x[5:7].contiguous())                       # batch invariance in eval mode
+        assert float((l2 - logit[5:7]).abs().max()) <= 2e-2 * float(logit.abs().max())
+    del logit, prob, l2
+    crit = criteria.ModelLoss(params)
+    bins = criteria.depth_to_bins(gt, params.depth_min, 1.1, params.dec_out_c)
+    net.train()
+    np.random.seed(3)
+    losses = []
+    for it in range(3):
+        net.zero_grad(set_to_none=True)
+        logit, prob = net(x)
+        loss = crit(criteria.bins_to_depth(prob, params.depth_bin_border), logit, bins, gt)
+        loss.backward()
+        if it == 0:
+            for k, p in net.named_parameters():
+                assert p.grad is not None and torch.isfinite(p.grad).all(), k
+            assert float(net.depth_model.encoder_modules.bottomup.res2[0].conv2.weight.grad.abs().max()) > 0
+        net._store.sgd_step(1e-3, 1e-4, momentum=0.9, weight_decay=5e-4)
+        losses.append(float(loss))
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+
+
+def test_config4_midas_32x3x384x384_with_midas_loss():
+    """MiDaS ResNeXt-101 32x8d, 32 images per GPU at 384 x 384, MidasLoss(0.5, 'ssimse') on channel 0."""
+    from mono_depth_estimation_amd import criteria
+    from mono_depth_estimation_amd.network import MiDaS
+    torch.manual_seed(2)
+    net = MiDaS.MidasNet(features=256).cuda()
+    with torch.no_grad():
+        net.scratch.output_conv[4].weight.mul_(0.05)
+    x, gt = _data(32, 384, 384, 6)
+    net.eval()
+    with torch.no_grad():
+        y = net(x)
+        assert y.shape == (32, 7, 384, 384) and torch.isfinite(y).all() and float(y.min()) >= 0 and float(y.max()) <= 1
+        y2 = net(x[3:5].contiguous())
+        assert float((y2 - y[3:5]).abs().max()) <= 2e-2
+    del y, y2
+    crit = criteria.MidasLoss(alpha=0.5, loss="ssimse")
+    net.train()
+    losses = []
+    for it in range(3):
+        net.zero_grad(set_to_none=True)
+        loss = crit(net(x)[:, :1], gt)
+        loss.backward()
+        if it == 0:
+            for k, p in net.named_parameters():
+                if "refinenet4.resConfUnit1" in k:
+                    continue                                   # never used by the forward pass (MiDaS.py:219)
+                assert p.grad is not None and torch.isfinite(p.grad).all(), k
+        net._store.adam_step(1e-5, 1e-4)
+        losses.append(float(loss))
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses

@@ -1,0 +1,109 @@
+"""End-to-end GPU parity of the HIP MiDaS network (mono_depth_estimation_amd.network.MiDaS.MidasNet) against
+the CPU oracle (oracle/nets.py: midas_forward, pinned to the reference's own network/MiDaS.py by tests/golden/midas_net.npz)
+and the reference's golden values, plus the configuration-4 property test at 32 x 3 x 384 x 384.
+
+Tolerances (bf16 MFMA path vs fp32), relative to what rounding the ORACLE's own activations to bf16 does (`noise`,
+measured 6e-3 on this fixture): eval output within 1.5 noise + 3e-3 of the oracle and of the reference; train-mode
+MidasLoss(0.5, 'ssimse') within 1 %; gradient norms within 15 % for 90 % of the tensors, direction cosine >= 0.95 in the
+decoder and >= 0.85 in the trunk."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import losses as L
+from oracle import nets
+from oracle import weights as W
+
+pytestmark = pytest.mark.gpu
+SIZE = (64, 96)
+
+
+def _rel(a, b):
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+@pytest.fixture(scope="module")
+def setup():
+    from mono_depth_estimation_amd.network import MiDaS
+    torch.manual_seed(0)
+    net = MiDaS.MidasNet(features=256)
+    sd = W.midas_fixture_state(net, 43)
+    rgb, tgt = W.synthetic_batch(43, 2, *SIZE)
+    P = nets.leaf_state(sd)
+    with torch.no_grad():
+        nets.midas_forward(P, rgb, True, momentum=1.0)
+    net.load_state_dict({k: v.clone() for k, v in P.items()})
+    return net.cuda(), P, rgb, tgt
+
+
+def test_midas_eval_against_oracle_and_reference(setup, golden):
+    net, P, rgb, tgt = setup
+    g = golden("midas_net")
+    net.eval()
+    with torch.no_grad():
+        y = net(rgb.cuda())
+        yo = nets.midas_forward(P, rgb, False)
+        yq = nets.midas_forward(P, rgb, False, q=nets.bf16_round)
+    assert y.shape == (2, 7, *SIZE) and y.dtype == torch.float32
+    noise, e_o, e_q, e_ref = _rel(yq, yo), _rel(y.cpu(), yo), _rel(y.cpu(), yq), _rel(y.cpu(), torch.from_numpy(g["eval_out"]))
+    print("MiDaS eval: HIP vs fp32 oracle %.3e, vs bf16-rounding oracle %.3e, vs reference %.3e; rounding noise %.3e" % (e_o, e_q, e_ref, noise))
+    assert noise < 1e-2 and e_o < 1.5 * noise + 3e-3 and e_ref < 1.5 * noise + 3e-3 and e_q < 1.2 * noise + 3e-3
+    t = tgt
+    m = t > 0
+    absrel = lambda d: float(((d[:, :1] - t).abs() / t.clamp(min=1e-9))[m].mean())
+    a_ref, a_hip = absrel(torch.from_numpy(g["eval_out"])), absrel(y.cpu())
+    print("MiDaS eval AbsRel(channel 0): reference %.5f, HIP %.5f" % (a_ref, a_hip))
+    assert abs(a_hip - a_ref) < 1e-3
+
+
+def test_midas_train_step_against_oracle_and_reference(setup, golden):
+    from mono_depth_estimation_amd import criteria
+    net, P0, rgb, tgt = setup
+    g = golden("midas_net")
+    net.train()
+    net.zero_grad(set_to_none=True)
+    y = net(rgb.cuda())
+    loss = criteria.MidasLoss(alpha=0.5, loss="ssimse")(y[:, :1], tgt.cuda())        # the drop-in HIP criterion
+    loss.backward()
+    ref_loss = float(g["train_loss"])
+    print("MiDaS train MidasLoss: reference %.5f, HIP %.5f" % (ref_loss, float(loss)))
+    assert abs(float(loss) - ref_loss) < 1e-2 * ref_loss
+    P = nets.leaf_state(P0, requires_grad=True)
+    L.midas_loss(nets.midas_forward(P, rgb, True)[:, :1], tgt, alpha=0.5, loss="ssimse").backward()
+    ratios, cosines = [], {}
+    for k, p in net.named_parameters():
+        go, gh = P[k].grad, p.grad.detach().cpu()
+        assert gh.shape == go.shape and torch.isfinite(gh).all(), k
+        if float(go.norm()) > 1e-9:
+            ratios.append(float(gh.norm() / go.norm()))
+            cosines[k] = float((gh * go).sum() / (gh.norm() * go.norm() + 1e-30))
+    ratios = np.array(ratios)
+    print("MiDaS gradient-norm ratios HIP / oracle, percentiles 1 10 50 90 99:", np.percentile(ratios, [1, 10, 50, 90, 99]))
+    assert np.mean(np.abs(ratios - 1) < 0.15) >= 0.9
+    for k in ("scratch.output_conv.4.weight", "scratch.output_conv.4.bias", "scratch.output_conv.2.weight", "scratch.output_conv.0.bias",
+              "scratch.refinenet1.resConfUnit2.conv2.weight", "scratch.refinenet1.resConfUnit1.conv1.bias", "scratch.refinenet4.resConfUnit2.conv1.weight",
+              "scratch.layer1_rn.weight", "scratch.layer4_rn.weight"):
+        assert cosines[k] >= 0.95, (k, cosines[k])
+    for k in ("pretrained.layer4.2.conv2.weight", "pretrained.layer3.11.conv2.weight", "pretrained.layer2.0.downsample.0.weight",
+              "pretrained.layer1.4.0.conv2.weight", "pretrained.layer1.0.weight"):
+        assert cosines[k] >= 0.85, (k, cosines[k])
+    # the unused RCU of the deepest fusion block (MiDaS.py:219: refinenet4 gets ONE input) receives no gradient
+    assert net.scratch.refinenet4.resConfUnit1.conv1.weight.grad is None or float(net.scratch.refinenet4.resConfUnit1.conv1.weight.grad.abs().max()) == 0.0
+    assert _rel(net.state_dict()["pretrained.layer4.2.bn3.running_mean"].cpu(), torch.from_numpy(g["rm_l4"])) < 2e-2
+
+
+def test_midas_adam_steps_reduce_the_loss(setup):
+    """modules/midas.py:94-105: Adam, encoder at 0.1 x LR; through the fused flat-range step."""
+    from mono_depth_estimation_amd import criteria
+    net, _, rgb, tgt = setup
+    crit = criteria.MidasLoss(alpha=0.5, loss="ssimse")
+    x, t = rgb.cuda(), tgt.cuda()
+    net.train()
+    losses = []
+    for _ in range(4):
+        net.zero_grad(set_to_none=True)
+        loss = crit(net(x)[:, :1], t)
+        loss.backward()
+        net._store.adam_step(1e-5, 1e-4)
+        losses.append(float(loss))
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses

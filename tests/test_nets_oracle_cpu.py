@@ -82,3 +82,48 @@ def test_vnl_oracle_train_step_matches_the_reference(vnl_fixture):
         assert abs(got - v) <= 2e-3 * v + 1e-6, (k, got, v)
     assert np.allclose(P["depth_model.encoder_modules.bottomup.res5.2.bn3.running_mean"].numpy(), g["rm_res5"], rtol=1e-4, atol=1e-6)
     assert np.allclose(P["depth_model.encoder_modules.bottomup_top.globalpool_bn.running_var"].numpy(), g["rv_aspp"], rtol=1e-4, atol=1e-7)
+
+
+# ---------------------------------------------------------------------------------------------- MiDaS
+MIDAS_SIZE = (64, 96)
+
+
+@pytest.fixture(scope="module")
+def midas_fixture():
+    from mono_depth_estimation_amd.network import MiDaS
+    torch.manual_seed(0)
+    mirror = MiDaS.MidasNet(features=256)
+    sd = W.midas_fixture_state(mirror, 43)
+    rgb, tgt = W.synthetic_batch(43, 2, *MIDAS_SIZE)
+    P = nets.leaf_state(sd)
+    with torch.no_grad():
+        nets.midas_forward(P, rgb, True, momentum=1.0)
+    return mirror, P, rgb, tgt
+
+
+def test_midas_parameter_tree_matches_the_reference(midas_fixture):
+    mirror, P, _, _ = midas_fixture
+    g = _golden("midas_net")
+    assert list(mirror.state_dict().keys()) == list(g["keys"])
+    assert sum(p.numel() for p in mirror.parameters()) == 105363143           # SURVEY 8c probe: 105.4 M
+    assert hasattr(mirror, "pretrained") and hasattr(mirror, "scratch")       # modules/midas.py:44,96-97
+    assert all(k.startswith(("pretrained.", "scratch.")) for k in mirror.state_dict())
+
+
+def test_midas_oracle_matches_the_reference(midas_fixture):
+    _, P0, rgb, tgt = midas_fixture
+    g = _golden("midas_net")
+    with torch.no_grad():
+        y = nets.midas_forward(P0, rgb, False)
+    assert y.shape == (2, 7, *MIDAS_SIZE)
+    assert np.allclose(y.numpy(), g["eval_out"], rtol=2e-4, atol=2e-6)
+    P = nets.leaf_state(P0, requires_grad=True)
+    y = nets.midas_forward(P, rgb, True)
+    loss = L.midas_loss(y[:, :1], tgt, alpha=0.5, loss="ssimse")
+    assert np.allclose(y.detach().numpy(), g["train_out"], rtol=2e-4, atol=2e-6)
+    assert np.allclose(float(loss.detach()), float(g["train_loss"]), rtol=2e-5)
+    loss.backward()
+    for k, v in zip(g["grad_names"], g["grad_norms"]):
+        got = float(P[k].grad.norm())
+        assert abs(got - v) <= 3e-3 * v + 1e-7, (k, got, v)
+    assert np.allclose(P["pretrained.layer4.2.bn3.running_mean"].numpy(), g["rm_l4"], rtol=1e-4, atol=1e-6)
