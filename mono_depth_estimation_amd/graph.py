@@ -125,46 +125,59 @@ class Conv(Op):
             Cin = self.conv.I
             assert x.C == Cin, "conv input has %d channels, the stored weight %d" % (x.C, Cin)
             G = 0
-        self.fdesc = ops.fwd_desc(x.N, x.H, x.W, x.ld, Cin, x.nbytes, k, stride, pad, O, o.ld, dil=dil)
+        # The kernels address an operand through a 32-bit buffer offset (< 2 GiB): a batch whose tensors are larger (VNL's
+        # 16 x 480 x 640 x 256 input of the prediction conv is 2.5 GB) runs as equal sub-batches over pointer-offset views;
+        # BatchNorm statistics and weight gradients accumulate across the launches anyway (atomics).
+        lim = (1 << 31) - (1 << 20)
+        per_img = max(x.H * x.W * x.ld, OH * OW * o.ld) * 2
+        self.chunk = x.N
+        while self.chunk * per_img > lim:
+            self.chunk = max(d for d in range(1, self.chunk) if x.N % d == 0)
+        n = self.chunk
+        xb, ob = (n * x.H * x.W * x.ld - x.c0) * 2, (n * OH * OW * o.ld - o.c0) * 2       # bytes addressable from the first element
+        self.fdesc = ops.fwd_desc(n, x.H, x.W, x.ld, Cin, xb, k, stride, pad, O, o.ld, dil=dil)
         self.fdesc.grouped = int(groups > 1)
         if need_dgrad:
             # (grouped: every 64-column tile of dx contracts the matching 64-channel window of dY)
-            self.ddescs, self.dzero = ops.dgrad_descs(x.N, x.H, x.W, x.ld, x.C, OH, OW, o.ld, O if groups == 1 else 64, o.nbytes,
+            self.ddescs, self.dzero = ops.dgrad_descs(n, x.H, x.W, x.ld, x.C, OH, OW, o.ld, O if groups == 1 else 64, ob,
                                                       k, stride, pad, dil=dil)
             for d in self.ddescs:
                 d.grouped = int(groups > 1)
+        M = n * OH * OW
         if groups > 1:
-            ks = ops.choose_ksplit(o.M, O // 64, 1, k * k, eng.cus, wg_per_cu=4, tile_elems=64 * 64)
+            ks = ops.choose_ksplit(M, O // 64, 1, k * k, eng.cus, wg_per_cu=4, tile_elems=64 * 64)
         else:
-            ks = eng._ksplit(o.M, O, Cin, k * k)
-        self.wdesc = ops.conv_wgrad_desc(x.N, x.H, x.W, x.ld, x.C, x.nbytes, OH, OW, o.ld, O, o.nbytes, k, stride, pad, ks, dil=dil)
+            ks = eng._ksplit(M, O, Cin, k * k)
+        self.wdesc = ops.conv_wgrad_desc(n, x.H, x.W, x.ld, x.C, xb, OH, OW, o.ld, O, ob, k, stride, pad, ks, dil=dil)
         self.wdesc.group_size = G
 
     def acts(self):
         return (self.out,) if self.own_out else ()
 
+    def _chunks(self):
+        return range(0, self.x.N, self.chunk)
+
     def fwd(self, train):
-        ops.conv_gemm(self.fdesc, self.x.t, self.conv.wf, self.out.t, self.site.part if (train and self.site is not None) else None)
+        stats = self.site.part if (train and self.site is not None) else None
+        n = self.chunk
+        for i in self._chunks():
+            ops.conv_gemm(self.fdesc, self.x.t[i:i + n], self.conv.wf, self.out.t[i:i + n], stats)
 
     def bwd(self):
-        x, o, eng = self.x, self.out, self.eng
-        og = _grad_of(o)
-        eng.wgrad(self.wdesc, og, x.t, self.conv.dw)
+        x, o, eng, n = self.x, self.out, self.eng, self.chunk
+        og = o.g
+        for i in self._chunks():
+            eng.wgrad(self.wdesc, og[i:i + n], x.t[i:i + n], self.conv.dw)
         if not self.need_dgrad:
             return
         acc = _take(x)
-        xg = _grad_of(x)
+        xg = x.g
         if self.dzero and not acc:
             xg.zero_()
-            acc = False
         for d in self.ddescs:
             d.accumulate = int(acc)
-            ops.conv_gemm(d, og, self.conv.wd, xg)
-
-
-def _grad_of(a):
-    """Gradient tensor of an activation: its own buffer, or the matching slice of its parent's."""
-    return a.g
+            for i in self._chunks():
+                ops.conv_gemm(d, og[i:i + n], self.conv.wd, xg[i:i + n])
 
 
 class BN(Op):

@@ -41,9 +41,9 @@ def test_config5_vnl_16x3x480x640_with_model_loss():
     crit = criteria.ModelLoss(params)
     bins = criteria.depth_to_bins(gt, params.depth_min, 1.1, params.dec_out_c)
     net.train()
-    np.random.seed(3)
     losses = []
-    for it in range(3):
+    for it in range(4):
+        np.random.seed(3)                                      # the same point triples every step: the loss values are comparable
         net.zero_grad(set_to_none=True)
         logit, prob = net(x)
         loss = crit(criteria.bins_to_depth(prob, params.depth_bin_border), logit, bins, gt)
@@ -52,7 +52,7 @@ def test_config5_vnl_16x3x480x640_with_model_loss():
             for k, p in net.named_parameters():
                 assert p.grad is not None and torch.isfinite(p.grad).all(), k
             assert float(net.depth_model.encoder_modules.bottomup.res2[0].conv2.weight.grad.abs().max()) > 0
-        net._store.sgd_step(1e-3, 1e-4, momentum=0.9, weight_decay=5e-4)
+        net._store.sgd_step(2e-3, 2e-3, momentum=0.9, weight_decay=5e-4)
         losses.append(float(loss))
     assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
 
