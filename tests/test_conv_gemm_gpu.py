@@ -143,8 +143,8 @@ def test_conv_rejects_bad_args():
     x = torch.zeros(1, 4, 4, 48, dtype=torch.bfloat16, device="cuda")
     w = torch.zeros(64, 1, 48, dtype=torch.bfloat16, device="cuda")
     out = torch.zeros(1, 4, 4, 64, dtype=torch.bfloat16, device="cuda")
-    d = ops.fwd_desc(1, 4, 4, 48, 48, x.numel() * 2, 1, 1, 0, 64, 64)
-    with pytest.raises(_lib.MdeError, match="multiple of 64"):
+    d = ops.fwd_desc(1, 4, 4, 48, 44, x.numel() * 2, 1, 1, 0, 64, 64)
+    with pytest.raises(_lib.MdeError, match="multiple of 8"):
         ops.conv_gemm(d, x, w, out)
 
 

@@ -133,9 +133,9 @@ def test_vnl_module_path_with_the_hip_criteria_and_sgd(setup):
     x, gt = rgb.cuda(), tgt.cuda().clone()
     bins = criteria.depth_to_bins(gt, params.depth_min, 1.1, params.dec_out_c)
     net.train()
-    np.random.seed(5)
     losses = []
     for _ in range(4):
+        np.random.seed(5)                         # VNL_Loss draws its point triples from numpy's global stream: same triples each step
         net.zero_grad(set_to_none=True)
         logit, prob = net(x)
         loss = crit(criteria.bins_to_depth(prob, params.depth_bin_border), logit, bins, gt)
