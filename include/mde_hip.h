@@ -123,7 +123,7 @@ int mde_head_conv_bwd(const void* x, const float* w, const float* dout, void* dx
 
 /* ------------------------------------------------------------------------------------
  * BatchNorm2d, training and eval mode (nn.BatchNorm2d everywhere in FCRN.py / torchvision).
- * Statistics are fp32; a "BN site" normalises C channels (C % 8 == 0, C <= 2048) of a
+ * Statistics are fp32; a "BN site" normalises C channels (C % 8 == 0, C <= 2048; wider ones are split by the caller) of a
  * [M = N*H*W][ld] bf16 tensor.
  *
  * Partial-sum buffers ("part"): fp32 [mde_stat_slots()][2][C].  Producers (mde_bn_stats,
@@ -139,6 +139,15 @@ int mde_bn_stats(const void* x, int64_t M, int C, int ld, float* part, void* str
 int mde_bn_finalize(float* part, int64_t M, int C, const float* gamma, const float* beta,
                     float* running_mean, float* running_var, float momentum, float eps, float* scale,
                     float* shift, float* save_mean, float* save_rstd, void* stream);
+/* The two halves of mde_bn_finalize, for BatchNorms that share batch moments (DenseNet: every later layer of a block
+ * normalises the same concatenated channels with its own gamma / beta / running statistics; torchvision densenet161 as
+ * Bts.py:283-292 uses it): mde_bn_moments turns a partial-sum buffer into mean and BIASED variance (fp32 [C]) and zeroes
+ * it; mde_bn_finalize_moments derives one BatchNorm's scale / shift / saved statistics from such moments and updates its
+ * running statistics (unbiased variance, `momentum`) exactly as mde_bn_finalize does. */
+int mde_bn_moments(float* part, int64_t M, int C, float* mean, float* var, void* stream);
+int mde_bn_finalize_moments(const float* mean, const float* var, int64_t M, int C, const float* gamma, const float* beta,
+                            float* running_mean, float* running_var, float momentum, float eps, float* scale, float* shift,
+                            float* save_mean, float* save_rstd, void* stream);
 /* Eval mode: scale/shift from running statistics. */
 int mde_bn_eval_scale_shift(const float* gamma, const float* beta, const float* running_mean,
                             const float* running_var, float eps, int C, float* scale, float* shift,
@@ -260,6 +269,19 @@ int mde_to_nchw_act_fwd(const void* x, int ldx, const float* bias, float* out, i
                         void* stream);
 int mde_to_nchw_act_bwd(const float* dout, const float* out, void* dx, int lddx, float* dbias, int N, int64_t HW, int C,
                         int act, float scale, void* stream);
+/* BTS plane heads (Bts.py:105-122 reduction_1x1's tail, :228-231 F.normalize, :124-146 local_planar_guidance): x bf16
+ * [N][h][w][ldx] holds the three plane parameters in channels 0..2; theta = sigmoid(x0) pi/3, phi = sigmoid(x1) 2 pi,
+ * dist = sigmoid(x2) max_depth, n = normalize(sin theta cos phi, sin theta sin phi, cos theta);
+ * out[n][i*up + a][j*up + b] = dist / (n1 u_b + n2 v_a + n3) / max_depth with u, v = (k - (up-1)/2) / up; out is fp32
+ * [N][h*up][w*up].  bwd writes dx bf16 [N][h][w][lddx] (channels 3..7 zero) from dout fp32 [N][h*up][w*up]. */
+int mde_plane_depth_fwd(const void* x, int ldx, float* out, int N, int h, int w, int up, float max_depth, void* stream);
+int mde_plane_depth_bwd(const void* x, int ldx, const float* dout, void* dx, int lddx, int N, int h, int w, int up, float max_depth,
+                        void* stream);
+/* A one-channel fp32 map [N][H][W] as one bf16 channel of an NHWC tensor at 1/step resolution (dst points at the channel,
+ * ld = its pixel stride): torch.cat([...], dim=1) of a depth map, after F.interpolate(scale_factor=1/step, mode='nearest')
+ * when step > 1 (Bts.py:234,238,247,251,263).  mde_slot_to_map_add is the gradient: dsrc[picked pixels] += dslot. */
+int mde_map_to_slot(const float* src, void* dst, int ld, int N, int H, int W, int step, void* stream);
+int mde_slot_to_map_add(const void* dslot, int ld, float* dsrc, int N, int H, int W, int step, void* stream);
 /* Block-diagonal packings of a grouped conv weight (VNL.py:638 `groups=cardinality`): src fp32 [O][T][G] (G = channels per
  * group, O == I, O % 64 == 0, G divides 64) -> fwd bf16 [O][T][64] for mde_conv_gemm(grouped) and dgrad bf16 [O][T][64]
  * (the transposed blocks, for the input gradient); either may be NULL. */

@@ -59,6 +59,8 @@ SIGNATURES = {
     "mde_stat_slots": (_I, []),
     "mde_bn_stats": (_I, [_P, _L, _I, _I, _P, _P]),
     "mde_bn_finalize": (_I, [_P, _L, _I, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P]),
+    "mde_bn_moments": (_I, [_P, _L, _I, _P, _P, _P]),
+    "mde_bn_finalize_moments": (_I, [_P, _P, _L, _I, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P]),
     "mde_bn_eval_scale_shift": (_I, [_P, _P, _P, _P, _F, _I, _P, _P, _P]),
     "mde_bn_apply": (_I, [_P, _I, _P, _P, _P, _I, _P, _P, _P, _I, _P, _L, _I, _I, _P]),
     "mde_bn_bwd_reduce": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _P, _P, _L, _I, _I, _P, _P]),
@@ -86,6 +88,10 @@ SIGNATURES = {
     "mde_softmax_head_bwd": (_I, [_P, _P, _P, _P, _I, _P, _I, _L, _I, _P]),
     "mde_to_nchw_act_fwd": (_I, [_P, _I, _P, _P, _I, _L, _I, _I, _F, _P]),
     "mde_to_nchw_act_bwd": (_I, [_P, _P, _P, _I, _P, _I, _L, _I, _I, _F, _P]),
+    "mde_plane_depth_fwd": (_I, [_P, _I, _P, _I, _I, _I, _I, _F, _P]),
+    "mde_plane_depth_bwd": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
+    "mde_map_to_slot": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "mde_slot_to_map_add": (_I, [_P, _I, _P, _I, _I, _I, _I, _P]),
     "mde_pack_grouped": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "mde_silog_ws_bytes": (_Z, []),
     "mde_silog_fwd": (_I, [_P, _P, _L, _F, _P, _P, _P]),

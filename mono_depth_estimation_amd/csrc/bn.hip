@@ -64,7 +64,7 @@ __global__ __launch_bounds__(NT) void bn_stats_k(const bf16_t* __restrict__ x, i
     float s1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_blk;
     const int64_t r1 = min(M, r0 + rows_per_blk);
-    for (int64_t r_ = r0 + rl; r_ < r1; r_ += rpb) {
+    for (int64_t r_ = rl < rpb ? r0 + rl : r1; r_ < r1; r_ += rpb) {      // (threads past the last whole row group idle)
         const int64_t r = MDE_BN_SNAKE ? M - 1 - r_ : r_;
         float v[8];
         ld8(x + r * ld + col * 8, v);
@@ -103,6 +103,45 @@ __global__ void bn_finalize_k(float* part, int64_t M, int C, const float* gamma,
     }
 }
 
+// Batch moments alone (mean, biased variance) out of a partial-sum buffer, which is zeroed; and the scale / shift of ONE
+// BatchNorm from given moments.  DenseNet (Bts.py:283-292 densenet161) normalises the same concatenated channels again in
+// every later layer of a block, each with its own gamma / beta / running statistics but the SAME batch moments: they
+// are computed once per 48-channel group, when it is produced.
+__global__ void bn_moments_k(float* part, int64_t M, int C, float* mean_out, float* var_out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int s = 0; s < MDE_STAT_SLOTS; ++s) {
+        float* p = part + (size_t)s * 2 * C;
+        s1 += (double)p[c];
+        s2 += (double)p[C + c];
+        p[c] = 0.f;
+        p[C + c] = 0.f;
+    }
+    const double mean = s1 / (double)M;
+    const double var = s2 / (double)M - mean * mean;
+    mean_out[c] = (float)mean;
+    var_out[c] = (float)(var > 0.0 ? var : 0.0);
+}
+__global__ void bn_finalize_moments_k(const float* mean_in, const float* var_in, int64_t M, int C, const float* gamma, const float* beta,
+                                      float* rmean, float* rvar, float momentum, float eps, float* scale, float* shift,
+                                      float* smean, float* srstd) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float mean = mean_in[c], var = var_in[c];
+    const float rstd = (float)(1.0 / sqrt((double)var + (double)eps));
+    const float sc = gamma[c] * rstd;
+    scale[c] = sc;
+    shift[c] = beta[c] - mean * sc;
+    smean[c] = mean;
+    srstd[c] = rstd;
+    if (rmean) {
+        const float unb = M > 1 ? (float)((double)var * (double)M / (double)(M - 1)) : var;
+        rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean;
+        rvar[c] = (1.f - momentum) * rvar[c] + momentum * unb;
+    }
+}
+
 __global__ void bn_eval_k(const float* gamma, const float* beta, const float* rmean, const float* rvar,
                           float eps, int C, float* scale, float* shift) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -127,7 +166,7 @@ __global__ __launch_bounds__(NT) void bn_apply_k(const bf16_t* __restrict__ x, i
         ldf8(rscale + col * 8, rsc);
         ldf8(rshift + col * 8, rsh);
     }
-    for (int64_t row_ = (int64_t)blockIdx.x * rpb + rl; row_ < M; row_ += (int64_t)gridDim.x * rpb) {
+    for (int64_t row_ = rl < rpb ? (int64_t)blockIdx.x * rpb + rl : M; row_ < M; row_ += (int64_t)gridDim.x * rpb) {
         const int64_t row = MDE_BN_SNAKE ? M - 1 - row_ : row_;
         float v[8], q[8];
         ld8(x + row * ldx + col * 8, v);
@@ -170,7 +209,7 @@ __global__ __launch_bounds__(NT) void bn_bwd_reduce_k(const bf16_t* __restrict__
     float s1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_blk;
     const int64_t r1 = min(M, r0 + rows_per_blk);
-    for (int64_t r_ = r0 + rl; r_ < r1; r_ += rpb) {
+    for (int64_t r_ = rl < rpb ? r0 + rl : r1; r_ < r1; r_ += rpb) {      // (threads past the last whole row group idle)
         const int64_t r = MDE_BN_SNAKE ? M - 1 - r_ : r_;
         float g[8], v[8], o[8];
         ld8(dout + r * ldd + col * 8, g);
@@ -229,7 +268,7 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_k(const bf16_t* __restrict__ 
     ldf8(coef + col * 8, c0);
     ldf8(coef + C + col * 8, c1);
     ldf8(coef + 2 * C + col * 8, c2);
-    for (int64_t row_ = (int64_t)blockIdx.x * rpb + rl; row_ < M; row_ += (int64_t)gridDim.x * rpb) {
+    for (int64_t row_ = rl < rpb ? (int64_t)blockIdx.x * rpb + rl : M; row_ < M; row_ += (int64_t)gridDim.x * rpb) {
         const int64_t row = MDE_BN_SNAKE ? M - 1 - row_ : row_;
         float g[8], v[8], o[8], d[8];
         ld8(dout + row * ldd + col * 8, g);
@@ -270,7 +309,7 @@ __global__ __launch_bounds__(NT) void bn_bwd_reduce2_k(const bf16_t* __restrict_
     float s1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sa[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sb[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_blk;
     const int64_t r1 = min(M, r0 + rows_per_blk);
-    for (int64_t r_ = r0 + rl; r_ < r1; r_ += rpb) {
+    for (int64_t r_ = rl < rpb ? r0 + rl : r1; r_ < r1; r_ += rpb) {      // (threads past the last whole row group idle)
         const int64_t r = MDE_BN_SNAKE ? M - 1 - r_ : r_;
         float g[8], va[8], vb[8];
         ld8(dout + r * ldd + col * 8, g);
@@ -324,7 +363,7 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply2_k(const bf16_t* __restrict__
     ldf8(coef_b + col * 8, b0);
     ldf8(coef_b + C + col * 8, b1);
     ldf8(coef_b + 2 * C + col * 8, b2);
-    for (int64_t row_ = (int64_t)blockIdx.x * rpb + rl; row_ < M; row_ += (int64_t)gridDim.x * rpb) {
+    for (int64_t row_ = rl < rpb ? (int64_t)blockIdx.x * rpb + rl : M; row_ < M; row_ += (int64_t)gridDim.x * rpb) {
         const int64_t row = MDE_BN_SNAKE ? M - 1 - row_ : row_;
         float g[8], va[8], vb[8], da[8], db[8];
         ld8(dout + row * ldd + col * 8, g);
@@ -344,8 +383,8 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply2_k(const bf16_t* __restrict__
 
 int check_site(const char* who, int64_t M, int C) {
     MDE_REQUIRE(M > 0 && C > 0, "%s: non-positive size", who);
-    MDE_REQUIRE(C % 8 == 0 && C <= MAXC && NT % (C / 8) == 0,
-                "%s: C=%d unsupported (need C %% 8 == 0, C <= %d, C/8 dividing %d)", who, C, MAXC, NT);
+    // (C / 8 need not divide the 256 threads: the threads past the last whole row group idle -- DenseNet's 48-channel growth)
+    MDE_REQUIRE(C % 8 == 0 && C <= MAXC, "%s: C=%d unsupported (need C %% 8 == 0, C <= %d)", who, C, MAXC);
     return MDE_OK;
 }
 bool al16(const void* p, int ld) { return ((uintptr_t)p % 16) == 0 && ld % 8 == 0; }
@@ -391,6 +430,25 @@ extern "C" int mde_bn_finalize(float* part, int64_t M, int C, const float* gamma
     bn_finalize_k<<<mde_cdiv(C, 64), 64, 0, (hipStream_t)stream>>>(part, M, C, gamma, beta, running_mean, running_var,
                                                                  momentum, eps, scale, shift, save_mean, save_rstd);
     MDE_LAUNCH_CHECK("bn_finalize_k");
+    return MDE_OK;
+}
+
+extern "C" int mde_bn_moments(float* part, int64_t M, int C, float* mean, float* var, void* stream) {
+    MDE_REQUIRE(part && mean && var && M > 0 && C > 0, "mde_bn_moments: bad argument");
+    bn_moments_k<<<mde_cdiv(C, 64), 64, 0, (hipStream_t)stream>>>(part, M, C, mean, var);
+    MDE_LAUNCH_CHECK("bn_moments_k");
+    return MDE_OK;
+}
+
+extern "C" int mde_bn_finalize_moments(const float* mean, const float* var, int64_t M, int C, const float* gamma, const float* beta,
+                                       float* running_mean, float* running_var, float momentum, float eps, float* scale,
+                                       float* shift, float* save_mean, float* save_rstd, void* stream) {
+    MDE_REQUIRE(mean && var && gamma && beta && scale && shift && save_mean && save_rstd, "mde_bn_finalize_moments: null argument");
+    MDE_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "mde_bn_finalize_moments: running stats must come in pairs");
+    MDE_REQUIRE(M > 0 && C > 0, "mde_bn_finalize_moments: non-positive size");
+    bn_finalize_moments_k<<<mde_cdiv(C, 64), 64, 0, (hipStream_t)stream>>>(mean, var, M, C, gamma, beta, running_mean, running_var,
+                                                                         momentum, eps, scale, shift, save_mean, save_rstd);
+    MDE_LAUNCH_CHECK("bn_finalize_moments_k");
     return MDE_OK;
 }
 

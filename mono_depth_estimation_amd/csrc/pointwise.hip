@@ -835,3 +835,148 @@ extern "C" int mde_pack_grouped(const float* src, void* fwd, void* dgrad, int O,
     MDE_LAUNCH_CHECK("pack_grouped_k");
     return MDE_OK;
 }
+
+// ------------------------------------------------------------------ BTS: plane coefficients -> local planar guidance depth
+// (Bts.py:105-122 reduction_1x1's tail, :228-231 F.normalize, :124-146 local_planar_guidance, /max_depth)
+namespace {
+
+struct Plane { float s0, s1, s2, st, ct, sp, cp, n[3], r, dist; };
+__device__ __forceinline__ Plane plane_of(const bf16_t* x, float max_depth) {
+    Plane p;
+    p.s0 = 1.f / (1.f + expf(-(float)x[0]));
+    p.s1 = 1.f / (1.f + expf(-(float)x[1]));
+    p.s2 = 1.f / (1.f + expf(-(float)x[2]));
+    const float theta = p.s0 * 1.0471975511965976f, phi = p.s1 * 6.283185307179586f;
+    sincosf(theta, &p.st, &p.ct);
+    sincosf(phi, &p.sp, &p.cp);
+    const float n0 = p.st * p.cp, n1 = p.st * p.sp, n2 = p.ct;
+    p.r = fmaxf(sqrtf(n0 * n0 + n1 * n1 + n2 * n2), 1e-12f);
+    p.n[0] = n0 / p.r; p.n[1] = n1 / p.r; p.n[2] = n2 / p.r;
+    p.dist = p.s2 * max_depth;
+    return p;
+}
+
+// x: bf16 [N][h][w][ldx] (channels 0..2);  out: fp32 [N][h*up][w*up] = dist / (n1 u + n2 v + n3) / max_depth
+__global__ __launch_bounds__(NT) void plane_depth_fwd_k(const bf16_t* __restrict__ x, int ldx, float* __restrict__ out, int N, int h, int w,
+                                                        int up, float max_depth) {
+    const int64_t total = (int64_t)N * h * w * up;          // one thread per (plane pixel, sub-row): `up` consecutive outputs
+    const int W = w * up, H = h * up;
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
+        const int a = (int)(i % up);
+        int64_t p = i / up;
+        const int j = (int)(p % w); p /= w;
+        const int ii = (int)(p % h);
+        const int64_t n = p / h;
+        const Plane pl = plane_of(x + ((n * h + ii) * (int64_t)w + j) * ldx, max_depth);
+        const float v = ((float)a - (float)(up - 1) * 0.5f) / (float)up;
+        float* o = out + (n * H + (int64_t)ii * up + a) * W + (int64_t)j * up;
+        for (int b = 0; b < up; ++b) {
+            const float u = ((float)b - (float)(up - 1) * 0.5f) / (float)up;
+            o[b] = pl.dist / (pl.n[0] * u + pl.n[1] * v + pl.n[2]) / max_depth;
+        }
+    }
+}
+
+// dx[n][i][j][0..2] from dout fp32 [N][H][W]; channels 3..7 of the 16-byte chunk are written as zero
+__global__ __launch_bounds__(NT) void plane_depth_bwd_k(const bf16_t* __restrict__ x, int ldx, const float* __restrict__ dout,
+                                                        bf16_t* __restrict__ dx, int lddx, int N, int h, int w, int up, float max_depth) {
+    const int64_t total = (int64_t)N * h * w;
+    const int W = w * up, H = h * up;
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
+        int64_t p = i;
+        const int j = (int)(p % w); p /= w;
+        const int ii = (int)(p % h);
+        const int64_t n = p / h;
+        const Plane pl = plane_of(x + i * ldx, max_depth);
+        float dn[3] = {0.f, 0.f, 0.f}, ddist = 0.f;
+        for (int a = 0; a < up; ++a) {
+            const float v = ((float)a - (float)(up - 1) * 0.5f) / (float)up;
+            const float* g = dout + (n * H + (int64_t)ii * up + a) * W + (int64_t)j * up;
+            for (int b = 0; b < up; ++b) {
+                const float u = ((float)b - (float)(up - 1) * 0.5f) / (float)up;
+                const float den = pl.n[0] * u + pl.n[1] * v + pl.n[2];
+                const float go = g[b] / max_depth;
+                ddist += go / den;
+                const float dden = -go * pl.dist / (den * den);
+                dn[0] += dden * u;
+                dn[1] += dden * v;
+                dn[2] += dden;
+            }
+        }
+        // F.normalize: d raw = (d unit - unit (unit . d unit)) / r
+        const float dot = pl.n[0] * dn[0] + pl.n[1] * dn[1] + pl.n[2] * dn[2];
+        const float r0 = (dn[0] - pl.n[0] * dot) / pl.r, r1 = (dn[1] - pl.n[1] * dot) / pl.r, r2 = (dn[2] - pl.n[2] * dot) / pl.r;
+        const float dtheta = r0 * pl.ct * pl.cp + r1 * pl.ct * pl.sp - r2 * pl.st;
+        const float dphi = -r0 * pl.st * pl.sp + r1 * pl.st * pl.cp;
+        bf16x8_t o;
+        o[0] = (bf16_t)(dtheta * 1.0471975511965976f * pl.s0 * (1.f - pl.s0));
+        o[1] = (bf16_t)(dphi * 6.283185307179586f * pl.s1 * (1.f - pl.s1));
+        o[2] = (bf16_t)(ddist * max_depth * pl.s2 * (1.f - pl.s2));
+#pragma unroll
+        for (int e = 3; e < 8; ++e) o[e] = (bf16_t)0.f;
+        *reinterpret_cast<bf16x8_t*>(dx + i * lddx) = o;
+    }
+}
+
+// One-channel fp32 map [N][H][W] <-> one bf16 channel of an NHWC tensor [N][H/step][W/step][ld] (F.interpolate(nearest,
+// scale 1/step) picks source pixel (step*y, step*x): Bts.py:234,247; torch.cat into a wider tensor: :238,251,263)
+__global__ __launch_bounds__(NT) void map_to_slot_k(const float* __restrict__ src, bf16_t* __restrict__ dst, int ld, int N, int H, int W, int step) {
+    const int h = H / step, w = W / step;
+    const int64_t total = (int64_t)N * h * w;
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
+        int64_t p = i;
+        const int x = (int)(p % w); p /= w;
+        const int y = (int)(p % h);
+        const int64_t n = p / h;
+        dst[i * ld] = (bf16_t)src[(n * H + (int64_t)y * step) * W + (int64_t)x * step];
+    }
+}
+__global__ __launch_bounds__(NT) void slot_to_map_add_k(const bf16_t* __restrict__ dslot, int ld, float* __restrict__ dsrc, int N, int H, int W,
+                                                        int step) {
+    const int h = H / step, w = W / step;
+    const int64_t total = (int64_t)N * h * w;
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
+        int64_t p = i;
+        const int x = (int)(p % w); p /= w;
+        const int y = (int)(p % h);
+        const int64_t n = p / h;
+        dsrc[(n * H + (int64_t)y * step) * W + (int64_t)x * step] += (float)dslot[i * ld];
+    }
+}
+
+}  // namespace
+
+extern "C" int mde_plane_depth_fwd(const void* x, int ldx, float* out, int N, int h, int w, int up, float max_depth, void* stream) {
+    MDE_REQUIRE(x && out && N > 0 && h > 0 && w > 0 && up >= 1 && up <= 16 && ldx >= 8 && ldx % 8 == 0 && max_depth > 0.f,
+                "mde_plane_depth_fwd: bad argument (up=%d, ldx=%d)", up, ldx);
+    plane_depth_fwd_k<<<grid_flat((int64_t)N * h * w * up), NT, 0, (hipStream_t)stream>>>((const bf16_t*)x, ldx, out, N, h, w, up, max_depth);
+    MDE_LAUNCH_CHECK("plane_depth_fwd_k");
+    return MDE_OK;
+}
+
+extern "C" int mde_plane_depth_bwd(const void* x, int ldx, const float* dout, void* dx, int lddx, int N, int h, int w, int up, float max_depth,
+                                   void* stream) {
+    MDE_REQUIRE(x && dout && dx && N > 0 && h > 0 && w > 0 && up >= 1 && up <= 16 && ldx >= 8 && ldx % 8 == 0 && lddx >= 8 &&
+                    lddx % 8 == 0 && PW_ALIGNED(dx) && max_depth > 0.f,
+                "mde_plane_depth_bwd: bad argument (up=%d, ldx=%d, lddx=%d)", up, ldx, lddx);
+    plane_depth_bwd_k<<<grid_flat((int64_t)N * h * w), NT, 0, (hipStream_t)stream>>>((const bf16_t*)x, ldx, dout, (bf16_t*)dx, lddx, N, h, w, up,
+                                                                                   max_depth);
+    MDE_LAUNCH_CHECK("plane_depth_bwd_k");
+    return MDE_OK;
+}
+
+extern "C" int mde_map_to_slot(const float* src, void* dst, int ld, int N, int H, int W, int step, void* stream) {
+    MDE_REQUIRE(src && dst && N > 0 && H > 0 && W > 0 && step >= 1 && H % step == 0 && W % step == 0 && ld > 0,
+                "mde_map_to_slot: bad argument (H=%d, W=%d, step=%d)", H, W, step);
+    map_to_slot_k<<<grid_flat((int64_t)N * (H / step) * (W / step)), NT, 0, (hipStream_t)stream>>>(src, (bf16_t*)dst, ld, N, H, W, step);
+    MDE_LAUNCH_CHECK("map_to_slot_k");
+    return MDE_OK;
+}
+
+extern "C" int mde_slot_to_map_add(const void* dslot, int ld, float* dsrc, int N, int H, int W, int step, void* stream) {
+    MDE_REQUIRE(dslot && dsrc && N > 0 && H > 0 && W > 0 && step >= 1 && H % step == 0 && W % step == 0 && ld > 0,
+                "mde_slot_to_map_add: bad argument (H=%d, W=%d, step=%d)", H, W, step);
+    slot_to_map_add_k<<<grid_flat((int64_t)N * (H / step) * (W / step)), NT, 0, (hipStream_t)stream>>>((const bf16_t*)dslot, ld, dsrc, N, H, W, step);
+    MDE_LAUNCH_CHECK("slot_to_map_add_k");
+    return MDE_OK;
+}

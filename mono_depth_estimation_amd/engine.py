@@ -38,9 +38,9 @@ class Act:
         if parent is None:
             self.ld = C
             self.t = torch.empty(N, H, W, C, dtype=torch.bfloat16, device=dev)
-        else:
+        else:                                             # (c0 is absolute: the channel offset inside the ROOT tensor)
             self.ld = parent.ld
-            self.t = parent.t[..., c0:c0 + C]
+            self.t = parent.t[..., c0 - parent.c0:c0 - parent.c0 + C]
         self._g = None
         self._gw = False         # gradient already written during the current backward (slices share their root's flag)
 
@@ -61,7 +61,9 @@ class Act:
 
     @property
     def nbytes(self):            # bytes addressable from the first element
-        root = self if self.parent is None else self.parent
+        root = self
+        while root.parent is not None:
+            root = root.parent
         return (root.t.numel() - self.c0) * 2
 
     def slice(self, c0, C):
@@ -114,6 +116,15 @@ class BNSite:
             mom = self.bn.momentum if self.bn.momentum is not None else 0.1
             ops.bn_finalize(self.part, M, self.C, self.gamma, self.beta, self.rmean, self.rvar, mom, self.eps,
                             self.scale, self.shift, self.smean, self.srstd)
+        else:
+            ops.bn_eval_scale_shift(self.gamma, self.beta, self.rmean, self.rvar, self.eps, self.C, self.scale, self.shift)
+
+    def finalize_moments(self, mean, var, M, train):
+        """As finalize, from batch moments another site already reduced (DenseNet: graph.PrefixBN)."""
+        if train:
+            mom = self.bn.momentum if self.bn.momentum is not None else 0.1
+            ops.bn_finalize_moments(mean, var, M, self.C, self.gamma, self.beta, self.rmean, self.rvar, mom, self.eps,
+                                    self.scale, self.shift, self.smean, self.srstd)
         else:
             ops.bn_eval_scale_shift(self.gamma, self.beta, self.rmean, self.rvar, self.eps, self.C, self.scale, self.shift)
 
@@ -611,6 +622,12 @@ class EngineCore:
         bo, bv = self.b_off[id(rm0)], self.b_off[id(rv0)]
         return BNSite(self, C, self.P[po:po + C], self.P[pb:pb + C], po, pb,
                       self.B[bo:bo + C], self.B[bv:bv + C], bns[0], bns[0].eps)
+
+    def _site_chunk(self, bn, c0, cn):
+        """A BN site over channels [c0, c0 + cn) of one BatchNorm (sites wider than the kernels' 2048 channels are split)."""
+        po, pb = self.p_off[id(bn.weight)] + c0, self.p_off[id(bn.bias)] + c0
+        bo, bv = self.b_off[id(bn.running_mean)] + c0, self.b_off[id(bn.running_var)] + c0
+        return BNSite(self, cn, self.P[po:po + cn], self.P[pb:pb + cn], po, pb, self.B[bo:bo + cn], self.B[bv:bv + cn], bn, bn.eps)
 
     def _ksplit(self, pixels, rows, cols, ntaps):
         ba, bb = (128 if rows % 128 == 0 else 64), (128 if cols % 128 == 0 else 64)

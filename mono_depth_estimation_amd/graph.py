@@ -221,11 +221,12 @@ class BN(Op):
 
     def bwd(self):
         c, o, res = self.c, self.out, self.res
-        assert not c.gw, "a pre-BN tensor has one consumer"
-        c.gw = True
+        acc = _take(c)
         if res is None:
-            self.site.backward(o.g, o, c, self.relu, c.g, mask_from_x=self.relu)
-        elif self.res_site is None:
+            self.site.backward(o.g, o, c, self.relu, c.g, accumulate=acc, mask_from_x=self.relu)
+            return
+        assert not acc, "a pre-BN tensor joined with a residual has one consumer"
+        if self.res_site is None:
             assert not res.gw, "identity-residual gradient must be the first writer"
             res.gw = True
             self.site.backward(o.g, o, c, self.relu, c.g, dres=res.g, relu_bits=self.bits)
@@ -397,6 +398,246 @@ class ToNCHW(Op):
         ops.to_nchw_act_bwd(self.douts[0], self.y, x.g, _ldg(x), dbias, x.N, x.H * x.W, self.C, self.act, self.scale)
 
 
+# ---------------------------------------------------------------------------------------------- ops of the BTS / DenseNet plans
+class ImageStem(Op):
+    """A 7x7/2 stem with any number of output channels (densenet161's conv0: 96, Bts.py:289): the fp32 NCHW image goes to
+    NHWC bf16 with its 3 channels zero-padded to 8, the 49 taps run as two launches of the GEMM kernel (32 + 17 taps, the
+    second accumulating), the BatchNorm statistics come from a stand-alone reduction.  No input gradient."""
+
+    def __init__(self, eng, conv, site, N, H, W):
+        self.eng, self.site = eng, site
+        self.w = eng._conv([conv.weight], need_dgrad=False)
+        O, Cp = self.w.O, self.w.I
+        assert Cp == 8 and conv.kernel_size == (7, 7) and conv.stride == (2, 2)
+        H2, W2 = ops.out_size(H, 7, 2, 3), ops.out_size(W, 7, 2, 3)
+        self.xin = Act(eng.dev, N, H, W, Cp)
+        self.out = Act(eng.dev, N, H2, W2, O)
+        taps = [(i - 3, j - 3, i * 7 + j) for i in range(7) for j in range(7)]
+        ks = eng._ksplit(N * H2 * W2, O, Cp, 32)
+        self.fd, self.wd = [], []
+        for part, acc in ((taps[:32], False), (taps[32:], True)):
+            self.fd.append(ops.conv_desc(N, H, W, Cp, Cp, self.xin.nbytes, H2, W2, 2, 2, part, 49, H2, W2, O, ncols=O, accumulate=acc))
+            self.wd.append(ops.wgrad_desc(N, H2, W2, O, O, self.out.nbytes, H, W, Cp, Cp, self.xin.nbytes, 2, 2, part, 49, False, ks))
+        self.x = None
+
+    def acts(self):
+        return (self.out,)
+
+    def fwd(self, train):
+        ops.nchw_to_nhwc_bf16_pad(self.x, self.xin.t, self.xin.C)
+        for d in self.fd:
+            ops.conv_gemm(d, self.xin.t, self.w.wf, self.out.t)
+        if train:
+            ops.bn_stats(self.out.t, self.out.M, self.out.C, self.out.ld, self.site.part)
+
+    def bwd(self):
+        for d in self.wd:
+            self.eng.wgrad(d, self.out.g, self.xin.t, self.w.dw)
+
+
+class MaxPool(Op):
+    """nn.MaxPool2d(3, 2, 1) on a contiguous NHWC tensor."""
+
+    def __init__(self, eng, x):
+        assert x.parent is None
+        self.x = x
+        H2, W2 = ops.out_size(x.H, 3, 2, 1), ops.out_size(x.W, 3, 2, 1)
+        self.out = Act(eng.dev, x.N, H2, W2, x.C)
+        self.idx = torch.empty(x.N, H2, W2, x.C, dtype=torch.uint8, device=eng.dev)
+
+    def acts(self):
+        return (self.out,)
+
+    def fwd(self, train):
+        x = self.x
+        ops.maxpool_fwd(x.t, self.out.t, self.idx, x.N, x.H, x.W, x.C)
+
+    def bwd(self):
+        x = self.x
+        if _take(x):
+            raise NotImplementedError("MaxPool backward must be the first writer of its input's gradient")
+        ops.maxpool_bwd(self.out.g, self.idx, x.g, x.N, x.H, x.W, x.C)
+
+
+class Nearest2(Op):
+    """F.interpolate(scale_factor=2, mode='nearest') (Bts.py:77)."""
+
+    def __init__(self, eng, x):
+        self.x = x
+        self.out = Act(eng.dev, x.N, 2 * x.H, 2 * x.W, x.C)
+
+    def acts(self):
+        return (self.out,)
+
+    def fwd(self, train):
+        x, o = self.x, self.out
+        ops.nearest2_fwd(x.t, x.ld, o.t, o.ld, x.N, x.H, x.W, x.C)
+
+    def bwd(self):
+        x, o = self.x, self.out
+        ops.sum2x2(o.g, _ldg(o), x.g, _ldg(x), x.N, x.H, x.W, x.C, 1.0, _take(x))
+
+
+class AvgPool2(Op):
+    """nn.AvgPool2d(2, 2) (densenet transitions), writing `out` (a channel slice of the next block's tensor)."""
+
+    def __init__(self, eng, x, out=None):
+        self.x = x
+        self.out = out if out is not None else Act(eng.dev, x.N, x.H // 2, x.W // 2, x.C)
+        self.own_out = out is None
+        assert x.H % 2 == 0 and x.W % 2 == 0
+
+    def acts(self):
+        return (self.out,) if self.own_out else ()
+
+    def fwd(self, train):
+        x, o = self.x, self.out
+        ops.sum2x2(x.t, x.ld, o.t, o.ld, o.N, o.H, o.W, o.C, 0.25)
+
+    def bwd(self):
+        x, o = self.x, self.out
+        ops.spread2x2(o.g, _ldg(o), x.g, _ldg(x), o.N, o.H, o.W, o.C, 0.25, _take(x))
+
+
+class StatsPass(Op):
+    """Batch statistics of a tensor no conv epilogue produced (a BatchNorm after an ELU: Bts.py:209,215,219): one reduction
+    pass into the site's partial sums, training mode only."""
+
+    def __init__(self, eng, x, site):
+        self.x, self.site = x, site
+
+    def fwd(self, train):
+        if train:
+            x = self.x
+            ops.bn_stats(x.t, x.M, x.C, x.ld, self.site.part)
+
+    def bwd(self):
+        pass
+
+
+class Moments(Op):
+    """Batch mean / biased variance of `x` (channels [c0, c0 + x.C) of a DenseNet block) into the block's moment vectors:
+    from `part` if a conv epilogue already accumulated the sums, else by a reduction pass.  Training mode only."""
+
+    def __init__(self, eng, x, mean, var, c0, part=None):
+        self.x, self.mean, self.var = x, mean[c0:c0 + x.C], var[c0:c0 + x.C]
+        self.part, self.own = (part, False) if part is not None else (ops.new_stat_buffer(x.C, eng.dev), True)
+
+    def fwd(self, train):
+        if train:
+            x = self.x
+            if self.own:
+                ops.bn_stats(x.t, x.M, x.C, x.ld, self.part)
+            ops.bn_moments(self.part, x.M, x.C, self.mean, self.var)
+
+    def bwd(self):
+        pass
+
+
+class PrefixBN(Op):
+    """BatchNorm (+ ReLU) over the first `x.C` channels of a concatenation whose batch moments are already known (DenseNet's
+    norm1 / transition norm / norm5: torchvision densenet161 as Bts.py:283-292 uses it).  Output is its own tensor; the input
+    gradient ACCUMULATES into the concatenation's gradient (every layer of the block adds its share).  Sites wider than the
+    kernels' 2048 channels run as equal channel chunks."""
+
+    def __init__(self, eng, x, bn, mean, var, relu=True, out=None):
+        self.eng, self.x, self.relu = eng, x, relu
+        self.out = out if out is not None else Act(eng.dev, x.N, x.H, x.W, x.C)
+        self.own_out = out is None
+        C = x.C
+        nch = -(-C // 2048)
+        step = -(-(C // 8) // nch) * 8
+        self.chunks = []
+        for c0 in range(0, C, step):
+            cn = min(step, C - c0)
+            self.chunks.append((eng._site_chunk(bn, c0, cn), x.slice(c0, cn), self.out.slice(c0, cn), mean[c0:c0 + cn], var[c0:c0 + cn]))
+
+    def acts(self):
+        return (self.out,) if self.own_out else ()
+
+    def fwd(self, train):
+        for s, xs, os_, mean, var in self.chunks:
+            s.finalize_moments(mean, var, xs.M, train)
+            ops.bn_apply(xs.t, xs.ld, s.scale, s.shift, os_.t, os_.ld, xs.M, xs.C, self.relu)
+
+    def bwd(self):
+        acc = _take(self.x)
+        for s, xs, os_, _, _ in self.chunks:
+            s.backward(os_.g, os_, xs, self.relu, xs.g, accumulate=acc, mask_from_x=self.relu)
+
+
+class F32Map:
+    """A one-channel fp32 map [N][1][H][W] with a gradient that every consumer ADDS into (zeroed, or set to the caller's
+    output gradient, at the start of a backward pass)."""
+
+    def __init__(self, dev, N, H, W):
+        self.N, self.H, self.W = N, H, W
+        self.t = torch.empty(N, 1, H, W, device=dev)
+        self.g = torch.zeros(N, 1, H, W, device=dev)
+
+
+class PlaneDepth(Op):
+    """reduction_1x1's plane parameters -> local planar guidance depth / max_depth (Bts.py:105-146,228-232), an output head."""
+
+    def __init__(self, eng, x, up, max_depth):
+        self.x, self.up, self.max_depth = x, up, max_depth
+        self.map = F32Map(eng.dev, x.N, x.H * up, x.W * up)
+        self.outputs, self.douts = (self.map.t,), [None]
+
+    def fwd(self, train):
+        x = self.x
+        ops.plane_depth_fwd(x.t, x.ld, self.map.t, x.N, x.H, x.W, self.up, self.max_depth)
+
+    def bwd(self):
+        x = self.x
+        assert not x.gw
+        x.gw = True
+        if self.douts[0] is not None:
+            self.map.g.add_(self.douts[0])
+        ops.plane_depth_bwd(x.t, x.ld, self.map.g, x.g, _ldg(x), x.N, x.H, x.W, self.up, self.max_depth)
+        self.map.g.zero_()
+
+
+class MapSlot(Op):
+    """torch.cat of a one-channel fp32 map into channel `ch` of a wider NHWC tensor, after F.interpolate(nearest,
+    1/step) when step > 1 (Bts.py:234,238,247,251,263)."""
+
+    def __init__(self, eng, m, cat, ch, step=1):
+        self.m, self.cat, self.ch, self.step = m, cat, ch, step
+        assert (cat.H * step, cat.W * step) == (m.H, m.W)
+
+    def fwd(self, train):
+        m, cat = self.m, self.cat
+        ops.map_to_slot(m.t, cat.t[..., self.ch:], cat.ld, m.N, m.H, m.W, self.step)
+
+    def bwd(self):
+        m, cat = self.m, self.cat
+        ops.slot_to_map_add(cat.g[..., self.ch:], _ldg(cat), m.g, m.N, m.H, m.W, self.step)
+
+
+class SigmoidMap(Op):
+    """reduction_1x1(is_final=True)'s tail (Bts.py:95-97,262): sigmoid of a one-channel conv output as an fp32 map that is
+    both an output head and a concatenated feature."""
+
+    def __init__(self, eng, x):
+        self.x = x
+        self.map = F32Map(eng.dev, x.N, x.H, x.W)
+        self.outputs, self.douts = (self.map.t,), [None]
+
+    def fwd(self, train):
+        x = self.x
+        ops.to_nchw_act_fwd(x.t, x.ld, None, self.map.t, x.N, x.H * x.W, 1, "sigmoid", 1.0)
+
+    def bwd(self):
+        x = self.x
+        assert not x.gw
+        x.gw = True
+        if self.douts[0] is not None:
+            self.map.g.add_(self.douts[0])
+        ops.to_nchw_act_bwd(self.map.g, self.map.t, x.g, _ldg(x), None, x.N, x.H * x.W, 1, "sigmoid", 1.0)
+        self.map.g.zero_()
+
+
 # ---------------------------------------------------------------------------------------------- the tape
 class TapeEngine(EngineCore):
     """Launch plan of one input shape: subclasses fill `self.tape` in `_plan` and name the image op (`self.stem`) and the
@@ -455,6 +696,9 @@ class TapeEngine(EngineCore):
         gradients into store.Gcur."""
         for a in self._acts:
             a.gw = False
+        for a in self._bufs:           # concatenation targets: consumers may cover only part of the channels, so every
+            a.g.zero_()                # writer accumulates onto a zeroed gradient
+            a.gw = True
         i = 0
         for h in self.heads:
             for k in range(len(h.outputs)):

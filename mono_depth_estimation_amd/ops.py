@@ -269,6 +269,15 @@ def bn_finalize(part, M, C_, gamma, beta, rmean, rvar, momentum, eps, scale, shi
                                       _p(scale), _p(shift), _p(smean), _p(srstd), _stream()), "mde_bn_finalize")
 
 
+def bn_moments(part, M, C_, mean, var):
+    check(_lib.load().mde_bn_moments(_p(part), M, C_, _p(mean), _p(var), _stream()), "mde_bn_moments")
+
+
+def bn_finalize_moments(mean, var, M, C_, gamma, beta, rmean, rvar, momentum, eps, scale, shift, smean, srstd):
+    check(_lib.load().mde_bn_finalize_moments(_p(mean), _p(var), M, C_, _p(gamma), _p(beta), _p(rmean), _p(rvar), momentum, eps,
+                                              _p(scale), _p(shift), _p(smean), _p(srstd), _stream()), "mde_bn_finalize_moments")
+
+
 def bn_eval_scale_shift(gamma, beta, rmean, rvar, eps, C_, scale, shift):
     check(_lib.load().mde_bn_eval_scale_shift(_p(gamma), _p(beta), _p(rmean), _p(rvar), eps, C_, _p(scale), _p(shift),
                                               _stream()), "mde_bn_eval_scale_shift")
@@ -418,6 +427,22 @@ def to_nchw_act_fwd(x, ldx, bias, out, N, HW, C_, act, scale=1.0):
 def to_nchw_act_bwd(dout, out, dx, lddx, dbias, N, HW, C_, act, scale=1.0):
     check(_lib.load().mde_to_nchw_act_bwd(_p(dout), _p(out), _p(dx), lddx, _p(dbias), N, HW, C_, ACT[act], scale, _stream()),
           "mde_to_nchw_act_bwd")
+
+
+def plane_depth_fwd(x, ldx, out, N, h, w, up, max_depth):
+    check(_lib.load().mde_plane_depth_fwd(_p(x), ldx, _p(out), N, h, w, up, max_depth, _stream()), "mde_plane_depth_fwd")
+
+
+def plane_depth_bwd(x, ldx, dout, dx, lddx, N, h, w, up, max_depth):
+    check(_lib.load().mde_plane_depth_bwd(_p(x), ldx, _p(dout), _p(dx), lddx, N, h, w, up, max_depth, _stream()), "mde_plane_depth_bwd")
+
+
+def map_to_slot(src, dst, ld, N, H, W, step=1):
+    check(_lib.load().mde_map_to_slot(_p(src), _p(dst), ld, N, H, W, step, _stream()), "mde_map_to_slot")
+
+
+def slot_to_map_add(dslot, ld, dsrc, N, H, W, step=1):
+    check(_lib.load().mde_slot_to_map_add(_p(dslot), ld, _p(dsrc), N, H, W, step, _stream()), "mde_slot_to_map_add")
 
 
 def pack_grouped(src, fwd, dgrad, O, T, G):

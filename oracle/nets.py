@@ -170,6 +170,115 @@ def midas_forward(P, x, train, blocks=(3, 4, 23, 3), groups=32, momentum=None, q
     return torch.sigmoid(n.conv(y, o + "4"))
 
 
+# ---------------------------------------------------------------------------------------------- BTS (network/Bts.py)
+def _bts_upconv(n, x, k):
+    """upconv.forward (Bts.py:76-80): nearest x2 -> 3x3 -> ELU."""
+    return n.q(F.elu(n.conv(n.q(F.interpolate(x, scale_factor=2, mode="nearest")), k + ".conv", pad=1)))
+
+
+def _bts_atrous(n, x, k, dil, bn_first=True):
+    """atrous_conv.forward (Bts.py:51-66): [BN(eps 1.1e-5)] -> ReLU -> 1x1 -> BN -> ReLU -> dilated 3x3; momentum 0.01."""
+    k = k + ".atrous_conv."
+    if bn_first:
+        x = n.bn(x, k + "first_bn", 0.01, 1.1e-5)
+    x = n.q(F.relu(x))
+    x = n.q(F.relu(n.bn(n.conv(x, k + "aconv_sequence.1"), k + "aconv_sequence.2", 0.01)))
+    return n.conv(x, k + "aconv_sequence.4", pad=dil, dil=dil)
+
+
+def _bts_reduc(n, x, k, max_depth, final=False):
+    """reduction_1x1.forward (Bts.py:83-122): 1x1 + ELU halvings down to 8 channels, then 3 plane parameters -> (n1, n2, n3,
+    distance), or (final) one sigmoid channel."""
+    keys = sorted({kk[len(k) + 7:].split(".")[0] for kk in n.P if kk.startswith(k + ".reduc.inter_")}, key=lambda t: (-int(t.split("_")[1]), -int(t.split("_")[2])))
+    for name in keys:
+        x = n.q(F.elu(n.conv(x, k + ".reduc." + name + ".0")))
+    if final:
+        return torch.sigmoid(n.conv(x, k + ".reduc.final.0"))
+    return _plane_from_params(n.q(n.conv(x, k + ".reduc.plane_params")), max_depth)
+
+
+def _plane_from_params(x, max_depth):
+    """Bts.py:112-120: three conv channels -> (n1, n2, n3, distance)."""
+    theta = torch.sigmoid(x[:, 0]) * math.pi / 3
+    phi = torch.sigmoid(x[:, 1]) * math.pi * 2
+    dist = torch.sigmoid(x[:, 2]) * max_depth
+    return torch.stack([torch.sin(theta) * torch.cos(phi), torch.sin(theta) * torch.sin(phi), torch.cos(theta), dist], 1)
+
+
+def _bts_lpg(plane_eq, up):
+    """local_planar_guidance.forward (Bts.py:132-146) -> N x H*up x W*up."""
+    e = plane_eq.repeat_interleave(up, 2).repeat_interleave(up, 3)
+    N, _, H, W = e.shape
+    u = (torch.arange(W, dtype=torch.float32) % up - (up - 1) * 0.5) / up
+    v = (torch.arange(H, dtype=torch.float32) % up - (up - 1) * 0.5) / up
+    return e[:, 3] / (e[:, 0] * u.view(1, 1, W) + e[:, 1] * v.view(1, H, 1) + e[:, 2])
+
+
+def _bts_plane_depth(n, feat, k, up, max_depth):
+    r = _bts_reduc(n, feat, k, max_depth)
+    eq = torch.cat([F.normalize(r[:, :3], 2, 1), r[:, 3:4]], 1)
+    return _bts_lpg(eq, up).unsqueeze(1) / max_depth
+
+
+def densenet_features(n, x, pfx, blocks=(6, 12, 36, 24)):
+    """torchvision densenet161 `.features` walked the way Bts.py:309-321 does -> [relu0, pool0, transition1, transition2, norm5]."""
+    skips = []
+    y = n.q(F.relu(n.bn(n.conv(x, pfx + "conv0", 2, 3), pfx + "norm0")))
+    skips.append(y)
+    y = F.max_pool2d(y, 3, 2, 1)
+    skips.append(y)
+    for b, cnt in enumerate(blocks):
+        for i in range(cnt):
+            k = pfx + "denseblock%d.denselayer%d." % (b + 1, i + 1)
+            t = n.q(F.relu(n.bn(y, k + "norm1")))
+            t = n.q(F.relu(n.bn(n.conv(t, k + "conv1"), k + "norm2")))
+            y = torch.cat([y, n.conv(t, k + "conv2", pad=1)], 1)
+        if b < len(blocks) - 1:
+            k = pfx + "transition%d." % (b + 1)
+            y = n.q(F.avg_pool2d(n.conv(n.q(F.relu(n.bn(y, k + "norm"))), k + "conv"), 2, 2))
+            if b < 2:
+                skips.append(y)
+    skips.append(n.bn(y, pfx + "norm5"))
+    return skips
+
+
+def bts_forward(P, x, train, max_depth=10.0, momentum=None, q=None):
+    """BtsModel.forward (Bts.py:324-333) with the densenet161_bts encoder -> the 5-tuple of bts.forward (Bts.py:205-278);
+    dataset 'nyu', no image residuals."""
+    n = Net(P, train, q=q, momentum=momentum)
+    s0, s1, s2, s3, dense = densenet_features(n, x, "encoder.base_model.")
+    d = "decoder."
+    bnk = lambda t, k: n.bn(t, d + k, 0.01, 1.1e-5)
+    dense = n.q(F.relu(dense))
+    up5 = n.q(bnk(_bts_upconv(n, dense, d + "upconv5"), "bn5"))
+    i5 = n.q(F.elu(n.conv(torch.cat([up5, s3], 1), d + "conv5.0", pad=1)))
+    up4 = n.q(bnk(_bts_upconv(n, i5, d + "upconv4"), "bn4"))
+    cat4 = torch.cat([up4, s2], 1)
+    i4 = n.q(bnk(n.q(F.elu(n.conv(cat4, d + "conv4.0", pad=1))), "bn4_2"))
+    d3 = _bts_atrous(n, i4, d + "daspp_3", 3, bn_first=False)
+    c = torch.cat([cat4, d3], 1)
+    d6 = _bts_atrous(n, c, d + "daspp_6", 6)
+    c = torch.cat([c, d6], 1)
+    d12 = _bts_atrous(n, c, d + "daspp_12", 12)
+    c = torch.cat([c, d12], 1)
+    d18 = _bts_atrous(n, c, d + "daspp_18", 18)
+    c = torch.cat([c, d18], 1)
+    d24 = _bts_atrous(n, c, d + "daspp_24", 24)
+    feat = n.q(F.elu(n.conv(torch.cat([i4, d3, d6, d12, d18, d24], 1), d + "daspp_conv.0", pad=1)))
+    d8 = _bts_plane_depth(n, feat, d + "reduc8x8", 8, max_depth)
+    up3 = n.q(bnk(_bts_upconv(n, feat, d + "upconv3"), "bn3"))
+    i3 = n.q(F.elu(n.conv(torch.cat([up3, s1, F.interpolate(d8, scale_factor=0.25, mode="nearest")], 1), d + "conv3.0", pad=1)))
+    d4 = _bts_plane_depth(n, i3, d + "reduc4x4", 4, max_depth)
+    up2 = n.q(bnk(_bts_upconv(n, i3, d + "upconv2"), "bn2"))
+    i2 = n.q(F.elu(n.conv(torch.cat([up2, s0, F.interpolate(d4, scale_factor=0.5, mode="nearest")], 1), d + "conv2.0", pad=1)))
+    d2 = _bts_plane_depth(n, i2, d + "reduc2x2", 2, max_depth)
+    up1 = _bts_upconv(n, i2, d + "upconv1")
+    r1 = _bts_reduc(n, up1, d + "reduc1x1", max_depth, final=True)
+    i1 = n.q(F.elu(n.conv(torch.cat([up1, r1, d2, d4, d8], 1), d + "conv1.0", pad=1)))
+    final = max_depth * torch.sigmoid(n.conv(i1, d + "get_depth.0", pad=1))
+    return d8, d4, d2, r1, final
+
+
 def leaf_state(sd, requires_grad=False):
     """A state dict as independent fp32 leaves (parameters optionally requiring grad; buffers never)."""
     out = {}

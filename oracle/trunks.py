@@ -70,3 +70,62 @@ def resnext101_32x8d():
 
 def resnext50_32x4d():
     return ResNeXt([3, 4, 6, 3], 32, 4)
+
+
+# ---------------------------------------------------------------------------------------------- DenseNet-161 (Bts.py:283-292)
+class _DenseLayer(nn.Module):
+    """torchvision.models.densenet._DenseLayer: BN -> ReLU -> 1x1 (bn_size * growth) -> BN -> ReLU -> 3x3 (growth) on the
+    concatenation of everything the block has produced so far."""
+
+    def __init__(self, cin, growth, bn_size):
+        super().__init__()
+        self.norm1 = nn.BatchNorm2d(cin)
+        self.relu1 = nn.ReLU(inplace=True)
+        self.conv1 = nn.Conv2d(cin, bn_size * growth, 1, bias=False)
+        self.norm2 = nn.BatchNorm2d(bn_size * growth)
+        self.relu2 = nn.ReLU(inplace=True)
+        self.conv2 = nn.Conv2d(bn_size * growth, growth, 3, padding=1, bias=False)
+
+    def forward(self, feats):
+        x = torch.cat(feats, 1)
+        return self.conv2(self.relu2(self.norm2(self.conv1(self.relu1(self.norm1(x))))))
+
+
+class _DenseBlock(nn.ModuleDict):
+    def __init__(self, n, cin, growth, bn_size):
+        super().__init__()
+        for i in range(n):
+            self.add_module("denselayer%d" % (i + 1), _DenseLayer(cin + i * growth, growth, bn_size))
+
+    def forward(self, x):
+        feats = [x]
+        for layer in self.values():
+            feats.append(layer(feats))
+        return torch.cat(feats, 1)
+
+
+class DenseNet(nn.Module):
+    """torchvision.models.densenet.DenseNet `.features` (the classifier is never used by Bts.py)."""
+
+    def __init__(self, growth=48, blocks=(6, 12, 36, 24), init=96, bn_size=4):
+        super().__init__()
+        feats = [("conv0", nn.Conv2d(3, init, 7, 2, 3, bias=False)), ("norm0", nn.BatchNorm2d(init)), ("relu0", nn.ReLU(inplace=True)),
+                 ("pool0", nn.MaxPool2d(3, 2, 1))]
+        c = init
+        for i, n in enumerate(blocks):
+            feats.append(("denseblock%d" % (i + 1), _DenseBlock(n, c, growth, bn_size)))
+            c += n * growth
+            if i != len(blocks) - 1:
+                feats.append(("transition%d" % (i + 1), nn.Sequential(OrderedDict([
+                    ("norm", nn.BatchNorm2d(c)), ("relu", nn.ReLU(inplace=True)), ("conv", nn.Conv2d(c, c // 2, 1, bias=False)),
+                    ("pool", nn.AvgPool2d(2, 2))]))))
+                c //= 2
+        feats.append(("norm5", nn.BatchNorm2d(c)))
+        self.features = nn.Sequential(OrderedDict(feats))
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight)
+
+
+def densenet161(pretrained=False):
+    return DenseNet(48, (6, 12, 36, 24), 96)

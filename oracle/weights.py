@@ -149,3 +149,22 @@ def midas_fixture_state(model, seed):
     sd[k] = (sd[k] * 0.01).to(torch.bfloat16).to(torch.float32)
     model.load_state_dict(sd)
     return sd
+
+
+def bts_fixture_state(model, seed):
+    """BTS parity fixture: net_conditioned_state (DenseNet has no residual sums to damp) with the three kinds of head conv
+    scaled down so their sigmoids are not saturated (He-scale weights on the BN-free ELU chains give pre-activations of
+    order 100): plane_params x 0.02, reduc1x1's final x 0.05, get_depth x 0.02.  Even so this net — 84 BatchNorms that each
+    re-normalise the concatenation, local planar guidance dividing by a plane-ray product — amplifies storage rounding:
+    rounding the fp32 oracle's activations to bf16 moves its five outputs by 3-10 %; the GPU tests bound the HIP path's
+    deviation by that noise."""
+    sd = net_conditioned_state(model, seed)
+    for k in sd:
+        if k.endswith("plane_params.weight"):
+            sd[k] = (sd[k] * 0.02).to(torch.bfloat16).to(torch.float32)
+        if k.endswith("reduc.final.0.weight"):
+            sd[k] = (sd[k] * 0.05).to(torch.bfloat16).to(torch.float32)
+    k = "decoder.get_depth.0.weight"
+    sd[k] = (sd[k] * 0.02).to(torch.bfloat16).to(torch.float32)
+    model.load_state_dict(sd)
+    return sd

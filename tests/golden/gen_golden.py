@@ -42,6 +42,8 @@ def _import_reference():
     tvm = types.ModuleType("torchvision.models")
     for n in (18, 34, 50, 101, 152):
         tvm.__dict__["resnet%d" % n] = (lambda n: (lambda pretrained=False: ofcrn.ResNetTrunk(n)))(n)
+    from oracle import trunks
+    tvm.densenet161 = trunks.densenet161
     tv.models = tvm
     sys.modules.setdefault("torchvision", tv)
     sys.modules.setdefault("torchvision.models", tvm)
@@ -547,6 +549,43 @@ def gen_midas_net(criteria):
         len(out["keys"]), sum(p.numel() for p in ref.parameters()), out["eval_out"].min(), out["eval_out"].max(), float(loss)))
 
 
+BTS_SIZE = (64, 96)
+
+
+def gen_bts_net(criteria):
+    """C2: the reference's own network/Bts.py (BtsModel: encoder's feature walk, bts decoder with upconv / atrous_conv /
+    reduction_1x1 / local_planar_guidance) over the densenet161 stand-in (oracle/trunks.py, handed over as
+    torchvision.models.densenet161).  Loss: criteria.silog_loss(0.85) on the final depth."""
+    from network import Bts
+    torch.manual_seed(0)
+    ref = Bts.BtsModel(bts_size=512, max_depth=10, out_channels=1, encoder_version="densenet161_bts")
+    W.bts_fixture_state(ref, 47)
+    H, Wd = BTS_SIZE
+    rgb, tgt = W.synthetic_batch(47, 2, H, Wd)
+    W.calibrate_running_stats(ref, rgb)
+    out = {"keys": np.array(list(ref.state_dict().keys()))}
+    names = ("d8", "d4", "d2", "r1", "final")
+    ref.eval()
+    with torch.no_grad():
+        ys = ref(rgb)
+    for nme, y in zip(names, ys):
+        out["eval_" + nme] = _np(y)
+    ref.train()
+    ys = ref(rgb)
+    loss = criteria.silog_loss(0.85)(ys[4], tgt * 10.0)
+    loss.backward()
+    for nme, y in zip(names, ys):
+        out["train_" + nme] = _np(y)
+    out["train_loss"] = _np(loss)
+    out["grad_names"], out["grad_norms"] = _grad_norms(ref)
+    sd = ref.state_dict()
+    out["rm_norm5"] = _np(sd["encoder.base_model.norm5.running_mean"])
+    out["rv_bn4_2"] = _np(sd["decoder.bn4_2.running_var"])
+    np.savez_compressed(os.path.join(HERE, "bts_net.npz"), **out)
+    print("bts_net.npz: %d keys, %d params, eval final range %.4f..%.4f, train loss %.5f" % (
+        len(out["keys"]), sum(p.numel() for p in ref.parameters()), out["eval_final"].min(), out["eval_final"].max(), float(loss)))
+
+
 def main():
     torch.set_num_threads(8)
     criteria, metrics, FCRN = _import_reference()
@@ -572,6 +611,8 @@ def main():
         gen_vnl_net(criteria)
     if want("midas_net"):
         gen_midas_net(criteria)
+    if want("bts_net"):
+        gen_bts_net(criteria)
 
 
 if __name__ == "__main__":

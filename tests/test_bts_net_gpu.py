@@ -1,0 +1,194 @@
+"""End-to-end GPU parity of the HIP BTS network (mono_depth_estimation_amd.network.Bts.BtsModel) against the
+CPU oracle (oracle/nets.py: bts_forward, pinned bit-for-bit to the reference's own network/Bts.py by
+tests/golden/bts_net.npz), the plane-depth kernel against torch autograd, and configuration 3 at 16 x 3 x 480 x 640.
+
+This net amplifies storage rounding (84 BatchNorms that each re-normalise a concatenation; local planar guidance divides
+by a plane-ray product): rounding the fp32 ORACLE's own activations to bf16 moves its five outputs by `noise` = 3-10 %.
+Tolerances are relative to that: every output within 1.5 noise + 1e-2 of the oracle and of the reference, train-mode SILog
+within 2 |loss(rounding oracle) - loss(reference)| + 1 %, gradient norms within 25 % for 85 % of the tensors."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import losses as L
+from oracle import nets
+from oracle import weights as W
+
+pytestmark = pytest.mark.gpu
+SIZE = (64, 96)
+NAMES = ("d8", "d4", "d2", "r1", "final")
+
+
+def _rel(a, b):
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def test_plane_depth_kernel_against_autograd():
+    """reduction_1x1's plane tail + F.normalize + local_planar_guidance (Bts.py:105-146,228-232) in one kernel, fwd and bwd."""
+    from mono_depth_estimation_amd import ops
+    for up in (8, 4, 2):
+        N, h, w, md = 2, 5, 7, 10.0
+        x = W.normal(up, "x", (N, 3, h, w), 1.5).to(torch.bfloat16).float()
+        xr = x.clone().requires_grad_(True)
+        ref = nets._bts_lpg(torch.cat([torch.nn.functional.normalize(nets._plane_from_params(xr, md)[:, :3], 2, 1),
+                                       nets._plane_from_params(xr, md)[:, 3:4]], 1), up).unsqueeze(1) / md
+        xd = torch.zeros(N, h, w, 8, dtype=torch.bfloat16, device="cuda")
+        xd[..., :3] = x.permute(0, 2, 3, 1).to(torch.bfloat16).cuda()
+        out = torch.empty(N, 1, h * up, w * up, device="cuda")
+        ops.plane_depth_fwd(xd, 8, out, N, h, w, up, md)
+        torch.cuda.synchronize()
+        assert torch.allclose(out.cpu(), ref.detach(), rtol=2e-5, atol=1e-6)
+        dy = W.normal(up, "dy", tuple(ref.shape))
+        ref.backward(dy)
+        dx = torch.full((N, h, w, 8), 5.0, dtype=torch.bfloat16, device="cuda")
+        ops.plane_depth_bwd(xd, 8, dy.cuda(), dx, 8, N, h, w, up, md)
+        torch.cuda.synchronize()
+        got = dx[..., :3].float().cpu().permute(0, 3, 1, 2)
+        err = (got - xr.grad).abs()
+        assert bool((err <= 2.0 ** -7 * xr.grad.abs() + 2.0 ** -8 * xr.grad.pow(2).mean().sqrt()).all()), float(err.max())
+        assert float(dx[..., 3:].float().abs().max()) == 0.0
+        # the concatenation slot: every step-th pixel of the map as one bf16 channel, and its gradient
+        cat = torch.zeros(N, h * up // 2, w * up // 2, 16, dtype=torch.bfloat16, device="cuda")
+        ops.map_to_slot(out, cat[..., 9:], 16, N, h * up, w * up, 2)
+        torch.cuda.synchronize()
+        assert torch.equal(cat[..., 9].float().cpu(), out.cpu()[:, 0, ::2, ::2].to(torch.bfloat16).float())
+        assert float(cat[..., :9].float().abs().max()) == 0.0 and float(cat[..., 10:].float().abs().max()) == 0.0
+        g = torch.zeros_like(out)
+        ops.slot_to_map_add(cat[..., 9:], 16, g, N, h * up, w * up, 2)
+        torch.cuda.synchronize()
+        assert torch.equal(g.cpu()[:, 0, ::2, ::2], cat[..., 9].float().cpu()) and float(g[:, 0, 1::2].abs().max()) == 0.0
+
+
+@pytest.fixture(scope="module")
+def setup():
+    from mono_depth_estimation_amd.network import Bts
+    torch.manual_seed(0)
+    net = Bts.BtsModel(bts_size=512, max_depth=10, out_channels=1, encoder_version="densenet161_bts")
+    sd = W.bts_fixture_state(net, 47)
+    rgb, tgt = W.synthetic_batch(47, 2, *SIZE)
+    P = nets.leaf_state(sd)
+    with torch.no_grad():
+        nets.bts_forward(P, rgb, True, momentum=1.0)
+    net.load_state_dict({k: v.clone() for k, v in P.items()})
+    return net.cuda(), P, rgb, tgt
+
+
+def test_bts_eval_against_oracle_and_reference(setup, golden):
+    net, P, rgb, tgt = setup
+    g = golden("bts_net")
+    net.eval()
+    with torch.no_grad():
+        ys = net(rgb.cuda())
+        yo = nets.bts_forward(P, rgb, False)
+        yq = nets.bts_forward(P, rgb, False, q=nets.bf16_round)
+    assert len(ys) == 5
+    for nme, y, o, q in zip(NAMES, ys, yo, yq):
+        assert y.shape == (2, 1, *SIZE) and y.dtype == torch.float32 and torch.isfinite(y).all()
+        noise, e_o, e_q, e_ref = _rel(q, o), _rel(y.cpu(), o), _rel(y.cpu(), q), _rel(y.cpu(), torch.from_numpy(g["eval_" + nme]))
+        print("BTS eval %-5s: HIP vs fp32 oracle %.3e, vs bf16-rounding oracle %.3e, vs reference %.3e; rounding noise %.3e" % (nme, e_o, e_q, e_ref, noise))
+        assert e_o < 1.5 * noise + 1e-2 and e_ref < 1.5 * noise + 1e-2, nme
+    t = tgt * 10.0
+    m = t > 0
+    absrel = lambda d: float(((d - t).abs() / t.clamp(min=1e-9))[m].mean())
+    a_ref, a_hip, a_q = absrel(torch.from_numpy(g["eval_final"])), absrel(ys[4].cpu()), absrel(yq[4])
+    print("BTS eval AbsRel(final depth): reference %.5f, HIP %.5f, bf16-rounding oracle %.5f" % (a_ref, a_hip, a_q))
+    assert abs(a_hip - a_ref) < 2.0 * abs(a_q - a_ref) + 5e-3
+
+
+def test_bts_train_step_against_oracle_and_reference(setup, golden):
+    from mono_depth_estimation_amd import criteria
+    net, P0, rgb, tgt = setup
+    g = golden("bts_net")
+    net.train()
+    net.zero_grad(set_to_none=True)
+    ys = net(rgb.cuda())
+    t = (tgt * 10.0).cuda()
+    loss = criteria.silog_loss(0.85)(ys[4], t)
+    # every head takes part in the backward pass (BTS trains on the final depth; the others are returned for inspection)
+    aux = sum((y * w).sum() for y, w in zip(ys[:4], (1e-4, 2e-4, 3e-4, 4e-4)))
+    (loss + aux).backward()
+    with torch.no_grad():
+        yq = nets.bts_forward(nets.leaf_state(P0), rgb, True, q=nets.bf16_round)
+        loss_q = float(L.silog(yq[4], tgt * 10.0, 0.85))
+    ref_loss = float(g["train_loss"])
+    print("BTS train SILog: reference %.4f, HIP %.4f, bf16-rounding oracle %.4f" % (ref_loss, float(loss), loss_q))
+    assert abs(float(loss) - ref_loss) < 2.0 * abs(loss_q - ref_loss) + 1e-2 * ref_loss
+    P = nets.leaf_state(P0, requires_grad=True)
+    yo = nets.bts_forward(P, rgb, True)
+    (L.silog(yo[4], tgt * 10.0, 0.85) + sum((y * w).sum() for y, w in zip(yo[:4], (1e-4, 2e-4, 3e-4, 4e-4)))).backward()
+    ratios, cosines = [], {}
+    for k, p in net.named_parameters():
+        go, gh = P[k].grad, p.grad.detach().cpu()
+        assert gh.shape == go.shape and torch.isfinite(gh).all(), k
+        if float(go.norm()) > 1e-9:
+            ratios.append(float(gh.norm() / go.norm()))
+            cosines[k] = float((gh * go).sum() / (gh.norm() * go.norm() + 1e-30))
+    ratios = np.array(ratios)
+    print("BTS gradient-norm ratios HIP / oracle, percentiles 1 10 50 90 99:", np.percentile(ratios, [1, 10, 50, 90, 99]))
+    show = ("decoder.get_depth.0.weight", "decoder.conv1.0.weight", "decoder.reduc1x1.reduc.final.0.weight", "decoder.reduc8x8.reduc.plane_params.weight",
+            "decoder.reduc2x2.reduc.inter_64_32.0.weight", "decoder.upconv1.conv.weight", "decoder.daspp_24.atrous_conv.first_bn.weight",
+            "decoder.daspp_conv.0.weight", "decoder.conv5.0.weight", "decoder.bn5.weight", "encoder.base_model.denseblock4.denselayer24.conv2.weight",
+            "encoder.base_model.denseblock3.denselayer1.norm1.weight", "encoder.base_model.transition1.conv.weight", "encoder.base_model.conv0.weight")
+    print("cosines:", {k: round(cosines[k], 3) for k in show})
+    assert np.mean(np.abs(ratios - 1) < 0.25) >= 0.85, np.percentile(ratios, [1, 10, 50, 90, 99])
+    for k in show[:6]:
+        assert cosines[k] >= 0.9, (k, cosines[k])
+    for k in show[6:]:
+        assert cosines[k] >= 0.6, (k, cosines[k])
+    sd = net.state_dict()
+    assert _rel(sd["encoder.base_model.norm5.running_mean"].cpu(), torch.from_numpy(g["rm_norm5"])) < 5e-2
+    assert _rel(sd["decoder.bn4_2.running_var"].cpu(), torch.from_numpy(g["rv_bn4_2"])) < 5e-2
+
+
+def test_bts_adamw_steps_reduce_the_loss(setup):
+    """modules/bts.py:139-152: AdamW eps 1e-3, weight decay 1e-2 on the encoder / 0 on the decoder, through the fused step."""
+    from mono_depth_estimation_amd import criteria
+    net, _, rgb, tgt = setup
+    crit = criteria.silog_loss(0.85)
+    x, t = rgb.cuda(), (tgt * 10.0).cuda()
+    net.train()
+    losses = []
+    for _ in range(4):
+        net.zero_grad(set_to_none=True)
+        loss = crit(net(x)[4], t)
+        loss.backward()
+        net._store.adam_step(1e-4, 1e-4, eps=1e-3, weight_decay=(1e-2, 0.0), decoupled=True)
+        losses.append(float(loss))
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+
+
+def test_config3_bts_16x3x480x640_with_silog():
+    """BTS DenseNet-161, bts_size 512, max_depth 1.0, 16 images at 480 x 640, SILog on the final depth."""
+    from mono_depth_estimation_amd import criteria
+    from mono_depth_estimation_amd.network import Bts
+    torch.manual_seed(4)
+    net = Bts.BtsModel(bts_size=512, max_depth=1.0, out_channels=1, encoder_version="densenet161_bts").cuda()
+    with torch.no_grad():
+        for k, p in net.named_parameters():
+            if k.endswith("plane_params.weight") or k.endswith("final.0.weight") or k == "decoder.get_depth.0.weight":
+                p.mul_(0.05)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(8)
+    x = torch.rand(16, 3, 480, 640, generator=g, device="cuda")
+    gt = (0.05 + 0.95 * torch.rand(16, 1, 480, 640, generator=g, device="cuda")).masked_fill(torch.rand(16, 1, 480, 640, generator=g, device="cuda") < 0.1, 0.0)
+    net.eval()
+    with torch.no_grad():
+        ys = net(x)
+        assert len(ys) == 5 and all(y.shape == (16, 1, 480, 640) and torch.isfinite(y).all() for y in ys)
+        assert float(ys[4].min()) >= 0 and float(ys[4].max()) <= 1.0
+        y2 = net(x[2:4].contiguous())
+        assert float((y2[4] - ys[4][2:4]).abs().max()) <= 5e-2
+    del ys, y2
+    crit = criteria.silog_loss(0.85)
+    net.train()
+    losses = []
+    for it in range(3):
+        net.zero_grad(set_to_none=True)
+        loss = crit(net(x)[4], gt)
+        loss.backward()
+        if it == 0:
+            for k, p in net.named_parameters():
+                assert p.grad is not None and torch.isfinite(p.grad).all(), k
+        net._store.adam_step(1e-4, 1e-4, eps=1e-3, weight_decay=(1e-2, 0.0), decoupled=True)
+        losses.append(float(loss))
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses

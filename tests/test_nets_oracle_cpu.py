@@ -127,3 +127,52 @@ def test_midas_oracle_matches_the_reference(midas_fixture):
         got = float(P[k].grad.norm())
         assert abs(got - v) <= 3e-3 * v + 1e-7, (k, got, v)
     assert np.allclose(P["pretrained.layer4.2.bn3.running_mean"].numpy(), g["rm_l4"], rtol=1e-4, atol=1e-6)
+
+
+# ---------------------------------------------------------------------------------------------- BTS
+BTS_SIZE = (64, 96)
+
+
+@pytest.fixture(scope="module")
+def bts_fixture():
+    from mono_depth_estimation_amd.network import Bts
+    torch.manual_seed(0)
+    mirror = Bts.BtsModel(bts_size=512, max_depth=10, out_channels=1, encoder_version="densenet161_bts")
+    sd = W.bts_fixture_state(mirror, 47)
+    rgb, tgt = W.synthetic_batch(47, 2, *BTS_SIZE)
+    P = nets.leaf_state(sd)
+    with torch.no_grad():
+        nets.bts_forward(P, rgb, True, momentum=1.0)
+    return mirror, P, rgb, tgt
+
+
+def test_bts_parameter_tree_matches_the_reference(bts_fixture):
+    mirror, P, _, _ = bts_fixture
+    g = _golden("bts_net")
+    assert list(mirror.state_dict().keys()) == list(g["keys"])
+    assert sum(p.numel() for p in mirror.parameters()) == 47000688            # SURVEY 8c probe: 47.0 M
+    assert hasattr(mirror, "encoder") and hasattr(mirror, "decoder")          # modules/bts.py:90,140-141
+    assert mirror.encoder.feat_out_channels == [96, 96, 192, 384, 2208] and mirror.decoder.bn5.momentum == 0.01
+
+
+def test_bts_oracle_matches_the_reference(bts_fixture):
+    _, P0, rgb, tgt = bts_fixture
+    g = _golden("bts_net")
+    names = ("d8", "d4", "d2", "r1", "final")
+    with torch.no_grad():
+        ys = nets.bts_forward(P0, rgb, False)
+    for nme, y in zip(names, ys):
+        assert y.shape == (2, 1, *BTS_SIZE)
+        assert np.allclose(y.numpy(), g["eval_" + nme], rtol=2e-4, atol=2e-6), nme
+    P = nets.leaf_state(P0, requires_grad=True)
+    ys = nets.bts_forward(P, rgb, True)
+    for nme, y in zip(names, ys):
+        assert np.allclose(y.detach().numpy(), g["train_" + nme], rtol=5e-4, atol=5e-6), nme
+    loss = L.silog(ys[4], tgt * 10.0, 0.85)
+    assert np.allclose(float(loss.detach()), float(g["train_loss"]), rtol=2e-5)
+    loss.backward()
+    for k, v in zip(g["grad_names"], g["grad_norms"]):
+        got = float(P[k].grad.norm())
+        assert abs(got - v) <= 3e-3 * v + 1e-7, (k, got, v)
+    assert np.allclose(P["encoder.base_model.norm5.running_mean"].numpy(), g["rm_norm5"], rtol=1e-4, atol=1e-6)
+    assert np.allclose(P["decoder.bn4_2.running_var"].numpy(), g["rv_bn4_2"], rtol=1e-4, atol=1e-7)
