@@ -129,3 +129,25 @@ class DenseNet(nn.Module):
 
 def densenet161(pretrained=False):
     return DenseNet(48, (6, 12, 36, 24), 96)
+
+
+# ---------------------------------------------------------------------------------------------- VGG-19 (BN) features (Eigen.py:74)
+class VGG19BN(nn.Module):
+    """torchvision.models.vgg19_bn(...)._modules['features']: configuration E with BatchNorm (conv3x3 -> BN -> ReLU, 'M' =
+    MaxPool2d(2, 2)); the classifier is never used by Eigen.py."""
+    cfg = [64, 64, "M", 128, 128, "M", 256, 256, 256, 256, "M", 512, 512, 512, 512, "M", 512, 512, 512, 512, "M"]
+
+    def __init__(self):
+        super().__init__()
+        layers, c = [], 3
+        for v in self.cfg:
+            if v == "M":
+                layers.append(nn.MaxPool2d(2, 2))
+            else:
+                layers += [nn.Conv2d(c, v, 3, padding=1), nn.BatchNorm2d(v), nn.ReLU(inplace=True)]
+                c = v
+        self.features = nn.Sequential(*layers)
+
+
+def vgg19_bn(pretrained=False):
+    return VGG19BN()

@@ -44,6 +44,7 @@ def _import_reference():
         tvm.__dict__["resnet%d" % n] = (lambda n: (lambda pretrained=False: ofcrn.ResNetTrunk(n)))(n)
     from oracle import trunks
     tvm.densenet161 = trunks.densenet161
+    tvm.vgg19_bn = trunks.vgg19_bn
     tv.models = tvm
     sys.modules.setdefault("torchvision", tv)
     sys.modules.setdefault("torchvision.models", tvm)
@@ -586,6 +587,43 @@ def gen_bts_net(criteria):
         len(out["keys"]), sum(p.numel() for p in ref.parameters()), out["eval_final"].min(), out["eval_final"].max(), float(loss)))
 
 
+def gen_eigen(criteria):
+    """C1 / BASELINE configuration 1 (CPU plumbing): the reference's own network/Eigen.py (Eigen, Scale2, Scale3, VGG) over
+    the vgg19_bn stand-in, 4 x 3 x 240 x 320 (the two Linear layers fix that input size; 64 x 64 is rejected by the
+    reference itself), with SILog (what BASELINE.json pairs it with) and MaskedDepthLoss (what
+    modules/eigen.py pairs it with) on the output resized to the target as eigen.py:30 does."""
+    from network import Eigen
+    torch.manual_seed(0)
+    ref = Eigen.Eigen(scale1="vgg", pretrained=False)
+    sd = W.fill_state_dict(ref, 53)
+    for k in sd:                                           # keep the 237 M-parameter Linear layers from saturating anything
+        if k.startswith("scale1.mlp"):
+            sd[k] = sd[k] * 0.3
+    ref.load_state_dict(sd)
+    rgb, tgt = W.synthetic_batch(53, 4, 240, 320)
+    W.calibrate_running_stats(ref, rgb)
+    out = {"n_params": np.int64(sum(p.numel() for p in ref.parameters())), "n_keys": np.int64(len(ref.state_dict()))}
+    ref.eval()
+    with torch.no_grad():
+        y = ref(rgb)
+    out["eval_out"] = _np(y)
+    ref.train()
+    y = ref(rgb)
+    up = torch.nn.functional.interpolate(y, (240, 320), mode="bilinear")
+    silog = criteria.silog_loss(0.85)(up + 0.1, tgt)       # (+0.1: the head ends in a ReLU, SILog needs a positive estimate)
+    md = criteria.MaskedDepthLoss()(up, tgt)
+    (silog + md).backward()
+    out["train_out"], out["train_silog"], out["train_masked_depth"] = _np(y), _np(silog), _np(md)
+    names = ["scale1.feature_extractor.0.weight", "scale1.feature_extractor.49.bias", "scale1.mlp1.bias", "scale1.mlp2.bias",
+             "scale1.upsample.weight", "scale2.conv.weight", "scale2.scale2_onestack.6.weight", "scale3.conv.bias",
+             "scale3.scale3_onestack.0.weight", "scale3.scale3_onestack.6.weight"]
+    pd = dict(ref.named_parameters())
+    out["grad_names"], out["grad_norms"] = np.array(names), np.array([float(pd[k].grad.norm()) for k in names], dtype=np.float32)
+    np.savez_compressed(os.path.join(HERE, "eigen.npz"), **out)
+    print("eigen.npz: %d params, out %s range %.4f..%.4f, silog %.5f masked_depth %.5f" % (
+        int(out["n_params"]), out["eval_out"].shape, out["eval_out"].min(), out["eval_out"].max(), float(silog), float(md)))
+
+
 def main():
     torch.set_num_threads(8)
     criteria, metrics, FCRN = _import_reference()
@@ -613,6 +651,8 @@ def main():
         gen_midas_net(criteria)
     if want("bts_net"):
         gen_bts_net(criteria)
+    if want("eigen"):
+        gen_eigen(criteria)
 
 
 if __name__ == "__main__":

@@ -176,3 +176,38 @@ def test_bts_oracle_matches_the_reference(bts_fixture):
         assert abs(got - v) <= 3e-3 * v + 1e-7, (k, got, v)
     assert np.allclose(P["encoder.base_model.norm5.running_mean"].numpy(), g["rm_norm5"], rtol=1e-4, atol=1e-6)
     assert np.allclose(P["decoder.bn4_2.running_var"].numpy(), g["rv_bn4_2"], rtol=1e-4, atol=1e-7)
+
+
+# ---------------------------------------------------------------------------------------------- Eigen (BASELINE config 1)
+def test_config1_eigen_cpu_forward_silog_matches_the_reference():
+    """BASELINE.json configuration 1: Eigen on the CPU, forward + SILog (plumbing, no GPU) — at 4 x 3 x 240 x 320, the only
+    input size the reference's two Linear layers accept — against the reference's own network/Eigen.py."""
+    from oracle import eigen
+    g = _golden("eigen")
+    torch.manual_seed(0)
+    net = eigen.EigenOracle()
+    assert sum(p.numel() for p in net.parameters()) == int(g["n_params"]) == 237495618 and len(net.state_dict()) == int(g["n_keys"])
+    sd = W.fill_state_dict(net, 53)
+    for k in sd:
+        if k.startswith("scale1.mlp"):
+            sd[k] = sd[k] * 0.3
+    net.load_state_dict(sd)
+    rgb, tgt = W.synthetic_batch(53, 4, 240, 320)
+    W.calibrate_running_stats(net, rgb)
+    net.eval()
+    with torch.no_grad():
+        y = net(rgb)
+    assert y.shape == (4, 1, 109, 149)
+    assert np.allclose(y.numpy(), g["eval_out"], rtol=2e-4, atol=2e-5)
+    net.train()
+    y = net(rgb)
+    up = torch.nn.functional.interpolate(y, (240, 320), mode="bilinear")
+    silog, md = L.silog(up + 0.1, tgt, 0.85), L.masked_depth(up, tgt)
+    assert np.allclose(y.detach().numpy(), g["train_out"], rtol=2e-4, atol=2e-5)
+    assert np.allclose(float(silog.detach()), float(g["train_silog"]), rtol=2e-5)
+    assert np.allclose(float(md.detach()), float(g["train_masked_depth"]), rtol=2e-5)
+    (silog + md).backward()
+    pd = dict(net.named_parameters())
+    for k, v in zip(g["grad_names"], g["grad_norms"]):
+        got = float(pd[str(k)].grad.norm())
+        assert abs(got - v) <= 2e-3 * v + 1e-8, (k, got, v)
