@@ -444,6 +444,7 @@ class MaxPool(Op):
         H2, W2 = ops.out_size(x.H, 3, 2, 1), ops.out_size(x.W, 3, 2, 1)
         self.out = Act(eng.dev, x.N, H2, W2, x.C)
         self.idx = torch.empty(x.N, H2, W2, x.C, dtype=torch.uint8, device=eng.dev)
+        self.tmp = None
 
     def acts(self):
         return (self.out,)
@@ -454,9 +455,15 @@ class MaxPool(Op):
 
     def bwd(self):
         x = self.x
-        if _take(x):
-            raise NotImplementedError("MaxPool backward must be the first writer of its input's gradient")
-        ops.maxpool_bwd(self.out.g, self.idx, x.g, x.N, x.H, x.W, x.C)
+        if not _take(x):
+            ops.maxpool_bwd(self.out.g, self.idx, x.g, x.N, x.H, x.W, x.C)
+            return
+        # the input also feeds a later consumer (densenet's relu0 is a decoder skip, Bts.py:206,250): route into a scratch
+        # tensor, then one in-place add pass
+        if self.tmp is None:
+            self.tmp = torch.empty_like(x.t)
+        ops.maxpool_bwd(self.out.g, self.idx, self.tmp, x.N, x.H, x.W, x.C)
+        ops.pw_fwd(self.tmp, x.C, None, x.g, _ldg(x), x.g, _ldg(x), x.M, x.C, None)
 
 
 class Nearest2(Op):
