@@ -92,7 +92,11 @@ __device__ __forceinline__ int chunk_off(int row, int kslot8) {
 // The LDS destination of a DMA is lane-linear, so the bank swizzle lives in the SOURCE k-slot
 // each lane fetches and in the fragment read address (guide rule 21).  Out-of-image taps use
 // an out-of-range buffer offset: the DMA then writes zeros (tools/probes/lds_dma_probe.hip).
-template <int BP, int BC, int NT, bool DMA, int NBUF>
+// PP = true ("ping-pong", 8 waves, 2-buffer DMA ring): the two waves of every SIMD run the SAME K-loop one barrier apart,
+// so one of them is always in its MFMA cluster while the other issues its LDS reads and DMA pieces (guide: the 8-phase
+// template's stagger; MI355X_MICROARCH "Two waves per SIMD" item 9).  In the lockstep loop both waves read together (LDS
+// saturated, matrix pipe idle) and then compute together (pipe shared): MFMA busy measured 41 %.
+template <int BP, int BC, int NT, bool DMA, int NBUF, bool PP = false>
 __global__ __launch_bounds__(NT, (NT == 256 && BP * BC >= 256 * 256) ? 1 : 2) void conv_gemm_nt(const KArgs a) {
     constexpr int NW = NT / 64;
     constexpr int RPL = NT / 8;          // tile rows covered by one load pass (8 chunks per row)
@@ -337,6 +341,155 @@ __global__ __launch_bounds__(NT, (NT == 256 && BP * BC >= 256 * 256) ? 1 : 2) vo
         constexpr int IPS = XR + WR;          // DMA instructions per wave per K-step
         constexpr int DIST = NBUF - 1;        // prefetch distance in K-steps
         int lbuf = 0, cbuf = 0;
+        if constexpr (PP) {
+            static_assert(!PP || (NW == 8 && NBUF == 2 && CF == 8 && WR == 4), "ping-pong: 8 waves, two LDS buffers, 256 columns");
+            // Group A = waves 0-3, group B = waves 4-7 (one of each per SIMD) run the SAME program, B one barrier interval
+            // behind A (one extra barrier up front).  A K-step is four intervals
+            //   R0: LDS reads of the pixel fragments (both k-halves, kept in registers) and of the first four column
+            //       fragments | M0: their 32 MFMAs | R1: reads of the other four column fragments | M1: 32 MFMAs
+            // so one group's M intervals are the other's R intervals: the matrix pipe always has a cluster to run, and
+            // the LDS / DMA traffic of one group hides under the other's MFMAs.
+            // DMA: after R0(s) of both groups the pixel tile and the first-half weight rows of buffer s&1 are dead (the
+            // pixel fragments live in registers), after R1(s) the rest.  So step s+2's pieces go out in two batches:
+            //   "early" (half the pixel pieces + weight rows of the first column half) in R1(s),
+            //   "late"  (the other pixel pieces + the second-half weight rows) in R0(s+1),
+            // 4 + 4 pieces per wave: every piece has >= 3 intervals (a late one) or 5 (an early one) to land, against one
+            // K-step = 4 intervals in the lockstep loop, with the same two buffers.  A wave waits (counted vmcnt: the
+            // newest early batch stays in flight) at the end of M1(s) (group A) / R1(s) (group B): both in front of the
+            // barrier after which step s+1 is first read.  No DMA is issued inside an M interval (measured +110 cycles
+            // per piece there).
+            constexpr int XE = (XR + 1) / 2;                    // pixel pieces of the early batch
+            constexpr int NEARLY = XE + 2;                      // pieces per early batch
+            const bool grpB = wv >= NW / 2;
+            int etap = 0, ecs = 0, ltap2 = 0, lcs2 = 0;        // load cursors of the early / late batch streams
+            auto advance = [&](int& tap, int& cs) { if (++cs == csteps) { cs = 0; ++tap; } };
+            auto issue_part = [&](int buf, int tap, int cs, int x0, int x1, int wpar) {
+                const uint32_t c0b = (uint32_t)(cs * BK) * 2u;
+                const bool kin = c0b < klimb;
+                const uint32_t tapoff = kin ? (uint32_t)s_tap[tap] * 2u + c0b : MDE_OOB_OFFSET;
+                const uint32_t woff = kin ? (uint32_t)s_tap[MDE_MAX_TAPS + tap] * 2u + c0b : MDE_OOB_OFFSET;
+                const uint32_t bit = 1u << tap;
+                char* xbuf = smem + buf * BUF_BYTES + wv * 1024;
+#pragma unroll
+                for (int q = 0; q < XR; ++q)
+                    if (q >= x0 && q < x1) {
+                        const uint32_t off = (dx_ok[q] & bit) ? dx_base[q] + tapoff : MDE_OOB_OFFSET;
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr)(xbuf + q * NW * 1024), 16, off, 0, 0, 0);
+                    }
+#pragma unroll
+                for (int q = 0; q < WR; ++q)
+                    if ((q & 1) == wpar) {                      // pieces 0, 2: weight rows of the waves' first column halves
+                        const uint32_t offw = dw_base[q] + woff;
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr)(xbuf + XT_BYTES + q * NW * 1024), 16, offw, 0, 0, 0);
+                    }
+            };
+            auto issue_early = [&](int buf) { issue_part(buf, etap, ecs, 0, XE, 0); advance(etap, ecs); };
+            auto issue_late = [&](int buf) { issue_part(buf, ltap2, lcs2, XE, XR, 1); advance(ltap2, lcs2); };
+            bf16x8_t fa[4][2], fb[PF][2];
+#define PP_BARRIER()                         \
+    __builtin_amdgcn_sched_barrier(0);       \
+    __builtin_amdgcn_s_barrier();            \
+    __builtin_amdgcn_sched_barrier(0)
+#ifdef MDE_PP_STAMP
+            // diagnostic build: cycles per phase of waves 0 and 4 of one workgroup into the `stats` buffer (as uint64):
+            // [0] R body, [1] barrier after R, [2] M body, [3] barrier after M, [4] vmcnt waits
+            uint64_t tacc[5] = {0, 0, 0, 0, 0};
+#define PP_T() __builtin_amdgcn_s_memtime()
+#define PP_ADD(i, t0) tacc[i] += PP_T() - (t0)
+#else
+#define PP_T() 0
+#define PP_ADD(i, t0)
+#endif
+            issue_early(0);
+            issue_late(0);                                      // step 0, both batches
+            if (nsteps > 1) {
+                issue_early(1);                                 // step 1's early batch ("R1(-1)")
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NEARLY) : "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            PP_BARRIER();
+            if (grpB) { PP_BARRIER(); }                         // the stagger: pairs with the end of A's R0(0)
+            for (int s = 0; s < nsteps; ++s) {
+                const int cur = s & 1, nxt = cur ^ 1;
+                const char* xb = smem + cur * BUF_BYTES + wp * (PF * 2048);
+                const char* wb = smem + cur * BUF_BYTES + XT_BYTES + wc * (CF * 2048);
+                // ---- R0
+                [[maybe_unused]] uint64_t t0 = PP_T();
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+                    for (int j = 0; j < PF; ++j) fb[j][kb] = *reinterpret_cast<const bf16x8_t*>(xb + j * 2048 + rd_off[kb]);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) fa[i][kb] = *reinterpret_cast<const bf16x8_t*>(wb + i * 2048 + rd_off[kb]);
+                }
+                if (s + 1 < nsteps) issue_late(nxt);            // step s+1: second pixel half + second-half weight rows
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                PP_ADD(0, t0); t0 = PP_T();
+                PP_BARRIER();
+                PP_ADD(1, t0); t0 = PP_T();
+                // ---- M0
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < PF; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][kb], fb[j][kb], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
+                PP_ADD(2, t0); t0 = PP_T();
+                PP_BARRIER();
+                PP_ADD(3, t0); t0 = PP_T();
+                // ---- R1
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) fa[i][kb] = *reinterpret_cast<const bf16x8_t*>(wb + (4 + i) * 2048 + rd_off[kb]);
+                const bool ahead = s + 2 < nsteps;
+                if (ahead) issue_early(cur);                    // step s+2 into the parts of this buffer nobody reads any more
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                PP_ADD(0, t0); t0 = PP_T();
+                if (grpB) {
+                    if (ahead) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NEARLY) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                PP_ADD(4, t0); t0 = PP_T();
+                PP_BARRIER();
+                PP_ADD(1, t0); t0 = PP_T();
+                // ---- M1
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < PF; ++j)
+                            acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][kb], fb[j][kb], acc[4 + i][j], 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
+                PP_ADD(2, t0); t0 = PP_T();
+                if (!grpB) {
+                    if (ahead) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NEARLY) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                PP_ADD(4, t0); t0 = PP_T();
+                PP_BARRIER();
+                PP_ADD(3, t0);
+            }
+#ifdef MDE_PP_STAMP
+            if (a.stats && blockIdx.x == 7 && lane == 0 && (wv == 0 || wv == 4)) {
+                uint64_t* o = reinterpret_cast<uint64_t*>(a.stats) + (wv ? 8 : 0);
+                for (int i = 0; i < 5; ++i) o[i] = tacc[i];
+                o[5] = (uint64_t)nsteps;
+            }
+#endif
+#undef PP_T
+#undef PP_ADD
+            if (!grpB) { PP_BARRIER(); }                        // A's matching barrier for B's stagger
+#undef PP_BARRIER
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        } else {
 #pragma unroll
         for (int q = 0; q < DIST; ++q)
             if (q < nsteps) { issue_dma(lbuf); lbuf = lbuf + 1 == NBUF ? 0 : lbuf + 1; }
@@ -482,6 +635,7 @@ __global__ __launch_bounds__(NT, (NT == 256 && BP * BC >= 256 * 256) ? 1 : 2) vo
             cbuf = cbuf + 1 == NBUF ? 0 : cbuf + 1;
         }
         __syncthreads();                      // staging ring is free for the epilogue
+        }   // !PP
     } else
     if constexpr (DEEP) {
         issue_loads(xa, wa);                              // step 0
@@ -653,13 +807,13 @@ constexpr size_t smem_bytes() {
            ((NT / 64) / (BC >= 128 ? 2 : 1)) * 2 * BC * sizeof(float) + 3 * MDE_MAX_TAPS * sizeof(int);
 }
 
-template <int BP, int BC, int NT, bool DMA, int NBUF>
+template <int BP, int BC, int NT, bool DMA, int NBUF, bool PP = false>
 int launch(KArgs& ka, int64_t M, hipStream_t st) {
     static bool attr_done = false;
     constexpr size_t smem = smem_bytes<BP, BC, NT, NBUF>();
     static_assert(smem <= 160 * 1024, "LDS budget");
     if (!attr_done) {
-        int rc = mde_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_nt<BP, BC, NT, DMA, NBUF>),
+        int rc = mde_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_nt<BP, BC, NT, DMA, NBUF, PP>),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem),
                                "hipFuncSetAttribute(conv_gemm_nt)");
         if (rc) return rc;
@@ -668,7 +822,7 @@ int launch(KArgs& ka, int64_t M, hipStream_t st) {
     (void)M;
     ka.nP = mde_cdiv(ka.m_end - ka.m_begin, BP);
     ka.nC = mde_cdiv(ka.d.ncols, BC);
-    conv_gemm_nt<BP, BC, NT, DMA, NBUF><<<dim3(ka.nP * ka.nC), dim3(NT), smem, st>>>(ka);
+    conv_gemm_nt<BP, BC, NT, DMA, NBUF, PP><<<dim3(ka.nP * ka.nC), dim3(NT), smem, st>>>(ka);
     MDE_LAUNCH_CHECK("conv_gemm_nt");
     return MDE_OK;
 }
@@ -677,14 +831,20 @@ int launch(KArgs& ka, int64_t M, hipStream_t st) {
 // (one 8-wave workgroup per CU for the 256-pixel tiles).  Diagnostics: MDE_CONV_TILE=<BP>x<BC>
 // forces a tile, MDE_CONV_PATH=reg selects the register-staged main loop instead of LDS-DMA.
 int pick_and_launch(KArgs& ka, int64_t M, hipStream_t st) {
-    static int forced = -1, reg = 0;
+    static int forced = -1, reg = 0, gpp = 0;
     if (forced < 0) {
+        // 8-wave tiles: MDE_CONV_PP=1 always the ping-pong loop, 0 never; default: where a tile has >= 18 K-steps (measured
+        // in-network: +2..4 % on the 9- and 25-tap layers, -3..6 % on the 1x1 layers whose 1-8 K-steps do not amortise
+        // its longer prologue)
+        const char* ppe = getenv("MDE_CONV_PP");
+        gpp = !ppe ? 2 : (strcmp(ppe, "0") != 0);
         const char* e = getenv("MDE_CONV_TILE");
         forced = !e ? 0 : !strcmp(e, "256x256") ? 1 : !strcmp(e, "128x128") ? 3 : !strcmp(e, "192x256") ? 5 : !strcmp(e, "128x64") ? 6 : !strcmp(e, "256x256w4") ? 7 : 0;
         const char* q = getenv("MDE_CONV_PATH");
         reg = q && !strcmp(q, "reg");
     }
     const int n = ka.d.ncols;
+    const bool pp = gpp == 1 || (gpp == 2 && ka.d.ntaps * ((ka.d.C + BK - 1) / BK) >= 18);
     if (n <= 64 || ka.d.grouped) {
         // 2-deep ring = 48 KB LDS = three workgroups per CU.  Measured alternatives, all slower on M = 2 457 600 / 614 400,
         // 64->64 3x3: 256x64 with 8 waves (423 / 423 TFLOP/s), 256x64 with 4 waves (365 / 343), 3-deep ring at two
@@ -734,14 +894,15 @@ int pick_and_launch(KArgs& ka, int64_t M, hipStream_t st) {
         KArgs k1 = ka, k2 = ka;
         k1.m_end = split;
         k2.m_begin = split;
-        int rc = launch<256, 256, 512, true, 2>(k1, M, st);
+        int rc = pp ? launch<256, 256, 512, true, 2, true>(k1, M, st) : launch<256, 256, 512, true, 2>(k1, M, st);
         if (rc) return rc;
         return launch<128, 128, 256, true, 2>(k2, M, st);
     }
-    if (forced == 0 && pick == 2) return launch<192, 256, 512, true, 2>(ka, M, st);
+    if (forced == 0 && pick == 2) return pp ? launch<192, 256, 512, true, 2, true>(ka, M, st) : launch<192, 256, 512, true, 2>(ka, M, st);
     if (forced == 1 || (forced == 0 && pick == 1))
-        return reg ? launch<256, 256, 512, false, 2>(ka, M, st) : launch<256, 256, 512, true, 2>(ka, M, st);
-    if (forced == 5) return launch<192, 256, 512, true, 2>(ka, M, st);
+        return reg ? launch<256, 256, 512, false, 2>(ka, M, st)
+                   : (pp ? launch<256, 256, 512, true, 2, true>(ka, M, st) : launch<256, 256, 512, true, 2>(ka, M, st));
+    if (forced == 5) return pp ? launch<192, 256, 512, true, 2, true>(ka, M, st) : launch<192, 256, 512, true, 2>(ka, M, st);
     if (forced == 6) return launch<128, 64, 256, true, 2>(ka, M, st);
     if (forced == 7) return launch<256, 256, 256, true, 2>(ka, M, st);   // 4 waves x (128 px x 128 ch), one workgroup per CU
     return reg ? launch<128, 128, 256, false, 2>(ka, M, st) : launch<128, 128, 256, true, 2>(ka, M, st);

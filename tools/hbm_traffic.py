@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
-"""Turn two rocprofv3 PMC passes over bench.py into profiles/r01_hbm_traffic.json.
+"""Turn two rocprofv3 PMC passes over bench.py into profiles/r02_hbm_traffic.json (tagged with the hash of the kernel
+sources it was collected on: bench.py quotes it only for those).
 
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_fetch -o p -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-launch-timing
   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_write -o p -- python3 bench.py ... (same)
-  python tools/hbm_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write <steps incl. warm-up> <conv calls/step> <wgrad calls/step> > profiles/r01_hbm_traffic.json
+  python tools/hbm_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write <steps incl. warm-up> <conv calls/step> <wgrad calls/step> > profiles/r02_hbm_traffic.json
 
 Counters are in KiB; FETCH_SIZE is doubled on gfx950 (it tallies 128-byte read requests as 64 bytes,
 MI355X_MICROARCH.md, HBM/rocprofv3 section); WRITE_SIZE is exact.  Bytes are reported per conv CALL (the
@@ -44,6 +45,10 @@ def main():
                     "(batch 32); FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B read requests as 64 B); "
                     "WRITE_SIZE exact; counters are in KiB. Bytes are per conv CALL (= bench.py launch unit). "
                     "Produced by tools/hbm_traffic.py." % (steps - 1))
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    out["_source_hash"] = bench.kernel_source_hash()
     json.dump(out, sys.stdout, indent=1)
     print()
 
