@@ -108,3 +108,56 @@ def load_adam_state_dict(module, sd):
         raise ValueError("optimizer state carries different step counts per parameter: %s" % sorted(steps))
     if steps:
         store.step_count = steps.pop()
+
+
+# ---------------------------------------------------------------------------------------------- pretrained-trunk bridges (N3)
+def vnl_resnext_keys(src_dict):
+    """reference network/VNL.py:44-67 (`convert_state_dict_resnext`): the ResNeXt ImageNet files the VNL authors ship
+    (`pretrained_models/ResNeXt-ImageNet/resnext{50,101}_32x4d.pth`) are nn.Sequential dumps of the original Torch7 model,
+    keys are index paths.  Top level: 0 = stem conv, 1 = stem BN, 4..7 = the four stages; inside a block the residual
+    branch is `<stage>.<block>.0.0.<k>`, itself a Sequential for the first two conv/BN pairs (one more index: 0 conv1,
+    1 bn1, 3 conv2, 4 bn2 -> 7-token keys) followed by conv3 (1) and bn3 (2), and the projection shortcut is
+    `<stage>.<block>.0.1.<k>` (0 conv, 1 bn) -> 6-token keys.  Returns {body key ('res2.0.conv1.weight', ...): tensor};
+    everything else (classifier, pooling) is dropped."""
+    inner = {0: "conv1.", 1: "bn1.", 3: "conv2.", 4: "bn2."}
+    outer = ({1: "conv3.", 2: "bn3."}, {0: "shortcut.conv.", 1: "shortcut.bn."})
+    out = {}
+    for k, v in src_dict.items():
+        t = k.split(".")
+        top = int(t[0])
+        if top == 0:
+            out["res1.conv1." + t[-1]] = v
+        elif top == 1:
+            out["res1.bn1." + t[-1]] = v
+        elif 4 <= top <= 7:
+            head = "res%d.%d." % (top - 2, int(t[1]))
+            if len(t) == 7:
+                out[head + inner[int(t[-2])] + t[-1]] = v
+            elif len(t) == 6:
+                out[head + outer[int(t[-3])][int(t[-2])] + t[-1]] = v
+    return out
+
+
+def load_vnl_imagenet_weights(model, path_or_dict, map_location="cpu"):
+    """reference VNL.py:70-95 (`load_pretrained_imagenet_weights`) for the ResNeXt encoders: copy every converted tensor
+    whose key exists in `model.depth_model.encoder_modules.bottomup` (a MetricDepthModel), report the others.  The
+    reference resolves the file under <cwd>/mono-depth-estimation/network/pretrained_models/...; here the caller names it."""
+    src = torch.load(path_or_dict, map_location=map_location) if isinstance(path_or_dict, str) else path_or_dict
+    body = model.depth_model.encoder_modules.bottomup
+    own = body.state_dict()
+    unknown = []
+    with torch.no_grad():
+        for k, v in vnl_resnext_keys(src).items():
+            if k in own:
+                own[k].copy_(v)
+            else:
+                unknown.append(k)
+    return unknown
+
+
+def load_midas_weights(model, path, map_location="cpu"):
+    """reference MiDaS.py:10-23 (`BaseModel.load`): a state_dict file, or a training checkpoint holding it under "model"."""
+    parameters = torch.load(path, map_location=map_location)
+    if "optimizer" in parameters:
+        parameters = parameters["model"]
+    model.load_state_dict(parameters)

@@ -387,6 +387,10 @@ class FlatStore:
             self._pack_jobs = None
         return c
 
+    def layer_boundaries(self):
+        """Flat offsets at which conv weights start (forward order): where dp.FlatGradReducer may cut its buckets."""
+        return sorted({0} | {self.p_off[id(p)] for p in self.params if p.dim() == 4})
+
     def conv_grouped(self, w, G):
         c = self.convs.get(id(w))
         if c is None:

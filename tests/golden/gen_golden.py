@@ -624,6 +624,27 @@ def gen_eigen(criteria):
         int(out["n_params"]), out["eval_out"].shape, out["eval_out"].min(), out["eval_out"].max(), float(silog), float(md)))
 
 
+def gen_vnl_keymap():
+    """N3: the reference's own convert_state_dict_resnext (VNL.py:44-67) on the index-path keys of the shipped
+    ResNeXt-ImageNet files, enumerated from the documented nn.Sequential structure -> {source key: body key} pairs."""
+    import json
+    from network import VNL
+    src = ["0.weight", "1.weight", "1.bias", "1.running_mean", "1.running_var", "10.1.weight", "10.1.bias", "8.weight"]
+    for stage, nblk in zip((4, 5, 6, 7), (3, 4, 6, 3)):
+        for b in range(nblk):
+            for idx, params in ((0, ("weight",)), (1, ("weight", "bias", "running_mean", "running_var")), (3, ("weight",)),
+                                (4, ("weight", "bias", "running_mean", "running_var"))):
+                src += ["%d.%d.0.0.0.%d.%s" % (stage, b, idx, p) for p in params]
+            src += ["%d.%d.0.0.1.weight" % (stage, b)] + ["%d.%d.0.0.2.%s" % (stage, b, p) for p in ("weight", "bias", "running_mean", "running_var")]
+            if b == 0:
+                src += ["%d.%d.0.1.0.weight" % (stage, b)] + ["%d.%d.0.1.1.%s" % (stage, b, p) for p in ("weight", "bias", "running_mean", "running_var")]
+    dst = VNL.convert_state_dict_resnext({k: i for i, k in enumerate(src)})
+    inv = {v: k for k, v in dst.items()}
+    pairs = {src[i]: inv[i] for i in sorted(inv)}
+    json.dump({"pairs": pairs, "dropped": [k for i, k in enumerate(src) if i not in inv]}, open(os.path.join(HERE, "vnl_keymap.json"), "w"), indent=0)
+    print("vnl_keymap.json: %d mapped, %d dropped" % (len(pairs), len(src) - len(pairs)))
+
+
 def main():
     torch.set_num_threads(8)
     criteria, metrics, FCRN = _import_reference()
@@ -653,6 +674,8 @@ def main():
         gen_bts_net(criteria)
     if want("eigen"):
         gen_eigen(criteria)
+    if want("vnl_keymap"):
+        gen_vnl_keymap()
 
 
 if __name__ == "__main__":

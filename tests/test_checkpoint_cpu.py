@@ -39,3 +39,27 @@ def test_checkpoint_key_handling():
     g1, g10 = checkpoint._param_groups(a)
     assert g1[0] is a.conv1.weight and g10[0] is a.conv2.weight and g10[-1] is a.conv3.weight
     assert len(g1) + len(g10) == len(list(a.parameters()))
+
+
+def test_vnl_resnext_key_bridge_matches_the_reference():
+    """N3: checkpoint.vnl_resnext_keys against the pairs the reference's own convert_state_dict_resnext (VNL.py:44-67)
+    produced (tests/golden/vnl_keymap.json), and load_vnl_imagenet_weights into the HIP module's body."""
+    import json
+    import os
+    from mono_depth_estimation_amd import checkpoint
+    from mono_depth_estimation_amd.network import VNL
+    from oracle import nets
+    g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "vnl_keymap.json")))
+    src = {k: i for i, k in enumerate(list(g["pairs"]) + g["dropped"])}
+    got = checkpoint.vnl_resnext_keys(src)
+    assert {k: got_k for got_k, i in got.items() for k in [list(src)[i]]} == g["pairs"]
+    torch.manual_seed(0)
+    net = VNL.MetricDepthModel(nets.vnl_params())
+    body = net.depth_model.encoder_modules.bottomup
+    own = body.state_dict()
+    assert set(g["pairs"].values()) == {k for k in own if not k.endswith("num_batches_tracked")}      # every body tensor is reachable
+    fake = {s: torch.full_like(own[d], float(i % 7)) for i, (s, d) in enumerate(g["pairs"].items())}
+    fake["10.1.weight"] = torch.zeros(3)
+    assert checkpoint.load_vnl_imagenet_weights(net, fake) == []
+    for i, (s, d) in enumerate(g["pairs"].items()):
+        assert float(body.state_dict()[d].flatten()[0]) == float(i % 7), d

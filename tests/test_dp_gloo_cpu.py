@@ -64,3 +64,48 @@ def test_flat_grad_reducer_world2():
     for p in procs:
         p.join(timeout=60)
     assert all(ok for _, ok, _ in res), res
+
+
+def _store_worker(rank, world, port, q):
+    """The reducer over a REAL flat gradient layout: FCRN ResNet-18's ParamStore (zero-padded decoder tensors, fused
+    up-projection entries, encoder / decoder ranges), cut at the store's layer boundaries, driven tail-first."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mono_depth_estimation_amd import dp
+    from mono_depth_estimation_amd.engine import ParamStore
+    from mono_depth_estimation_amd.network import FCRN
+    torch.manual_seed(0)
+    net = FCRN.ResNet(layers=18, output_size=(64, 96), out_channels=1, pretrained=False)
+    store = ParamStore(net, torch.device("cpu"))
+    ok = True
+    for wire in (None, torch.bfloat16):
+        store.G.zero_()
+        for i, p in enumerate(store.params):                       # small integers: exact in bf16, sums exact too
+            store.view_of(store.G, p).fill_(float((i % 5) + 1) * (rank + 1))
+        bounds = store.layer_boundaries()
+        red = dp.FlatGradReducer(store.G, bounds, target_bytes=4 << 20, wire_dtype=wire)
+        assert len(red.buckets) >= 3 and red.buckets[0][1] == store.G.numel() and red.buckets[-1][0] == 0
+        for off in reversed(bounds):
+            red.ready(off)
+        red.finish()
+        tot = sum(r + 1 for r in range(world))
+        for i, p in enumerate(store.params):
+            ok = ok and bool((store.view_of(store.G, p) == float((i % 5) + 1) * tot).all())
+        # the zero padding of the stored 32- / 16-channel tensors stays zero (sum of zeros)
+        real = sum(p.numel() for p in store.params)
+        ok = ok and abs(float(store.G.count_nonzero()) - real) < 1
+    q.put((rank, ok, len(red.buckets)))
+    dist.destroy_process_group()
+
+
+def test_flat_grad_reducer_on_the_fcrn_store_layout():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_store_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(ok for _, ok, _ in res), res

@@ -211,3 +211,24 @@ def test_wcel_and_bin_mapping_full_size():
     d = gt.cuda().clamp(dmin, dmax)
     ratio = (torch.log10(centre) - torch.log10(d)).abs().squeeze(1)[valid]
     assert float(ratio.max()) <= 0.5 * interval * (1 + 1e-3)
+
+
+def test_vnl_device_sampling_opt_in():
+    """The opt-in on-device draw of the point triples: same index range and count as the reference's host draw, seeded by a
+    torch.Generator, a loss of the same magnitude, gradients flowing; the default (host numpy stream) is untouched."""
+    from mono_depth_estimation_amd import criteria
+    H, Wd = 96, 128
+    pred, gt = W.uniform(5, "p", (2, 1, H, Wd), 0.2, 1.0).cuda(), W.uniform(5, "g", (2, 1, H, Wd), 0.2, 1.0).cuda()
+    host = criteria.VNL_Loss(60.0, 60.0, (H, Wd))
+    np.random.seed(1)
+    l_host = float(host(gt, pred))
+    g = torch.Generator(device="cuda")
+    g.manual_seed(7)
+    dev = criteria.VNL_Loss(60.0, 60.0, (H, Wd), device_sampling=True, generator=g)
+    p = pred.clone().requires_grad_(True)
+    l1 = dev(gt, p)
+    l1.backward()
+    g.manual_seed(7)
+    l2 = float(dev(gt, pred))
+    assert float(l1) == l2 and torch.isfinite(p.grad).all() and float(p.grad.abs().sum()) > 0
+    assert abs(float(l1) - l_host) < 0.2 * l_host          # another sample of the same estimator
