@@ -38,6 +38,23 @@ int mde_abi_version(void);
 int mde_device_cu_count(int* out);
 
 /* ------------------------------------------------------------------------------------
+ * Deterministic mode (opt-in).  Every cross-workgroup floating-point sum of a training step — BatchNorm partial sums,
+ * split-K weight gradients, bias gradients — is an atomic add whose order changes from run to run; a last-bit
+ * difference flips a bf16 rounding somewhere and a deep net amplifies it (two identical train steps at 32 x 480 x 640
+ * differ by ~0.26 relative L2 in the trunk gradients).  With the mode on, every such addend is split exactly into two
+ * integers and added with 64-bit integer atomics, which are order-independent: the step becomes bit-reproducible.
+ * gbase: the flat fp32 gradient buffer all weight / bias gradients of the step land in (n elements); scratch: caller-owned,
+ * mde_det_scratch_bytes(n) bytes, ZEROED by the caller once.  mde_det_flush adds the integer sums into gbase (and
+ * re-zeroes them): call it after the last backward kernel, before anything reads the gradients.  While the mode is on,
+ * BatchNorm partial-sum buffers are interpreted as integers too (same size; they must be zero when the mode is switched).
+ * Process-wide state (one process per GPU); set it from the thread that launches the kernels.
+ * ---------------------------------------------------------------------------------- */
+size_t mde_det_scratch_bytes(int64_t n);
+int mde_set_deterministic(int on, float* gbase, void* scratch, int64_t n);
+int mde_deterministic(void);
+int mde_det_flush(void* stream);
+
+/* ------------------------------------------------------------------------------------
  * Implicit-GEMM convolution on MFMA (bf16 in, fp32 accumulate).
  * Replaces every nn.Conv2d on the FCRN path: torchvision Bottleneck convs (called at
  * reference network/FCRN.py:305,318-323), conv2 (FCRN.py:334), the UpProj 5x5/3x3 convs

@@ -50,6 +50,10 @@ SIGNATURES = {
     "mde_last_error": (C.c_char_p, []),
     "mde_abi_version": (_I, []),
     "mde_device_cu_count": (_I, [C.POINTER(_I)]),
+    "mde_det_scratch_bytes": (_Z, [_L]),
+    "mde_set_deterministic": (_I, [_I, _P, _P, _L]),
+    "mde_deterministic": (_I, []),
+    "mde_det_flush": (_I, [_P]),
     "mde_conv_gemm": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P]),
     "mde_conv_wgrad": (_I, [C.POINTER(WgradDesc), _P, _P, _P, _P]),
     "mde_stem_conv_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),

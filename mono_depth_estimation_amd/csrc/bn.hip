@@ -43,8 +43,26 @@ __device__ __forceinline__ void ldf8(const float* p, float (&v)[8]) {
 }
 
 // Workgroup-level combine of per-thread column sums into part[slot][2][C].
+// det: the per-thread sums are combined in a FIXED order (row lane 0, 1, ...) and leave the workgroup as integer atomics
+// (mde_common.h: deterministic mode); otherwise LDS float atomics + global float atomics.
 __device__ __forceinline__ void flush_sums(const float (&s1)[8], const float (&s2)[8], int col, int C,
-                                           float* part, float* sh) {
+                                           float* part, float* sh, int det) {
+    if (det) {
+        const int cpr = C >> 3, rpb = NT / cpr;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            sh[threadIdx.x * 16 + e] = s1[e];
+            sh[threadIdx.x * 16 + 8 + e] = s2[e];
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < 2 * C; i += NT) {
+            const int which = i / C, c = i - which * C;
+            float t = 0.f;
+            for (int q = 0; q < rpb; ++q) t += sh[(q * cpr + (c >> 3)) * 16 + which * 8 + (c & 7)];
+            mde_stat_add(part, C, blockIdx.x, which, c, t, 1);
+        }
+        return;
+    }
     for (int i = threadIdx.x; i < 2 * C; i += NT) sh[i] = 0.f;
     __syncthreads();
 #pragma unroll
@@ -58,7 +76,7 @@ __device__ __forceinline__ void flush_sums(const float (&s1)[8], const float (&s
 }
 
 __global__ __launch_bounds__(NT) void bn_stats_k(const bf16_t* __restrict__ x, int64_t M, int C, int ld,
-                                                 float* part, int rows_per_blk) {
+                                                 float* part, int rows_per_blk, int det) {
     __shared__ float sh[2 * MAXC];
     const int cpr = C >> 3, rpb = NT / cpr, col = threadIdx.x % cpr, rl = threadIdx.x / cpr;
     float s1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -71,22 +89,15 @@ __global__ __launch_bounds__(NT) void bn_stats_k(const bf16_t* __restrict__ x, i
 #pragma unroll
         for (int e = 0; e < 8; ++e) { s1[e] += v[e]; s2[e] += v[e] * v[e]; }
     }
-    flush_sums(s1, s2, col, C, part, sh);
+    flush_sums(s1, s2, col, C, part, sh, det);
 }
 
 __global__ void bn_finalize_k(float* part, int64_t M, int C, const float* gamma, const float* beta,
                               float* rmean, float* rvar, float momentum, float eps, float* scale,
-                              float* shift, float* smean, float* srstd) {
+                              float* shift, float* smean, float* srstd, int det) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    double s1 = 0.0, s2 = 0.0;
-    for (int s = 0; s < MDE_STAT_SLOTS; ++s) {
-        float* p = part + (size_t)s * 2 * C;
-        s1 += (double)p[c];
-        s2 += (double)p[C + c];
-        p[c] = 0.f;
-        p[C + c] = 0.f;
-    }
+    const double s1 = mde_stat_take(part, C, 0, c, det), s2 = mde_stat_take(part, C, 1, c, det);
     const double mean = s1 / (double)M;
     double var = s2 / (double)M - mean * mean;
     var = var > 0.0 ? var : 0.0;
@@ -107,17 +118,10 @@ __global__ void bn_finalize_k(float* part, int64_t M, int C, const float* gamma,
 // BatchNorm from given moments.  DenseNet (Bts.py:283-292 densenet161) normalises the same concatenated channels again in
 // every later layer of a block, each with its own gamma / beta / running statistics but the SAME batch moments: they
 // are computed once per 48-channel group, when it is produced.
-__global__ void bn_moments_k(float* part, int64_t M, int C, float* mean_out, float* var_out) {
+__global__ void bn_moments_k(float* part, int64_t M, int C, float* mean_out, float* var_out, int det) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    double s1 = 0.0, s2 = 0.0;
-    for (int s = 0; s < MDE_STAT_SLOTS; ++s) {
-        float* p = part + (size_t)s * 2 * C;
-        s1 += (double)p[c];
-        s2 += (double)p[C + c];
-        p[c] = 0.f;
-        p[C + c] = 0.f;
-    }
+    const double s1 = mde_stat_take(part, C, 0, c, det), s2 = mde_stat_take(part, C, 1, c, det);
     const double mean = s1 / (double)M;
     const double var = s2 / (double)M - mean * mean;
     mean_out[c] = (float)mean;
@@ -196,7 +200,7 @@ __global__ __launch_bounds__(NT) void bn_bwd_reduce_k(const bf16_t* __restrict__
                                                       const float* __restrict__ smean, const float* __restrict__ srstd,
                                                       const float* __restrict__ msc, const float* __restrict__ msh,
                                                       const uint8_t* __restrict__ bits, int64_t M, int C, float* part,
-                                                      int rows_per_blk) {
+                                                      int rows_per_blk, int det) {
     __shared__ float sh[2 * MAXC];
     const int cpr = C >> 3, rpb = NT / cpr, col = threadIdx.x % cpr, rl = threadIdx.x / cpr;
     float mu[8], rs[8], ms[8], mh[8];
@@ -226,21 +230,14 @@ __global__ __launch_bounds__(NT) void bn_bwd_reduce_k(const bf16_t* __restrict__
             s2[e] += ge * ((v[e] - mu[e]) * rs[e]);
         }
     }
-    flush_sums(s1, s2, col, C, part, sh);
+    flush_sums(s1, s2, col, C, part, sh, det);
 }
 
 __global__ void bn_bwd_finalize_k(float* part, int64_t M, int C, const float* gamma, const float* srstd,
-                                  float* dgamma, float* dbeta, float* coef) {
+                                  float* dgamma, float* dbeta, float* coef, int det) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    double s1 = 0.0, s2 = 0.0;
-    for (int s = 0; s < MDE_STAT_SLOTS; ++s) {
-        float* p = part + (size_t)s * 2 * C;
-        s1 += (double)p[c];
-        s2 += (double)p[C + c];
-        p[c] = 0.f;
-        p[C + c] = 0.f;
-    }
+    const double s1 = mde_stat_take(part, C, 0, c, det), s2 = mde_stat_take(part, C, 1, c, det);
     if (dgamma) dgamma[c] += (float)s2;
     if (dbeta) dbeta[c] += (float)s1;
     coef[c] = gamma[c] * srstd[c];
@@ -298,7 +295,7 @@ __global__ __launch_bounds__(NT) void bn_bwd_reduce2_k(const bf16_t* __restrict_
                                                        const float* __restrict__ mean_a, const float* __restrict__ rstd_a,
                                                        const float* __restrict__ mean_b, const float* __restrict__ rstd_b,
                                                        const uint8_t* __restrict__ bits, int64_t M, int C, float* part_a,
-                                                       float* part_b, int rows_per_blk) {
+                                                       float* part_b, int rows_per_blk, int det) {
     __shared__ float sh[3 * MAXC];
     const int cpr = C >> 3, rpb = NT / cpr, col = threadIdx.x % cpr, rl = threadIdx.x / cpr;
     float mua[8], rsa[8], mub[8], rsb[8];
@@ -323,6 +320,27 @@ __global__ __launch_bounds__(NT) void bn_bwd_reduce2_k(const bf16_t* __restrict_
             sa[e] += ge * ((va[e] - mua[e]) * rsa[e]);
             sb[e] += ge * ((vb[e] - mub[e]) * rsb[e]);
         }
+    }
+    if (det) {                                   // fixed-order combine, integer atomics (see flush_sums)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            sh[threadIdx.x * 24 + e] = s1[e];
+            sh[threadIdx.x * 24 + 8 + e] = sa[e];
+            sh[threadIdx.x * 24 + 16 + e] = sb[e];
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < 3 * C; i += NT) {
+            const int which = i / C, c = i - which * C;
+            float t = 0.f;
+            for (int q = 0; q < rpb; ++q) t += sh[(q * cpr + (c >> 3)) * 24 + which * 8 + (c & 7)];
+            if (which == 0) {
+                mde_stat_add(part_a, C, blockIdx.x, 0, c, t, 1);
+                mde_stat_add(part_b, C, blockIdx.x, 0, c, t, 1);
+            } else {
+                mde_stat_add(which == 1 ? part_a : part_b, C, blockIdx.x, 1, c, t, 1);
+            }
+        }
+        return;
     }
     for (int i = threadIdx.x; i < 3 * C; i += NT) sh[i] = 0.f;
     __syncthreads();
@@ -416,7 +434,7 @@ extern "C" int mde_bn_stats(const void* x, int64_t M, int C, int ld, float* part
     MDE_REQUIRE(al16(x, ld), "mde_bn_stats: x must be 16-byte aligned with ld %% 8 == 0");
     int nblk, rows;
     reduce_geometry(M, C, &nblk, &rows);
-    bn_stats_k<<<nblk, NT, 0, (hipStream_t)stream>>>((const bf16_t*)x, M, C, ld, part, rows);
+    bn_stats_k<<<nblk, NT, 0, (hipStream_t)stream>>>((const bf16_t*)x, M, C, ld, part, rows, g_mde_det.on);
     MDE_LAUNCH_CHECK("bn_stats_k");
     return MDE_OK;
 }
@@ -428,14 +446,14 @@ extern "C" int mde_bn_finalize(float* part, int64_t M, int C, const float* gamma
     MDE_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "mde_bn_finalize: running stats must come in pairs");
     MDE_REQUIRE(M > 0 && C > 0, "mde_bn_finalize: non-positive size");
     bn_finalize_k<<<mde_cdiv(C, 64), 64, 0, (hipStream_t)stream>>>(part, M, C, gamma, beta, running_mean, running_var,
-                                                                 momentum, eps, scale, shift, save_mean, save_rstd);
+                                                                 momentum, eps, scale, shift, save_mean, save_rstd, g_mde_det.on);
     MDE_LAUNCH_CHECK("bn_finalize_k");
     return MDE_OK;
 }
 
 extern "C" int mde_bn_moments(float* part, int64_t M, int C, float* mean, float* var, void* stream) {
     MDE_REQUIRE(part && mean && var && M > 0 && C > 0, "mde_bn_moments: bad argument");
-    bn_moments_k<<<mde_cdiv(C, 64), 64, 0, (hipStream_t)stream>>>(part, M, C, mean, var);
+    bn_moments_k<<<mde_cdiv(C, 64), 64, 0, (hipStream_t)stream>>>(part, M, C, mean, var, g_mde_det.on);
     MDE_LAUNCH_CHECK("bn_moments_k");
     return MDE_OK;
 }
@@ -497,13 +515,13 @@ extern "C" int mde_bn_bwd_reduce(const void* dout, int ldd, const void* out, int
     hipStream_t st = (hipStream_t)stream;
     const bf16_t *d = (const bf16_t*)dout, *o = (const bf16_t*)out, *xp = (const bf16_t*)x;
     if (!relu)
-        bn_bwd_reduce_k<0><<<nblk, NT, 0, st>>>(d, ldd, o, ldo, xp, ldx, save_mean, save_rstd, nullptr, nullptr, nullptr, M, C, part, rows);
+        bn_bwd_reduce_k<0><<<nblk, NT, 0, st>>>(d, ldd, o, ldo, xp, ldx, save_mean, save_rstd, nullptr, nullptr, nullptr, M, C, part, rows, g_mde_det.on);
     else if (recompute)
-        bn_bwd_reduce_k<2><<<nblk, NT, 0, st>>>(d, ldd, o, ldo, xp, ldx, save_mean, save_rstd, mask_scale, mask_shift, nullptr, M, C, part, rows);
+        bn_bwd_reduce_k<2><<<nblk, NT, 0, st>>>(d, ldd, o, ldo, xp, ldx, save_mean, save_rstd, mask_scale, mask_shift, nullptr, M, C, part, rows, g_mde_det.on);
     else if (packed)
-        bn_bwd_reduce_k<3><<<nblk, NT, 0, st>>>(d, ldd, o, ldo, xp, ldx, save_mean, save_rstd, nullptr, nullptr, relu_bits, M, C, part, rows);
+        bn_bwd_reduce_k<3><<<nblk, NT, 0, st>>>(d, ldd, o, ldo, xp, ldx, save_mean, save_rstd, nullptr, nullptr, relu_bits, M, C, part, rows, g_mde_det.on);
     else
-        bn_bwd_reduce_k<1><<<nblk, NT, 0, st>>>(d, ldd, o, ldo, xp, ldx, save_mean, save_rstd, nullptr, nullptr, nullptr, M, C, part, rows);
+        bn_bwd_reduce_k<1><<<nblk, NT, 0, st>>>(d, ldd, o, ldo, xp, ldx, save_mean, save_rstd, nullptr, nullptr, nullptr, M, C, part, rows, g_mde_det.on);
     MDE_LAUNCH_CHECK("bn_bwd_reduce_k");
     return MDE_OK;
 }
@@ -520,7 +538,7 @@ extern "C" int mde_bn_bwd_reduce2(const void* dout, int ldd, const void* xa, int
     reduce_geometry(M, C, &nblk, &rows);
     bn_bwd_reduce2_k<<<nblk, NT, 0, (hipStream_t)stream>>>((const bf16_t*)dout, ldd, (const bf16_t*)xa, ldxa, (const bf16_t*)xb,
                                                            ldxb, save_mean_a, save_rstd_a, save_mean_b, save_rstd_b, relu_bits,
-                                                           M, C, part_a, part_b, rows);
+                                                           M, C, part_a, part_b, rows, g_mde_det.on);
     MDE_LAUNCH_CHECK("bn_bwd_reduce2_k");
     return MDE_OK;
 }
@@ -545,7 +563,7 @@ extern "C" int mde_bn_bwd_apply2(const void* dout, int ldd, const void* xa, int 
 extern "C" int mde_bn_bwd_finalize(float* part, int64_t M, int C, const float* gamma, const float* save_rstd,
                                    float* dgamma, float* dbeta, float* coef, void* stream) {
     MDE_REQUIRE(part && gamma && save_rstd && coef && M > 0 && C > 0, "mde_bn_bwd_finalize: bad argument");
-    bn_bwd_finalize_k<<<mde_cdiv(C, 64), 64, 0, (hipStream_t)stream>>>(part, M, C, gamma, save_rstd, dgamma, dbeta, coef);
+    bn_bwd_finalize_k<<<mde_cdiv(C, 64), 64, 0, (hipStream_t)stream>>>(part, M, C, gamma, save_rstd, dgamma, dbeta, coef, g_mde_det.on);
     MDE_LAUNCH_CHECK("bn_bwd_finalize_k");
     return MDE_OK;
 }

@@ -76,6 +76,7 @@ struct KArgs {
     int32_t nP, nC;   // tiles along pixels / columns
     int32_t vec_ok;   // 16-byte stores allowed
     int32_t col_fastest;  // tile order: 1 = all column tiles of a pixel tile are neighbours (activation tile reused from L2)
+    int32_t det;          // deterministic mode: BatchNorm partial sums leave the workgroup as integer atomics (mde_common.h)
 };
 
 // byte offset of the 16-byte chunk (row, kslot8) inside a swizzled tile
@@ -738,7 +739,7 @@ __global__ __launch_bounds__(NT, (NT == 256 && BP * BC >= 256 * 256) ? 1 : 2) vo
                     float sum = 0.f;
 #pragma unroll
                     for (int q = 0; q < WAVES_P; ++q) sum += s_stat[(q * 2 + which) * BC + ch];
-                    atomicAdd(a.stats + ((size_t)(pi % MDE_STAT_SLOTS) * 2 + which) * d.ncols + n0 + ch, sum);
+                    mde_stat_add(a.stats, d.ncols, (uint32_t)pi, which, n0 + ch, sum, a.det);
                 }
             }
         }
@@ -954,6 +955,7 @@ extern "C" int mde_conv_gemm(const mde_conv_desc* d, const void* in, const void*
         }
         ka.col_fastest = order;
     }
+    ka.det = g_mde_det.on;
     ka.vec_ok = (d->ld_out % 8 == 0) && (((uintptr_t)out % 16) == 0);
     return pick_and_launch(ka, M, reinterpret_cast<hipStream_t>(stream));
 }

@@ -160,7 +160,7 @@ constexpr int FKS = 6;             // k-steps of 32 (24 groups of 8)
 #endif
 __global__ __launch_bounds__(NTF, 1) void stem_fwd_k(const float* __restrict__ x, const float* __restrict__ w,
                                                      bf16_t* __restrict__ out, float* stats, int N, int H, int W, int OH,
-                                                     int OW) {
+                                                     int OW, int det) {
     using G = StemGeo<FTY>;
     __shared__ uint32_t patch[2][G::WORDS + G::ZPAD];
     __shared__ float s_red[NTF / 64][2][64];
@@ -277,7 +277,7 @@ __global__ __launch_bounds__(NTF, 1) void stem_fwd_k(const float* __restrict__ x
             float v = 0.f;
 #pragma unroll
             for (int q = 0; q < NTF / 64; ++q) v += s_red[q][which][ch];
-            atomicAdd(stats + ((size_t)(blockIdx.x % MDE_STAT_SLOTS) * 2 + which) * 64 + ch, v);
+            mde_stat_add(stats, 64, blockIdx.x, which, ch, v, det);
         }
     }
 }
@@ -313,7 +313,7 @@ __device__ __forceinline__ void stem_dy_issue(i32x4_t (&dv)[SDQ], const __amdgpu
 }
 
 __global__ __launch_bounds__(NT, 2) void stem_wgrad_k(const float* __restrict__ x, const bf16_t* __restrict__ dout,
-                                                      float* __restrict__ dw, int N, int H, int W, int OH, int OW) {
+                                                      float* __restrict__ dw, int N, int H, int W, int OH, int OW, MdeDetDev det) {
     using G = StemGeo<WTY>;
     __shared__ uint32_t patch[G::WORDS + G::ZPAD];
     __shared__ __attribute__((aligned(16))) char dyt[WTY * STX * 128];
@@ -401,7 +401,7 @@ __global__ __launch_bounds__(NT, 2) void stem_wgrad_k(const float* __restrict__ 
 #pragma unroll
         for (int cb = 0; cb < 4; ++cb)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) atomicAdd(dw + (cb * 16 + lg * 4 + r) * SK + k, acc[cb][f][r]);
+            for (int r = 0; r < 4; ++r) mde_grad_add(dw + (cb * 16 + lg * 4 + r) * SK + k, acc[cb][f][r], det);
     }
 }
 
@@ -492,7 +492,8 @@ __global__ __launch_bounds__(NT) void head_dgrad_k(const float* __restrict__ w, 
 // channels [co0, co0 + COG).
 template <int COG>
 __global__ __launch_bounds__(NT) void head_wgrad_k(const bf16_t* __restrict__ x, const float* __restrict__ dout,
-                                                   float* __restrict__ dw, int N, int H, int W, int Cin, int Cout, int co0) {
+                                                   float* __restrict__ dw, int N, int H, int W, int Cin, int Cout, int co0,
+                                                   MdeDetDev det) {
     __shared__ float red[NT / 64][COG * 9 * 64];   // Cin <= 64 per pass (lpp <= 8)
     const int lpp = Cin >> 3;
     const int c8 = threadIdx.x % lpp, pl = threadIdx.x / lpp, ppb = NT / lpp;
@@ -539,7 +540,7 @@ __global__ __launch_bounds__(NT) void head_wgrad_k(const bf16_t* __restrict__ x,
         if (co0 + g < Cout) {
             float s = 0.f;
             for (int q = 0; q < NT / 64; ++q) s += red[q][(g * 9 + t) * 64 + c];
-            atomicAdd(dw + ((int64_t)(co0 + g) * 9 + t) * Cin + c, s);
+            mde_grad_add(dw + ((int64_t)(co0 + g) * 9 + t) * Cin + c, s, det);
         }
     }
 }
@@ -680,7 +681,7 @@ __global__ __launch_bounds__(NT) void head1_dgrad_k(const float* __restrict__ w,
 // weight gradient, input-stationary: every activation is converted once and meets the nine dout
 // values around it:  dw[(ky,kx)][c] += dout[p - (ky-1, kx-1)] * x[p][c]
 __global__ __launch_bounds__(NT) void head1_wgrad_k(const bf16_t* __restrict__ x, const float* __restrict__ dout,
-                                                    float* __restrict__ dw, int N, int H, int W) {
+                                                    float* __restrict__ dw, int N, int H, int W, MdeDetDev det) {
     __shared__ float red[NT / 64][9 * 64];
     const int c8 = threadIdx.x & 7, grp = threadIdx.x >> 3;
     f32x2_t acc[9][4];
@@ -750,7 +751,7 @@ __global__ __launch_bounds__(NT) void head1_wgrad_k(const bf16_t* __restrict__ x
         float s = 0.f;
 #pragma unroll
         for (int q = 0; q < NT / 64; ++q) s += red[q][i];
-        atomicAdd(dw + i, s);
+        mde_grad_add(dw + i, s, det);
     }
 }
 
@@ -824,7 +825,7 @@ extern "C" int mde_stem_conv_fwd(const float* x, const float* w, void* out, floa
     MDE_REQUIRE((int64_t)3 * H * W < (1 << 27), "mde_stem_conv_fwd: image plane too large");
     const int64_t cap = cu_count();                         // persistent: one 8-wave workgroup per CU
     const int grid = (int)(ntiles > cap ? cap : ntiles);
-    stem_fwd_k<<<grid, NTF, 0, (hipStream_t)stream>>>(x, w, (bf16_t*)out, stats, N, H, W, OH, OW);
+    stem_fwd_k<<<grid, NTF, 0, (hipStream_t)stream>>>(x, w, (bf16_t*)out, stats, N, H, W, OH, OW, g_mde_det.on);
     MDE_LAUNCH_CHECK("stem_fwd_k");
     return MDE_OK;
 }
@@ -839,7 +840,7 @@ extern "C" int mde_stem_conv_wgrad(const float* x, const void* dout, float* dw, 
     const int64_t ntiles = (int64_t)N * ((OH + WTY - 1) / WTY) * ((OW + STX - 1) / STX);
     const int64_t cap = 2 * (int64_t)cu_count();
     const int grid = (int)(ntiles > cap ? cap : ntiles);
-    stem_wgrad_k<<<grid, NT, 0, (hipStream_t)stream>>>(x, (const bf16_t*)dout, dw, N, H, W, OH, OW);
+    stem_wgrad_k<<<grid, NT, 0, (hipStream_t)stream>>>(x, (const bf16_t*)dout, dw, N, H, W, OH, OW, mde_det_dev());
     MDE_LAUNCH_CHECK("stem_wgrad_k");
     return MDE_OK;
 }
@@ -871,7 +872,7 @@ extern "C" int mde_head_conv_bwd(const void* x, const float* w, const float* dou
         }
         if (dw) {
             const int g = head1_grid(N, H, W);
-            head1_wgrad_k<<<g > 1024 ? 1024 : g, NT, 0, st>>>((const bf16_t*)x, dout, dw, N, H, W);
+            head1_wgrad_k<<<g > 1024 ? 1024 : g, NT, 0, st>>>((const bf16_t*)x, dout, dw, N, H, W, mde_det_dev());
             MDE_LAUNCH_CHECK("head1_wgrad_k");
         }
         return MDE_OK;
@@ -884,11 +885,11 @@ extern "C" int mde_head_conv_bwd(const void* x, const float* w, const float* dou
         const int grid = px_grid((int64_t)N * H * W, NT / (Cin / 8));
         const int g = grid > 1024 ? 1024 : grid;
         if (Cout == 1) {
-            head_wgrad_k<1><<<g, NT, 0, st>>>((const bf16_t*)x, dout, dw, N, H, W, Cin, Cout, 0);
+            head_wgrad_k<1><<<g, NT, 0, st>>>((const bf16_t*)x, dout, dw, N, H, W, Cin, Cout, 0, mde_det_dev());
             MDE_LAUNCH_CHECK("head_wgrad_k");
         } else {
             for (int co0 = 0; co0 < Cout; co0 += 2) {
-                head_wgrad_k<2><<<g, NT, 0, st>>>((const bf16_t*)x, dout, dw, N, H, W, Cin, Cout, co0);
+                head_wgrad_k<2><<<g, NT, 0, st>>>((const bf16_t*)x, dout, dw, N, H, W, Cin, Cout, co0, mde_det_dev());
                 MDE_LAUNCH_CHECK("head_wgrad_k");
             }
         }

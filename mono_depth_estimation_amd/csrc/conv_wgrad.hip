@@ -32,6 +32,7 @@ struct KArgs {
     int32_t nA, nB;       // tiles along rows / cols
     int32_t Crows, Ccols;
     int32_t gsize;        // grouped convolution: channels per group (0 = dense)
+    MdeDetDev det;        // deterministic mode: partial tiles are added as integers into the gradient's int64 shadow
     uint32_t inv_gw, inv_ghw;
 };
 
@@ -257,14 +258,14 @@ __global__ __launch_bounds__(NT, 2) void conv_wgrad_tn(const KArgs a) {
                     const int row = rbase + r;
                     const int gc = col - (row / a.gsize) * a.gsize;
                     if (row < a.Crows && gc >= 0 && gc < a.gsize)
-                        atomicAdd(a.dw + ((size_t)row * d.otaps_total + otap) * a.gsize + gc, acc[i][j][r]);
+                        mde_grad_add(a.dw + ((size_t)row * d.otaps_total + otap) * a.gsize + gc, acc[i][j][r], a.det);
                 }
             } else if (col < a.Ccols) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int row = rbase + r;
                     if (row < a.Crows)
-                        atomicAdd(a.dw + (size_t)row * rstride + (size_t)otap * a.Ccols + col, acc[i][j][r]);
+                        mde_grad_add(a.dw + (size_t)row * rstride + (size_t)otap * a.Ccols + col, acc[i][j][r], a.det);
                 }
             }
         }
@@ -327,6 +328,12 @@ extern "C" int mde_conv_wgrad(const mde_wgrad_desc* d, const void* direct, const
     ka.Crows = ga ? d->Cg : d->Cd;
     ka.Ccols = ga ? d->Cd : d->Cg;
     ka.gsize = d->group_size;
+    ka.det = mde_det_dev();
+    if (ka.det.scratch) {
+        const int64_t nw = (int64_t)ka.Crows * d->otaps_total * (d->group_size ? d->group_size : ka.Ccols);
+        MDE_REQUIRE(dw >= g_mde_det.gbase && dw + nw <= g_mde_det.gbase + g_mde_det.n,
+                    "mde_conv_wgrad: deterministic mode is on and dw lies outside the registered gradient buffer");
+    }
     const int ba = (ka.Crows % 128 == 0 && !ka.gsize) ? 128 : 64;
     const int bb = (ka.Ccols % 128 == 0 && !ka.gsize) ? 128 : 64;
     ka.nA = mde_cdiv(ka.Crows, ba);

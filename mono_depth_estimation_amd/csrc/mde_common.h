@@ -41,6 +41,25 @@ int mde_check_hip(hipError_t e, const char* what);
 
 static inline int mde_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
+// ---------------------------------------------------------------- deterministic mode (mde_set_deterministic)
+// Every cross-workgroup floating-point sum (BatchNorm partial sums, split-K weight gradients, bias gradients) is an
+// atomic add whose order changes from run to run; a last-bit difference flips a bf16 rounding and a deep net amplifies it.
+// In deterministic mode each addend is split EXACTLY into two integers (v * 2^20 rounded, and the remainder * 2^60) that
+// are added with 64-bit integer atomics: integer addition is associative, so the sum does not depend on the order.
+struct MdeDet {
+    int on;
+    float* gbase;          // the flat fp32 gradient buffer weight / bias gradients are accumulated into ...
+    long long* scratch;    // ... and its integer shadow: 2 x int64 per element, zero between backward passes
+    long long n;           // elements of gbase
+};
+extern MdeDet g_mde_det;
+struct MdeDetDev {         // kernel argument: scratch == nullptr -> plain float atomics
+    float* gbase;
+    long long* scratch;
+};
+static inline MdeDetDev mde_det_dev() { return g_mde_det.on ? MdeDetDev{g_mde_det.gbase, g_mde_det.scratch} : MdeDetDev{nullptr, nullptr}; }
+#define MDE_DET_SLOTS 8    // a partial-sum buffer [MDE_STAT_SLOTS][2][C] floats holds [MDE_DET_SLOTS][2][C][2] int64 in this mode
+
 // ---------------------------------------------------------------- device helpers
 #ifdef __HIPCC__
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t mde_rsrc(const void* p, uint32_t bytes) {
@@ -63,6 +82,46 @@ __device__ __forceinline__ float mde_row16_sum(float v) {
     MDE_DPP_ADD(0x121)  // row_ror:1
 #undef MDE_DPP_ADD
     return v;
+}
+
+__device__ __forceinline__ void mde_det_add2(long long* p, float v) {
+    const double vd = (double)v;
+    const long long a = __double2ll_rn(vd * 1048576.0);
+    const double r = vd - (double)a * (1.0 / 1048576.0);
+    atomicAdd(reinterpret_cast<unsigned long long*>(p), (unsigned long long)a);
+    atomicAdd(reinterpret_cast<unsigned long long*>(p + 1), (unsigned long long)__double2ll_rn(r * 1152921504606846976.0));
+}
+__device__ __forceinline__ double mde_det_value(const long long* p) {
+    return (double)p[0] * (1.0 / 1048576.0) + (double)p[1] * (1.0 / 1152921504606846976.0);
+}
+// one addend of a BatchNorm partial-sum buffer `part` (logical [slot][2][C]); wg picks the slot
+__device__ __forceinline__ void mde_stat_add(float* part, int C, uint32_t wg, int which, int c, float v, int det) {
+    if (!det) atomicAdd(part + ((size_t)(wg % MDE_STAT_SLOTS) * 2 + which) * C + c, v);
+    else mde_det_add2(reinterpret_cast<long long*>(part) + (((size_t)(wg % MDE_DET_SLOTS) * 2 + which) * C + c) * 2, v);
+}
+// sum over the slots of entry (which, c), leaving it zeroed
+__device__ __forceinline__ double mde_stat_take(float* part, int C, int which, int c, int det) {
+    double s = 0.0;
+    if (!det) {
+        for (int k = 0; k < MDE_STAT_SLOTS; ++k) {
+            float* p = part + ((size_t)k * 2 + which) * C + c;
+            s += (double)*p;
+            *p = 0.f;
+        }
+    } else {
+        for (int k = 0; k < MDE_DET_SLOTS; ++k) {
+            long long* p = reinterpret_cast<long long*>(part) + (((size_t)k * 2 + which) * C + c) * 2;
+            s += mde_det_value(p);
+            p[0] = 0;
+            p[1] = 0;
+        }
+    }
+    return s;
+}
+// one addend of a weight / bias gradient element
+__device__ __forceinline__ void mde_grad_add(float* dst, float v, const MdeDetDev& dd) {
+    if (!dd.scratch) atomicAdd(dst, v);
+    else mde_det_add2(dd.scratch + 2 * (dst - dd.gbase), v);
 }
 
 __device__ __forceinline__ float mde_wave_sum(float v) {

@@ -73,7 +73,7 @@ __global__ __launch_bounds__(NT) void pw_fwd_k(const bf16_t* __restrict__ x, int
 // g = dout * act'(out);  dx (+)= g;  dr (+)= g;  dbias += sum_rows g
 __global__ __launch_bounds__(NT) void pw_bwd_k(const bf16_t* __restrict__ dout, int ldd, const bf16_t* __restrict__ out, int ldo,
                                                bf16_t* __restrict__ dx, int lddx, int acc_x, bf16_t* __restrict__ dr, int lddr,
-                                               int acc_r, float* __restrict__ dbias, int64_t M, int C, int act) {
+                                               int acc_r, float* __restrict__ dbias, int64_t M, int C, int act, MdeDetDev det) {
     __shared__ float red[NT * 8];
     const int cpr = C >> 3;
     const int tpr = cpr < NT ? cpr : NT;
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(NT) void pw_bwd_k(const bf16_t* __restrict__ dout, 
                 for (int e = 0; e < 8; ++e) {
                     float t = 0.f;
                     for (int q = 0; q < rpb; ++q) t += red[(q * tpr + tc) * 8 + e];
-                    atomicAdd(dbias + c8 * 8 + e, t);
+                    mde_grad_add(dbias + c8 * 8 + e, t, det);
                 }
             }
             __syncthreads();
@@ -495,7 +495,7 @@ __global__ __launch_bounds__(NT) void softmax_head_fwd_k(const bf16_t* __restric
 constexpr int SM_MAXC = 64;
 __global__ __launch_bounds__(NT) void softmax_head_bwd_k(const float* __restrict__ dlogit, const float* __restrict__ dprob,
                                                          const float* __restrict__ prob, bf16_t* __restrict__ dx, int lddx,
-                                                         float* __restrict__ dbias, int N, int64_t HW, int C) {
+                                                         float* __restrict__ dbias, int N, int64_t HW, int C, MdeDetDev det) {
     extern __shared__ float sm[];
     float* tile = sm;
     float* red = sm + (size_t)C * 65;
@@ -552,7 +552,7 @@ __global__ __launch_bounds__(NT) void softmax_head_bwd_k(const float* __restrict
             const int c = q + 4 * k;
             if (c < C) {                            // (uniform per wave: q and k are)
                 const float t = mde_wave_sum(bsum[k]);
-                if (p == 0) atomicAdd(dbias + c, t);
+                if (p == 0) mde_grad_add(dbias + c, t, det);
             }
         }
     }
@@ -575,7 +575,7 @@ __global__ __launch_bounds__(NT) void to_nchw_act_fwd_k(const bf16_t* __restrict
 // dx[n][p][c] = dout * scale * act'(out / scale);  dbias[c] += sum dx   (C <= 64 for the bias gradient registers)
 __global__ __launch_bounds__(NT) void to_nchw_act_bwd_k(const float* __restrict__ dout, const float* __restrict__ out,
                                                         bf16_t* __restrict__ dx, int lddx, float* __restrict__ dbias, int N, int64_t HW,
-                                                        int C, int act, float scale) {
+                                                        int C, int act, float scale, MdeDetDev det) {
     __shared__ float red[NT / 64][64];
     const int64_t total = (int64_t)N * HW;
     float bs[64];
@@ -612,7 +612,7 @@ __global__ __launch_bounds__(NT) void to_nchw_act_bwd_k(const float* __restrict_
             }
         }
         __syncthreads();
-        if (threadIdx.x < C) atomicAdd(dbias + threadIdx.x, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+        if (threadIdx.x < C) mde_grad_add(dbias + threadIdx.x, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x], det);
     }
 }
 
@@ -660,7 +660,7 @@ extern "C" int mde_pw_bwd(const void* dout, int ldd, const void* out, int ldo, v
                 "mde_pw_bwd: operands must be 16-byte aligned with ld %% 8 == 0");
     const int tpr = C / 8 < NT ? C / 8 : NT;
     pw_bwd_k<<<grid_rows(M, NT / tpr), NT, 0, (hipStream_t)stream>>>((const bf16_t*)dout, ldd, (const bf16_t*)out, ldo, (bf16_t*)dx, lddx,
-                                                                   acc_x, (bf16_t*)dr, lddr, acc_r, dbias, M, C, act);
+                                                                   acc_x, (bf16_t*)dr, lddr, acc_r, dbias, M, C, act, mde_det_dev());
     MDE_LAUNCH_CHECK("pw_bwd_k");
     return MDE_OK;
 }
@@ -802,7 +802,7 @@ extern "C" int mde_softmax_head_bwd(const float* dlogit, const float* dprob, con
         attr = true;
     }
     const int64_t ntiles = (int64_t)N * ((HW + SM_PIX - 1) / SM_PIX);
-    softmax_head_bwd_k<<<(int)(ntiles < 1024 ? ntiles : 1024), NT, smem, (hipStream_t)stream>>>(dlogit, dprob, prob, (bf16_t*)dx, lddx, dbias, N, HW, C);
+    softmax_head_bwd_k<<<(int)(ntiles < 1024 ? ntiles : 1024), NT, smem, (hipStream_t)stream>>>(dlogit, dprob, prob, (bf16_t*)dx, lddx, dbias, N, HW, C, mde_det_dev());
     MDE_LAUNCH_CHECK("softmax_head_bwd_k");
     return MDE_OK;
 }
@@ -823,7 +823,7 @@ extern "C" int mde_to_nchw_act_bwd(const float* dout, const float* out, void* dx
                 "mde_to_nchw_act_bwd: bad argument (C=%d <= 64, lddx=%d)", C, lddx);
     int grid = grid_flat((int64_t)N * HW);
     if (grid > 1024) grid = 1024;
-    to_nchw_act_bwd_k<<<grid, NT, 0, (hipStream_t)stream>>>(dout, out, (bf16_t*)dx, lddx, dbias, N, HW, C, act, scale);
+    to_nchw_act_bwd_k<<<grid, NT, 0, (hipStream_t)stream>>>(dout, out, (bf16_t*)dx, lddx, dbias, N, HW, C, act, scale, mde_det_dev());
     MDE_LAUNCH_CHECK("to_nchw_act_bwd_k");
     return MDE_OK;
 }

@@ -215,6 +215,31 @@ class FlatStore:
         self._fp_state, self._fp_valid = None, False     # device fingerprint of P (refresh_weights(check_data=True))
         self.step_count = 0
         self._flatten_parameters()
+        self.deterministic, self._det_scratch = False, None
+        if os.environ.get("MDE_DETERMINISTIC", "0") == "1":
+            self.set_deterministic(True)
+
+    # ---- opt-in deterministic mode (include/mde_hip.h: mde_set_deterministic): bit-reproducible training steps
+    def set_deterministic(self, on=True):
+        """Every cross-workgroup sum of a step (BatchNorm statistics, split-K weight gradients, bias gradients) becomes an
+        order-independent integer accumulation: two runs from the same state give bit-identical gradients.  Costs one
+        extra pass over the gradient buffer per step and 16 bytes of scratch per parameter; the gradient exchange of
+        dp.FlatGradReducer then starts after backward instead of overlapping it.  Process-wide kernel state: switch it
+        between steps, and use it on one module at a time."""
+        self.deterministic = bool(on)
+        if not on:
+            ops.set_deterministic(False)
+
+    def det_begin(self):
+        """Point the kernels' integer gradient shadow at the buffer this backward accumulates into."""
+        if self.deterministic:
+            if self._det_scratch is None:
+                self._det_scratch = ops.det_scratch(self.G)
+            ops.set_deterministic(True, self.Gcur, self._det_scratch)
+
+    def det_end(self):
+        if self.deterministic:
+            ops.det_flush()
 
     def _layout(self):
         """-> (plist, blist, n_encoder_entries, no_pad).  plist: [(kind, [tensors])] in flat order, a fused entry lists
@@ -733,6 +758,7 @@ class FCRNEngine(EngineCore):
     # ------------------------------------------------------------------ execution
     def forward(self, x, train, check_data=False):
         assert x.shape == (self.N, self.cin, self.H, self.W) and x.dtype == torch.float32 and x.is_contiguous()
+        self.store.det_begin()
         self.store.refresh_weights(check_data=check_data)
         self.x = x
         s = self.stem_site
@@ -772,6 +798,10 @@ class FCRNEngine(EngineCore):
         consumer_waits_side: the callback orders itself behind self.side (dp.FlatGradReducer(extra_streams=
         [eng.side])); otherwise the side stream is joined into the current one before every call."""
         assert dy.shape == self.y.shape and dy.dtype == torch.float32 and dy.is_contiguous()
+        det = self.store.deterministic
+        self.store.det_begin()
+        if det:
+            progress, on_progress = on_progress, None     # the gradients reach G only with the final flush
         f = self.feat
         for L in self.layers:
             L.reset_grad_flags()
@@ -794,6 +824,9 @@ class FCRNEngine(EngineCore):
             for d in self.stem_wd:
                 self.wgrad(d, self.stem_c.g, self.xin.t, self.stem_w.dw)
         self.join_side()
+        self.store.det_end()
+        if det:
+            on_progress = progress
         if on_progress is not None:
             on_progress(0)
 

@@ -690,6 +690,7 @@ class TapeEngine(EngineCore):
 
     def forward(self, x, train, check_data=False):
         assert x.dtype == torch.float32 and x.is_contiguous() and tuple(x.shape) == (self.N, 3, self.H, self.W), tuple(x.shape)
+        self.store.det_begin()
         self.store.refresh_weights(check_data=check_data)
         self.stem.x = x
         for op in self.tape:
@@ -701,6 +702,7 @@ class TapeEngine(EngineCore):
     def backward(self, douts):
         """douts: one fp32 gradient (or None) per output tensor, in the order forward returned them.  Adds the parameter
         gradients into store.Gcur."""
+        self.store.det_begin()
         for a in self._acts:
             a.gw = False
         for a in self._bufs:           # concatenation targets: consumers may cover only part of the channels, so every
@@ -715,6 +717,7 @@ class TapeEngine(EngineCore):
         for op in reversed(self.tape):
             op.bwd()
         self.join_side()
+        self.store.det_end()
 
     def grad_boundaries(self):
         return [0, self.store.encoder_numel]

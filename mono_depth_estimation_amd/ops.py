@@ -145,6 +145,20 @@ def _timed(kind, flops, fn, tag=""):
     TIMER.records.append((kind, flops, e0, e1, tag))
 
 
+def set_deterministic(on, gbase=None, scratch=None):
+    n = gbase.numel() if gbase is not None else 0
+    check(_lib.load().mde_set_deterministic(int(on), _p(gbase), _p(scratch), n), "mde_set_deterministic")
+
+
+def det_scratch(gbase):
+    """Zeroed integer shadow of a flat gradient buffer (2 x int64 per element)."""
+    return torch.zeros(2 * gbase.numel(), dtype=torch.int64, device=gbase.device)
+
+
+def det_flush():
+    check(_lib.load().mde_det_flush(_stream()), "mde_det_flush")
+
+
 def conv_gemm(desc, x, w, out, stats=None):
     lib = _lib.load()
     if TIMER is None:

@@ -112,5 +112,5 @@ def test_ddp_averages_gradients_of_a_tape_module(tmp_path):
     mp.spawn(_tape_worker, args=(2, path, 29611, out), nprocs=2, join=True)
     r = torch.load(out)
     print(r)
-    assert r["n"] > 600 and r["local_median"] > 0.3
+    assert r["n"] > 300 and r["local_median"] > 0.3
     assert r["worst"] < 8e-2 and r["median"] < 2e-2, r

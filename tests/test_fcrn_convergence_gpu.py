@@ -74,3 +74,43 @@ def test_loss_curves_agree_and_trained_state_absrel():
     # weights here are NOT bf16-representable (free-running Adam): bf16 weight quantisation alone moves AbsRel by ~1e-4
     # (DESIGN section 4), yet the north-star bound holds here too: measured |dAbsRel| 1.7e-5, output rel L2 1.4e-3
     assert abs(ah - ao) < 1e-4 and rel < 1e-2
+
+
+def _one_step_grads(net, x, t, crit):
+    net.zero_grad(set_to_none=True)
+    loss = crit(net(x), t)
+    loss.backward()
+    return float(loss), net._store.grad_buffer().clone()
+
+
+def test_deterministic_mode_is_bit_reproducible():
+    """with store.set_deterministic(True) two identical training steps at a size where the default path
+    is NOT reproducible (8 x 3 x 240 x 320: BatchNorm partial sums and split-K weight gradients are float atomics) give
+    bit-identical losses and gradients, and they agree with the default path's to its own run-to-run noise."""
+    from mono_depth_estimation_amd import criteria
+    from mono_depth_estimation_amd.network import FCRN
+    size = (240, 320)
+    torch.manual_seed(5)
+    net = FCRN.ResNet(layers=50, output_size=size, out_channels=1, pretrained=False)
+    with torch.no_grad():
+        net.conv3.weight.mul_(0.05)
+    net = net.cuda().train()
+    x = torch.rand(8, 3, *size, device="cuda")
+    t = torch.rand(8, 1, *size, device="cuda") * 0.9 + 0.05
+    crit = criteria.silog_loss(0.85)
+    _one_step_grads(net, x, t, crit)                                      # builds the plan, warms up
+    l0, g0 = _one_step_grads(net, x, t, crit)
+    l1, g1 = _one_step_grads(net, x, t, crit)
+    noise = float((g1 - g0).norm() / g0.norm())
+    net._store.set_deterministic(True)
+    ld0, d0 = _one_step_grads(net, x, t, crit)
+    ld1, d1 = _one_step_grads(net, x, t, crit)
+    ld2, d2 = _one_step_grads(net, x, t, crit)
+    net._store.set_deterministic(False)
+    print("default path: run-to-run gradient difference %.3e (loss %.6f / %.6f); deterministic: %.3e, loss %.6f / %.6f; det vs default %.3e" % (
+        noise, l0, l1, float((d1 - d0).abs().max()), ld0, ld1, float((d0 - g0).norm() / g0.norm())))
+    assert ld0 == ld1 == ld2 and torch.equal(d0, d1) and torch.equal(d1, d2)
+    assert float((d0 - g0).norm() / g0.norm()) <= max(3.0 * noise, 1e-3)
+    # the default path after the switch back still works and the partial-sum buffers were left clean
+    l2, g2 = _one_step_grads(net, x, t, crit)
+    assert abs(l2 - l0) < 1e-2 * abs(l0) and float((g2 - g0).norm() / g0.norm()) <= max(3.0 * noise, 1e-3)

@@ -9,9 +9,10 @@ Tolerances (bf16 tensor-core path vs fp32 reference), stated per check:
     (that net amplifies perturbations ~700x; see test docstring and DESIGN.md).
   * train-mode SILog: within 1 % (He-init) / 0.2 % (conditioned) of the reference's value.
   * layer-isolated (teacher-forced) checks against an oracle that rounds to bf16 where the
-    HIP path does: forward relL2 <= 1e-2; input/weight gradients relL2 <= 1e-1 on ReLU blocks
-    (ReLU-mask flips of near-zero activations between two slightly different forwards give
-    sqrt(flip rate) ~ 5 %), <= 1e-2 on the ReLU-free conv2/bn2 layer.
+    HIP path does: forward relL2 <= 8e-3; input/weight gradients per layer class at ~1.5-2x the
+    measured maxima (bottlenecks 9e-2 / 1.2e-1, up-projections 4e-2 / 5e-2, the ReLU-free conv2/bn2
+    layer 6e-3): ReLU-mask flips of near-zero activations between two slightly different forwards
+    give sqrt(flip rate) ~ 5 % on the ReLU blocks.
 Free-running deep comparisons in train mode are NOT asserted at this tiny size (2 x 96 x 128:
 layer4 sees 24 samples per channel, and batch-statistics BN amplifies rounding ~200x).
 """
@@ -225,9 +226,11 @@ def test_layers_teacher_forced(setup):
     torch.cuda.synchronize()
     for r in report:
         print("%-10s fwd %.3e  dx %.3e  dW %.3e" % r)
+    # gates per layer class, ~1.5-2x the measured maxima (bottlenecks: dx 2.7-5.4e-2, dW 4.3-7.7e-2; conv2/bn2: 2.4e-3;
+    # up1: 3.8e-2 / 4.2e-2; up2-4: dx 1.5-1.9e-2, dW 0.8-2.3e-2; forward 1.3-4.1e-3 everywhere)
     for n, e_f, e_b, e_w in report:
-        lim = 1e-2 if n == "bn2" else 1e-1
-        assert e_f <= 1e-2 and e_b <= lim and e_w <= lim, (n, e_f, e_b, e_w)
+        lb, lw = (6e-3, 6e-3) if n == "bn2" else (8e-2, 7e-2) if n == "up1" else (4e-2, 5e-2) if n.startswith("up") else (9e-2, 1.2e-1)
+        assert e_f <= 8e-3 and e_b <= lb and e_w <= lw, (n, e_f, e_b, e_w)
 
 
 def test_fused_adam_training_reduces_loss(setup):
