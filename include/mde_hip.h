@@ -304,9 +304,39 @@ int mde_slot_to_map_add(const void* dslot, int ld, float* dsrc, int N, int H, in
  * (the transposed blocks, for the input gradient); either may be NULL. */
 int mde_pack_grouped(const float* src, void* fwd, void* dgrad, int O, int T, int G, void* stream);
 
+/* ---- DORN pieces (network/Dorn.py) ---- */
+/* nn.MaxPool2d(3, 2, 1, ceil_mode=True) (Dorn.py:235): as mde_maxpool_fwd / _bwd with the output size of ATen's ceil rule
+ * (OH = ceil((H - 1) / 2) + 1, minus one if the last window would start beyond the padded input); out / idx are
+ * [N][OH][OW][C].  ceil_mode == 0 is exactly mde_maxpool_fwd / _bwd. */
+int mde_maxpool_fwd2(const void* x, void* out, uint8_t* idx, int N, int H, int W, int C, int ceil_mode, void* stream);
+int mde_maxpool_bwd2(const void* dout, const uint8_t* idx, void* dx, int N, int H, int W, int C, int ceil_mode, void* stream);
+/* nn.Dropout2d as data (Dorn.py:59,107,109): out[n][p][c] = x[n][p][c] * m[n][c] (+ out when accumulate), m fp32 [N][C] holding
+ * 0 or 1 / (1 - p); bf16 [N * HW][ld] tensors, C % 8 == 0.  The gradient is the same call on the output gradient. */
+int mde_chan_scale(const void* x, int ldx, const float* m, void* out, int ldo, int N, int64_t HW, int C, int accumulate, void* stream);
+/* FullImageEncoder's pooling (Dorn.py:58,72-74): nn.AvgPool2d(k, stride=s, padding=p) (count_include_pad, floor mode) of a
+ * bf16 NHWC map, times m[n][c] (the Dropout2d scale, may be NULL), written in the order of `x.view(-1, C * OH * OW)` of the
+ * NCHW result: out bf16 [N][C * OH * OW], OH = (H + 2p - k) / s + 1 — what nn.Linear's weight contracts as stored.
+ * bwd: dx[n][y][x][c] (+)= m[n][c] / k^2 * sum of dout over the windows containing (y, x). */
+int mde_avgpool_flat_fwd(const void* x, int ldx, const float* m, void* out, int N, int H, int W, int C, int k, int s, int p, void* stream);
+int mde_avgpool_flat_bwd(const void* dout, const float* m, void* dx, int lddx, int N, int H, int W, int C, int k, int s, int p,
+                         int accumulate, void* stream);
+/* OrdinalRegressionLayer (Dorn.py:288-318): x bf16 [N * HW][ldx] with channel 2k = A_k, 2k + 1 = B_k (K <= 128);
+ * prob fp32 [N][K][HW] = softmax over the pair (clamp(A_k, 1e-8, 1e4), clamp(B_k, 1e-8, 1e4)) at index 1;
+ * label int64 [N][HW] = #{k : prob > 0.5}.  bwd: dx bf16 [N * HW][lddx] (every channel written, padding zero):
+ * dB_k = dprob * prob * (1 - prob) where B_k lies inside the clamp range, dA_k = -(the same) where A_k does. */
+int mde_ordinal_fwd(const void* x, int ldx, float* prob, int64_t* label, int N, int64_t HW, int K, void* stream);
+int mde_ordinal_bwd(const float* dprob, const void* x, int ldx, void* dx, int lddx, int N, int64_t HW, int K, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * Losses and metrics (criteria.py / metrics.py), fp32 in, fp32/fp64 accumulation.
  * ---------------------------------------------------------------------------------- */
+/* ordLoss (criteria.py:734-787): prob fp32 [N][K][HW], target fp32 [N][HW] (the SID label, NOT truncated: the reference
+ * compares the plane index k with it as floats; NaN takes neither branch):
+ * loss = -(sum_{k <= t} log clamp(P_k, 1e-8, 1e8) + sum_{k > t} log clamp(1 - P_k, 1e-8, 1e8)) / (N * HW).
+ * ws >= mde_ord_loss_ws_bytes().  bwd: grad fp32 [N][K][HW] = *gscale * d loss / d prob (zero where a clamp is active). */
+size_t mde_ord_loss_ws_bytes(void);
+int mde_ord_loss_fwd(const float* prob, const float* target, int N, int K, int64_t HW, void* ws, float* loss, void* stream);
+int mde_ord_loss_bwd(const float* prob, const float* target, int N, int K, int64_t HW, const float* gscale, float* grad, void* stream);
 /* SILog (criteria.py:724-732).  ws: >= mde_silog_ws_bytes() bytes, zeroed by the call.
  * loss: 1 float.  grad (optional): d loss / d est, same shape as est, scaled by *gscale
  * (device pointer to 1 float = upstream gradient; NULL -> 1). */

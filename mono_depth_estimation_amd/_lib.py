@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MDE_LIB_PATH") or os.path.join(_HERE, "libmde_hip.so")   # override: diagnostic builds only
-ABI_VERSION = 5
+ABI_VERSION = 6
 MAX_TAPS = 32
 
 
@@ -97,6 +97,16 @@ SIGNATURES = {
     "mde_map_to_slot": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "mde_slot_to_map_add": (_I, [_P, _I, _P, _I, _I, _I, _I, _P]),
     "mde_pack_grouped": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "mde_maxpool_fwd2": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "mde_maxpool_bwd2": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "mde_chan_scale": (_I, [_P, _I, _P, _P, _I, _I, _L, _I, _I, _P]),
+    "mde_avgpool_flat_fwd": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "mde_avgpool_flat_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "mde_ordinal_fwd": (_I, [_P, _I, _P, _P, _I, _L, _I, _P]),
+    "mde_ordinal_bwd": (_I, [_P, _P, _I, _P, _I, _I, _L, _I, _P]),
+    "mde_ord_loss_ws_bytes": (_Z, []),
+    "mde_ord_loss_fwd": (_I, [_P, _P, _I, _I, _L, _P, _P, _P]),
+    "mde_ord_loss_bwd": (_I, [_P, _P, _I, _I, _L, _P, _P, _P]),
     "mde_silog_ws_bytes": (_Z, []),
     "mde_silog_fwd": (_I, [_P, _P, _L, _F, _P, _P, _P]),
     "mde_silog_bwd": (_I, [_P, _P, _L, _F, _P, _P, _P, _P]),

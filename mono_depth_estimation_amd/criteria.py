@@ -17,6 +17,9 @@ kernels in csrc/losses.hip; no CPU fallback):
       the triples are drawn on the host from the GLOBAL numpy RNG with the reference's exact sequence of
       calls (select_index), so a seeded run samples the same pixels as the reference.
   ModelLoss(args)(pred_depth, pred_logit, depth_bins, depth_gt)   criteria.py:1047-1062
+  ordLoss()(ord_labels, target)                        criteria.py:734-787   (DORN's loss; csrc/ordinal.hip)
+      ord_labels: the ordinal probabilities N x K x H x W; target: the SID label map N x 1 x H x W as modules/dorn.py:102-107
+      computes it (a float tensor, not truncated: plane k counts as "<= target" by a float comparison, as in the reference).
   bins_to_depth(depth_bin, depth_bin_border), depth_to_bins(depth, depth_min, depth_max, dec_out_c)
       modules/vnl.py:202-230 (methods of the reference's VNLModule; free functions here, kernels in
       csrc/vnl_losses.hip)
@@ -277,6 +280,47 @@ class TrimmedProcrustesLoss(nn.Module):
         loss, pn = _ProcrustesFunction.apply(prediction, target, self.alpha if self.alpha > 0 else 0.0, self.scales, True)
         self.prediction_ssi = pn.detach()
         return loss
+
+
+# ------------------------------------------------------------------------------ DORN (csrc/ordinal.hip)
+class _OrdLossFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, prob, target):
+        ctx.in_dtype = prob.dtype
+        x = prob.contiguous().float()
+        N, K = x.shape[0], x.shape[1]
+        HW = x.numel() // (N * K)
+        if target.numel() != N * HW:
+            raise ValueError("ordLoss: ordinal probabilities %s need %d targets, got %s" % (tuple(prob.shape), N * HW, tuple(target.shape)))
+        t = target.to(device=x.device, dtype=torch.float32).contiguous()
+        ws = ops.ord_loss_ws(x.device)
+        loss = torch.empty(1, device=x.device)
+        ops.ord_loss_fwd(x, t, N, K, HW, ws, loss)
+        ctx.save_for_backward(x, t)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, gout):
+        x, t = ctx.saved_tensors
+        N, K = x.shape[0], x.shape[1]
+        grad = torch.empty_like(x)
+        ops.ord_loss_bwd(x, t, N, K, x.numel() // (N * K), gout.contiguous().float().reshape(1), grad)
+        return grad.to(ctx.in_dtype), None
+
+
+class ordLoss(nn.Module):
+    """criteria.py:734-787: the average over pixels of the ordinal log-likelihood."""
+
+    def __init__(self):
+        super(ordLoss, self).__init__()
+        self.loss = 0.0
+
+    def forward(self, ord_labels, target):
+        _need_gpu(ord_labels, "ordLoss")
+        if ord_labels.dim() != 4:
+            raise ValueError("ordLoss: ord_labels must be N x K x H x W, got %s" % (tuple(ord_labels.shape),))
+        self.loss = _OrdLossFunction.apply(ord_labels, target)
+        return self.loss
 
 
 # ------------------------------------------------------------------------------ VNL configuration (csrc/vnl_losses.hip)

@@ -261,24 +261,39 @@ extern "C" int mde_pixel_shuffle2(void* src, int ld_src, void* dst, int ld_dst, 
     return MDE_OK;
 }
 
-extern "C" int mde_maxpool_fwd(const void* x, void* out, uint8_t* idx, int N, int H, int W, int C, void* stream) {
+static inline int maxpool_out(int in, int ceil_mode) {
+    if (!ceil_mode) return (in + 2 - 3) / 2 + 1;
+    int o = (in + 2 - 3 + 1) / 2 + 1;             // ceil((in + 2p - k) / s) + 1
+    if ((o - 1) * 2 >= in + 1) --o;               // ATen: the last window must start inside the input or its left padding
+    return o;
+}
+
+extern "C" int mde_maxpool_fwd2(const void* x, void* out, uint8_t* idx, int N, int H, int W, int C, int ceil_mode, void* stream) {
     MDE_REQUIRE(x && out && idx && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "mde_maxpool_fwd: bad argument (C %% 8 == 0)");
     MDE_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)out % 16) == 0 && ((uintptr_t)idx % 8) == 0, "mde_maxpool_fwd: alignment");
-    const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
+    const int OH = maxpool_out(H, ceil_mode), OW = maxpool_out(W, ceil_mode);
     maxpool_fwd_k<<<grid_for((int64_t)N * OH * OW * (C / 8)), NT, 0, (hipStream_t)stream>>>(
         (const bf16_t*)x, (bf16_t*)out, idx, N, H, W, C, OH, OW);
     MDE_LAUNCH_CHECK("maxpool_fwd_k");
     return MDE_OK;
 }
 
-extern "C" int mde_maxpool_bwd(const void* dout, const uint8_t* idx, void* dx, int N, int H, int W, int C, void* stream) {
+extern "C" int mde_maxpool_bwd2(const void* dout, const uint8_t* idx, void* dx, int N, int H, int W, int C, int ceil_mode, void* stream) {
     MDE_REQUIRE(dout && dx && idx && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "mde_maxpool_bwd: bad argument (C %% 8 == 0)");
     MDE_REQUIRE(((uintptr_t)dout % 16) == 0 && ((uintptr_t)dx % 16) == 0 && ((uintptr_t)idx % 8) == 0, "mde_maxpool_bwd: alignment");
-    const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
+    const int OH = maxpool_out(H, ceil_mode), OW = maxpool_out(W, ceil_mode);
     maxpool_bwd_k<<<grid_for((int64_t)N * H * W * (C / 8)), NT, 0, (hipStream_t)stream>>>(
         (const bf16_t*)dout, idx, (bf16_t*)dx, N, H, W, C, OH, OW);
     MDE_LAUNCH_CHECK("maxpool_bwd_k");
     return MDE_OK;
+}
+
+extern "C" int mde_maxpool_fwd(const void* x, void* out, uint8_t* idx, int N, int H, int W, int C, void* stream) {
+    return mde_maxpool_fwd2(x, out, idx, N, H, W, C, 0, stream);
+}
+
+extern "C" int mde_maxpool_bwd(const void* dout, const uint8_t* idx, void* dx, int N, int H, int W, int C, void* stream) {
+    return mde_maxpool_bwd2(dout, idx, dx, N, H, W, C, 0, stream);
 }
 
 static inline float ac_scale(int in, int out) { return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f; }

@@ -412,6 +412,18 @@ class FlatStore:
             self._pack_jobs = None
         return c
 
+    def linear(self, w, need_dgrad=True):
+        """An nn.Linear weight [O][I] as the 1x1 convolution it is: its natural storage is already the GEMM operand
+        [O][1][I] (Dorn.py:64 global_fc; O and I multiples of 8, so nothing is padded)."""
+        c = self.convs.get(id(w))
+        if c is None:
+            O, I = w.shape
+            assert w.dim() == 2 and O % 8 == 0 and I % 8 == 0 and self.sdims[id(w)] == (O * I,), (tuple(w.shape), self.sdims[id(w)])
+            c = Conv(self, self.p_off[id(w)], O, 1, I, need_dgrad)
+            self.convs[id(w)] = c
+            self._pack_jobs = None
+        return c
+
     def layer_boundaries(self):
         """Flat offsets at which conv weights start (forward order): where dp.FlatGradReducer may cut its buckets."""
         return sorted({0} | {self.p_off[id(p)] for p in self.params if p.dim() == 4})

@@ -109,7 +109,7 @@ class Conv(Op):
     def __init__(self, eng, x, w, k, stride=1, pad=0, dil=1, groups=1, out=None, site=None, need_dgrad=True):
         self.eng, self.x, self.site, self.need_dgrad = eng, x, site, need_dgrad
         store = eng.store
-        O = store.sdims[id(w)][0]
+        O = store.sdims[id(w)][0] if w.dim() == 4 else w.shape[0]
         OH, OW = ops.out_size(x.H, k, stride, pad, dil), ops.out_size(x.W, k, stride, pad, dil)
         self.out = out if out is not None else Act(eng.dev, x.N, OH, OW, O)
         o = self.out
@@ -121,7 +121,7 @@ class Conv(Op):
             self.conv = store.conv_grouped(w, G)
             Cin = 64
         else:
-            self.conv = store.conv([w], need_dgrad)
+            self.conv = store.conv([w], need_dgrad) if w.dim() == 4 else store.linear(w, need_dgrad)   # nn.Linear: a 1x1 conv
             Cin = self.conv.I
             assert x.C == Cin, "conv input has %d channels, the stored weight %d" % (x.C, Cin)
             G = 0
@@ -400,24 +400,27 @@ class ToNCHW(Op):
 
 # ---------------------------------------------------------------------------------------------- ops of the BTS / DenseNet plans
 class ImageStem(Op):
-    """A 7x7/2 stem with any number of output channels (densenet161's conv0: 96, Bts.py:289): the fp32 NCHW image goes to
-    NHWC bf16 with its 3 channels zero-padded to 8, the 49 taps run as two launches of the GEMM kernel (32 + 17 taps, the
-    second accumulating), the BatchNorm statistics come from a stand-alone reduction.  No input gradient."""
+    """A k x k stem conv on the image with any number of output channels (densenet161's 7x7/2 conv0: 96 channels, Bts.py:289;
+    DORN's 3x3/2 conv1, Dorn.py:224): the fp32 NCHW image goes to NHWC bf16 with its 3 channels zero-padded to 8, the taps
+    run as launches of the GEMM kernel of at most 32 taps each (7x7: 32 + 17, the second accumulating), the BatchNorm
+    statistics come from a stand-alone reduction.  No input gradient."""
 
     def __init__(self, eng, conv, site, N, H, W):
         self.eng, self.site = eng, site
         self.w = eng._conv([conv.weight], need_dgrad=False)
         O, Cp = self.w.O, self.w.I
-        assert Cp == 8 and conv.kernel_size == (7, 7) and conv.stride == (2, 2)
-        H2, W2 = ops.out_size(H, 7, 2, 3), ops.out_size(W, 7, 2, 3)
+        k, st, pd = conv.kernel_size[0], conv.stride[0], conv.padding[0]
+        assert Cp == 8 and conv.kernel_size == (k, k) and conv.stride == (st, st) and conv.padding == (pd, pd) and conv.dilation == (1, 1)
+        H2, W2 = ops.out_size(H, k, st, pd), ops.out_size(W, k, st, pd)
         self.xin = Act(eng.dev, N, H, W, Cp)
         self.out = Act(eng.dev, N, H2, W2, O)
-        taps = [(i - 3, j - 3, i * 7 + j) for i in range(7) for j in range(7)]
-        ks = eng._ksplit(N * H2 * W2, O, Cp, 32)
+        taps = [(i - pd, j - pd, i * k + j) for i in range(k) for j in range(k)]
+        ks = eng._ksplit(N * H2 * W2, O, Cp, min(32, k * k))
         self.fd, self.wd = [], []
-        for part, acc in ((taps[:32], False), (taps[32:], True)):
-            self.fd.append(ops.conv_desc(N, H, W, Cp, Cp, self.xin.nbytes, H2, W2, 2, 2, part, 49, H2, W2, O, ncols=O, accumulate=acc))
-            self.wd.append(ops.wgrad_desc(N, H2, W2, O, O, self.out.nbytes, H, W, Cp, Cp, self.xin.nbytes, 2, 2, part, 49, False, ks))
+        for t0 in range(0, k * k, 32):
+            part = taps[t0:t0 + 32]
+            self.fd.append(ops.conv_desc(N, H, W, Cp, Cp, self.xin.nbytes, H2, W2, st, st, part, k * k, H2, W2, O, ncols=O, accumulate=t0 > 0))
+            self.wd.append(ops.wgrad_desc(N, H2, W2, O, O, self.out.nbytes, H, W, Cp, Cp, self.xin.nbytes, st, st, part, k * k, False, ks))
         self.x = None
 
     def acts(self):
@@ -436,12 +439,12 @@ class ImageStem(Op):
 
 
 class MaxPool(Op):
-    """nn.MaxPool2d(3, 2, 1) on a contiguous NHWC tensor."""
+    """nn.MaxPool2d(3, 2, 1[, ceil_mode=True]) on a contiguous NHWC tensor."""
 
-    def __init__(self, eng, x):
+    def __init__(self, eng, x, ceil_mode=False):
         assert x.parent is None
-        self.x = x
-        H2, W2 = ops.out_size(x.H, 3, 2, 1), ops.out_size(x.W, 3, 2, 1)
+        self.x, self.ceil = x, ceil_mode
+        H2, W2 = ops.maxpool_out_size(x.H, ceil_mode), ops.maxpool_out_size(x.W, ceil_mode)
         self.out = Act(eng.dev, x.N, H2, W2, x.C)
         self.idx = torch.empty(x.N, H2, W2, x.C, dtype=torch.uint8, device=eng.dev)
         self.tmp = None
@@ -451,18 +454,18 @@ class MaxPool(Op):
 
     def fwd(self, train):
         x = self.x
-        ops.maxpool_fwd(x.t, self.out.t, self.idx, x.N, x.H, x.W, x.C)
+        ops.maxpool_fwd(x.t, self.out.t, self.idx, x.N, x.H, x.W, x.C, self.ceil)
 
     def bwd(self):
         x = self.x
         if not _take(x):
-            ops.maxpool_bwd(self.out.g, self.idx, x.g, x.N, x.H, x.W, x.C)
+            ops.maxpool_bwd(self.out.g, self.idx, x.g, x.N, x.H, x.W, x.C, self.ceil)
             return
         # the input also feeds a later consumer (densenet's relu0 is a decoder skip, Bts.py:206,250): route into a scratch
         # tensor, then one in-place add pass
         if self.tmp is None:
             self.tmp = torch.empty_like(x.t)
-        ops.maxpool_bwd(self.out.g, self.idx, self.tmp, x.N, x.H, x.W, x.C)
+        ops.maxpool_bwd(self.out.g, self.idx, self.tmp, x.N, x.H, x.W, x.C, self.ceil)
         ops.pw_fwd(self.tmp, x.C, None, x.g, _ldg(x), x.g, _ldg(x), x.M, x.C, None)
 
 
@@ -643,6 +646,88 @@ class SigmoidMap(Op):
             self.map.g.add_(self.douts[0])
         ops.to_nchw_act_bwd(self.map.g, self.map.t, x.g, _ldg(x), None, x.N, x.H * x.W, 1, "sigmoid", 1.0)
         self.map.g.zero_()
+
+
+# ---------------------------------------------------------------------------------------------- ops of the DORN plan
+class ChannelDropout(Op):
+    """nn.Dropout2d(p) (Dorn.py:59,107,109): whole channels of an image are zeroed with probability p, the rest scaled by
+    1 / (1 - p); identity in eval mode.  The mask [N][C] is drawn with torch's device generator (torch.manual_seed governs
+    it) unless `fixed` holds one (parity tests hand the same mask to the oracle); the kernels take it as data."""
+
+    def __init__(self, eng, x, p, out=None):
+        self.x, self.p = x, float(p)
+        self.out = out if out is not None else Act(eng.dev, x.N, x.H, x.W, x.C)
+        self.own_out = out is None
+        self.mask = torch.ones(x.N, x.C, device=eng.dev)
+        self.fixed = None
+
+    def acts(self):
+        return (self.out,) if self.own_out else ()
+
+    def draw(self, train):
+        if not train or self.p == 0.0:
+            self.mask.fill_(1.0)
+        elif self.fixed is not None:
+            self.mask.copy_(self.fixed)
+        elif self.p >= 1.0:
+            self.mask.zero_()
+        else:
+            self.mask.bernoulli_(1.0 - self.p).div_(1.0 - self.p)
+
+    def fwd(self, train):
+        x, o = self.x, self.out
+        self.draw(train)
+        ops.chan_scale(x.t, x.ld, self.mask, o.t, o.ld, x.N, x.H * x.W, x.C)
+
+    def bwd(self):
+        x, o = self.x, self.out
+        ops.chan_scale(o.g, _ldg(o), self.mask, x.g, _ldg(x), x.N, x.H * x.W, x.C, accumulate=_take(x))
+
+
+class PooledFlat(ChannelDropout):
+    """FullImageEncoder's front (Dorn.py:58-62,72-74): AvgPool2d(k, k, k // 2) -> Dropout2d -> `view(-1, C * h * w)`; the
+    output is the [N][1][1][C * h * w] row nn.Linear contracts, in the NCHW order of the reference's flatten."""
+
+    def __init__(self, eng, x, k, p):
+        self.x, self.p, self.k, self.pad = x, float(p), k, k // 2
+        self.oh, self.ow = (x.H + 2 * self.pad - k) // k + 1, (x.W + 2 * self.pad - k) // k + 1
+        self.out = Act(eng.dev, x.N, 1, 1, x.C * self.oh * self.ow)
+        self.own_out = True
+        self.mask = torch.ones(x.N, x.C, device=eng.dev)
+        self.fixed = None
+
+    def fwd(self, train):
+        x = self.x
+        self.draw(train)
+        ops.avgpool_flat_fwd(x.t, x.ld, self.mask, self.out.t, x.N, x.H, x.W, x.C, self.k, self.k, self.pad)
+
+    def bwd(self):
+        x = self.x
+        ops.avgpool_flat_bwd(self.out.g, self.mask, x.g, _ldg(x), x.N, x.H, x.W, x.C, self.k, self.k, self.pad, accumulate=_take(x))
+
+
+class OrdinalHead(Op):
+    """OrdinalRegressionLayer (Dorn.py:288-318): outputs (decode_c int64 [N][1][H][W], ord_c1 fp32 [N][K][H][W])."""
+
+    def __init__(self, eng, x, K):
+        self.x, self.K = x, K
+        self.label = torch.empty(x.N, 1, x.H, x.W, dtype=torch.int64, device=eng.dev)
+        self.prob = torch.empty(x.N, K, x.H, x.W, device=eng.dev)
+        self.outputs = (self.label, self.prob)
+        self.douts = [None, None]
+
+    def fwd(self, train):
+        x = self.x
+        ops.ordinal_fwd(x.t, x.ld, self.prob, self.label, x.N, x.H * x.W, self.K)
+
+    def bwd(self):
+        x = self.x
+        assert not x.gw
+        x.gw = True
+        if self.douts[1] is None:
+            x.g.zero_()
+            return
+        ops.ordinal_bwd(self.douts[1], x.t, x.ld, x.g, _ldg(x), x.N, x.H * x.W, self.K)
 
 
 # ---------------------------------------------------------------------------------------------- the tape

@@ -340,12 +340,55 @@ def pixel_shuffle2(src, ld_src, dst, ld_dst, N, h, w, C_, inverse=False):
           "mde_pixel_shuffle2")
 
 
-def maxpool_fwd(x, out, idx, N, H, W, C_):
-    check(_lib.load().mde_maxpool_fwd(_p(x), _p(out), _p(idx), N, H, W, C_, _stream()), "mde_maxpool_fwd")
+def maxpool_fwd(x, out, idx, N, H, W, C_, ceil_mode=False):
+    check(_lib.load().mde_maxpool_fwd2(_p(x), _p(out), _p(idx), N, H, W, C_, int(ceil_mode), _stream()), "mde_maxpool_fwd2")
 
 
-def maxpool_bwd(dout, idx, dx, N, H, W, C_):
-    check(_lib.load().mde_maxpool_bwd(_p(dout), _p(idx), _p(dx), N, H, W, C_, _stream()), "mde_maxpool_bwd")
+def maxpool_bwd(dout, idx, dx, N, H, W, C_, ceil_mode=False):
+    check(_lib.load().mde_maxpool_bwd2(_p(dout), _p(idx), _p(dx), N, H, W, C_, int(ceil_mode), _stream()), "mde_maxpool_bwd2")
+
+
+def maxpool_out_size(n, ceil_mode=False):
+    """Output size of nn.MaxPool2d(3, 2, 1[, ceil_mode=True]) (ATen's rule; Dorn.py:235)."""
+    if not ceil_mode:
+        return (n + 2 - 3) // 2 + 1
+    o = -(-(n + 2 - 3) // 2) + 1
+    return o - 1 if (o - 1) * 2 >= n + 1 else o
+
+
+# ---- DORN pieces (csrc/ordinal.hip)
+def chan_scale(x, ldx, m, out, ldo, N, HW, C_, accumulate=False):
+    check(_lib.load().mde_chan_scale(_p(x), ldx, _p(m), _p(out), ldo, N, HW, C_, int(accumulate), _stream()), "mde_chan_scale")
+
+
+def avgpool_flat_fwd(x, ldx, m, out, N, H, W, C_, k, s, p):
+    check(_lib.load().mde_avgpool_flat_fwd(_p(x), ldx, _p(m) if m is not None else None, _p(out), N, H, W, C_, k, s, p, _stream()),
+          "mde_avgpool_flat_fwd")
+
+
+def avgpool_flat_bwd(dout, m, dx, lddx, N, H, W, C_, k, s, p, accumulate=False):
+    check(_lib.load().mde_avgpool_flat_bwd(_p(dout), _p(m) if m is not None else None, _p(dx), lddx, N, H, W, C_, k, s, p, int(accumulate),
+                                           _stream()), "mde_avgpool_flat_bwd")
+
+
+def ordinal_fwd(x, ldx, prob, label, N, HW, K):
+    check(_lib.load().mde_ordinal_fwd(_p(x), ldx, _p(prob), _p(label), N, HW, K, _stream()), "mde_ordinal_fwd")
+
+
+def ordinal_bwd(dprob, x, ldx, dx, lddx, N, HW, K):
+    check(_lib.load().mde_ordinal_bwd(_p(dprob), _p(x), ldx, _p(dx), lddx, N, HW, K, _stream()), "mde_ordinal_bwd")
+
+
+def ord_loss_ws(device="cuda"):
+    return torch.zeros((_lib.load().mde_ord_loss_ws_bytes() + 7) // 8, dtype=torch.float64, device=device)
+
+
+def ord_loss_fwd(prob, target, N, K, HW, ws, loss):
+    check(_lib.load().mde_ord_loss_fwd(_p(prob), _p(target), N, K, HW, _p(ws), _p(loss), _stream()), "mde_ord_loss_fwd")
+
+
+def ord_loss_bwd(prob, target, N, K, HW, gscale, grad):
+    check(_lib.load().mde_ord_loss_bwd(_p(prob), _p(target), N, K, HW, _p(gscale), _p(grad), _stream()), "mde_ord_loss_bwd")
 
 
 def upsample_sigmoid_fwd(x, out, N, H, W, C_, OH, OW):

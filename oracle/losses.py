@@ -300,3 +300,25 @@ def depth_to_bins(depth, depth_min, depth_max, C):
     bins[bins == C] = C - 1
     depth[invalid] = -1.0
     return bins, depth
+
+
+def ord_loss(ord_labels, target):
+    """ordLoss.forward (criteria.py:744-787): plane index k against the (float) SID label by type promotion."""
+    N, C, H, W = ord_labels.shape
+    K = torch.arange(C, dtype=torch.int32).view(1, C, 1, 1).expand(N, C, H, W)
+    m0, m1 = (K <= target), (K > target)
+    s = torch.sum(torch.log(torch.clamp(ord_labels[m0], min=1e-8, max=1e8))) + \
+        torch.sum(torch.log(torch.clamp(1.0 - ord_labels[m1], min=1e-8, max=1e8)))
+    return s / (-(N * H * W))
+
+
+def sid_labels(depth, alpha, beta, ord_num):
+    """DORNModule.depth_to_label (modules/dorn.py:102-107, SID): the FLOAT label map the module hands to ordLoss."""
+    a, b, k = torch.tensor(float(alpha)), torch.tensor(float(beta)), torch.tensor(int(ord_num)).int()
+    return k * torch.log(depth / a) / torch.log(b / a)
+
+
+def sid_depth(label, alpha, beta, ord_num):
+    """DORNModule.label_to_depth (modules/dorn.py:95-100, SID)."""
+    a, b, k = torch.tensor(float(alpha)), torch.tensor(float(beta)), torch.tensor(int(ord_num)).int()
+    return torch.exp(torch.log(a) + torch.log(b / a) * label / k)

@@ -5,7 +5,7 @@ require grad for gradient parity, BN running statistics updated in place in trai
 keys the way the reference's forward walks its modules.  One dict therefore loads into the reference model, drives this
 oracle and loads into the HIP module.  Cited lines are under /root/reference.
 
-Pinned by tests/golden/{vnl_net,midas_net,bts_net,eigen}.npz, minted by tests/golden/gen_golden.py from the reference's own
+Pinned by tests/golden/{vnl_net,midas_net,bts_net,eigen,dorn_net}.npz, minted by tests/golden/gen_golden.py from the reference's own
 classes (imported with stand-ins for the absent torchvision / torch.hub trunks, whose architecture is restated from
 their public definitions — see that script's docstring).
 """
@@ -311,6 +311,69 @@ def eigen_forward(P, img, train, momentum=None):
     for j in (0, 2, 4, 6):
         z = F.relu(n.conv(z, "scale3.scale3_onestack.%d" % j, pad=2))
     return z
+
+
+# ---------------------------------------------------------------------------------------------- DORN (network/Dorn.py)
+def ordinal_layer(x):
+    """OrdinalRegressionLayer.forward (Dorn.py:288-318) -> (decode_c, ord_c1)."""
+    N, C, H, W = x.shape
+    K = C // 2
+    A = x[:, ::2].reshape(N, 1, K * H * W)
+    B = x[:, 1::2].reshape(N, 1, K * H * W)
+    c = torch.clamp(torch.cat((A, B), dim=1), min=1e-8, max=1e4)
+    p1 = F.softmax(c, dim=1)[:, 1].reshape(-1, K, H, W)
+    return torch.sum(p1 > 0.5, dim=1).view(-1, 1, H, W), p1
+
+
+def dorn_forward(P, x, train, size, kernel_size=16, pyramid=(4, 8, 12), dropout=0.5, blocks=(3, 4, 23, 3), masks=None, momentum=None,
+                 q=None, return_logits=False):
+    """DORN.forward (Dorn.py:340-344): ResNet.forward (:264-273, Bottleneck :152-175) -> SceneUnderstandingModule.forward
+    (:110-124, FullImageEncoder :66-80) -> OrdinalRegressionLayer.  The three nn.Dropout2d of the scene module draw from
+    torch's global generator in the reference's order (encoder, concat_process.0, concat_process.2) when `masks` is None;
+    otherwise masks[i] is the [N][C] scale (0 or 1 / (1 - p)) to apply — how the GPU tests hand over the HIP run's draw."""
+    n = Net(P, train, q, momentum)
+    b = "backbone.backbone."
+    y = x
+    for i, st in ((1, 2), (2, 1), (3, 1)):
+        y = n.q(F.relu(n.bn(n.conv(y, b + "conv%d" % i, st, 1), b + "bn%d" % i)))
+    y = F.max_pool2d(y, 3, 2, 1, ceil_mode=True)
+    for li, (nb, stride, dil) in enumerate(zip(blocks, (1, 2, 1, 1), (1, 1, 2, 4))):
+        for bi in range(nb):
+            k, st = b + "layer%d.%d" % (li + 1, bi), (stride if bi == 0 else 1)
+            a = n.q(F.relu(n.bn(n.conv(y, k + ".conv1"), k + ".bn1")))
+            a = n.q(F.relu(n.bn(n.conv(a, k + ".conv2", st, dil, dil), k + ".bn2")))
+            a = n.bn(n.conv(a, k + ".conv3"), k + ".bn3")
+            r = n.bn(n.conv(y, k + ".downsample.0", st), k + ".downsample.1") if k + ".downsample.0.weight" in P else y
+            y = n.q(F.relu(a + r))
+    drops = [0]
+
+    def drop(t):
+        i = drops[0]
+        drops[0] += 1
+        if masks is not None:
+            return t * masks[i].view(t.shape[0], t.shape[1], 1, 1) if train else t
+        return F.dropout2d(t, dropout, train)
+
+    def cbr(t, k, pad=0, dil=1):
+        if k + ".1.weight" in P:                                                   # conv -> BN -> ReLU
+            return n.q(F.relu(n.bn(n.conv(t, k + ".0", 1, pad, dil), k + ".1")))
+        return n.q(F.relu(n.conv(t, k + ".0", 1, pad, dil)))                       # biased conv -> ReLU
+
+    s = "SceneUnderstandingModule."
+    N, _, Hf, Wf = y.shape
+    x1 = n.q(drop(F.avg_pool2d(y, kernel_size, kernel_size, kernel_size // 2))).reshape(N, -1)
+    x1 = n.q(F.relu(n.q(F.linear(x1, P[s + "encoder.global_fc.weight"])) + P[s + "encoder.global_fc.bias"])).view(N, 512, 1, 1)
+    x1 = n.q(n.conv(x1, s + "encoder.conv1"))
+    feats = [F.interpolate(x1, size=(Hf, Wf), mode="bilinear", align_corners=True)]
+    feats.append(cbr(cbr(y, s + "aspp1.0"), s + "aspp1.1"))
+    for i, d in enumerate(pyramid):
+        feats.append(cbr(cbr(y, s + "aspp%d.0" % (i + 2), d, d), s + "aspp%d.1" % (i + 2)))
+    z = n.q(drop(torch.cat(feats, 1)))
+    z = n.q(drop(cbr(z, s + "concat_process.1")))
+    z = n.q(n.conv(z, s + "concat_process.3"))
+    z = n.q(F.interpolate(z, size=tuple(size), mode="bilinear", align_corners=True))
+    label, prob = ordinal_layer(z)
+    return (label, prob, z) if return_logits else (label, prob)
 
 
 def leaf_state(sd, requires_grad=False):

@@ -168,3 +168,19 @@ def bts_fixture_state(model, seed):
     sd[k] = (sd[k] * 0.02).to(torch.bfloat16).to(torch.float32)
     model.load_state_dict(sd)
     return sd
+
+
+def dorn_fixture_state(model, seed):
+    """DORN parity fixture: fill_state_dict with every conv / Linear weight exactly bf16-representable, the last BatchNorm
+    of each of the 33 residual branches damped to 0.05 (see fcrn_conditioned_state) and the final 1x1 conv scaled by 0.05 so
+    the ordinal logits are of order 1 (the layer clamps them to [1e-8, 1e4] and takes pairwise softmaxes)."""
+    sd = fill_state_dict(model, seed)
+    for k in sd:
+        if sd[k].ndim >= 2:
+            if k.endswith("concat_process.3.weight"):
+                sd[k] = sd[k] * 0.05
+            sd[k] = sd[k].to(torch.bfloat16).to(torch.float32)
+        elif k.endswith(".bn3.weight") and ".layer" in k:
+            sd[k] = sd[k] * 0.05
+    model.load_state_dict(sd)
+    return sd

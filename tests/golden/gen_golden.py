@@ -624,6 +624,57 @@ def gen_eigen(criteria):
         int(out["n_params"]), out["eval_out"].shape, out["eval_out"].min(), out["eval_out"].max(), float(silog), float(md)))
 
 
+DORN_ARGS = dict(input_size=(65, 81), kernel_size=4, ord_num=12, alpha=0.02, beta=10.0, discretization="SID", pretrained=0,
+                 pyramid=[2, 3, 4], batch_norm=0, dropout=0.5)
+
+
+def gen_dorn_net(criteria):
+    """N4: the reference's own network/Dorn.py (DORN: dilated ResNet-101, SceneUnderstandingModule with its three Dropout2d,
+    OrdinalRegressionLayer) at 2 x 3 x 65 x 81 with criteria.ordLoss on the SID label map modules/dorn.py:102-107 computes
+    (restated inline: modules/ does not import here), both scene-module variants (batch_norm 0 / 1), and ordLoss alone on
+    random probabilities with targets that include 0, a negative, -inf and NaN (depth 0 / negative under the log)."""
+    from network import Dorn
+    out = {}
+    for bn in (0, 1):
+        args = types.SimpleNamespace(**dict(DORN_ARGS, batch_norm=bn))
+        torch.manual_seed(0)
+        ref = Dorn.DORN(args)
+        W.dorn_fixture_state(ref, 59 + bn)
+        H, Wd = args.input_size
+        rgb, tgt = W.synthetic_batch(59, 2, H, Wd)
+        torch.manual_seed(7)                                   # (the calibration pass runs in train mode: its Dropout2d draw too)
+        W.calibrate_running_stats(ref, rgb)
+        pre = "bn%d_" % bn
+        out[pre + "keys"] = np.array(list(ref.state_dict().keys()))
+        ref.eval()
+        with torch.no_grad():
+            label, prob = ref(rgb)
+        out[pre + "eval_label"], out[pre + "eval_prob"] = label.numpy().astype(np.int16), _np(prob)
+        ref.train()
+        torch.manual_seed(1234)                                # the three Dropout2d draw from the global generator
+        label, prob = ref(rgb)
+        a, b, k = torch.tensor(args.alpha).float(), torch.tensor(args.beta).float(), torch.tensor(args.ord_num).int()
+        y_sid = k * torch.log((tgt * 10.0) / a) / torch.log(b / a)          # modules/dorn.py:102-104
+        loss = criteria.ordLoss()(prob, y_sid)
+        loss.backward()
+        out[pre + "train_label"], out[pre + "train_prob"], out[pre + "train_loss"] = label.numpy().astype(np.int16), _np(prob), _np(loss)
+        out[pre + "grad_names"], out[pre + "grad_norms"] = _grad_norms(ref)
+        sd = ref.state_dict()
+        out[pre + "rm_l4"] = _np(sd["backbone.backbone.layer4.2.bn3.running_mean"])
+        print("dorn_net bn=%d: %d keys, %d params, eval labels %d..%d (mean %.2f), train loss %.5f" % (
+            bn, len(sd), sum(p.numel() for p in ref.parameters()), int(label.min()), int(label.max()), float(label.float().mean()), float(loss)))
+    g = torch.Generator().manual_seed(61)
+    prob = torch.rand(2, 12, 9, 11, generator=g)
+    prob[0, 3, 2, 2], prob[1, 5, 4, 4], prob[0, 0, 0, 0] = 0.0, 1.0, 1e-9      # the clamps
+    t = torch.rand(2, 1, 9, 11, generator=g) * 14.0 - 1.0
+    t[0, 0, 0, 1], t[0, 0, 0, 2], t[1, 0, 3, 3], t[1, 0, 5, 5] = 3.0, float("-inf"), float("nan"), 0.0
+    prob.requires_grad_(True)
+    loss = criteria.ordLoss()(prob, t)
+    loss.backward()
+    out["ord_prob"], out["ord_target"], out["ord_loss"], out["ord_grad"] = _np(prob), _np(t), _np(loss), _np(prob.grad)
+    np.savez_compressed(os.path.join(HERE, "dorn_net.npz"), **out)
+
+
 def gen_vnl_keymap():
     """N3: the reference's own convert_state_dict_resnext (VNL.py:44-67) on the index-path keys of the shipped
     ResNeXt-ImageNet files, enumerated from the documented nn.Sequential structure -> {source key: body key} pairs."""
@@ -674,6 +725,8 @@ def main():
         gen_bts_net(criteria)
     if want("eigen"):
         gen_eigen(criteria)
+    if want("dorn_net"):
+        gen_dorn_net(criteria)
     if want("vnl_keymap"):
         gen_vnl_keymap()
 

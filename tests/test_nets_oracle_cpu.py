@@ -211,3 +211,55 @@ def test_config1_eigen_cpu_forward_silog_matches_the_reference():
     for k, v in zip(g["grad_names"], g["grad_norms"]):
         got = float(pd[str(k)].grad.norm())
         assert abs(got - v) <= 2e-3 * v + 1e-8, (k, got, v)
+
+
+# ---------------------------------------------------------------------------------------------- DORN
+DORN_ARGS = dict(input_size=(65, 81), kernel_size=4, ord_num=12, alpha=0.02, beta=10.0, discretization="SID", pretrained=0,
+                 pyramid=[2, 3, 4], batch_norm=0, dropout=0.5)
+DORN_KW = dict(size=(65, 81), kernel_size=4, pyramid=(2, 3, 4), dropout=0.5)
+
+
+def dorn_fixture(bn):
+    import types
+    from mono_depth_estimation_amd.network import Dorn
+    mirror = Dorn.DORN(types.SimpleNamespace(**dict(DORN_ARGS, batch_norm=bn)))
+    sd = W.dorn_fixture_state(mirror, 59 + bn)
+    rgb, tgt = W.synthetic_batch(59, 2, 65, 81)
+    P = nets.leaf_state(sd, requires_grad=True)
+    torch.manual_seed(7)
+    with torch.no_grad():
+        nets.dorn_forward(P, rgb, True, momentum=1.0, **DORN_KW)     # = weights.calibrate_running_stats on the reference
+    return mirror, P, rgb, tgt
+
+
+@pytest.mark.parametrize("bn", [0, 1])
+def test_dorn_parameter_tree_and_oracle_match_the_reference(bn):
+    mirror, P, rgb, tgt = dorn_fixture(bn)
+    g, pre = _golden("dorn_net"), "bn%d_" % bn
+    assert list(mirror.state_dict().keys()) == list(g[pre + "keys"])
+    assert sum(p.numel() for p in mirror.parameters()) == (88031192, 88037336)[bn]
+    enc = [k for k, _ in mirror.named_parameters() if k.startswith("backbone.")]       # dorn.py:188-191: the 1x group
+    assert len(enc) == 3 * 3 + 33 * 9 + 4 * 3 and hasattr(mirror, "SceneUnderstandingModule") and hasattr(mirror.backbone, "backbone")
+    with torch.no_grad():
+        label, prob = nets.dorn_forward(P, rgb, False, **DORN_KW)
+    assert np.abs(prob.numpy() - g[pre + "eval_prob"]).max() < 2e-5
+    assert (label.numpy() != g[pre + "eval_label"]).mean() < 1e-3                     # (a probability within 1e-6 of 0.5 may flip)
+    torch.manual_seed(1234)
+    label, prob = nets.dorn_forward(P, rgb, True, **DORN_KW)
+    assert np.abs(prob.detach().numpy() - g[pre + "train_prob"]).max() < 5e-5
+    loss = L.ord_loss(prob, L.sid_labels(tgt * 10.0, 0.02, 10.0, 12))
+    assert abs(float(loss) - float(g[pre + "train_loss"])) < 2e-4 * float(g[pre + "train_loss"])
+    loss.backward()
+    norms = dict(zip(g[pre + "grad_names"], g[pre + "grad_norms"]))
+    bad = [(k, float(P[k].grad.norm()), float(v)) for k, v in norms.items() if abs(float(P[k].grad.norm()) - float(v)) > 3e-3 * float(v) + 1e-7]
+    assert not bad, bad[:5]
+    assert np.abs(P["backbone.backbone.layer4.2.bn3.running_mean"].numpy() - g[pre + "rm_l4"]).max() < 1e-5
+
+
+def test_ord_loss_oracle_matches_the_reference():
+    g = _golden("dorn_net")
+    prob = torch.tensor(g["ord_prob"], requires_grad=True)
+    loss = L.ord_loss(prob, torch.tensor(g["ord_target"]))
+    loss.backward()
+    assert abs(float(loss) - float(g["ord_loss"])) < 1e-5
+    assert np.abs(prob.grad.numpy() - g["ord_grad"]).max() < 1e-6
