@@ -240,10 +240,12 @@ int mde_upsample_sigmoid_bwd(const float* dout, const float* out, float* dx, int
 int mde_pw_fwd(const void* x, int ldx, const float* bias, const void* r, int ldr, void* out, int ldo, int64_t M, int C,
                int act, void* stream);
 /* g = dout * act'(out) (the derivative is taken from the forward OUTPUT; out may be NULL for act 0);
- * dx = g or dx += g (acc_x), likewise dr (the residual's gradient; may be NULL); dbias[c] += sum over rows of g (fp32,
- * atomics; may be NULL).  dx may be NULL when only dbias / dr are wanted. */
+ * dx = g or dx += g (acc_x), likewise dr (the residual's gradient; may be NULL); dbias[c] += sum over rows of g (fp32;
+ * may be NULL).  bias_part (optional): a zeroed BatchNorm-style partial-sum buffer [mde_stat_slots()][2][C] the workgroups
+ * spread their bias-gradient atomics over (returned zeroed; one extra tiny launch folds it into dbias) — without it every
+ * workgroup adds into dbias directly, which serialises on wide maps.  dx may be NULL when only dbias / dr are wanted. */
 int mde_pw_bwd(const void* dout, int ldd, const void* out, int ldo, void* dx, int lddx, int acc_x, void* dr, int lddr,
-               int acc_r, float* dbias, int64_t M, int C, int act, void* stream);
+               int acc_r, float* dbias, float* bias_part, int64_t M, int C, int act, void* stream);
 /* out[n][c] = scale * sum_p x[n][p][c]: nn.AdaptiveAvgPool2d(1) with scale = 1/HW (VNL.py:207,221,359,367), and the
  * gradient of a spatial broadcast with scale = 1.  x: [N][HW][ldx]; out: bf16 [N][ldo]. */
 int mde_spatial_sum(const void* x, int ldx, int N, int64_t HW, int C, float scale, void* out, int ldo, void* stream);

@@ -78,7 +78,7 @@ SIGNATURES = {
     "mde_upsample_sigmoid_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "mde_upsample_sigmoid_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "mde_pw_fwd": (_I, [_P, _I, _P, _P, _I, _P, _I, _L, _I, _I, _P]),
-    "mde_pw_bwd": (_I, [_P, _I, _P, _I, _P, _I, _I, _P, _I, _I, _P, _L, _I, _I, _P]),
+    "mde_pw_bwd": (_I, [_P, _I, _P, _I, _P, _I, _I, _P, _I, _I, _P, _P, _L, _I, _I, _P]),
     "mde_spatial_sum": (_I, [_P, _I, _I, _L, _I, _F, _P, _I, _P]),
     "mde_spatial_bcast": (_I, [_P, _I, _F, _P, _I, _I, _L, _I, _I, _P]),
     "mde_gate_fwd": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _L, _I, _P]),

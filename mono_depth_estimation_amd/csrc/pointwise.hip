@@ -73,7 +73,8 @@ __global__ __launch_bounds__(NT) void pw_fwd_k(const bf16_t* __restrict__ x, int
 // g = dout * act'(out);  dx (+)= g;  dr (+)= g;  dbias += sum_rows g
 __global__ __launch_bounds__(NT) void pw_bwd_k(const bf16_t* __restrict__ dout, int ldd, const bf16_t* __restrict__ out, int ldo,
                                                bf16_t* __restrict__ dx, int lddx, int acc_x, bf16_t* __restrict__ dr, int lddr,
-                                               int acc_r, float* __restrict__ dbias, int64_t M, int C, int act, MdeDetDev det) {
+                                               int acc_r, float* __restrict__ dbias, float* __restrict__ part, int64_t M, int C, int act,
+                                               MdeDetDev det) {
     __shared__ float red[NT * 8];
     const int cpr = C >> 3;
     const int tpr = cpr < NT ? cpr : NT;
@@ -134,12 +135,20 @@ __global__ __launch_bounds__(NT) void pw_bwd_k(const bf16_t* __restrict__ dout, 
                 for (int e = 0; e < 8; ++e) {
                     float t = 0.f;
                     for (int q = 0; q < rpb; ++q) t += red[(q * tpr + tc) * 8 + e];
-                    mde_grad_add(dbias + c8 * 8 + e, t, det);
+                    if (part) mde_stat_add(part, C, blockIdx.x, 0, c8 * 8 + e, t, det.scratch != nullptr);
+                    else mde_grad_add(dbias + c8 * 8 + e, t, det);
                 }
             }
             __syncthreads();
         }
     }
+}
+
+// dbias[c] += the slots of a partial-sum buffer (left zeroed): thousands of workgroups adding into one cache line of
+// dbias serialise in L2 (measured: pw_bwd_k 7x slower than pw_fwd_k on MiDaS' 256-channel maps); 32 slots spread them.
+__global__ void bias_take_k(float* part, int C, float* dbias, MdeDetDev det) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) mde_grad_add(dbias + c, (float)mde_stat_take(part, C, 0, c, det.scratch != nullptr), det);
 }
 
 // ------------------------------------------------------------------ per-image spatial sums / broadcasts
@@ -491,8 +500,12 @@ __global__ __launch_bounds__(NT) void softmax_head_fwd_k(const bf16_t* __restric
 }
 
 // dx[p][c] = dlogit[c][p] + prob[c][p] * (dprob[c][p] - sum_c' dprob[c'][p] * prob[c'][p]);  dbias[c] += sum_p dx[p][c]
-// MAXC: channels per wave slot held in registers for the bias gradient (C <= 4 * MAXC)
+// A thread (pixel p, wave slot q) owns channels q, q + 4, ...: their prob / dprob values are loaded ONCE into registers by an
+// unrolled loop (KMAX loads in flight per operand; the first version walked them in a run-time loop, one dependent load pair
+// at a time, and was latency-bound at 0.7 TB/s), used for the dot product and again for the gradient.  The bias gradient is
+// summed from the finished LDS tile by one thread per channel (one register) and added once per workgroup at the end.
 constexpr int SM_MAXC = 64;
+template <int KMAX>
 __global__ __launch_bounds__(NT) void softmax_head_bwd_k(const float* __restrict__ dlogit, const float* __restrict__ dprob,
                                                          const float* __restrict__ prob, bf16_t* __restrict__ dx, int lddx,
                                                          float* __restrict__ dbias, int N, int64_t HW, int C, MdeDetDev det) {
@@ -503,33 +516,39 @@ __global__ __launch_bounds__(NT) void softmax_head_bwd_k(const float* __restrict
     const int64_t tiles_per_img = (HW + SM_PIX - 1) / SM_PIX;
     const int64_t ntiles = (int64_t)N * tiles_per_img;
     const int p = threadIdx.x & 63, q = threadIdx.x >> 6;
-    float bsum[SM_MAXC];
-#pragma unroll
-    for (int k = 0; k < SM_MAXC; ++k) bsum[k] = 0.f;
+    float bacc = 0.f;                              // bias gradient of channel threadIdx.x
     for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
         const int64_t n = t / tiles_per_img;
         const int64_t hw0 = (t - n * tiles_per_img) * SM_PIX;
         const int npix = (int)min((int64_t)SM_PIX, HW - hw0);
         const bool in = p < npix;
         const int64_t base = n * C * HW + hw0 + p;
+        float P[KMAX], D[KMAX];
         float dot = 0.f;
-        if (dprob && in)
-            for (int c = q; c < C; c += 4) dot += dprob[base + (int64_t)c * HW] * prob[base + (int64_t)c * HW];
+        if (dprob) {
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) {
+                const int c = q + 4 * k;
+                const bool ok = in && c < C;
+                P[k] = ok ? prob[base + (int64_t)c * HW] : 0.f;
+                D[k] = ok ? dprob[base + (int64_t)c * HW] : 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) dot += P[k] * D[k];
+        }
         red[q * 64 + p] = dot;
         __syncthreads();
         dot = red[p] + red[64 + p] + red[128 + p] + red[192 + p];
+        float L[KMAX];
 #pragma unroll
-        for (int k = 0; k < SM_MAXC; ++k) {
+        for (int k = 0; k < KMAX; ++k) {
             const int c = q + 4 * k;
-            if (c < C) {
-                float g = 0.f;
-                if (in) {
-                    if (dlogit) g = dlogit[base + (int64_t)c * HW];
-                    if (dprob) g += prob[base + (int64_t)c * HW] * (dprob[base + (int64_t)c * HW] - dot);
-                }
-                tile[c * 65 + p] = g;
-                bsum[k] += g;
-            }
+            L[k] = (dlogit && in && c < C) ? dlogit[base + (int64_t)c * HW] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            const int c = q + 4 * k;
+            if (c < C) tile[c * 65 + p] = L[k] + (dprob ? P[k] * (D[k] - dot) : 0.f);
         }
         __syncthreads();
         for (int i = threadIdx.x; i < SM_PIX * cpr; i += NT) {
@@ -544,18 +563,16 @@ __global__ __launch_bounds__(NT) void softmax_head_bwd_k(const float* __restrict
                 *reinterpret_cast<bf16x8_t*>(dx + (n * HW + hw0 + pr) * lddx + c8 * 8) = o;
             }
         }
+        if (dbias && (int)threadIdx.x < C) {       // (pixels beyond npix hold zeros: written as 0 above for !in)
+            const float* row = tile + threadIdx.x * 65;
+            float sacc = 0.f;
+#pragma unroll 8
+            for (int j = 0; j < SM_PIX; ++j) sacc += row[j];
+            bacc += sacc;
+        }
         __syncthreads();
     }
-    if (dbias) {
-#pragma unroll
-        for (int k = 0; k < SM_MAXC; ++k) {
-            const int c = q + 4 * k;
-            if (c < C) {                            // (uniform per wave: q and k are)
-                const float t = mde_wave_sum(bsum[k]);
-                if (p == 0) mde_grad_add(dbias + c, t, det);
-            }
-        }
-    }
+    if (dbias && (int)threadIdx.x < C) mde_grad_add(dbias + threadIdx.x, bacc, det);
 }
 
 // ------------------------------------------------------------------ out[n][c][p] = scale * act(x[n][p][c] + bias[c])   (small C heads)
@@ -652,7 +669,7 @@ extern "C" int mde_pw_fwd(const void* x, int ldx, const float* bias, const void*
 }
 
 extern "C" int mde_pw_bwd(const void* dout, int ldd, const void* out, int ldo, void* dx, int lddx, int acc_x, void* dr, int lddr,
-                          int acc_r, float* dbias, int64_t M, int C, int act, void* stream) {
+                          int acc_r, float* dbias, float* bias_part, int64_t M, int C, int act, void* stream) {
     MDE_REQUIRE(dout && (out || act == 0) && (dx || dr || dbias) && M > 0 && C > 0 && C % 8 == 0 && act >= 0 && act <= 3,
                 "mde_pw_bwd: bad argument (C=%d, act=%d)", C, act);
     MDE_REQUIRE(ldd % 8 == 0 && (!out || ldo % 8 == 0) && (!dx || lddx % 8 == 0) && (!dr || lddr % 8 == 0) && PW_ALIGNED(dout) &&
@@ -660,8 +677,13 @@ extern "C" int mde_pw_bwd(const void* dout, int ldd, const void* out, int ldo, v
                 "mde_pw_bwd: operands must be 16-byte aligned with ld %% 8 == 0");
     const int tpr = C / 8 < NT ? C / 8 : NT;
     pw_bwd_k<<<grid_rows(M, NT / tpr), NT, 0, (hipStream_t)stream>>>((const bf16_t*)dout, ldd, (const bf16_t*)out, ldo, (bf16_t*)dx, lddx,
-                                                                   acc_x, (bf16_t*)dr, lddr, acc_r, dbias, M, C, act, mde_det_dev());
+                                                                   acc_x, (bf16_t*)dr, lddr, acc_r, dbias, dbias ? bias_part : nullptr, M, C, act,
+                                                                   mde_det_dev());
     MDE_LAUNCH_CHECK("pw_bwd_k");
+    if (dbias && bias_part) {
+        bias_take_k<<<mde_cdiv(C, 64), 64, 0, (hipStream_t)stream>>>(bias_part, C, dbias, mde_det_dev());
+        MDE_LAUNCH_CHECK("bias_take_k");
+    }
     return MDE_OK;
 }
 
@@ -795,14 +817,19 @@ extern "C" int mde_softmax_head_bwd(const float* dlogit, const float* dprob, con
     const size_t smem = ((size_t)C * 65 + 4 * 64) * sizeof(float);
     static bool attr = false;
     if (!attr) {
-        int rc = mde_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&softmax_head_bwd_k),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (4 * SM_MAXC * 65 + 256) * 4),
-                               "hipFuncSetAttribute(softmax_head_bwd_k)");
-        if (rc) return rc;
+        for (const void* f : {reinterpret_cast<const void*>(&softmax_head_bwd_k<40>), reinterpret_cast<const void*>(&softmax_head_bwd_k<SM_MAXC>)}) {
+            int rc = mde_check_hip(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (4 * SM_MAXC * 65 + 256) * 4),
+                                   "hipFuncSetAttribute(softmax_head_bwd_k)");
+            if (rc) return rc;
+        }
         attr = true;
     }
     const int64_t ntiles = (int64_t)N * ((HW + SM_PIX - 1) / SM_PIX);
-    softmax_head_bwd_k<<<(int)(ntiles < 1024 ? ntiles : 1024), NT, smem, (hipStream_t)stream>>>(dlogit, dprob, prob, (bf16_t*)dx, lddx, dbias, N, HW, C, mde_det_dev());
+    const int grid = (int)(ntiles < 2048 ? ntiles : 2048);
+    if (C <= 160)
+        softmax_head_bwd_k<40><<<grid, NT, smem, (hipStream_t)stream>>>(dlogit, dprob, prob, (bf16_t*)dx, lddx, dbias, N, HW, C, mde_det_dev());
+    else
+        softmax_head_bwd_k<SM_MAXC><<<grid, NT, smem, (hipStream_t)stream>>>(dlogit, dprob, prob, (bf16_t*)dx, lddx, dbias, N, HW, C, mde_det_dev());
     MDE_LAUNCH_CHECK("softmax_head_bwd_k");
     return MDE_OK;
 }

@@ -249,6 +249,7 @@ class Pw(Op):
             v, off = eng.store.vec(bias)
             assert v.numel() == x.C, (v.numel(), x.C)
             self.bias, self.b_off = v, off
+        self.part = ops.new_stat_buffer(x.C, eng.dev) if bias is not None else None
 
     def acts(self):
         return (self.out,) if self.own_out else ()
@@ -263,7 +264,7 @@ class Pw(Op):
         acc_r = _take(r) if r is not None else False
         dbias = self.eng.store.Gcur[self.b_off:self.b_off + x.C] if self.bias is not None else None
         ops.pw_bwd(o.g, _ldg(o), o.t, o.ld, x.g, _ldg(x), acc_x, r.g if r is not None else None, _ldg(r) if r is not None else 0,
-                   acc_r, dbias, x.M, x.C, self.act)
+                   acc_r, dbias, x.M, x.C, self.act, bias_part=self.part)
 
 
 def _ldg(a):

@@ -423,9 +423,9 @@ def pw_fwd(x, ldx, bias, r, ldr, out, ldo, M, C_, act):
     check(_lib.load().mde_pw_fwd(_p(x), ldx, _p(bias), _p(r), ldr, _p(out), ldo, M, C_, ACT[act], _stream()), "mde_pw_fwd")
 
 
-def pw_bwd(dout, ldd, out, ldo, dx, lddx, acc_x, dr, lddr, acc_r, dbias, M, C_, act):
-    check(_lib.load().mde_pw_bwd(_p(dout), ldd, _p(out), ldo, _p(dx), lddx, int(acc_x), _p(dr), lddr, int(acc_r), _p(dbias), M,
-                                 C_, ACT[act], _stream()), "mde_pw_bwd")
+def pw_bwd(dout, ldd, out, ldo, dx, lddx, acc_x, dr, lddr, acc_r, dbias, M, C_, act, bias_part=None):
+    check(_lib.load().mde_pw_bwd(_p(dout), ldd, _p(out), ldo, _p(dx), lddx, int(acc_x), _p(dr), lddr, int(acc_r), _p(dbias),
+                                 _p(bias_part), M, C_, ACT[act], _stream()), "mde_pw_bwd")
 
 
 def spatial_sum(x, ldx, N, HW, C_, scale, out, ldo):

@@ -2,7 +2,7 @@
 """Training throughput of BASELINE.json configurations 3 / 4 / 5 at their per-GPU sizes on one MI355X (module path: network
 forward -> drop-in criterion -> backward -> fused optimiser step), one JSON line per configuration.
 
-    python tools/config_bench.py [vnl] [midas] [bts] [--steps K] [--warmup W]
+    python tools/config_bench.py [vnl] [midas] [bts] [dorn] [--steps K] [--warmup W]
 
 GMAC figures are SURVEY.md 8a's dense-as-written forward MACs per image (x 6 = training FLOP)."""
 import argparse
@@ -103,6 +103,46 @@ def bts(args):
             "images_per_sec": n / dt, "fwd_gmac_per_image": 121.48, "step_mfma_frac": n / dt * 121.48 * 6e9 / (PEAK * 1e12)}
 
 
+def plan_gmac(net):
+    """Forward multiply-accumulates per image of the launch plan the module just ran (dense convs as written, grouped convs by
+    their own group width), from the tape's conv ops."""
+    from mono_depth_estimation_amd import graph as G
+    eng = next(iter(net._engines.values()))
+    macs = 0
+    for op in eng.tape:
+        if isinstance(op, G.Conv):
+            o, c = op.out, op.conv
+            macs += o.N * o.H * o.W * c.O * c.T * (getattr(c, "G", 0) or c.I)
+        elif isinstance(op, (G.Stem, G.ImageStem)):
+            o = op.c if isinstance(op, G.Stem) else op.out
+            macs += o.N * o.H * o.W * o.C * op.w.T * 3
+    return macs / eng.N / 1e9
+
+
+def dorn(args):
+    """The DORN module's defaults (modules/dorn.py:205-217): 257 x 353, ord_num 68, SGD with weight decay, backbone 1x / scene module 10x."""
+    from types import SimpleNamespace
+    from mono_depth_estimation_amd import criteria
+    from mono_depth_estimation_amd.network import Dorn
+    a = SimpleNamespace(input_size=(257, 353), kernel_size=16, ord_num=68.0, alpha=0.02, beta=10.0, discretization="SID", pretrained=0,
+                        pyramid=[4, 8, 12], batch_norm=0, dropout=0.5)
+    torch.manual_seed(0)
+    net = Dorn.DORN(a).cuda().train()
+    n = args.batch or 16
+    x, gt = data(n, 257, 353)
+    t = 68.0 * torch.log(gt.clamp(min=1e-3) * 10.0 / 0.02) / float(np.log(10.0 / 0.02))
+    crit = criteria.ordLoss()
+
+    def step():
+        net.zero_grad(set_to_none=True)
+        crit(net(x)[1], t).backward()
+        net._store.sgd_step(1e-4, 1e-3, momentum=0.0, weight_decay=5e-4)
+    dt = timed(step, args.steps, args.warmup)
+    g = plan_gmac(net)
+    return {"config": "DORN dilated ResNet-101, ord_num 68, %dx3x257x353, ordLoss, SGD" % n, "ms_per_step": 1e3 * dt,
+            "images_per_sec": n / dt, "fwd_gmac_per_image": g, "step_mfma_frac": n / dt * g * 6e9 / (PEAK * 1e12)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("which", nargs="*", default=["vnl", "midas"])
@@ -111,7 +151,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0)
     args = ap.parse_args()
     for w in args.which:
-        out = {"vnl": vnl, "midas": midas, "bts": bts}[w](args)
+        out = {"vnl": vnl, "midas": midas, "bts": bts, "dorn": dorn}[w](args)
         out = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in out.items()}
         print(json.dumps(out), flush=True)
         torch.cuda.empty_cache()
