@@ -329,6 +329,22 @@ int mde_avgpool_flat_bwd(const void* dout, const float* m, void* dx, int lddx, i
 int mde_ordinal_fwd(const void* x, int ldx, float* prob, int64_t* label, int N, int64_t HW, int K, void* stream);
 int mde_ordinal_bwd(const float* dprob, const void* x, int ldx, void* dx, int lddx, int N, int64_t HW, int K, void* stream);
 
+/* ---- MyNet pieces (network/MyNet.py) ---- */
+/* Weighter's tail (MyNet.py:96-119): flatten(start_dim=2) -> nn.Linear(HW, 1) over the pixel axis -> sum over channels ->
+ * sigmoid, of a bf16 [N][HW][lda] map with C channels: scale[n] = sigmoid(sum_p w[p] * sum_c a[n][p][c] + C * b[0]).
+ * pre: N floats of scratch (the pre-activation).  bwd: da (+)= dpre[n] * w[p] with dpre = dscale * s * (1 - s),
+ * dw[p] += sum_n dpre[n] * sum_c a, db[0] += C * sum_n dpre[n]. */
+int mde_weighted_pool_fwd(const void* a, int lda, const float* w, const float* b, float* pre, float* scale, int N, int64_t HW, int C,
+                          void* stream);
+int mde_weighted_pool_bwd(const float* dscale, const float* scale, const void* a, int lda, const float* w, void* da, int ldda,
+                          int accumulate, float* dw, float* db, int N, int64_t HW, int C, void* stream);
+/* my_decoder's output (MyNet.py:152-155): out[n][p] = factor * (m0 * s0[n] + m1 * s1[n] + m2 * s2[n]) over fp32 maps [N][HW]
+ * and per-image scales [N].  bwd: dm_k += factor * dout * s_k[n] (accumulating), ds [3][N] = factor * sum_p dout * m_k. */
+int mde_combine3_fwd(const float* m0, const float* m1, const float* m2, const float* s0, const float* s1, const float* s2, float factor,
+                     int N, int64_t HW, float* out, void* stream);
+int mde_combine3_bwd(const float* dout, const float* m0, const float* m1, const float* m2, const float* s0, const float* s1,
+                     const float* s2, float factor, int N, int64_t HW, float* dm0, float* dm1, float* dm2, float* ds, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * Losses and metrics (criteria.py / metrics.py), fp32 in, fp32/fp64 accumulation.
  * ---------------------------------------------------------------------------------- */

@@ -104,6 +104,10 @@ SIGNATURES = {
     "mde_avgpool_flat_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "mde_ordinal_fwd": (_I, [_P, _I, _P, _P, _I, _L, _I, _P]),
     "mde_ordinal_bwd": (_I, [_P, _P, _I, _P, _I, _I, _L, _I, _P]),
+    "mde_weighted_pool_fwd": (_I, [_P, _I, _P, _P, _P, _P, _I, _L, _I, _P]),
+    "mde_weighted_pool_bwd": (_I, [_P, _P, _P, _I, _P, _P, _I, _I, _P, _P, _I, _L, _I, _P]),
+    "mde_combine3_fwd": (_I, [_P, _P, _P, _P, _P, _P, _F, _I, _L, _P, _P]),
+    "mde_combine3_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _F, _I, _L, _P, _P, _P, _P, _P]),
     "mde_ord_loss_ws_bytes": (_Z, []),
     "mde_ord_loss_fwd": (_I, [_P, _P, _I, _I, _L, _P, _P, _P]),
     "mde_ord_loss_bwd": (_I, [_P, _P, _I, _I, _L, _P, _P, _P]),

@@ -377,3 +377,161 @@ extern "C" int mde_ord_loss_bwd(const float* prob, const float* target, int N, i
     MDE_LAUNCH_CHECK("ord_loss_bwd_k");
     return MDE_OK;
 }
+
+// =================================================================================== MyNet pieces (network/MyNet.py)
+namespace {
+
+// Weighter's tail (MyNet.py:96-119): a [N][HW][lda] bf16 with C channels -> flatten(start_dim=2) -> nn.Linear(HW, 1) over the
+// pixel axis -> sum over the C channels -> sigmoid:  scale[n] = sigmoid( sum_p w[p] * (sum_c a[n][p][c]) + C * b ).
+// pre[n] accumulates the double sum (zeroed by the caller's init launch).
+__global__ void zero_f32_k(float* p, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0.f;
+}
+
+__global__ __launch_bounds__(NT) void weighted_pool_fwd_k(const bf16_t* __restrict__ a, int lda, const float* __restrict__ w, int64_t HW, int C,
+                                                          float* __restrict__ pre) {
+    __shared__ double sh[NT / 64];
+    const int n = blockIdx.y, cpr = C >> 3;
+    const int64_t total = HW * cpr;
+    double part = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
+        const int64_t p = i / cpr;
+        const int col = (int)(i - p * cpr);
+        const bf16x8_t v = *reinterpret_cast<const bf16x8_t*>(a + ((int64_t)n * HW + p) * lda + col * 8);
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += (float)v[e];
+        part += (double)(s * w[p]);
+    }
+    const double t = block_sum_d(part, sh);
+    if (threadIdx.x == 0) atomicAdd(pre + n, (float)t);
+}
+
+__global__ void weighted_pool_finish_k(const float* __restrict__ pre, const float* __restrict__ b, int C, int N, float* __restrict__ scale) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n < N) scale[n] = 1.f / (1.f + expf(-(pre[n] + (float)C * b[0])));
+}
+
+// dpre[n] = dscale[n] * s (1 - s);  da[n][p][c] (+)= dpre[n] * w[p];  dw[p] += sum_n dpre[n] * sum_c a[n][p][c];  db += C * sum_n dpre[n]
+__global__ __launch_bounds__(NT) void weighted_pool_bwd_k(const float* __restrict__ dscale, const float* __restrict__ scale,
+                                                          const bf16_t* __restrict__ a, int lda, const float* __restrict__ w,
+                                                          bf16_t* __restrict__ da, int ldda, int acc, float* __restrict__ dw,
+                                                          float* __restrict__ db, int N, int64_t HW, int C, MdeDetDev det) {
+    const int cpr = C >> 3;
+    for (int64_t p = (int64_t)blockIdx.x * NT + threadIdx.x; p < HW; p += (int64_t)gridDim.x * NT) {
+        const float wp = w[p];
+        float gw = 0.f;
+        for (int n = 0; n < N; ++n) {
+            const float s = scale[n], dp = dscale[n] * s * (1.f - s);
+            float rs = 0.f;
+            for (int col = 0; col < cpr; ++col) {
+                const int64_t off = ((int64_t)n * HW + p);
+                const bf16x8_t v = *reinterpret_cast<const bf16x8_t*>(a + off * lda + col * 8);
+                bf16x8_t o;
+                if (acc) o = *reinterpret_cast<const bf16x8_t*>(da + off * ldda + col * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    rs += (float)v[e];
+                    o[e] = (bf16_t)(dp * wp + (acc ? (float)o[e] : 0.f));
+                }
+                *reinterpret_cast<bf16x8_t*>(da + off * ldda + col * 8) = o;
+            }
+            gw += dp * rs;
+        }
+        mde_grad_add(dw + p, gw, det);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        float g = 0.f;
+        for (int n = 0; n < N; ++n) g += dscale[n] * scale[n] * (1.f - scale[n]);
+        mde_grad_add(db, (float)C * g, det);
+    }
+}
+
+// depth = factor * (m0 * s0[n] + m1 * s1[n] + m2 * s2[n])  (MyNet.py:152-155: / 3.0, * 10.0), fp32 maps [N][HW]
+__global__ __launch_bounds__(NT) void combine3_fwd_k(const float* __restrict__ m0, const float* __restrict__ m1, const float* __restrict__ m2,
+                                                     const float* __restrict__ s0, const float* __restrict__ s1, const float* __restrict__ s2,
+                                                     float factor, int64_t HW, int64_t total, float* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
+        const int64_t n = i / HW;
+        out[i] = factor * (m0[i] * s0[n] + m1[i] * s1[n] + m2[i] * s2[n]);
+    }
+}
+
+// dm_k += factor * dout * s_k[n];  ds_k[n] += factor * sum_p dout * m_k   (ds zeroed by the caller's init launch)
+__global__ __launch_bounds__(NT) void combine3_bwd_k(const float* __restrict__ dout, const float* __restrict__ m0, const float* __restrict__ m1,
+                                                     const float* __restrict__ m2, const float* __restrict__ s0, const float* __restrict__ s1,
+                                                     const float* __restrict__ s2, float factor, int64_t HW, float* __restrict__ dm0,
+                                                     float* __restrict__ dm1, float* __restrict__ dm2, float* __restrict__ ds) {
+    __shared__ double sh[NT / 64];
+    const int n = blockIdx.y;
+    const float a0 = factor * s0[n], a1 = factor * s1[n], a2 = factor * s2[n];
+    double p0 = 0.0, p1 = 0.0, p2 = 0.0;
+    for (int64_t p = (int64_t)blockIdx.x * NT + threadIdx.x; p < HW; p += (int64_t)gridDim.x * NT) {
+        const int64_t i = (int64_t)n * HW + p;
+        const float g = dout[i];
+        p0 += (double)(g * m0[i]);
+        p1 += (double)(g * m1[i]);
+        p2 += (double)(g * m2[i]);
+        dm0[i] += g * a0;
+        dm1[i] += g * a1;
+        dm2[i] += g * a2;
+    }
+    const double t0 = block_sum_d(p0, sh), t1 = block_sum_d(p1, sh), t2 = block_sum_d(p2, sh);
+    if (threadIdx.x == 0) {
+        atomicAdd(ds + n, factor * (float)t0);
+        atomicAdd(ds + gridDim.y + n, factor * (float)t1);
+        atomicAdd(ds + 2 * gridDim.y + n, factor * (float)t2);
+    }
+}
+
+}  // namespace
+
+extern "C" int mde_weighted_pool_fwd(const void* a, int lda, const float* w, const float* b, float* pre, float* scale, int N, int64_t HW,
+                                     int C, void* stream) {
+    MDE_REQUIRE(a && w && b && pre && scale && N > 0 && HW > 0 && C > 0 && C % 8 == 0 && lda % 8 == 0 && lda >= C && ORD_ALIGNED(a),
+                "mde_weighted_pool_fwd: bad argument (C=%d, lda=%d)", C, lda);
+    hipStream_t st = (hipStream_t)stream;
+    zero_f32_k<<<mde_cdiv(N, 64), 64, 0, st>>>(pre, N);
+    MDE_LAUNCH_CHECK("zero_f32_k");
+    int gx = grid_flat(HW * (C / 8));
+    if (gx > 64) gx = 64;
+    weighted_pool_fwd_k<<<dim3(gx, N), NT, 0, st>>>((const bf16_t*)a, lda, w, HW, C, pre);
+    MDE_LAUNCH_CHECK("weighted_pool_fwd_k");
+    weighted_pool_finish_k<<<mde_cdiv(N, 64), 64, 0, st>>>(pre, b, C, N, scale);
+    MDE_LAUNCH_CHECK("weighted_pool_finish_k");
+    return MDE_OK;
+}
+
+extern "C" int mde_weighted_pool_bwd(const float* dscale, const float* scale, const void* a, int lda, const float* w, void* da, int ldda,
+                                     int accumulate, float* dw, float* db, int N, int64_t HW, int C, void* stream) {
+    MDE_REQUIRE(dscale && scale && a && w && da && dw && db && N > 0 && HW > 0 && C > 0 && C % 8 == 0 && lda % 8 == 0 && ldda % 8 == 0 &&
+                    lda >= C && ldda >= C && ORD_ALIGNED(a) && ORD_ALIGNED(da),
+                "mde_weighted_pool_bwd: bad argument (C=%d, lda=%d, ldda=%d)", C, lda, ldda);
+    weighted_pool_bwd_k<<<grid_flat(HW), NT, 0, (hipStream_t)stream>>>(dscale, scale, (const bf16_t*)a, lda, w, (bf16_t*)da, ldda, accumulate, dw, db,
+                                                                      N, HW, C, mde_det_dev());
+    MDE_LAUNCH_CHECK("weighted_pool_bwd_k");
+    return MDE_OK;
+}
+
+extern "C" int mde_combine3_fwd(const float* m0, const float* m1, const float* m2, const float* s0, const float* s1, const float* s2,
+                                float factor, int N, int64_t HW, float* out, void* stream) {
+    MDE_REQUIRE(m0 && m1 && m2 && s0 && s1 && s2 && out && N > 0 && HW > 0, "mde_combine3_fwd: bad argument");
+    const int64_t total = (int64_t)N * HW;
+    combine3_fwd_k<<<grid_flat(total), NT, 0, (hipStream_t)stream>>>(m0, m1, m2, s0, s1, s2, factor, HW, total, out);
+    MDE_LAUNCH_CHECK("combine3_fwd_k");
+    return MDE_OK;
+}
+
+extern "C" int mde_combine3_bwd(const float* dout, const float* m0, const float* m1, const float* m2, const float* s0, const float* s1,
+                                const float* s2, float factor, int N, int64_t HW, float* dm0, float* dm1, float* dm2, float* ds, void* stream) {
+    MDE_REQUIRE(dout && m0 && m1 && m2 && s0 && s1 && s2 && dm0 && dm1 && dm2 && ds && N > 0 && HW > 0, "mde_combine3_bwd: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    zero_f32_k<<<mde_cdiv(3 * N, 64), 64, 0, st>>>(ds, 3 * N);
+    MDE_LAUNCH_CHECK("zero_f32_k");
+    int gx = grid_flat(HW);
+    if (gx > 128) gx = 128;
+    combine3_bwd_k<<<dim3(gx, N), NT, 0, st>>>(dout, m0, m1, m2, s0, s1, s2, factor, HW, dm0, dm1, dm2, ds);
+    MDE_LAUNCH_CHECK("combine3_bwd_k");
+    return MDE_OK;
+}

@@ -471,14 +471,15 @@ class MaxPool(Op):
 
 
 class Nearest2(Op):
-    """F.interpolate(scale_factor=2, mode='nearest') (Bts.py:77)."""
+    """F.interpolate(scale_factor=2, mode='nearest') (Bts.py:77) / nn.Upsample(scale_factor=2) (MyNet.py:20,44)."""
 
-    def __init__(self, eng, x):
+    def __init__(self, eng, x, out=None):
         self.x = x
-        self.out = Act(eng.dev, x.N, 2 * x.H, 2 * x.W, x.C)
+        self.out = out if out is not None else Act(eng.dev, x.N, 2 * x.H, 2 * x.W, x.C)
+        self.own_out = out is None
 
     def acts(self):
-        return (self.out,)
+        return (self.out,) if self.own_out else ()
 
     def fwd(self, train):
         x, o = self.x, self.out
@@ -729,6 +730,118 @@ class OrdinalHead(Op):
             x.g.zero_()
             return
         ops.ordinal_bwd(self.douts[1], x.t, x.ld, x.g, _ldg(x), x.N, x.H * x.W, self.K)
+
+
+# ---------------------------------------------------------------------------------------------- ops of the MyNet plan
+class ConvT(Op):
+    """nn.ConvTranspose2d(Cin, Cout, k, stride=2, padding=p) with (2h + 2p - k) / 2 + 1 == h, no bias here (MyNet.py:61-63: k 4,
+    p 1).  A transposed convolution IS the input gradient of the strided convolution with the same weight tensor
+    [Cin][Cout][k][k] read as that convolution's [O][I][kh][kw] (engine.DeConvLayer): forward = the stride-2 output phases
+    over the transposed packing, input gradient = that convolution's forward over d(out), weight gradient = its weight
+    gradient with activation and output gradient exchanged."""
+
+    def __init__(self, eng, x, w, k, pad):
+        self.eng, self.x = eng, x
+        self.w = eng.store.conv([w])                       # O = Cin, I = Cout (storage, possibly padded to 8)
+        Cin, C = self.w.O, self.w.I
+        assert x.C == Cin and ops.out_size(2 * x.H, k, 2, pad) == x.H and ops.out_size(2 * x.W, k, 2, pad) == x.W, (x.C, Cin, k, pad)
+        N, h, wd = x.N, x.H, x.W
+        self.out = Act(eng.dev, N, 2 * h, 2 * wd, C)
+        o = self.out
+        self.fdescs, self.fzero = ops.dgrad_descs(N, 2 * h, 2 * wd, o.ld, C, h, wd, x.ld, Cin, x.nbytes, k, 2, pad)
+        self.ddesc = ops.fwd_desc(N, 2 * h, 2 * wd, o.ld, C, o.nbytes, k, 2, pad, Cin, x.ld)
+        self.wdesc = ops.conv_wgrad_desc(N, 2 * h, 2 * wd, o.ld, C, o.nbytes, h, wd, x.ld, Cin, x.nbytes, k, 2, pad,
+                                         eng._ksplit(x.M, Cin, C, k * k))
+
+    def acts(self):
+        return (self.out,)
+
+    def fwd(self, train):
+        if self.fzero:
+            self.out.t.zero_()
+        for d in self.fdescs:
+            ops.conv_gemm(d, self.x.t, self.w.wd, self.out.t)
+
+    def bwd(self):
+        x, o = self.x, self.out
+        self.eng.wgrad(self.wdesc, x.t, o.g, self.w.dw)
+        self.ddesc.accumulate = int(_take(x))
+        ops.conv_gemm(self.ddesc, o.g, self.w.wf, x.g)
+
+
+class PixelShuffle2(Op):
+    """nn.PixelShuffle(2) (MyNet.py:37,46,48): [N][h][w][4C] -> [N][2h][2w][C], a permutation (and its inverse for the gradient)."""
+
+    def __init__(self, eng, x, out=None):
+        assert x.C % 32 == 0, "PixelShuffle(2): 4 x (a multiple of 8) channels"
+        self.x = x
+        self.out = out if out is not None else Act(eng.dev, x.N, 2 * x.H, 2 * x.W, x.C // 4)
+        self.own_out = out is None
+        self.tmp = None
+
+    def acts(self):
+        return (self.out,) if self.own_out else ()
+
+    def fwd(self, train):
+        x, o = self.x, self.out
+        ops.pixel_shuffle2(x.t, x.ld, o.t, o.ld, x.N, x.H, x.W, o.C)
+
+    def bwd(self):
+        x, o = self.x, self.out
+        if not _take(x):
+            ops.pixel_shuffle2(x.g, _ldg(x), o.g, _ldg(o), x.N, x.H, x.W, o.C, inverse=True)
+            return
+        if self.tmp is None:                               # the input has another consumer: permute into scratch, then add
+            self.tmp = torch.empty(x.N, x.H, x.W, x.C, dtype=torch.bfloat16, device=x.t.device)
+        ops.pixel_shuffle2(self.tmp, x.C, o.g, _ldg(o), x.N, x.H, x.W, o.C, inverse=True)
+        ops.pw_fwd(self.tmp, x.C, None, x.g, _ldg(x), x.g, _ldg(x), x.M, x.C, None)
+
+
+class WeightedPool(Op):
+    """Weighter's tail (MyNet.py:96-119): flatten -> nn.Linear(HW, 1) -> sum over channels -> sigmoid: one fp32 scale per image
+    (`scale`, with its gradient `dscale` written by the consumer)."""
+
+    def __init__(self, eng, x, linear, dscale):
+        self.eng, self.x = eng, x
+        self.w, self.w_off = eng.store.vec(linear.weight)
+        self.b, self.b_off = eng.store.vec(linear.bias)
+        assert linear.weight.shape == (1, x.H * x.W), (tuple(linear.weight.shape), x.H, x.W)
+        self.pre = torch.empty(x.N, device=eng.dev)
+        self.scale = torch.empty(x.N, device=eng.dev)
+        self.dscale = dscale
+
+    def fwd(self, train):
+        x = self.x
+        ops.weighted_pool_fwd(x.t, x.ld, self.w, self.b, self.pre, self.scale, x.N, x.H * x.W, x.C)
+
+    def bwd(self):
+        x, G_ = self.x, self.eng.store.Gcur
+        HW = x.H * x.W
+        ops.weighted_pool_bwd(self.dscale, self.scale, x.t, x.ld, self.w, x.g, _ldg(x), _take(x), G_[self.w_off:self.w_off + HW],
+                              G_[self.b_off:self.b_off + 1], x.N, HW, x.C)
+
+
+class Combine3(Op):
+    """my_decoder's output (MyNet.py:152-155): factor * sum_k map_k * scale_k[n], the module's fp32 N x 1 x H x W result."""
+
+    def __init__(self, eng, maps, factor):
+        m = maps[0]
+        self.maps, self.factor = maps, float(factor)
+        self.ds = torch.zeros(3, m.N, device=eng.dev)              # the three WeightedPool ops read their row of it
+        self.scales = None                                           # set once the WeightedPool ops exist
+        self.y = torch.empty(m.N, 1, m.H, m.W, device=eng.dev)
+        self.outputs, self.douts = (self.y,), [None]
+
+    def fwd(self, train):
+        m = self.maps[0]
+        ops.combine3_fwd([a.t for a in self.maps], self.scales, self.factor, m.N, m.H * m.W, self.y)
+
+    def bwd(self):
+        m = self.maps[0]
+        if self.douts[0] is None:
+            self.ds.zero_()
+            return
+        ops.combine3_bwd(self.douts[0], [a.t for a in self.maps], self.scales, self.factor, m.N, m.H * m.W, [a.g for a in self.maps], self.ds)
 
 
 # ---------------------------------------------------------------------------------------------- the tape

@@ -379,6 +379,25 @@ def ordinal_bwd(dprob, x, ldx, dx, lddx, N, HW, K):
     check(_lib.load().mde_ordinal_bwd(_p(dprob), _p(x), ldx, _p(dx), lddx, N, HW, K, _stream()), "mde_ordinal_bwd")
 
 
+def weighted_pool_fwd(a, lda, w, b, pre, scale, N, HW, C_):
+    check(_lib.load().mde_weighted_pool_fwd(_p(a), lda, _p(w), _p(b), _p(pre), _p(scale), N, HW, C_, _stream()), "mde_weighted_pool_fwd")
+
+
+def weighted_pool_bwd(dscale, scale, a, lda, w, da, ldda, accumulate, dw, db, N, HW, C_):
+    check(_lib.load().mde_weighted_pool_bwd(_p(dscale), _p(scale), _p(a), lda, _p(w), _p(da), ldda, int(accumulate), _p(dw), _p(db), N, HW, C_,
+                                            _stream()), "mde_weighted_pool_bwd")
+
+
+def combine3_fwd(maps, scales, factor, N, HW, out):
+    check(_lib.load().mde_combine3_fwd(_p(maps[0]), _p(maps[1]), _p(maps[2]), _p(scales[0]), _p(scales[1]), _p(scales[2]), factor, N, HW,
+                                       _p(out), _stream()), "mde_combine3_fwd")
+
+
+def combine3_bwd(dout, maps, scales, factor, N, HW, dmaps, ds):
+    check(_lib.load().mde_combine3_bwd(_p(dout), _p(maps[0]), _p(maps[1]), _p(maps[2]), _p(scales[0]), _p(scales[1]), _p(scales[2]), factor,
+                                       N, HW, _p(dmaps[0]), _p(dmaps[1]), _p(dmaps[2]), _p(ds), _stream()), "mde_combine3_bwd")
+
+
 def ord_loss_ws(device="cuda"):
     return torch.zeros((_lib.load().mde_ord_loss_ws_bytes() + 7) // 8, dtype=torch.float64, device=device)
 

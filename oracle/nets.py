@@ -5,7 +5,7 @@ require grad for gradient parity, BN running statistics updated in place in trai
 keys the way the reference's forward walks its modules.  One dict therefore loads into the reference model, drives this
 oracle and loads into the HIP module.  Cited lines are under /root/reference.
 
-Pinned by tests/golden/{vnl_net,midas_net,bts_net,eigen,dorn_net}.npz, minted by tests/golden/gen_golden.py from the reference's own
+Pinned by tests/golden/{vnl_net,midas_net,bts_net,eigen,dorn_net,mynet}.npz, minted by tests/golden/gen_golden.py from the reference's own
 classes (imported with stand-ins for the absent torchvision / torch.hub trunks, whose architecture is restated from
 their public definitions — see that script's docstring).
 """
@@ -374,6 +374,50 @@ def dorn_forward(P, x, train, size, kernel_size=16, pyramid=(4, 8, 12), dropout=
     z = n.q(F.interpolate(z, size=tuple(size), mode="bilinear", align_corners=True))
     label, prob = ordinal_layer(z)
     return (label, prob, z) if return_logits else (label, prob)
+
+
+# ---------------------------------------------------------------------------------------------- MyNet (network/MyNet.py)
+def _my_pre(n, x, k, stride=1):
+    """Conv2d.forward (MyNet.py:11-15): ELU -> BN -> conv."""
+    return n.conv(n.q(n.bn(n.q(F.elu(x)), k + ".bn")), k + ".conv", stride, 1)
+
+
+def _my_rcu(n, x, k):
+    """ResidualConvUnit.forward (MyNet.py:218-230)."""
+    y = n.q(F.relu(n.conv(n.q(F.relu(x)), k + ".conv1", pad=1)))
+    return n.q(n.conv(y, k + ".conv2", pad=1) + x)
+
+
+def mynet_forward(P, x, train, momentum=None, q=None, blocks=(6, 12, 36, 24)):
+    """MyModel.forward (MyNet.py:270-272) with a DenseNet encoder: encoder.forward (:181-192) -> my_decoder.forward (:135-157).
+    x: N x 3 x H x W at the model's input_size (GlobalConsitency's adaptive max-pool is then the identity; restated as the
+    pooling call all the same)."""
+    n = Net(P, train, q=q, momentum=momentum)
+    s0, s1, s2, s3, dense = densenet_features(n, x, "encoder.base_model.", blocks)
+    d = "decoder."
+    dense = n.q(F.relu(dense))
+    x0, x1 = _my_rcu(n, s0, d + "refine0.resConfUnit2"), _my_rcu(n, s1, d + "refine1.resConfUnit2")
+    x2, x3 = _my_rcu(n, s2, d + "refine2.resConfUnit2"), _my_rcu(n, s3, d + "refine3.resConfUnit2")
+    up = lambda t: F.interpolate(t, scale_factor=2, mode="nearest")
+    half = (x.shape[2] // 2, x.shape[3] // 2)
+    g = torch.cat([F.adaptive_max_pool2d(x0, half), F.adaptive_max_pool2d(up(x1), half)], 1)
+    glob = _my_pre(n, _my_pre(n, g, d + "global_con.conv"), d + "global_con.conv_final")
+    a = _my_pre(n, F.pixel_shuffle(x1, 2), d + "details.down", 2)
+    t = torch.cat([a, F.pixel_shuffle(x2, 2)], 1)
+    t = _my_pre(n, _my_pre(n, _my_pre(n, t, d + "details.conv"), d + "details.conv2"), d + "details.conv_final")
+    detail = up(t)
+    tc = lambda t, k: n.q(n.q(F.conv_transpose2d(t, P[d + k + ".weight"], None, stride=2, padding=1)) + P[d + k + ".bias"].view(1, -1, 1, 1))
+    sc = torch.cat([x2, tc(x3, "sharpness.tconv0"), tc(tc(dense, "sharpness.tconv1"), "sharpness.tconv2")], 1)
+    sharp = n.q(F.relu(n.conv(up(sc), d + "sharpness.up0.1", pad=1)))
+    sharp = n.q(F.relu(n.conv(up(sharp), d + "sharpness.up1.1", pad=1)))
+    depth = lambda t: torch.sigmoid(n.conv(up(t), d + "get_depth.1", pad=1))
+    w, b = P[d + "weighter.mlp.weight"], P[d + "weighter.mlp.bias"]
+
+    def weight(t):
+        v = n.q(_my_pre(n, t, d + "weighter.conv", 2)).flatten(2)
+        return torch.sigmoid(torch.sum(F.linear(v, w, b), dim=1))[:, None, None]
+    out = depth(glob) * weight(glob) + depth(detail) * weight(detail) + depth(sharp) * weight(sharp)
+    return out / 3.0 * 10.0
 
 
 def leaf_state(sd, requires_grad=False):

@@ -184,3 +184,18 @@ def dorn_fixture_state(model, seed):
             sd[k] = sd[k] * 0.05
     model.load_state_dict(sd)
     return sd
+
+
+def mynet_fixture_state(model, seed):
+    """MyNet parity fixture: net_conditioned_state with the depth head scaled by 0.05 and the weighter's Linear by 0.004 (its input is a sum over 32 channels x HW / 16 pixels; He-scale
+    weights on the BN-free branch tails saturate both sigmoids), Linear / ConvTranspose weights bf16-representable too."""
+    sd = net_conditioned_state(model, seed)
+    for k in sd:
+        if k.endswith("get_depth.1.weight"):
+            sd[k] = sd[k] * 0.05
+        if k.endswith("weighter.mlp.weight"):
+            sd[k] = sd[k] * 0.004
+        if sd[k].ndim >= 2:
+            sd[k] = sd[k].to(torch.bfloat16).to(torch.float32)
+    model.load_state_dict(sd)
+    return sd

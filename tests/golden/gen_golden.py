@@ -675,6 +675,41 @@ def gen_dorn_net(criteria):
     np.savez_compressed(os.path.join(HERE, "dorn_net.npz"), **out)
 
 
+MYNET_SIZE = (64, 96)
+
+
+def gen_mynet(criteria):
+    """N4: the reference's own network/MyNet.py (MyModel: encoder's feature walk, my_decoder with its residual units, the three
+    branches, the shared depth head and the weighter) over the densenet161 stand-in at 2 x 3 x 64 x 96 = the model's
+    input_size, with criteria.MidasLoss(alpha=0.5, loss='mse', reduction='batch-based') (modules/my.py:36)."""
+    from network import MyNet
+    torch.manual_seed(0)
+    ref = MyNet.MyModel(input_size=MYNET_SIZE, encoder_version="densenet161_bts")
+    W.mynet_fixture_state(ref, 71)
+    rgb, tgt = W.synthetic_batch(71, 2, *MYNET_SIZE)
+    W.calibrate_running_stats(ref, rgb)
+    out = {"keys": np.array(list(ref.state_dict().keys()))}
+    ref.eval()
+    with torch.no_grad():
+        out["eval_out"] = _np(ref(rgb))
+    ref.train()
+    y = ref(rgb)
+    loss = criteria.MidasLoss(alpha=0.5, loss="mse", reduction="batch-based")(y, tgt * 10.0)
+    loss.backward()
+    out["train_out"], out["train_loss"] = _np(y), _np(loss)
+    names, norms = [], []
+    for k, p in ref.named_parameters():
+        if p.grad is not None:
+            names.append(k)
+            norms.append(float(p.grad.norm()))
+    out["grad_names"], out["grad_norms"] = np.array(names), np.array(norms, dtype=np.float32)
+    out["no_grad"] = np.array([k for k, p in ref.named_parameters() if p.grad is None])
+    out["rv_weighter"] = _np(ref.state_dict()["decoder.weighter.conv.bn.running_var"])
+    np.savez_compressed(os.path.join(HERE, "mynet.npz"), **out)
+    print("mynet.npz: %d keys, %d params, eval range %.4f..%.4f, train loss %.5f, %d parameters without gradient" % (
+        len(out["keys"]), sum(p.numel() for p in ref.parameters()), out["eval_out"].min(), out["eval_out"].max(), float(loss), len(out["no_grad"])))
+
+
 def gen_vnl_keymap():
     """N3: the reference's own convert_state_dict_resnext (VNL.py:44-67) on the index-path keys of the shipped
     ResNeXt-ImageNet files, enumerated from the documented nn.Sequential structure -> {source key: body key} pairs."""
@@ -727,6 +762,8 @@ def main():
         gen_eigen(criteria)
     if want("dorn_net"):
         gen_dorn_net(criteria)
+    if want("mynet"):
+        gen_mynet(criteria)
     if want("vnl_keymap"):
         gen_vnl_keymap()
 

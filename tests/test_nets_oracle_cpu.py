@@ -263,3 +263,43 @@ def test_ord_loss_oracle_matches_the_reference():
     loss.backward()
     assert abs(float(loss) - float(g["ord_loss"])) < 1e-5
     assert np.abs(prob.grad.numpy() - g["ord_grad"]).max() < 1e-6
+
+
+# ---------------------------------------------------------------------------------------------- MyNet
+MYNET_SIZE = (64, 96)
+
+
+@pytest.fixture(scope="module")
+def mynet_fixture():
+    from mono_depth_estimation_amd.network import MyNet
+    torch.manual_seed(0)
+    mirror = MyNet.MyModel(input_size=MYNET_SIZE, encoder_version="densenet161_bts")
+    sd = W.mynet_fixture_state(mirror, 71)
+    rgb, tgt = W.synthetic_batch(71, 2, *MYNET_SIZE)
+    P = nets.leaf_state(sd, requires_grad=True)
+    with torch.no_grad():
+        nets.mynet_forward(P, rgb, True, momentum=1.0)
+    return mirror, P, rgb, tgt
+
+
+def test_mynet_parameter_tree_and_oracle_match_the_reference(mynet_fixture):
+    mirror, P, rgb, tgt = mynet_fixture
+    g = _golden("mynet")
+    assert list(mirror.state_dict().keys()) == list(g["keys"])
+    assert sum(p.numel() for p in mirror.parameters()) == 58045437
+    assert all(k.startswith("encoder.") or k.startswith("decoder.") for k, _ in mirror.named_parameters())       # my.py:67-69
+    with torch.no_grad():
+        y = nets.mynet_forward(P, rgb, False)
+    assert y.shape == (2, 1, *MYNET_SIZE)
+    assert np.abs(y.numpy() - g["eval_out"]).max() < 2e-4 * np.abs(g["eval_out"]).max()
+    y = nets.mynet_forward(P, rgb, True)
+    assert np.abs(y.detach().numpy() - g["train_out"]).max() < 2e-4 * np.abs(g["train_out"]).max()
+    loss = L.midas_loss(y, tgt * 10.0, alpha=0.5, loss="mse")
+    assert abs(float(loss) - float(g["train_loss"])) < 1e-4 * float(g["train_loss"])
+    loss.backward()
+    norms = dict(zip(g["grad_names"], g["grad_norms"]))
+    bad = [(k, float(P[k].grad.norm()), float(v)) for k, v in norms.items() if abs(float(P[k].grad.norm()) - float(v)) > 3e-3 * float(v) + 1e-7]
+    assert not bad, bad[:5]
+    # FeatureFusionBlock gets ONE input (MyNet.py:137-140): resConfUnit1 of every refine block never sees a gradient
+    assert sorted(g["no_grad"]) == sorted(k for k in P if ".resConfUnit1." in k) and all(P[k].grad is None for k in g["no_grad"])
+    assert np.abs(P["decoder.weighter.conv.bn.running_var"].numpy() - g["rv_weighter"]).max() < 1e-4 * np.abs(g["rv_weighter"]).max()
