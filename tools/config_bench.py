@@ -2,7 +2,7 @@
 """Training throughput of BASELINE.json configurations 3 / 4 / 5 at their per-GPU sizes on one MI355X (module path: network
 forward -> drop-in criterion -> backward -> fused optimiser step), one JSON line per configuration.
 
-    python tools/config_bench.py [vnl] [midas] [bts] [dorn] [--steps K] [--warmup W]
+    python tools/config_bench.py [vnl] [midas] [bts] [dorn] [mynet] [--steps K] [--warmup W]
 
 GMAC figures are SURVEY.md 8a's dense-as-written forward MACs per image (x 6 = training FLOP)."""
 import argparse
@@ -113,6 +113,9 @@ def plan_gmac(net):
         if isinstance(op, G.Conv):
             o, c = op.out, op.conv
             macs += o.N * o.H * o.W * c.O * c.T * (getattr(c, "G", 0) or c.I)
+        elif isinstance(op, G.ConvT):
+            x, c = op.x, op.w
+            macs += x.N * x.H * x.W * c.O * c.T * c.I
         elif isinstance(op, (G.Stem, G.ImageStem)):
             o = op.c if isinstance(op, G.Stem) else op.out
             macs += o.N * o.H * o.W * o.C * op.w.T * 3
@@ -143,6 +146,26 @@ def dorn(args):
             "images_per_sec": n / dt, "fwd_gmac_per_image": g, "step_mfma_frac": n / dt * g * 6e9 / (PEAK * 1e12)}
 
 
+def mynet(args):
+    """The MyNet module's defaults (modules/my.py:27-36,66-70,160): 384 x 384, batch 16, MidasLoss(0.5, 'mse'), Adam 1x / 10x."""
+    from mono_depth_estimation_amd import criteria
+    from mono_depth_estimation_amd.network import MyNet
+    torch.manual_seed(0)
+    net = MyNet.MyModel().cuda().train()
+    n = args.batch or 16
+    x, gt = data(n, 384, 384)
+    crit = criteria.MidasLoss(alpha=0.5, loss="mse", reduction="batch-based")
+
+    def step():
+        net.zero_grad(set_to_none=True)
+        crit(net(x), gt * 10.0).backward()
+        net._store.adam_step(1e-4, 1e-3)
+    dt = timed(step, args.steps, args.warmup)
+    g = plan_gmac(net)
+    return {"config": "MyNet DenseNet-161, %dx3x384x384, MidasLoss(0.5, mse), Adam" % n, "ms_per_step": 1e3 * dt,
+            "images_per_sec": n / dt, "fwd_gmac_per_image": g, "step_mfma_frac": n / dt * g * 6e9 / (PEAK * 1e12)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("which", nargs="*", default=["vnl", "midas"])
@@ -151,7 +174,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0)
     args = ap.parse_args()
     for w in args.which:
-        out = {"vnl": vnl, "midas": midas, "bts": bts, "dorn": dorn}[w](args)
+        out = {"vnl": vnl, "midas": midas, "bts": bts, "dorn": dorn, "mynet": mynet}[w](args)
         out = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in out.items()}
         print(json.dumps(out), flush=True)
         torch.cuda.empty_cache()
