@@ -98,7 +98,7 @@ __device__ __forceinline__ int chunk_off(int row, int kslot8) {
 // template's stagger; MI355X_MICROARCH "Two waves per SIMD" item 9).  In the lockstep loop both waves read together (LDS
 // saturated, matrix pipe idle) and then compute together (pipe shared): MFMA busy measured 41 %.
 template <int BP, int BC, int NT, bool DMA, int NBUF, bool PP = false>
-__global__ __launch_bounds__(NT, (NT == 256 && BP * BC >= 256 * 256) ? 1 : 2) void conv_gemm_nt(const KArgs a) {
+__global__ __launch_bounds__(NT, (NT == 256 && BP * BC >= 256 * 256) ? 1 : (NBUF == 1 ? 4 : 2)) void conv_gemm_nt(const KArgs a) {
     constexpr int NW = NT / 64;
     constexpr int RPL = NT / 8;          // tile rows covered by one load pass (8 chunks per row)
     constexpr int XP = BP / RPL;         // X chunks per thread per K-step
@@ -112,12 +112,14 @@ __global__ __launch_bounds__(NT, (NT == 256 && BP * BC >= 256 * 256) ? 1 : 2) vo
     constexpr int BUF_BYTES = XT_BYTES + WT_BYTES;
     constexpr int ROWB = BC * 2 + 16;    // epilogue tile row pitch (bytes)
     // the epilogue re-tiles through LDS; when the whole tile does not fit, in EPASS pixel slabs
-    constexpr int EPASS = (BP * ROWB <= 2 * BUF_BYTES) ? 1 : 2;
+    constexpr int STG_BYTES = (NBUF < 2 ? NBUF : 2) * BUF_BYTES;         // LDS the epilogue may stage through
+    constexpr int EPASS = (BP * ROWB <= STG_BYTES) ? 1 : (BP * ROWB <= 2 * STG_BYTES) ? 2 : 4;
     constexpr int EROWS = BP / EPASS;    // pixel rows per epilogue pass
     static_assert(WAVES_P * WAVES_C == NW && PF * 16 * WAVES_P == BP && CF * 16 * WAVES_C == BC && PF >= 2 && PF <= 8, "wave tiling");
     static_assert(XP >= 1 && WP >= 1 && XP * RPL == BP && WP * RPL == BC, "load tiling");
-    static_assert(EROWS * ROWB <= 2 * BUF_BYTES && (WAVES_P % EPASS) == 0, "epilogue slab fits in the staging buffers");
-    static_assert(NBUF == 2 || (DMA && NBUF == 3), "register staging uses two LDS buffers");
+    static_assert(EROWS * ROWB <= STG_BYTES && (WAVES_P % EPASS) == 0, "epilogue slab fits in the staging buffers");
+    static_assert(NBUF == 2 || (DMA && (NBUF == 1 || NBUF == 3)), "register staging uses two LDS buffers");
+    static_assert(NBUF != 1 || !PP, "the single-buffer loop has no ping-pong form");
     constexpr int XR = BP / 8 / NW, WR = BC / 8 / NW;   // DMA regions (8 rows) per wave per K-step
     static_assert(!DMA || (XR >= 1 && WR >= 1 && XR * NW * 8 == BP && WR * NW * 8 == BC && NW % 2 == 0), "DMA tiling");
 
@@ -490,6 +492,20 @@ __global__ __launch_bounds__(NT, (NT == 256 && BP * BC >= 256 * 256) ? 1 : 2) vo
 #undef PP_BARRIER
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
+        } else if constexpr (NBUF == 1) {
+            // Short-K shapes (1x1 convolutions over 64 ... 256 channels are one to four K-steps: all prologue and
+            // epilogue, HBM-bound): ONE staging buffer, so that twice as many workgroups fit a CU and one workgroup's
+            // operand fetch overlaps its neighbours' epilogue stores — the overlap a ring inside one workgroup cannot give
+            // a loop this short.
+            for (int s = 0; s < nsteps; ++s) {
+                if (s) __builtin_amdgcn_s_barrier();          // every wave is done reading step s-1
+                issue_dma(0);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                compute(0);
+            }
+            __syncthreads();
         } else {
 #pragma unroll
         for (int q = 0; q < DIST; ++q)
@@ -840,7 +856,7 @@ int pick_and_launch(KArgs& ka, int64_t M, hipStream_t st) {
         const char* ppe = getenv("MDE_CONV_PP");
         gpp = !ppe ? 2 : (strcmp(ppe, "0") != 0);
         const char* e = getenv("MDE_CONV_TILE");
-        forced = !e ? 0 : !strcmp(e, "256x256") ? 1 : !strcmp(e, "128x128") ? 3 : !strcmp(e, "192x256") ? 5 : !strcmp(e, "128x64") ? 6 : !strcmp(e, "256x256w4") ? 7 : 0;
+        forced = !e ? 0 : !strcmp(e, "256x256") ? 1 : !strcmp(e, "128x128") ? 3 : !strcmp(e, "192x256") ? 5 : !strcmp(e, "128x64") ? 6 : !strcmp(e, "256x256w4") ? 7 : !strcmp(e, "128x128s") ? 8 : !strcmp(e, "128x256s") ? 9 : 0;
         const char* q = getenv("MDE_CONV_PATH");
         reg = q && !strcmp(q, "reg");
     }
@@ -868,6 +884,20 @@ int pick_and_launch(KArgs& ka, int64_t M, hipStream_t st) {
         if (const char* e = getenv("MDE_CONV_RATES")) sscanf(e, "%lf,%lf", &r256, &r192);   // diagnostics: refit
     }
     const int nc256 = mde_cdiv(n, 256), nc128 = mde_cdiv(n, 128);
+    // Short K (1x1 convolutions over <= 512 channels: at most 8 K-steps, HBM-bound, mostly prologue and epilogue): the
+    // single-buffer 128x128 tile at four workgroups per CU, whose fetches overlap the neighbours' epilogue stores.  Measured
+    // in-network (tools/short_k_sweep.sh): -12 % summed over the 1x1 shapes of the step that qualify, e.g. 64 -> 256 channels
+    // at 614 400 pixels 116 -> 97 us (accumulating: 158 -> 123); shapes with 16+ K-steps or too few tiles are not faster.
+    {
+        static int sk = -1;
+        if (sk < 0) {
+            const char* e = getenv("MDE_CONV_SHORTK");
+            sk = !(e && !strcmp(e, "0"));
+        }
+        const int nst = ka.d.ntaps * ((ka.d.C + BK - 1) / BK);
+        if (sk && forced == 0 && !reg && nst <= 8 && (int64_t)mde_cdiv(M, 128) * nc128 >= 2 * cus)
+            return launch<128, 128, 256, true, 1>(ka, M, st);
+    }
     const int64_t p256 = mde_cdiv(M, 256), t256 = p256 * nc256;
     auto rounds = [](int64_t tiles, int64_t slots) { return (tiles + slots - 1) / slots; };
     const double c128 = (double)rounds((int64_t)mde_cdiv(M, 128) * nc128, 2 * cus) * 32768.0;
@@ -906,6 +936,8 @@ int pick_and_launch(KArgs& ka, int64_t M, hipStream_t st) {
     if (forced == 5) return pp ? launch<192, 256, 512, true, 2, true>(ka, M, st) : launch<192, 256, 512, true, 2>(ka, M, st);
     if (forced == 6) return launch<128, 64, 256, true, 2>(ka, M, st);
     if (forced == 7) return launch<256, 256, 256, true, 2>(ka, M, st);   // 4 waves x (128 px x 128 ch), one workgroup per CU
+    if (forced == 8) return launch<128, 128, 256, true, 1>(ka, M, st);   // single staging buffer: four workgroups per CU
+    if (forced == 9) return launch<128, 256, 512, true, 1>(ka, M, st);   // single staging buffer, 256 columns: two per CU
     return reg ? launch<128, 128, 256, false, 2>(ka, M, st) : launch<128, 128, 256, true, 2>(ka, M, st);
 }
 

@@ -46,8 +46,10 @@ def _assert_close(got, ref, what, tol=2.0 ** -8):
     (1, 13, 17, 64, 192, 3, 2, 1),     # stride 2, odd sizes, ragged column tile
     (2, 9, 11, 192, 320, 1, 2, 0),     # 1x1 stride 2 (downsample)
     (1, 10, 10, 64, 72, 5, 1, 2),      # 25 taps, columns not a multiple of the tile
-    (2, 160, 241, 64, 256, 1, 1, 0),   # 302 tiles of 256x256 > 256 CUs: full rounds + 128x128 tail launch
-    (2, 160, 121, 64, 256, 1, 1, 0),   # 152 tiles of 256x256 (59% fill): the cost model takes 192x256 (202 tiles, ragged)
+    (2, 160, 241, 64, 256, 1, 1, 0),   # short K (1 step), 1206 tiles of 128x128: the single-buffer tile, four workgroups per CU
+    (2, 160, 241, 200, 136, 1, 1, 0),  # the same with a K tail (4 steps, the last one 8 channels) and a ragged column tile
+    (2, 160, 241, 64, 256, 3, 1, 1),   # 302 tiles of 256x256 > 256 CUs: full rounds + 128x128 tail launch
+    (2, 160, 121, 64, 256, 3, 1, 1),   # 152 tiles of 256x256 (59% fill): the cost model takes 192x256 (202 tiles, ragged)
 ])
 def test_conv_forward(N, H, Wd, Cin, Cout, k, s, p):
     from mono_depth_estimation_amd import ops
@@ -76,7 +78,8 @@ def test_conv_forward(N, H, Wd, Cin, Cout, k, s, p):
     (1, 13, 17, 128, 64, 3, 2, 1),     # odd input size
     (2, 10, 12, 64, 128, 1, 2, 0),     # 1x1 stride 2: three empty phases -> zero fill
     (2, 8, 8, 192, 64, 1, 1, 0),
-    (2, 160, 241, 256, 64, 1, 1, 0),   # split launch (256x256 rounds + 128x128 tail), also with accumulate
+    (2, 160, 241, 256, 64, 1, 1, 0),   # short K: the single-buffer tile, also with accumulate
+    (2, 160, 241, 256, 64, 3, 1, 1),   # split launch (256x256 rounds + 128x128 tail), also with accumulate
 ])
 def test_conv_dgrad(N, H, Wd, Cin, Cout, k, s, p):
     from mono_depth_estimation_amd import ops
