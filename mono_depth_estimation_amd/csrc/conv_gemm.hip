@@ -856,7 +856,7 @@ int pick_and_launch(KArgs& ka, int64_t M, hipStream_t st) {
         const char* ppe = getenv("MDE_CONV_PP");
         gpp = !ppe ? 2 : (strcmp(ppe, "0") != 0);
         const char* e = getenv("MDE_CONV_TILE");
-        forced = !e ? 0 : !strcmp(e, "256x256") ? 1 : !strcmp(e, "128x128") ? 3 : !strcmp(e, "192x256") ? 5 : !strcmp(e, "128x64") ? 6 : !strcmp(e, "256x256w4") ? 7 : !strcmp(e, "128x128s") ? 8 : !strcmp(e, "128x256s") ? 9 : 0;
+        forced = !e ? 0 : !strcmp(e, "256x256") ? 1 : !strcmp(e, "128x128") ? 3 : !strcmp(e, "192x256") ? 5 : !strcmp(e, "128x64") ? 6 : !strcmp(e, "256x256w4") ? 7 : !strcmp(e, "128x128s") ? 8 : !strcmp(e, "128x256s") ? 9 : !strcmp(e, "128x64s") ? 10 : 0;
         const char* q = getenv("MDE_CONV_PATH");
         reg = q && !strcmp(q, "reg");
     }
@@ -866,7 +866,15 @@ int pick_and_launch(KArgs& ka, int64_t M, hipStream_t st) {
         // 2-deep ring = 48 KB LDS = three workgroups per CU.  Measured alternatives, all slower on M = 2 457 600 / 614 400,
         // 64->64 3x3: 256x64 with 8 waves (423 / 423 TFLOP/s), 256x64 with 4 waves (365 / 343), 3-deep ring at two
         // workgroups per CU (443 / 456) against 487 / 576: occupancy beats prefetch depth and bigger tiles here.
-        return reg ? launch<128, 64, 256, false, 2>(ka, M, st) : launch<128, 64, 256, true, 2>(ka, M, st);
+        // and a single 24 KB buffer at FIVE workgroups per CU beats the 2-deep ring at three on every 64-column shape of the
+        // step (in-network: 9 taps at 2 457 600 pixels 348 -> 301 us, at 614 400 90 -> 77; 1x1 256 -> 64: 81 -> 75)
+        static int ring64 = -1;
+        if (ring64 < 0) {
+            const char* e = getenv("MDE_CONV_RING64");
+            ring64 = e && !strcmp(e, "1");
+        }
+        if (reg) return launch<128, 64, 256, false, 2>(ka, M, st);
+        return (ring64 || forced == 6) ? launch<128, 64, 256, true, 2>(ka, M, st) : launch<128, 64, 256, true, 1>(ka, M, st);
     }
     static int cus = 0;
     if (!cus) {
@@ -900,10 +908,23 @@ int pick_and_launch(KArgs& ka, int64_t M, hipStream_t st) {
     }
     const int64_t p256 = mde_cdiv(M, 256), t256 = p256 * nc256;
     auto rounds = [](int64_t tiles, int64_t slots) { return (tiles + slots - 1) / slots; };
-    const double c128 = (double)rounds((int64_t)mde_cdiv(M, 128) * nc128, 2 * cus) * 32768.0;
+    const int64_t t128 = (int64_t)mde_cdiv(M, 128) * nc128;
+    const double c128 = (double)rounds(t128, 2 * cus) * 32768.0;
     double best = c128;
-    int pick = 0;                                               // 0: 128x128, 1: 256x256, 2: 192x256, 3: 256x256 + 128x128 tail
+    int pick = 0;                                               // 0: 128x128, 1: 256x256, 2: 192x256, 3: 256x256 + 128x128 tail, 4: 128x128 single buffer
     int32_t split = 0;
+    if (!reg) {
+        // the single-buffer 128x128 tile, four workgroups per CU: a partial last round costs it little (the workgroups left
+        // share the CU among fewer), so its rounds count fractionally, with a floor of one (fitted in-network)
+        static double rs = 0.0;
+        if (rs == 0.0) {
+            rs = 1.05;
+            if (const char* e = getenv("MDE_CONV_RATE_S")) rs = atof(e);
+        }
+        const double fr = (double)t128 / (double)(4 * cus);
+        const double cs = (fr > 1.0 ? fr : 1.0) * 65536.0 / rs;
+        if (rs > 0.0 && cs < best) { best = cs; pick = 4; }
+    }
     if (n >= 256 && !reg) {
         const double c256 = (double)rounds(t256, cus) * 65536.0 / r256;
         const double c192 = (double)rounds((int64_t)mde_cdiv(M, 192) * nc256, cus) * 49152.0 / r192;
@@ -929,6 +950,7 @@ int pick_and_launch(KArgs& ka, int64_t M, hipStream_t st) {
         if (rc) return rc;
         return launch<128, 128, 256, true, 2>(k2, M, st);
     }
+    if (forced == 0 && pick == 4) return launch<128, 128, 256, true, 1>(ka, M, st);
     if (forced == 0 && pick == 2) return pp ? launch<192, 256, 512, true, 2, true>(ka, M, st) : launch<192, 256, 512, true, 2>(ka, M, st);
     if (forced == 1 || (forced == 0 && pick == 1))
         return reg ? launch<256, 256, 512, false, 2>(ka, M, st)
