@@ -70,8 +70,11 @@ __device__ __forceinline__ bf16x8_t read_frag_tr(const char* tile, int k0, int c
 // DMA: tiles are filled by LDS-DMA (buffer_load ... lds; one wave-instruction = 1 KiB = 4 rows x 256 B
 // or 8 rows x 128 B) instead of VGPR staging + ds_write; the destination is lane-linear, so the XOR
 // chunk swizzle of tile_off<> is applied to the SOURCE chunk each lane fetches.
-template <int BA, int BB, bool GA, bool DMA>
-__global__ __launch_bounds__(NT, 2) void conv_wgrad_tn(const KArgs a) {
+// NBUF = 1: ONE staging buffer (fetch -> wait -> MFMA per K-step), so twice as many workgroups fit a CU and overlap each
+// other's fetches and MFMAs (conv_gemm.hip's single-buffer tiles: occupancy beat the ring there on nearly every shape).
+template <int BA, int BB, bool GA, bool DMA, int NBUF = 2>
+__global__ __launch_bounds__(NT, NBUF == 1 ? 4 : 2) void conv_wgrad_tn(const KArgs a) {
+    static_assert(NBUF == 2 || (NBUF == 1 && DMA), "single-buffer form: LDS-DMA loop only");
     constexpr int FA = BA / 32, FB = BB / 32;      // 16-wide fragments per wave along rows / cols
     constexpr int AT_BYTES = BKP * BA * 2, BT_BYTES = BKP * BB * 2;
     constexpr int BUF_BYTES = AT_BYTES + BT_BYTES;
@@ -192,7 +195,7 @@ __global__ __launch_bounds__(NT, 2) void conv_wgrad_tn(const KArgs a) {
         // wave, one pixel per lane, two steps ahead, waves taking turns) into s_goff[step&1][64] =
         // byte offset of the pixel's channel 0, or an out-of-range offset.  Decoding per lane and per
         // DMA made this loop VALU-bound (~170 VALU per wave per K-step against 32 MFMAs).
-        uint32_t* s_goff = reinterpret_cast<uint32_t*>(smem + 2 * BUF_BYTES);
+        uint32_t* s_goff = reinterpret_cast<uint32_t*>(smem + NBUF * BUF_BYTES);
         auto decode_step = [&](int s) {
             const uint32_t o = gathered_off(kbeg + s * BKP + lane, 0);
             s_goff[(s & 1) * BKP + lane] = o;
@@ -220,6 +223,17 @@ __global__ __launch_bounds__(NT, 2) void conv_wgrad_tn(const KArgs a) {
         if (wv == 0) decode_step(0);
         if (wv == 1 && nsteps > 1) decode_step(1);
         __syncthreads();
+        if constexpr (NBUF == 1) {
+            for (int s = 0; s < nsteps; ++s) {
+                if (s) __builtin_amdgcn_s_barrier();        // everyone left step s-1: the buffer and offset slot (s+1)&1 are free
+                issue_dma(s, 0);
+                if (s >= 1 && s + 1 < nsteps && wv == (s & 3)) decode_step(s + 1);
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                compute(0);
+            }
+        } else {
         issue_dma(0, 0);
         for (int s = 0; s < nsteps; ++s) {
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -228,6 +242,7 @@ __global__ __launch_bounds__(NT, 2) void conv_wgrad_tn(const KArgs a) {
             if (s + 1 < nsteps) issue_dma(s + 1, (s + 1) & 1);
             if (s + 2 < nsteps && wv == (s & 3)) decode_step(s + 2);   // slot (s&1) was last read before this barrier
             compute(s & 1);
+        }
         }
     } else {
         issue_loads(0);
@@ -274,12 +289,24 @@ __global__ __launch_bounds__(NT, 2) void conv_wgrad_tn(const KArgs a) {
 template <int BA, int BB, bool GA>
 int launch(const KArgs& ka, int nblk, hipStream_t st) {
     constexpr size_t smem = 2 * (size_t)BKP * (BA + BB) * 2 + 2 * BKP * sizeof(uint32_t);
-    static int reg = -1;                  // MDE_WGRAD_PATH=reg: register-staged main loop (diagnostics)
+    constexpr size_t smem1 = (size_t)BKP * (BA + BB) * 2 + 2 * BKP * sizeof(uint32_t);
+    // MDE_WGRAD_PATH=reg: register-staged main loop (diagnostics); MDE_WGRAD_NBUF=1|2 forces the single-buffer / ring form.
+    // Default: the ring, except for grids of at least four workgroups per CU (the large-channel 9- and 25-tap layers whose
+    // fitted split-K is small): there the single-buffer form's doubled occupancy wins (in-network: 512x512 channels, 25 taps,
+    // 38 400 pixels 693 -> 544 us; 1024x1024, 25 taps, 9 600 pixels 745 -> 598 us), everywhere else it loses 10-20 %.
+    static int reg = -1, nbuf = 0, cus = 256;
     if (reg < 0) {
         const char* e = getenv("MDE_WGRAD_PATH");
         reg = e && !strcmp(e, "reg");
+        const char* nb = getenv("MDE_WGRAD_NBUF");
+        nbuf = !nb ? 0 : !strcmp(nb, "1") ? 1 : 2;
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
     }
+    const bool single = nbuf == 1 || (nbuf == 0 && nblk >= 4 * cus && BA * BB >= 128 * 128);
     if (reg) conv_wgrad_tn<BA, BB, GA, false><<<dim3(nblk), dim3(NT), smem, st>>>(ka);
+    else if (single) conv_wgrad_tn<BA, BB, GA, true, 1><<<dim3(nblk), dim3(NT), smem1, st>>>(ka);
     else conv_wgrad_tn<BA, BB, GA, true><<<dim3(nblk), dim3(NT), smem, st>>>(ka);
     MDE_LAUNCH_CHECK("conv_wgrad_tn");
     return MDE_OK;
