@@ -145,14 +145,21 @@ def main():
         if args.batch % world:
             sys.exit("bench.py --scaling strong: global batch %d is not divisible by %d GPUs" % (args.batch, world))
         args.batch //= world                                  # from here on: images per GPU
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # MDE_BENCH_DEVICE / MDE_DIST_BACKEND: rehearsal of the N > 1 path on a one-GPU box (every rank on device 0, gloo instead of
+    # RCCL, which refuses two ranks on one device): tests/test_bench_multirank_gpu.py.  The driver's runs set neither.
+    dev_index = int(os.environ.get("MDE_BENCH_DEVICE", local_rank))
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     import torch.distributed as dist
     use_dist = world > 1 or "RANK" in os.environ          # launched by torch.distributed.run (also with 1 rank)
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        backend = os.environ.get("MDE_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from mono_depth_estimation_amd import dp, ops
     from mono_depth_estimation_amd.network import FCRN
@@ -215,6 +222,15 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt)
     final_loss = float(loss)
+    # replicas must hold bit-identical weights after the timed steps (every rank applies the same reduced gradient): the
+    # spread of a checksum of the flat parameter buffer over the ranks, 0.0 when the exchange works
+    drift = None
+    if use_dist:
+        cs = torch.stack([store.P.double().sum(), store.P.double().square().sum()])
+        hi, lo = cs.clone(), cs.clone()
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        drift = float((hi - lo).abs().max())
     log("timed region done: %.1f ms/step" % (1e3 * dt / args.steps))
 
     if rank == 0:
@@ -227,7 +243,7 @@ def main():
                                    "depth, train step = fwd + SILog(0.85) + bwd + Adam(lr, 10*lr)%s" % (
                                        args.batch, " + flat-gradient all-reduce (RCCL, %s buckets)" % args.grad_dtype if world > 1 else ""),
                        "global_batch": args.batch * world, "per_gpu_batch": args.batch, "parallelism": "dp%d" % world,
-                       "final_loss": round(final_loss, 5)},
+                       "final_loss": round(final_loss, 5), **({"replica_drift": drift} if drift is not None else {})},
             "step_mfma_frac": round(ips * ALGO_GFLOP_PER_IMAGE / 1e3 / (world * PEAK_BF16_TFLOPS), 4),
         }
         if timer is not None and args.per_shape:

@@ -56,6 +56,8 @@ class FlatGradReducer:
         # MDE_DP_FORCE=1: run the collectives even with one rank (rehearses the RCCL / stream / event
         # path on a single GPU; an all-reduce over one rank is the identity)
         self.active = self.world > 1 or (dist.is_initialized() and os.environ.get("MDE_DP_FORCE") == "1")
+        if os.environ.get("MDE_DP_DISABLE") == "1":     # diagnostics: no exchange at all (the multi-rank test's negative control)
+            self.active = False
         self.buckets = make_buckets(flat.numel(), boundaries, target_bytes, flat.element_size())
         self.stream = torch.cuda.Stream() if flat.is_cuda else None
         self.wire = {}                     # bucket start -> (wire buffer, shard) when the wire format differs / rs_ag

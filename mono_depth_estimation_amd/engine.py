@@ -673,8 +673,8 @@ class EngineCore:
     def _ksplit(self, pixels, rows, cols, ntaps):
         ba, bb = (128 if rows % 128 == 0 else 64), (128 if cols % 128 == 0 else 64)
         lds = 2 * 64 * (ba + bb) * 2 + 512           # conv_wgrad_tn's staging ring + offset table
-        return ops.choose_ksplit(pixels, -(-rows // ba), -(-cols // bb), ntaps, self.cus, wg_per_cu=min(8, (160 * 1024) // lds),
-                                 tile_elems=ba * bb)
+        wgpc = int(os.environ.get("MDE_WGRAD_WGPC", "0")) or min(8, (160 * 1024) // lds)      # (diagnostics: occupancy the split-K model assumes)
+        return ops.choose_ksplit(pixels, -(-rows // ba), -(-cols // bb), ntaps, self.cus, wg_per_cu=wgpc, tile_elems=ba * bb)
 
 
     def wgrad(self, desc, a, b, dw):
