@@ -862,6 +862,7 @@ int pick_and_launch(KArgs& ka, int64_t M, hipStream_t st) {
     }
     const int n = ka.d.ncols;
     const bool pp = gpp == 1 || (gpp == 2 && ka.d.ntaps * ((ka.d.C + BK - 1) / BK) >= 18);
+    if (forced == 10 && !ka.d.grouped) return launch<128, 64, 256, true, 1>(ka, M, st);      // diagnostics: 64-column single-buffer tile everywhere
     if (n <= 64 || ka.d.grouped) {
         // 2-deep ring = 48 KB LDS = three workgroups per CU.  Measured alternatives, all slower on M = 2 457 600 / 614 400,
         // 64->64 3x3: 256x64 with 8 waves (423 / 423 TFLOP/s), 256x64 with 4 waves (365 / 343), 3-deep ring at two
