@@ -345,6 +345,25 @@ int mde_combine3_fwd(const float* m0, const float* m1, const float* m2, const fl
 int mde_combine3_bwd(const float* dout, const float* m0, const float* m1, const float* m2, const float* s0, const float* s1,
                      const float* s2, float factor, int N, int64_t HW, float* dm0, float* dm1, float* dm2, float* ds, void* stream);
 
+/* ---- Input pipeline (modules/base_module.py:234-284), Pillow's 8-bit arithmetic bit for bit; images are uint8 H x W x C ---- */
+/* functional.to_pil_image of a float tensor C x H x W: (v / divisor) * 255 truncated to uint8 (divisor: the `depth / s` in front,
+ * 1 for the image). */
+int mde_aug_to_u8(const float* src, int C, int H, int W, float divisor, uint8_t* dst, void* stream);
+/* PIL Image.resize(BILINEAR) of an 8-bit image (Resample.c): the horizontal pass over source rows [y0, y0 + rows) into tmp
+ * (only the rows the vertical pass reads), then the vertical pass; each rounds to uint8.  bounds: int32 [out][2] = (first
+ * input index, count), k: int32 [out][ksize] 22-bit fixed-point coefficients (the caller computes them in double as Pillow's
+ * precompute_coeffs does); an axis whose size does not change passes NULL tables. */
+int mde_aug_resample_u8(const uint8_t* src, int H, int W, int C, const int32_t* hbounds, const int32_t* hk, int hksize, int OW,
+                        const int32_t* vbounds, const int32_t* vk, int vksize, int OH, int y0, int rows, uint8_t* tmp, uint8_t* dst,
+                        void* stream);
+/* PIL Image.transform(AFFINE, NEAREST) as Image.rotate uses it (Geometry.c affine_fixed): coef = the six 16.16 fixed-point
+ * coefficients (a0, a1, a2 + half-pixel terms, a3, a4, a5 + ...); pixels that map outside the image are 0. */
+int mde_aug_affine_nearest_u8(const uint8_t* src, int H, int W, int C, const int32_t* coef, uint8_t* dst, void* stream);
+/* CenterCrop -> hflip -> np.array(img, float32) / 255 -> to_tensor: uint8 H x W x C -> float32 C x oh x ow; lut: the 256
+ * quotients (computed by the host exactly as numpy does). */
+int mde_aug_crop_flip_to_float(const uint8_t* src, int H, int W, int C, int top, int left, int oh, int ow, int flip, const float* lut,
+                               float* dst, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * Losses and metrics (criteria.py / metrics.py), fp32 in, fp32/fp64 accumulation.
  * ---------------------------------------------------------------------------------- */

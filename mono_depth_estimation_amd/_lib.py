@@ -108,6 +108,10 @@ SIGNATURES = {
     "mde_weighted_pool_bwd": (_I, [_P, _P, _P, _I, _P, _P, _I, _I, _P, _P, _I, _L, _I, _P]),
     "mde_combine3_fwd": (_I, [_P, _P, _P, _P, _P, _P, _F, _I, _L, _P, _P]),
     "mde_combine3_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _F, _I, _L, _P, _P, _P, _P, _P]),
+    "mde_aug_to_u8": (_I, [_P, _I, _I, _I, _F, _P, _P]),
+    "mde_aug_resample_u8": (_I, [_P, _I, _I, _I, _P, _P, _I, _I, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
+    "mde_aug_affine_nearest_u8": (_I, [_P, _I, _I, _I, _P, _P, _P]),
+    "mde_aug_crop_flip_to_float": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
     "mde_ord_loss_ws_bytes": (_Z, []),
     "mde_ord_loss_fwd": (_I, [_P, _P, _I, _I, _L, _P, _P, _P]),
     "mde_ord_loss_bwd": (_I, [_P, _P, _I, _I, _L, _P, _P, _P]),

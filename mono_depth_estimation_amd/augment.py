@@ -1,0 +1,183 @@
+"""The reference's input pipeline on the device: `train_preprocess` / `val_preprocess` of
+modules/base_module.py:234-284 — ToPILImage, Resize, ±5° rotation, Resize, CenterCrop, horizontal flip, to_tensor — for a sample
+that is already in HBM, with Pillow's 8-bit arithmetic reproduced bit for bit by the kernels of csrc/augment.hip (PIL's
+BILINEAR resize = two separable passes of 22-bit fixed-point triangle filters with antialiasing, each rounded to uint8;
+PIL's rotate(NEAREST) = a 16.16 fixed-point affine walk).  The reference runs this per sample on CPU workers; at ~1 000
+images/s per GPU eight workers no longer keep up.
+
+The random draws stay on the host and in the reference's order (`draw_train_params`: np.random.uniform three times), so a seeded
+run augments every sample exactly as the reference does.  No CPU fallback: tensors must live on the GPU.
+
+    rgb, depth = augment.train_preprocess(rgb, depth, resize_to=250, output_size=(240, 320))        # FCRNModule's sizes
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+from .ops import _p, _stream, check
+
+PRECISION_BITS = 32 - 8 - 2
+_coeff_cache, _lut_cache = {}, {}
+
+
+def _coeffs(in_size, out_size, device):
+    """Pillow's precompute_coeffs + normalize_coeffs_8bpc (src/libImaging/Resample.c) for the bilinear filter, in double on the
+    host, cached per (in, out, device) -> (bounds int32 [out][2], kk int32 [out][ksize], ksize, first row, row count)."""
+    key = (in_size, out_size, str(device))
+    hit = _coeff_cache.get(key)
+    if hit is not None:
+        return hit
+    scale = float(in_size) / out_size
+    filterscale = max(scale, 1.0)
+    support = 1.0 * filterscale
+    ksize = int(math.ceil(support)) * 2 + 1
+    bounds = np.zeros((out_size, 2), dtype=np.int32)
+    kk = np.zeros((out_size, ksize), dtype=np.int32)
+    ss = 1.0 / filterscale
+    for xx in range(out_size):
+        center = (xx + 0.5) * scale
+        xmin = max(int(center - support + 0.5), 0)
+        xmax = min(int(center + support + 0.5), in_size) - xmin
+        k = np.zeros(ksize, dtype=np.float64)
+        ww = 0.0
+        for x in range(xmax):
+            v = abs((x + xmin - center + 0.5) * ss)
+            w = 1.0 - v if v < 1.0 else 0.0
+            k[x] = w
+            ww += w
+        if ww != 0.0:
+            k[:xmax] /= ww
+        bounds[xx] = (xmin, xmax)
+        for x in range(ksize):
+            kk[xx, x] = int(-0.5 + k[x] * (1 << PRECISION_BITS)) if k[x] < 0 else int(0.5 + k[x] * (1 << PRECISION_BITS))
+    out = (torch.from_numpy(bounds).to(device), torch.from_numpy(kk).to(device), ksize, int(bounds[0, 0]), int(bounds[-1, 0] + bounds[-1, 1] - bounds[0, 0]))
+    _coeff_cache[key] = out
+    return out
+
+
+def _lut(device):
+    t = _lut_cache.get(str(device))
+    if t is None:
+        t = torch.from_numpy(np.arange(256, dtype=np.float32) / 255.0).to(device)       # np.array(img, float32) / 255.0, entry by entry
+        _lut_cache[str(device)] = t
+    return t
+
+
+def resized_size(w, h, size):
+    """torchvision functional.resize with an int: the shorter edge becomes `size`."""
+    short, long_ = (w, h) if w <= h else (h, w)
+    new_long = int(size * long_ / short)
+    return (size, new_long) if w <= h else (new_long, size)
+
+
+def to_u8(t, divisor=1.0):
+    """C x H x W float (or H x W x C uint8, returned as is) -> H x W x C uint8 as transforms.ToPILImage does."""
+    if t.dtype == torch.uint8:
+        return t.contiguous()
+    Cc, H, W = t.shape
+    out = torch.empty(H, W, Cc, dtype=torch.uint8, device=t.device)
+    check(_lib.load().mde_aug_to_u8(_p(t.contiguous().float()), Cc, H, W, float(np.float32(divisor)), _p(out), _stream()), "mde_aug_to_u8")
+    return out
+
+
+def resize_u8(img, out_w, out_h):
+    """PIL Image.resize((out_w, out_h), BILINEAR) of an H x W x C uint8 image."""
+    H, W, Cc = img.shape
+    if (W, H) == (out_w, out_h):
+        return img
+    hb = hk = vb = vk = None
+    hks = vks = 0
+    y0, rows = 0, H
+    if out_w != W:
+        hb, hk, hks, _, _ = _coeffs(W, out_w, img.device)
+    if out_h != H:
+        vb, vk, vks, y0v, rowsv = _coeffs(H, out_h, img.device)
+        if hb is not None:
+            y0, rows = y0v, rowsv
+    tmp = torch.empty(rows, out_w, Cc, dtype=torch.uint8, device=img.device) if (hb is not None and vb is not None) else None
+    out = torch.empty(out_h, out_w, Cc, dtype=torch.uint8, device=img.device)
+    check(_lib.load().mde_aug_resample_u8(_p(img), H, W, Cc, _p(hb), _p(hk), hks, out_w, _p(vb), _p(vk), vks, out_h, y0, rows, _p(tmp), _p(out),
+                                          _stream()), "mde_aug_resample_u8")
+    return out
+
+
+def rotate_u8(img, angle):
+    """PIL Image.rotate(angle, NEAREST, expand=False) of an H x W x C uint8 image."""
+    H, W, Cc = img.shape
+    ang = angle % 360.0
+    if ang == 0:                                         # Image.rotate's shortcuts
+        return img
+    if ang == 180:
+        return img.flip(0, 1).contiguous()
+    if ang in (90, 270) and W == H:
+        return torch.rot90(img, 1 if ang == 90 else 3, (0, 1)).contiguous()
+    cx, cy = W / 2.0, H / 2.0
+    rad = -math.radians(ang)
+    m = [round(math.cos(rad), 15), round(math.sin(rad), 15), 0.0, round(-math.sin(rad), 15), round(math.cos(rad), 15), 0.0]
+    m[2] = m[0] * -cx + m[1] * -cy + m[2] + cx
+    m[5] = m[3] * -cx + m[4] * -cy + m[5] + cy
+    fix = lambda v: int(math.floor(v * 65536.0 + 0.5))
+    coef = (C.c_int32 * 6)(fix(m[0]), fix(m[1]), fix(m[2] + m[0] * 0.5 + m[1] * 0.5), fix(m[3]), fix(m[4]), fix(m[5] + m[3] * 0.5 + m[4] * 0.5))
+    out = torch.empty_like(img)
+    check(_lib.load().mde_aug_affine_nearest_u8(_p(img), H, W, Cc, C.cast(coef, C.c_void_p), _p(out), _stream()), "mde_aug_affine_nearest_u8")
+    return out
+
+
+def crop_flip_to_float(img, output_size, flip):
+    """CenterCrop(output_size) -> hflip (if flip) -> np.array(img, float32) / 255.0 -> to_tensor: C x oh x ow float32."""
+    H, W, Cc = img.shape
+    oh, ow = output_size
+    if oh > H or ow > W:
+        raise ValueError("center crop %s of a %dx%d image (torchvision would pad; the reference's sizes never need it)" % (output_size, H, W))
+    top, left = int(round((H - oh) / 2.0)), int(round((W - ow) / 2.0))
+    out = torch.empty(Cc, oh, ow, device=img.device)
+    check(_lib.load().mde_aug_crop_flip_to_float(_p(img), H, W, Cc, top, left, oh, ow, int(bool(flip)), _p(_lut(img.device)), _p(out), _stream()),
+          "mde_aug_crop_flip_to_float")
+    return out
+
+
+def draw_train_params():
+    """The three draws of train_preprocess, in its order (base_module.py:235,247,259), from the global numpy RNG."""
+    s = np.random.uniform(1, 1.5)
+    angle = np.random.uniform(-5, 5)
+    flip = np.random.uniform(0, 1) > 0.5
+    return s, angle, flip
+
+
+def _need_gpu(t):
+    if not t.is_cuda:
+        raise RuntimeError("mono_depth_estimation_amd.augment runs on MI355X only (tensor on %s); no CPU fallback" % t.device)
+
+
+def _stack_depth(depth, divisor):
+    layers = [d.reshape(1, d.shape[-2], d.shape[-1]) for d in depth]
+    return to_u8(torch.cat(layers, 0) if len(layers) > 1 else layers[0], divisor)
+
+
+def train_preprocess(rgb, depth, resize_to, output_size, params=None):
+    """base_module.py:234-265 for one sample on the device.  rgb: 3 x H x W float in [0, 1] (or H x W x 3 uint8); depth: a sequence
+    of 1 x H x W float layers.  -> (3 x oh x ow, D x oh x ow) float32.  params = (s, angle, flip) or None to draw them."""
+    _need_gpu(rgb)
+    s, angle, flip = params if params is not None else draw_train_params()
+    outs = []
+    for img in (to_u8(rgb), _stack_depth(list(depth), s)):        # the D depth layers travel as one D-channel image
+        H, W, _ = img.shape
+        w1, h1 = resized_size(W, H, resize_to)
+        img = rotate_u8(resize_u8(img, w1, h1), angle)
+        w2, h2 = resized_size(w1, h1, int(resize_to * s))
+        outs.append(crop_flip_to_float(resize_u8(img, w2, h2), output_size, flip))
+    return outs[0], outs[1]
+
+
+def val_preprocess(rgb, depth, resize_to, output_size):
+    """base_module.py:267-281 for one sample on the device."""
+    _need_gpu(rgb)
+    outs = []
+    for img in (to_u8(rgb), _stack_depth(list(depth), 1.0)):
+        H, W, _ = img.shape
+        w1, h1 = resized_size(W, H, resize_to)
+        outs.append(crop_flip_to_float(resize_u8(img, w1, h1), output_size, False))
+    return outs[0], outs[1]

@@ -710,6 +710,25 @@ def gen_mynet(criteria):
         len(out["keys"]), sum(p.numel() for p in ref.parameters()), out["eval_out"].min(), out["eval_out"].max(), float(loss), len(out["no_grad"])))
 
 
+def gen_augment():
+    """N2: the input pipeline of modules/base_module.py:234-284 as oracle/augment.py composes it over PIL ITSELF (torchvision's
+    wrappers are absent and restated there; Pillow 12.2 does every image operation): a 120 x 160 sample with two depth layers,
+    four seeded train draws and the val path, stored as uint8 (the outputs are k / 255)."""
+    from oracle import augment as OA
+    rng = np.random.RandomState(11)
+    rgb = torch.from_numpy(rng.rand(3, 120, 160).astype(np.float32))
+    depth = [torch.from_numpy(rng.rand(1, 120, 160).astype(np.float32)) for _ in range(2)]
+    out = {"rgb": _np(rgb), "depth": _np(torch.cat(depth, 0))}
+    for seed in range(4):
+        np.random.seed(seed)
+        r, d = OA.train_preprocess(rgb, depth, 64, (56, 72))
+        out["train%d_rgb" % seed], out["train%d_depth" % seed] = np.round(_np(r) * 255).astype(np.uint8), np.round(_np(d) * 255).astype(np.uint8)
+    r, d = OA.val_preprocess(rgb, depth, 64, (56, 72))
+    out["val_rgb"], out["val_depth"] = np.round(_np(r) * 255).astype(np.uint8), np.round(_np(d) * 255).astype(np.uint8)
+    np.savez_compressed(os.path.join(HERE, "augment.npz"), **out)
+    print("augment.npz: PIL", __import__("PIL").__version__)
+
+
 def gen_vnl_keymap():
     """N3: the reference's own convert_state_dict_resnext (VNL.py:44-67) on the index-path keys of the shipped
     ResNeXt-ImageNet files, enumerated from the documented nn.Sequential structure -> {source key: body key} pairs."""
@@ -764,6 +783,8 @@ def main():
         gen_dorn_net(criteria)
     if want("mynet"):
         gen_mynet(criteria)
+    if want("augment"):
+        gen_augment()
     if want("vnl_keymap"):
         gen_vnl_keymap()
 
