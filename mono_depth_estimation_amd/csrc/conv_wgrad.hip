@@ -34,6 +34,7 @@ struct KArgs {
     int32_t gsize;        // grouped convolution: channels per group (0 = dense)
     MdeDetDev det;        // deterministic mode: partial tiles are added as integers into the gradient's int64 shadow
     uint32_t inv_gw, inv_ghw;
+    int32_t skip_store;   // diagnostics (MDE_WGRAD_NOSTORE=1): the epilogue's atomics are skipped (timing only: results are wrong)
 };
 
 // byte offset of 16-byte chunk `ch` of row `row` in a [64][CH] bf16 tile, CH = 128 or 64
@@ -258,6 +259,15 @@ __global__ __launch_bounds__(NT, NBUF == 1 ? 4 : 2) void conv_wgrad_tn(const KAr
     }
 
     // epilogue: fp32 atomic accumulation into dw[row][otap][col]
+    if (a.skip_store) {
+        float keep = 0.f;
+#pragma unroll
+        for (int i = 0; i < FA; ++i)
+#pragma unroll
+            for (int j = 0; j < FB; ++j) keep += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+        if (keep == 123456.789f) a.dw[0] = keep;      // (keeps the accumulators alive)
+        return;
+    }
     const int otap = d.otap[tap];
     const size_t rstride = (size_t)d.otaps_total * a.Ccols;
 #pragma unroll
@@ -356,6 +366,14 @@ extern "C" int mde_conv_wgrad(const mde_wgrad_desc* d, const void* direct, const
     ka.Ccols = ga ? d->Cd : d->Cg;
     ka.gsize = d->group_size;
     ka.det = mde_det_dev();
+    {
+        static int ns = -1;
+        if (ns < 0) {
+            const char* e = getenv("MDE_WGRAD_NOSTORE");
+            ns = e && !strcmp(e, "1");
+        }
+        ka.skip_store = ns;
+    }
     if (ka.det.scratch) {
         const int64_t nw = (int64_t)ka.Crows * d->otaps_total * (d->group_size ? d->group_size : ka.Ccols);
         MDE_REQUIRE(dw >= g_mde_det.gbase && dw + nw <= g_mde_det.gbase + g_mde_det.n,
