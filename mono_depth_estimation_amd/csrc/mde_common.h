@@ -99,19 +99,32 @@ __device__ __forceinline__ void mde_stat_add(float* part, int C, uint32_t wg, in
     if (!det) atomicAdd(part + ((size_t)(wg % MDE_STAT_SLOTS) * 2 + which) * C + c, v);
     else mde_det_add2(reinterpret_cast<long long*>(part) + (((size_t)(wg % MDE_DET_SLOTS) * 2 + which) * C + c) * 2, v);
 }
-// sum over the slots of entry (which, c), leaving it zeroed
+// sum over the slots of entry (which, c), leaving it zeroed.  All loads are issued before the first store: with the zeroing
+// store inside the load loop the compiler must keep load k+1 behind store k (same array), and the 32 L2 round trips ran back
+// to back — 8 us for a finalize kernel that does nothing else, 128 of them per step.
 __device__ __forceinline__ double mde_stat_take(float* part, int C, int which, int c, int det) {
     double s = 0.0;
     if (!det) {
-        for (int k = 0; k < MDE_STAT_SLOTS; ++k) {
-            float* p = part + ((size_t)k * 2 + which) * C + c;
-            s += (double)*p;
-            *p = 0.f;
-        }
+        float v[MDE_STAT_SLOTS];
+#pragma unroll
+        for (int k = 0; k < MDE_STAT_SLOTS; ++k) v[k] = part[((size_t)k * 2 + which) * C + c];
+#pragma unroll
+        for (int k = 0; k < MDE_STAT_SLOTS; ++k) s += (double)v[k];
+#pragma unroll
+        for (int k = 0; k < MDE_STAT_SLOTS; ++k) part[((size_t)k * 2 + which) * C + c] = 0.f;
     } else {
+        long long v[MDE_DET_SLOTS][2];
+#pragma unroll
+        for (int k = 0; k < MDE_DET_SLOTS; ++k) {
+            const long long* p = reinterpret_cast<const long long*>(part) + (((size_t)k * 2 + which) * C + c) * 2;
+            v[k][0] = p[0];
+            v[k][1] = p[1];
+        }
+#pragma unroll
+        for (int k = 0; k < MDE_DET_SLOTS; ++k) s += mde_det_value(v[k]);
+#pragma unroll
         for (int k = 0; k < MDE_DET_SLOTS; ++k) {
             long long* p = reinterpret_cast<long long*>(part) + (((size_t)k * 2 + which) * C + c) * 2;
-            s += mde_det_value(p);
             p[0] = 0;
             p[1] = 0;
         }
