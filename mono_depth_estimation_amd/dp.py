@@ -15,10 +15,13 @@ import torch
 import torch.distributed as dist
 
 
-def make_buckets(total, boundaries, target_bytes, elem_bytes=4):
+def make_buckets(total, boundaries, target_bytes, elem_bytes=4, head_bytes=None):
     """Cut [0, total) into contiguous buckets, walking from the TAIL (backward order), closing a
     bucket at the first layer boundary after it reached target_bytes.  `boundaries`: sorted
-    element offsets at which layers start.  Returns [(start, end)] in launch (tail-first) order."""
+    element offsets at which layers start.  Returns [(start, end)] in launch (tail-first) order.
+    The LAST bucket (the head of the buffer: the first layers, whose gradients backward finishes last) cannot overlap
+    with anything — its exchange is exposed in full — so a small piece of at most head_bytes (default target / 8) is cut
+    off its front at a layer boundary: the bulk of it goes out while the first layers are still in backward."""
     cuts = sorted(set(b for b in boundaries if 0 < b < total))
     buckets, end = [], total
     want = max(1, target_bytes // elem_bytes)
@@ -27,6 +30,11 @@ def make_buckets(total, boundaries, target_bytes, elem_bytes=4):
             buckets.append((b, end))
             end = b
     if end > 0:
+        head = max(1, (head_bytes if head_bytes is not None else target_bytes // 8) // elem_bytes)
+        inner = [b for b in cuts if b < end and b <= head]
+        if inner and end > 2 * head:
+            buckets.append((inner[-1], end))
+            end = inner[-1]
         buckets.append((0, end))
     return buckets
 
