@@ -207,6 +207,10 @@ def main():
     # Per-launch HIP events (the roofline leg) are recorded during ONE step of the timed region, the
     # last one: an event pair around every GEMM launch serialises neighbouring kernels and costs
     # ~1.3 ms per instrumented step (measured: 34.4 vs 33.0 ms/step with every step instrumented).
+    # In that step the weight-gradient GEMMs also stay on the main stream (engine.EngineCore.wgrad), so
+    # every duration describes ONE kernel; in the other steps they overlap the BatchNorm chain from a
+    # second stream (the rocprofv3 summary that must agree with these events is taken with
+    # MDE_WGRAD_STREAM=0: profiles/).
     timer = None if args.no_launch_timing else ops.LaunchTimer()
     timed_launch_steps = 0 if timer is None else 1
     t0 = time.perf_counter()
@@ -266,6 +270,8 @@ def main():
                 "avg_launch_gflop": round(fl / max(n, 1) / 1e9, 3),
                 "share_of_step_time": round(sec / timed_launch_steps / (dt / args.steps), 4),
                 "timed_launch_steps": timed_launch_steps,
+                "timed_launch_mode": "one stream (each duration is one kernel alone); the other steps run the weight-gradient GEMMs "
+                                     "on a second stream" if eng.side is not None else "one stream",
             }
             if "conv_wgrad_tn" in summ:
                 n2, fl2, sec2 = summ["conv_wgrad_tn"]

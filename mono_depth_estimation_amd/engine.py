@@ -644,9 +644,12 @@ class EngineCore:
         self.P, self.G, self.B, self.Pb = store.P, store.G, store.B, store.Pb
         self.p_off, self.b_off, self.params = store.p_off, store.b_off, store.params
         self.cus = torch.cuda.get_device_properties(self.dev).multi_processor_count
-        # opt-in (MDE_WGRAD_STREAM=1): ~1 % faster, but per-kernel durations then include the overlap with
-        # the other stream, so the roofline leg of bench.py and the rocprofv3 summaries stop describing one kernel
-        self.side = torch.cuda.Stream(self.dev) if os.environ.get("MDE_WGRAD_STREAM", "0") == "1" else None
+        # The weight-gradient GEMMs run on a second stream beside the input-gradient / BatchNorm chain (MDE_WGRAD_STREAM=0: one
+        # stream).  With the round-1 kernels (64-128 KB of LDS per workgroup: nothing else fits beside them on a CU) this bought
+        # 1 %; with the single-buffer tiles (36 KB) the two streams' workgroups share the CUs and the HBM-bound BatchNorm passes
+        # overlap the MFMA-bound weight gradients: 999 -> 1 048 images/s.  Per-kernel durations then include the overlap, so
+        # while ops.TIMER is recording (bench.py's roofline leg: one instrumented step) everything runs on ONE stream.
+        self.side = torch.cuda.Stream(self.dev) if os.environ.get("MDE_WGRAD_STREAM", "1") == "1" else None
         self.side_busy = False
 
     def attach_grads(self):
@@ -680,8 +683,9 @@ class EngineCore:
     def wgrad(self, desc, a, b, dw):
         """Weight-gradient GEMM of one conv.  It only reads dY and the activation, so it can run beside the
         input-gradient GEMM of the same layer: on a second stream its workgroups fill the CUs that the other
-        kernel's partial last round leaves idle (opt-in: MDE_WGRAD_STREAM=1; measured 32.9 -> 32.6 ms/step)."""
-        if self.side is None:
+        kernel leaves idle and its MFMAs overlap the HBM-bound BatchNorm passes (MDE_WGRAD_STREAM=0 turns it off; a step that
+        is being timed per launch — ops.TIMER — stays on one stream so that each duration describes one kernel)."""
+        if self.side is None or ops.TIMER is not None:
             ops.conv_wgrad(desc, a, b, dw)
             return
         cur = torch.cuda.current_stream()
