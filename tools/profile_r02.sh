@@ -6,6 +6,11 @@ export TMPDIR=/tmp
 O=gpurun_out/prof_r02
 rm -rf $O; mkdir -p $O
 B="bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-launch-timing"
+# (a) the default command: weight-gradient GEMMs on a second stream, per-kernel durations include the overlap
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats2 -o p -- python3 bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-launch-timing > $O/stats2.log 2>&1
+# (b) everything on one stream: each duration is one kernel alone (what bench.py's instrumented step measures); the counter
+#     passes below use the same setting
+export MDE_WGRAD_STREAM=0
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o p -- python3 bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-launch-timing > $O/stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o p -- python3 $B > $O/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o p -- python3 $B > $O/write.log 2>&1
@@ -28,5 +33,6 @@ for d in ("pmc_sq1","pmc_sq2"):
             w.write(key+": "+"  ".join("%s %.4g"%(c,v) for c,v in sorted(tot[key].items()))+"\n")
     print(open(O+"/"+d+"_summary.txt").read())
 PY
-f=$(ls $O/stats/*/*kernel_stats.csv 2>/dev/null | head -1); [ -z "$f" ] && f=$(find $O/stats -name "*kernel_stats.csv" | head -1); cp "$f" $O/kernel_stats.csv; head -12 $O/kernel_stats.csv
+f=$(find $O/stats -name "*kernel_stats.csv" | head -1); cp "$f" $O/kernel_stats.csv; head -12 $O/kernel_stats.csv
+f=$(find $O/stats2 -name "*kernel_stats.csv" | head -1); cp "$f" $O/kernel_stats_two_streams.csv
 cat $O/hbm_traffic.json
