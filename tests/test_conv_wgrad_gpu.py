@@ -30,7 +30,7 @@ def _assert_close(got, ref, what, tol=1e-3):
     (2, 12, 20, 64, 128, 3, 1, 1, 1),
     (2, 12, 20, 64, 128, 3, 1, 1, 3),     # split-K with a ragged last slice
     (3, 9, 11, 128, 64, 1, 1, 0, 2),      # 64-row tile, pixel count not a multiple of 64
-    (1, 14, 18, 128, 192, 3, 2, 1, 2),    # stride 2; 192 rows -> 64-wide tiles
+    (1, 14, 18, 128, 192, 3, 2, 1, 2),    # stride 2; 192 rows -> one launch of 128-row tiles + one of 64-row tiles
     (2, 10, 12, 256, 128, 1, 2, 0, 1),    # 1x1 stride 2
     (1, 30, 40, 64, 64, 3, 1, 1, 4),
 ])
