@@ -18,6 +18,9 @@ constexpr int MAXC = 2048;
 // to back, and the layer-1-sized tensors (315 MB) exceed the 256 MB Infinity Cache, so the END of the tensor is what
 // is still cached when the consumer starts; the next consumer in turn finds this pass's last-written rows at the
 // front.  Measured in-network: 32.26 -> 32.16 ms/step.
+#ifndef MDE_BN_UNROLL
+#define MDE_BN_UNROLL 4          // rows in flight per thread in the apply passes (read + write streams: +3 % forward, +7 % backward)
+#endif
 #ifndef MDE_BN_SNAKE
 #define MDE_BN_SNAKE 1
 #endif
@@ -170,6 +173,7 @@ __global__ __launch_bounds__(NT) void bn_apply_k(const bf16_t* __restrict__ x, i
         ldf8(rscale + col * 8, rsc);
         ldf8(rshift + col * 8, rsh);
     }
+#pragma unroll MDE_BN_UNROLL
     for (int64_t row_ = rl < rpb ? (int64_t)blockIdx.x * rpb + rl : M; row_ < M; row_ += (int64_t)gridDim.x * rpb) {
         const int64_t row = MDE_BN_SNAKE ? M - 1 - row_ : row_;
         float v[8], q[8];
@@ -213,6 +217,7 @@ __global__ __launch_bounds__(NT) void bn_bwd_reduce_k(const bf16_t* __restrict__
     float s1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_blk;
     const int64_t r1 = min(M, r0 + rows_per_blk);
+    // (no unrolling here: four rows in flight measured 8-17 % SLOWER for this read-only pass)
     for (int64_t r_ = rl < rpb ? r0 + rl : r1; r_ < r1; r_ += rpb) {      // (threads past the last whole row group idle)
         const int64_t r = MDE_BN_SNAKE ? M - 1 - r_ : r_;
         float g[8], v[8], o[8];
@@ -252,7 +257,7 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_k(const bf16_t* __restrict__ 
                                                      const float* __restrict__ smean, const float* __restrict__ srstd,
                                                      const float* __restrict__ msc, const float* __restrict__ msh,
                                                      const uint8_t* __restrict__ bits, const float* __restrict__ coef,
-                                                     int64_t M, int C, bf16_t* dx, int ldxo, int accumulate, bf16_t* dres,
+                                                     int64_t M, int C, bf16_t* __restrict__ dx, int ldxo, int accumulate, bf16_t* __restrict__ dres,
                                                      int ldres) {
     const int cpr = C >> 3, rpb = NT / cpr, col = threadIdx.x % cpr, rl = threadIdx.x / cpr;
     float mu[8], rs[8], c0[8], c1[8], c2[8], ms[8], mh[8];
@@ -265,6 +270,7 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_k(const bf16_t* __restrict__ 
     ldf8(coef + col * 8, c0);
     ldf8(coef + C + col * 8, c1);
     ldf8(coef + 2 * C + col * 8, c2);
+#pragma unroll MDE_BN_UNROLL
     for (int64_t row_ = rl < rpb ? (int64_t)blockIdx.x * rpb + rl : M; row_ < M; row_ += (int64_t)gridDim.x * rpb) {
         const int64_t row = MDE_BN_SNAKE ? M - 1 - row_ : row_;
         float g[8], v[8], o[8], d[8];
@@ -381,6 +387,7 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply2_k(const bf16_t* __restrict__
     ldf8(coef_b + col * 8, b0);
     ldf8(coef_b + C + col * 8, b1);
     ldf8(coef_b + 2 * C + col * 8, b2);
+#pragma unroll MDE_BN_UNROLL
     for (int64_t row_ = rl < rpb ? (int64_t)blockIdx.x * rpb + rl : M; row_ < M; row_ += (int64_t)gridDim.x * rpb) {
         const int64_t row = MDE_BN_SNAKE ? M - 1 - row_ : row_;
         float g[8], va[8], vb[8], da[8], db[8];
