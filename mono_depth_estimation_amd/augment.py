@@ -126,13 +126,16 @@ def rotate_u8(img, angle):
     return out
 
 
-def crop_flip_to_float(img, output_size, flip):
-    """CenterCrop(output_size) -> hflip (if flip) -> np.array(img, float32) / 255.0 -> to_tensor: C x oh x ow float32."""
+def crop_flip_to_float(img, output_size, flip, top=None, left=None):
+    """CenterCrop(output_size) (or the crop at (top, left)) -> hflip (if flip) -> np.array(img, float32) / 255.0 -> to_tensor:
+    C x oh x ow float32."""
     H, W, Cc = img.shape
     oh, ow = output_size
     if oh > H or ow > W:
-        raise ValueError("center crop %s of a %dx%d image (torchvision would pad; the reference's sizes never need it)" % (output_size, H, W))
-    top, left = int(round((H - oh) / 2.0)), int(round((W - ow) / 2.0))
+        raise ValueError("crop %s of a %dx%d image (torchvision would pad a center crop / refuse a random one; the reference's sizes "
+                         "never need it)" % (output_size, H, W))
+    if top is None:
+        top, left = int(round((H - oh) / 2.0)), int(round((W - ow) / 2.0))
     out = torch.empty(Cc, oh, ow, device=img.device)
     check(_lib.load().mde_aug_crop_flip_to_float(_p(img), H, W, Cc, top, left, oh, ow, int(bool(flip)), _p(_lut(img.device)), _p(out), _stream()),
           "mde_aug_crop_flip_to_float")
@@ -181,3 +184,44 @@ def val_preprocess(rgb, depth, resize_to, output_size):
         w1, h1 = resized_size(W, H, resize_to)
         outs.append(crop_flip_to_float(resize_u8(img, w1, h1), output_size, False))
     return outs[0], outs[1]
+
+
+# ---------------------------------------------------------------------------------------------- modules/bts.py:154-217
+def bts_draw_train_params(w, h, output_size):
+    """The draws of BtsModule.train_preprocess in its order: RandomRotation.get_params (torch's global generator), np.random.choice
+    of the resize target, RandomCrop.get_params on the resized image (two torch.randint draws) and the flip (np.random.uniform)."""
+    cw = int(round(w * (1.0 - 0.05))) - int(round(w * 0.05))
+    ch = int(round(h * (1.0 - 0.05))) - int(round(h * 0.05))
+    angle = float(torch.empty(1).uniform_(-2.5, 2.5).item())
+    size = int(np.random.choice([512, 518, 550, 600, 650, 720]))
+    rw, rh = resized_size(cw, ch, size)
+    th, tw = output_size
+    if rh < th or rw < tw:
+        raise ValueError("Required crop size %s is larger than input image size %s" % ((th, tw), (rh, rw)))
+    if (rw, rh) == (tw, th):
+        i = j = 0
+    else:
+        i = int(torch.randint(0, rh - th + 1, size=(1,)).item())
+        j = int(torch.randint(0, rw - tw + 1, size=(1,)).item())
+    flip = np.random.uniform(0, 1) > 0.5
+    return angle, size, i, j, flip
+
+
+def bts_train_preprocess(rgb, depth, output_size, params=None):
+    """modules/bts.py:154-199 for one sample on the device: 5 % margin crop (PIL rounds the float box half-to-even), ±2.5° rotation,
+    random resize, random crop, flip, / 255.  params = (angle, size, top, left, flip) or None to draw them."""
+    _need_gpu(rgb)
+    imgs = [to_u8(rgb), _stack_depth(list(depth), 1.0)]
+    H, W, _ = imgs[0].shape
+    l, t, r, b = (int(round(v)) for v in (W * 0.05, H * 0.05, W * (1.0 - 0.05), H * (1.0 - 0.05)))      # Image.crop: map(int, map(round, box))
+    angle, size, i, j, flip = params if params is not None else bts_draw_train_params(W, H, output_size)
+    outs = []
+    for img in imgs:
+        img = rotate_u8(img[t:b, l:r].contiguous(), angle)
+        h1, w1, _ = img.shape
+        w2, h2 = resized_size(w1, h1, size)
+        outs.append(crop_flip_to_float(resize_u8(img, w2, h2), output_size, flip, top=i, left=j))
+    return outs[0], outs[1]
+
+
+bts_val_preprocess = val_preprocess          # modules/bts.py:202-217: the same operations as the base module's (Resize, CenterCrop, / 255)

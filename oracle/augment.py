@@ -112,6 +112,46 @@ def val_preprocess(rgb, depth, resize_to, output_size):
     return out[0], torch.cat(out[1:], dim=0)
 
 
+# ---------------------------------------------------------------------------------------------- modules/bts.py:154-217
+def bts_draw_train_params(w, h, output_size):
+    """The draws of BtsModule.train_preprocess in its order: transforms.RandomRotation.get_params([-2.5, 2.5]) (torch's global
+    generator: `torch.empty(1).uniform_(a, b).item()`), np.random.choice of the resize target, transforms.RandomCrop.get_params
+    on the RESIZED image (two torch.randint draws, none if the sizes already match) and the flip (np.random.uniform).
+    (w, h): the sample's size before the 5 % margin crop."""
+    cw = int(round(w * (1.0 - 0.05))) - int(round(w * 0.05))
+    ch = int(round(h * (1.0 - 0.05))) - int(round(h * 0.05))
+    angle = float(torch.empty(1).uniform_(-2.5, 2.5).item())
+    size = int(np.random.choice([512, 518, 550, 600, 650, 720]))
+    rw, rh = resized_size(cw, ch, size)
+    th, tw = output_size
+    if rh < th or rw < tw:
+        raise ValueError("Required crop size %s is larger than input image size %s" % ((th, tw), (rh, rw)))
+    if (rw, rh) == (tw, th):
+        i = j = 0
+    else:
+        i = int(torch.randint(0, rh - th + 1, size=(1,)).item())
+        j = int(torch.randint(0, rw - tw + 1, size=(1,)).item())
+    flip = np.random.uniform(0, 1) > 0.5
+    return angle, size, i, j, flip
+
+
+def bts_train_preprocess(rgb, depth, output_size, params=None):
+    """modules/bts.py:154-199: 5 % margin crop (PIL rounds the float box), rotation, random resize, random crop, flip, / 255."""
+    imgs = [to_pil(rgb)] + [to_pil(d) for d in depth]
+    w, h = imgs[0].size
+    box = (w * 0.05, h * 0.05, w * (1.0 - 0.05), h * (1.0 - 0.05))
+    angle, size, i, j, flip = params if params is not None else bts_draw_train_params(w, h, output_size)
+    imgs = [im.crop(box) for im in imgs]
+    imgs = [rotate(im, angle) for im in imgs]
+    imgs = [resize(im, size) for im in imgs]
+    th, tw = output_size
+    imgs = [im.crop((j, i, j + tw, i + th)) for im in imgs]
+    if flip:
+        imgs = [hflip(im) for im in imgs]
+    out = [to_tensor_div255(im) for im in imgs]
+    return out[0], torch.cat(out[1:], dim=0)
+
+
 # ---------------------------------------------------------------------------------------------- Pillow's arithmetic, restated
 def pil_coeffs(in_size, out_size):
     """precompute_coeffs + normalize_coeffs_8bpc for the bilinear ("triangle", support 1) filter over the whole axis.
