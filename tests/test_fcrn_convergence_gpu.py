@@ -114,3 +114,33 @@ def test_deterministic_mode_is_bit_reproducible():
     # the default path after the switch back still works and the partial-sum buffers were left clean
     l2, g2 = _one_step_grads(net, x, t, crit)
     assert abs(l2 - l0) < 1e-2 * abs(l0) and float((g2 - g0).norm() / g0.norm()) <= max(3.0 * noise, 1e-3)
+
+
+def test_weight_gradient_stream_changes_nothing_but_the_schedule():
+    """The weight-gradient GEMMs run on a second stream by default (engine.EngineCore.wgrad).  In deterministic mode every sum is
+    order-independent, so a step with the second stream and a step without it must produce BIT-identical gradients: a race
+    between the streams (a gradient read before it is complete, an activation overwritten under a pending GEMM) would show."""
+    from mono_depth_estimation_amd import criteria
+    from mono_depth_estimation_amd.network import FCRN
+    torch.manual_seed(0)
+    net = FCRN.ResNet(layers=50, output_size=(128, 160), out_channels=1, pretrained=False).cuda().train()
+    net._store.set_deterministic(True)
+    try:
+        rgb, tgt = W.synthetic_batch(5, 4, 128, 160)
+        x, t = rgb.cuda(), tgt.cuda()
+        crit = criteria.silog_loss(0.85)
+
+        def grads():
+            net.zero_grad(set_to_none=True)
+            crit(net(x), t).backward()
+            return torch.cat([p.grad.flatten() for p in net.parameters()]).clone()
+        g_two = grads()
+        eng = next(iter(net._engines.values()))
+        assert eng.side is not None, "the second stream is the default"
+        side, eng.side = eng.side, None
+        g_one = grads()
+        eng.side = side
+        g_again = grads()
+        assert torch.equal(g_two, g_one) and torch.equal(g_two, g_again)
+    finally:
+        net._store.set_deterministic(False)
