@@ -65,3 +65,33 @@ def test_midas_loss_curves_agree_with_the_oracle():
     rel, noise = float((yh - yo).norm() / yo.norm()), float((yq - yo).norm() / yo.norm())
     print("trained-like state, eval: HIP vs oracle %.3e (bf16-rounding noise of the oracle %.3e)" % (rel, noise))
     assert rel < 1.5 * noise + 3e-3
+
+
+def test_tape_weight_gradient_stream_changes_nothing_but_the_schedule():
+    """As tests/test_fcrn_convergence_gpu.py's two-stream check, for a tape-run network: in deterministic mode a MiDaS step with the
+    weight-gradient stream and one without it give BIT-identical gradients."""
+    from mono_depth_estimation_amd import criteria
+    from mono_depth_estimation_amd.network import MiDaS
+    torch.manual_seed(0)
+    net = MiDaS.MidasNet(features=256)
+    W.midas_fixture_state(net, 43)
+    net = net.cuda().train()
+    net._store.set_deterministic(True)
+    try:
+        rgb, tgt = W.synthetic_batch(43, 2, *SIZE)
+        x, t = rgb.cuda(), tgt.cuda()
+        crit = criteria.MidasLoss(alpha=0.5, loss="ssimse")
+
+        def grads():
+            net.zero_grad(set_to_none=True)
+            crit(net(x)[:, :1], t).backward()
+            return torch.cat([p.grad.flatten() for p in net.parameters() if p.grad is not None]).clone()
+        g_two = grads()
+        eng = next(iter(net._engines.values()))
+        assert eng.side is not None
+        side, eng.side = eng.side, None
+        g_one = grads()
+        eng.side = side
+        assert torch.equal(g_two, g_one) and torch.equal(g_two, grads())
+    finally:
+        net._store.set_deterministic(False)
