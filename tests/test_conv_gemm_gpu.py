@@ -180,3 +180,54 @@ def test_atrous_conv_fwd_dgrad_wgrad(N, H, Wd, Cin, Cout, dil):
     _assert_close(_nchw(out), ref.detach(), "atrous fwd d=%d" % dil)
     _assert_close(_nchw(dx), xi.grad, "atrous dgrad d=%d" % dil)
     _assert_close(dw.cpu(), wi.grad.permute(0, 2, 3, 1).reshape(Cout, 9, Cin), "atrous wgrad d=%d" % dil)
+
+
+def test_random_shapes_fwd_dgrad_wgrad():
+    """Seeded sweep over convolution geometries (kernel 1 / 3 / 5, stride 1 / 2, dilation 1 / 2, channel counts that are
+    multiples of 8 but not of 64, pixel counts on both sides of the tile-selection thresholds: single-buffer 128x128 and
+    128x64 tiles, the 2-deep ring, the 256-column tiles, mixed row tiles of the weight gradient): forward + BatchNorm
+    statistics, input gradient and weight gradient against torch on the same bf16-rounded operands."""
+    from mono_depth_estimation_amd import ops
+    rng = __import__("numpy").random.RandomState(2024)
+    chans = [8, 24, 48, 64, 72, 96, 128, 152, 192, 200, 256, 320]
+    for trial in range(24):
+        k = int(rng.choice([1, 1, 3, 3, 5]))
+        s = int(rng.choice([1, 1, 2]))
+        dil = int(rng.choice([1, 1, 2])) if k == 3 and s == 1 else 1
+        p = dil * (k // 2)
+        Cin, Cout = int(rng.choice(chans)), int(rng.choice(chans))
+        N = int(rng.choice([1, 2, 3]))
+        big = trial % 3 == 0                                     # every third case has > 512 tiles of 128 pixels
+        H, Wd = (int(rng.randint(150, 260)), int(rng.randint(150, 300))) if big else (int(rng.randint(7, 60)), int(rng.randint(7, 60)))
+        if big and k == 5:
+            k, p = 3, dil
+        x = _bf(torch.randn(N, Cin, H, Wd, generator=torch.Generator().manual_seed(trial)))
+        w = _bf(torch.randn(Cout, Cin, k, k, generator=torch.Generator().manual_seed(100 + trial)) * (2.0 / (k * k * Cin)) ** 0.5)
+        xi, wi = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+        ref = F.conv2d(xi, wi, stride=s, padding=p, dilation=dil)
+        OH, OW = ref.shape[2:]
+        dy = _bf(torch.randn(tuple(ref.shape), generator=torch.Generator().manual_seed(200 + trial)))
+        ref.backward(dy)
+        xd, dyd = _nhwc(x), _nhwc(dy)
+        tag = "trial %d: N%d %dx%d C%d->%d k%d s%d d%d" % (trial, N, H, Wd, Cin, Cout, k, s, dil)
+        out = torch.empty(N, OH, OW, Cout, dtype=torch.bfloat16, device="cuda")
+        stats = ops.new_stat_buffer(Cout)
+        ops.conv_gemm(ops.fwd_desc(N, H, Wd, Cin, Cin, xd.numel() * 2, k, s, p, Cout, Cout, dil=dil), xd, _pack_fwd(w), out, stats)
+        _assert_close(_nchw(out), ref.detach(), tag + " fwd")
+        st = stats.sum(0).cpu()
+        r1, r2 = ref.detach().sum((0, 2, 3)), (ref.detach() ** 2).sum((0, 2, 3))
+        assert torch.allclose(st[0], r1, rtol=2e-3, atol=2e-2 * r2.max().sqrt().item()), tag + " stats"
+        assert torch.allclose(st[1], r2, rtol=2e-3, atol=2e-3 * r2.max().item()), tag + " stats"
+        dx = torch.full((N, H, Wd, Cin), 3.0, dtype=torch.bfloat16, device="cuda")
+        descs, zero = ops.dgrad_descs(N, H, Wd, Cin, Cin, OH, OW, Cout, Cout, dyd.numel() * 2, k, s, p, dil=dil)
+        if zero:
+            dx.zero_()
+        for d in descs:
+            ops.conv_gemm(d, dyd, _pack_dgrad(w), dx)
+        _assert_close(_nchw(dx), xi.grad, tag + " dgrad")
+        dw = torch.zeros(Cout, k * k, Cin, device="cuda")
+        ks = int(rng.choice([1, 2, 5]))
+        ops.conv_wgrad(ops.conv_wgrad_desc(N, H, Wd, Cin, Cin, xd.numel() * 2, OH, OW, Cout, Cout, dyd.numel() * 2, k, s, p, ks, dil=dil),
+                       dyd, xd, dw)
+        torch.cuda.synchronize()
+        _assert_close(dw.cpu(), wi.grad.permute(0, 2, 3, 1).reshape(Cout, k * k, Cin), tag + " wgrad", tol=2.0 ** -7)
