@@ -1,5 +1,9 @@
 #!/usr/bin/env python3
-"""Per-phase cycle stamps of the ping-pong conv loop (diagnostic build -DMDE_PP_STAMP, see conv_gemm.hip):
+"""Per-phase cycle stamps of the ping-pong conv loop (diagnostic build -DMDE_PP_STAMP, see conv_gemm.hip).  Build the diagnostic
+library in-tree (gpurun ships in-tree .so files) and point the binding at it:
+   cd mono_depth_estimation_amd/csrc && for f in *.hip; do hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off \
+       $([ $f = conv_gemm.hip ] && echo -DMDE_PP_STAMP) -c $f -o /tmp/st_${f%.hip}.o; done && \
+       hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/probes/libmde_stamp.so /tmp/st_*.o
    MDE_LIB_PATH=tools/probes/libmde_stamp.so python tools/pp_stamp.py H W N Cin Cout k"""
 import os
 import sys
