@@ -126,8 +126,9 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH, help="images per GPU (weak scaling) / global batch (strong scaling)")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="weak: --batch images on EVERY GPU; strong: --batch images split over the GPUs (SURVEY 8e)")
-    ap.add_argument("--grad-dtype", choices=("bf16", "fp32"), default=os.environ.get("MDE_DP_GRAD_DTYPE", "bf16"),
-                    help="wire format of the gradient all-reduce buckets (N > 1)")
+    ap.add_argument("--grad-dtype", choices=("bf16", "fp32"), default=os.environ.get("MDE_DP_GRAD_DTYPE", "fp32"),
+                    help="wire format of the gradient all-reduce buckets (N > 1).  fp32 is what the reference's DDP sums in and the "
+                         "default; bf16 halves the bytes on xGMI, is opt-in and is named in config.grad_wire_dtype")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-launch-timing", action="store_true")
     ap.add_argument("--per-shape", action="store_true", help="print a per-shape table of the GEMM launches to stderr")

@@ -840,6 +840,7 @@ extern "C" int mde_stem_conv_wgrad(const float* x, const void* dout, float* dw, 
     const int64_t ntiles = (int64_t)N * ((OH + WTY - 1) / WTY) * ((OW + STX - 1) / STX);
     const int64_t cap = 2 * (int64_t)cu_count();
     const int grid = (int)(ntiles > cap ? cap : ntiles);
+    MDE_DET_REQUIRE("mde_stem_conv_wgrad", dw, (int64_t)64 * 7 * 7 * 3);
     stem_wgrad_k<<<grid, NT, 0, (hipStream_t)stream>>>(x, (const bf16_t*)dout, dw, N, H, W, OH, OW, mde_det_dev());
     MDE_LAUNCH_CHECK("stem_wgrad_k");
     return MDE_OK;
@@ -864,6 +865,7 @@ extern "C" int mde_head_conv_bwd(const void* x, const float* w, const float* dou
     MDE_REQUIRE(x && w && dout && (dx || dw), "mde_head_conv_bwd: null argument");
     if (int rc = head_check("mde_head_conv_bwd", N, H, W, Cin, Cout)) return rc;
     MDE_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)dx % 16) == 0, "mde_head_conv_bwd: x/dx must be 16-byte aligned");
+    MDE_DET_REQUIRE("mde_head_conv_bwd", dw, (int64_t)Cout * 9 * Cin);
     hipStream_t st = (hipStream_t)stream;
     if (Cout == 1 && Cin == 64 && (int64_t)N * H * W * 128 < MDE_OOB_OFFSET) {
         if (dx) {

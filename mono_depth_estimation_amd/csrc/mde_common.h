@@ -58,6 +58,15 @@ struct MdeDetDev {         // kernel argument: scratch == nullptr -> plain float
     long long* scratch;
 };
 static inline MdeDetDev mde_det_dev() { return g_mde_det.on ? MdeDetDev{g_mde_det.gbase, g_mde_det.scratch} : MdeDetDev{nullptr, nullptr}; }
+// In deterministic mode a gradient destination is addressed as scratch + 2 * (dst - gbase): every entry point that hands
+// mde_det_dev() to a kernel first checks that [dst, dst + n) lies inside the registered buffer (a destination outside it
+// would turn into out-of-bounds 64-bit atomics).  dst == nullptr (gradient not requested) passes.
+static inline bool mde_det_in_range(const float* dst, int64_t n) {
+    return !g_mde_det.on || !dst || (dst >= g_mde_det.gbase && dst + n <= g_mde_det.gbase + g_mde_det.n);
+}
+#define MDE_DET_REQUIRE(who, dst, n)                    \
+    MDE_REQUIRE(mde_det_in_range((dst), (n)),           \
+                "%s: deterministic mode is on and " #dst " lies outside the registered gradient buffer", who)
 #define MDE_DET_SLOTS 8    // a partial-sum buffer [MDE_STAT_SLOTS][2][C] floats holds [MDE_DET_SLOTS][2][C][2] int64 in this mode
 
 // ---------------------------------------------------------------- device helpers
@@ -84,7 +93,16 @@ __device__ __forceinline__ float mde_row16_sum(float v) {
     return v;
 }
 
+// A non-finite addend has no integer image (the conversion would give 0 or INT64_MIN and the sum would come out finite):
+// it POISONS the slot instead -- the low word is overwritten with INT64_MAX, which no sum of remainders can bring back
+// under 2^61 (each remainder is < 2^39) -- and mde_det_value reads a poisoned slot as NaN, so divergence still shows.
+// (The split is exact for normal floats; for float denormals r * 2^60 is rounded: still order-independent.)
+#define MDE_DET_POISON 0x7FFFFFFFFFFFFFFFll
 __device__ __forceinline__ void mde_det_add2(long long* p, float v) {
+    if (!(fabsf(v) <= 3.4028234663852886e38f)) {
+        atomicExch(reinterpret_cast<unsigned long long*>(p + 1), (unsigned long long)MDE_DET_POISON);
+        return;
+    }
     const double vd = (double)v;
     const long long a = __double2ll_rn(vd * 1048576.0);
     const double r = vd - (double)a * (1.0 / 1048576.0);
@@ -92,6 +110,7 @@ __device__ __forceinline__ void mde_det_add2(long long* p, float v) {
     atomicAdd(reinterpret_cast<unsigned long long*>(p + 1), (unsigned long long)__double2ll_rn(r * 1152921504606846976.0));
 }
 __device__ __forceinline__ double mde_det_value(const long long* p) {
+    if (p[1] >= (1ll << 61) || p[1] <= -(1ll << 61)) return __builtin_nan("");
     return (double)p[0] * (1.0 / 1048576.0) + (double)p[1] * (1.0 / 1152921504606846976.0);
 }
 // one addend of a BatchNorm partial-sum buffer `part` (logical [slot][2][C]); wg picks the slot

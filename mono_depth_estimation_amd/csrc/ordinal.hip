@@ -508,6 +508,8 @@ extern "C" int mde_weighted_pool_bwd(const float* dscale, const float* scale, co
     MDE_REQUIRE(dscale && scale && a && w && da && dw && db && N > 0 && HW > 0 && C > 0 && C % 8 == 0 && lda % 8 == 0 && ldda % 8 == 0 &&
                     lda >= C && ldda >= C && ORD_ALIGNED(a) && ORD_ALIGNED(da),
                 "mde_weighted_pool_bwd: bad argument (C=%d, lda=%d, ldda=%d)", C, lda, ldda);
+    MDE_DET_REQUIRE("mde_weighted_pool_bwd", dw, HW);
+    MDE_DET_REQUIRE("mde_weighted_pool_bwd", db, (int64_t)1);
     weighted_pool_bwd_k<<<grid_flat(HW), NT, 0, (hipStream_t)stream>>>(dscale, scale, (const bf16_t*)a, lda, w, (bf16_t*)da, ldda, accumulate, dw, db,
                                                                       N, HW, C, mde_det_dev());
     MDE_LAUNCH_CHECK("weighted_pool_bwd_k");

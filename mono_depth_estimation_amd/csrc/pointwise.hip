@@ -675,6 +675,7 @@ extern "C" int mde_pw_bwd(const void* dout, int ldd, const void* out, int ldo, v
     MDE_REQUIRE(ldd % 8 == 0 && (!out || ldo % 8 == 0) && (!dx || lddx % 8 == 0) && (!dr || lddr % 8 == 0) && PW_ALIGNED(dout) &&
                     (!out || PW_ALIGNED(out)) && (!dx || PW_ALIGNED(dx)) && (!dr || PW_ALIGNED(dr)),
                 "mde_pw_bwd: operands must be 16-byte aligned with ld %% 8 == 0");
+    MDE_DET_REQUIRE("mde_pw_bwd", dbias, (int64_t)C);
     const int tpr = C / 8 < NT ? C / 8 : NT;
     pw_bwd_k<<<grid_rows(M, NT / tpr), NT, 0, (hipStream_t)stream>>>((const bf16_t*)dout, ldd, (const bf16_t*)out, ldo, (bf16_t*)dx, lddx,
                                                                    acc_x, (bf16_t*)dr, lddr, acc_r, dbias, dbias ? bias_part : nullptr, M, C, act,
@@ -814,6 +815,7 @@ extern "C" int mde_softmax_head_bwd(const float* dlogit, const float* dprob, con
     MDE_REQUIRE((dlogit || dprob) && (prob || !dprob) && dx && N > 0 && HW > 0 && C > 0 && C <= 4 * SM_MAXC && lddx % 8 == 0 &&
                     lddx >= (C + 7) / 8 * 8 && PW_ALIGNED(dx),
                 "mde_softmax_head_bwd: bad argument (C=%d <= %d, lddx=%d)", C, 4 * SM_MAXC, lddx);
+    MDE_DET_REQUIRE("mde_softmax_head_bwd", dbias, (int64_t)C);
     const size_t smem = ((size_t)C * 65 + 4 * 64) * sizeof(float);
     static bool attr = false;
     if (!attr) {
@@ -848,6 +850,7 @@ extern "C" int mde_to_nchw_act_bwd(const float* dout, const float* out, void* dx
     MDE_REQUIRE(dout && out && dx && N > 0 && HW > 0 && C > 0 && C <= 64 && lddx % 8 == 0 && lddx >= (C + 7) / 8 * 8 && act >= 0 &&
                     act <= 3 && scale != 0.f && PW_ALIGNED(dx),
                 "mde_to_nchw_act_bwd: bad argument (C=%d <= 64, lddx=%d)", C, lddx);
+    MDE_DET_REQUIRE("mde_to_nchw_act_bwd", dbias, (int64_t)C);
     int grid = grid_flat((int64_t)N * HW);
     if (grid > 1024) grid = 1024;
     to_nchw_act_bwd_k<<<grid, NT, 0, (hipStream_t)stream>>>(dout, out, (bf16_t*)dx, lddx, dbias, N, HW, C, act, scale, mde_det_dev());

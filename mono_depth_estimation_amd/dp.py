@@ -39,6 +39,17 @@ def make_buckets(total, boundaries, target_bytes, elem_bytes=4, head_bytes=None)
     return buckets
 
 
+class _Pending:
+    """A wire-format bucket whose collective is in flight: wait() joins it and widens the result back into the gradient."""
+
+    def __init__(self, work, view, buf, n):
+        self.work, self.view, self.buf, self.n = work, view, buf, n
+
+    def wait(self):
+        self.work.wait()
+        self.view.copy_(self.buf[:self.n])
+
+
 class FlatGradReducer:
     """Sum-all-reduce of a flat gradient tensor in tail-first buckets, overlapped with backward.
 
@@ -58,7 +69,16 @@ class FlatGradReducer:
         self.flat, self.group = flat, group
         self.wire_dtype = wire_dtype if wire_dtype is not None and wire_dtype != flat.dtype else None
         self.algo = algo or os.environ.get("MDE_DP_ALGO", "allreduce")
-        assert self.algo in ("allreduce", "rs_ag"), self.algo
+        if self.algo not in ("allreduce", "rs_ag"):
+            raise ValueError("FlatGradReducer: algo must be 'allreduce' or 'rs_ag', got %r" % (self.algo,))
+        backend = dist.get_backend(group) if dist.is_initialized() else None
+        if self.algo == "rs_ag" and backend is not None and backend != "nccl":
+            raise ValueError("FlatGradReducer: algo='rs_ag' needs reduce_scatter_tensor / all_gather_into_tensor, which the "
+                             "%r backend does not implement; use algo='allreduce' there" % (backend,))
+        # nccl (RCCL): Work.wait() only orders the CURRENT stream behind the collective, so the widening copy can be queued
+        # right away on the exchange stream; other backends (gloo, the CPU rehearsal) block the host in wait(), so there the
+        # wait and the copy-back are deferred to finish() and backward keeps running while the bucket is on the wire
+        self._defer = backend != "nccl"
         self.extra_streams = [s for s in extra_streams if s is not None]
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         # MDE_DP_FORCE=1: run the collectives even with one rank (rehearses the RCCL / stream / event
@@ -92,11 +112,15 @@ class FlatGradReducer:
         n = end - start
         buf[:n].copy_(view)                                     # fp32 -> wire dtype (padding stays zero)
         if shard is None:
-            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+            work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         else:
-            dist.reduce_scatter_tensor(shard, buf, op=dist.ReduceOp.SUM, group=self.group)
-            dist.all_gather_into_tensor(buf, shard, group=self.group)
-        view.copy_(buf[:n])
+            dist.reduce_scatter_tensor(shard, buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            work = dist.all_gather_into_tensor(buf, shard, group=self.group, async_op=True)   # same communicator: ordered
+        if self._defer:
+            self.works.append(_Pending(work, view, buf, n))
+        else:
+            work.wait()                                         # orders the exchange stream, does not block the host
+            view.copy_(buf[:n])
 
     def _launch(self, start, end):
         if self.stream is not None:
@@ -120,8 +144,13 @@ class FlatGradReducer:
     def finish(self):
         if self.active:
             self.ready(0)
-            for w in self.works:
-                w.wait()
+            if self.stream is not None:
+                with torch.cuda.stream(self.stream):
+                    for w in self.works:
+                        w.wait()
+            else:
+                for w in self.works:
+                    w.wait()
             if self.stream is not None:
                 torch.cuda.current_stream().wait_stream(self.stream)
         self.reset()

@@ -43,6 +43,7 @@ class Act:
             self.t = parent.t[..., c0 - parent.c0:c0 - parent.c0 + C]
         self._g = None
         self._gw = False         # gradient already written during the current backward (slices share their root's flag)
+        self.concat_root = False  # TapeEngine.buf(): gradient zeroed and flagged written before every backward
 
     @property
     def gw(self):
@@ -65,6 +66,12 @@ class Act:
         while root.parent is not None:
             root = root.parent
         return (root.t.numel() - self.c0) * 2
+
+    def root(self):
+        a = self
+        while a.parent is not None:
+            a = a.parent
+        return a
 
     def slice(self, c0, C):
         return Act(None, self.N, self.H, self.W, C, parent=self, c0=self.c0 + c0)
@@ -231,11 +238,15 @@ class FlatStore:
             ops.set_deterministic(False)
 
     def det_begin(self):
-        """Point the kernels' integer gradient shadow at the buffer this backward accumulates into."""
+        """Program the library's (process-wide) accumulation mode for THIS store's forward / backward: the integer gradient
+        shadow pointed at the buffer this backward accumulates into, or the mode switched OFF -- a store that is not
+        deterministic must not run under a mode (and a gradient base) another store left behind."""
         if self.deterministic:
             if self._det_scratch is None:
                 self._det_scratch = ops.det_scratch(self.G)
             ops.set_deterministic(True, self.Gcur, self._det_scratch)
+        else:
+            ops.set_deterministic(False)
 
     def det_end(self):
         if self.deterministic:

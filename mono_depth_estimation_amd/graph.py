@@ -62,6 +62,11 @@ class Op:
 
 def _take(x):
     """-> accumulate flag for a write into x.g, marking it written."""
+    if x.parent is not None and not x.root().concat_root:
+        # the written-flag is shared by a root and all its slices: a first writer that covers only part of the channels
+        # would make the writers of the other channels accumulate onto uninitialised memory, unless the root is a
+        # concatenation target (TapeEngine.buf), whose gradient is zeroed and flagged before every backward
+        raise AssertionError("gradient write into a channel slice whose root is not a TapeEngine.buf() concatenation target")
     acc = x.gw
     x.gw = True
     return acc
@@ -863,6 +868,7 @@ class TapeEngine(EngineCore):
         """A zero-initialised activation the plan owns (concatenation targets: producers write channel slices of it)."""
         a = Act(self.dev, N, H, W, C)
         a.t.zero_()
+        a.concat_root = True
         self._bufs.append(a)
         return a
 

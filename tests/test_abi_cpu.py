@@ -57,6 +57,34 @@ def test_argument_validation_without_a_gpu(lib):
         _lib.check(-1, "x")
 
 
+def test_deterministic_mode_refuses_gradients_outside_the_registered_buffer(lib):
+    """In deterministic mode a gradient destination is addressed relative to the registered flat buffer: every entry point
+    that accumulates a weight / bias gradient must refuse (rc = -1, before any launch) one that lies outside it."""
+    P = C.c_void_p
+    base, n = 1 << 20, 1000                                            # registered: [base, base + 4 n)
+    assert lib.mde_set_deterministic(1, P(base), P(1 << 24), n) == 0
+    try:
+        inside, outside = P(base + 64), P(base + 4 * n + 4096)
+        a = P(1 << 16)                                                  # any non-null, 16-byte aligned operand
+        calls = {
+            "mde_pw_bwd": lambda db: lib.mde_pw_bwd(a, 64, a, 64, a, 64, 0, None, 0, 0, db, a, 128, 64, 1, None),
+            "mde_to_nchw_act_bwd": lambda db: lib.mde_to_nchw_act_bwd(a, a, a, 8, db, 1, 64, 8, 1, 1.0, None),
+            "mde_softmax_head_bwd": lambda db: lib.mde_softmax_head_bwd(a, a, a, a, 152, db, 1, 64, 150, None),
+            "mde_stem_conv_wgrad": lambda dw: lib.mde_stem_conv_wgrad(a, a, dw, 1, 32, 32, None),
+            "mde_head_conv_bwd": lambda dw: lib.mde_head_conv_bwd(a, a, a, a, dw, 1, 8, 8, 64, 1, None),
+            "mde_weighted_pool_bwd": lambda dw: lib.mde_weighted_pool_bwd(a, a, a, 64, a, a, 64, 0, dw, inside, 1, 16, 64, None),
+        }
+        for name, call in calls.items():
+            assert call(outside) == -1, name
+            msg = lib.mde_last_error()
+            assert b"deterministic mode" in msg and name.encode() in msg, (name, msg)
+        # a destination that only starts inside the buffer is refused too (its range runs past the end)
+        assert calls["mde_stem_conv_wgrad"](P(base + 4 * (n - 10))) == -1
+    finally:
+        assert lib.mde_set_deterministic(0, None, None, 0) == 0
+    assert lib.mde_deterministic() == 0
+
+
 def test_product_has_no_oracle_dependency():
     """The shipped package must never import the CPU oracle (no fallback path)."""
     pkg = os.path.join(ROOT, "mono_depth_estimation_amd")

@@ -49,6 +49,30 @@ def _worker(rank, world, port, q):
     red.ready(0)
     red.finish()
     ok = ok and torch.equal(g, torch.full((n,), float(world)))
+    # bf16 on the wire against fp32 on the wire, gradient-like data (wide dynamic range, both signs): the relative L2 error of
+    # the summed bucket is bounded by bf16's half-ulp on each addend and once on the sum (2^-9 each, independent): asserted
+    # at 2^-8; fp32 on the wire (bench.py's default, what the reference's DDP sums in) agrees with the hand-made sum exactly
+    gen = torch.Generator().manual_seed(7)
+    base = [torch.randn(n, generator=gen) * torch.exp(4.0 * torch.randn(n, generator=gen)) for _ in range(world)]
+    exact = sum(b.double() for b in base)
+    g = base[rank].clone()
+    red = dp.FlatGradReducer(g, bounds, target_bytes=8192)
+    red.ready(0)
+    red.finish()
+    ok = ok and float((g.double() - exact).norm() / exact.norm()) < 1e-6
+    g = base[rank].clone()
+    red = dp.FlatGradReducer(g, bounds, target_bytes=8192, wire_dtype=torch.bfloat16)
+    red.ready(0)
+    red.finish()
+    rel = float((g.double() - exact).norm() / exact.norm())
+    ok = ok and 0.0 < rel < 2.0 ** -8
+    # algorithms the backend cannot run, or that do not exist, are refused when the reducer is built
+    for bad, exc in (("rs_ag", ValueError), ("ring", ValueError)):
+        try:
+            dp.FlatGradReducer(g, bounds, target_bytes=8192, algo=bad)
+            ok = False
+        except exc:
+            pass
     q.put((rank, ok, len(red.buckets)))
     dist.destroy_process_group()
 
