@@ -24,6 +24,7 @@ sys.path.insert(0, ROOT)
 H, W, BATCH = 480, 640, 32
 PEAK_BF16_TFLOPS = 2500.0                 # dense MFMA bf16 (MI355X_MICROARCH.md)
 ALGO_GFLOP_PER_IMAGE = 410.9              # useful conv MACs x 2 x 3 (fwd+dgrad+wgrad)
+ALGO_CONV_BYTES_PER_CALL = 153.8e6        # 22.0 GB per step (in + out + weights of the 143 forward / input-gradient calls, bf16) / 143
 
 
 def synthetic(n, seed, device):
@@ -118,17 +119,179 @@ def cpu_baseline(threads):
                       % (n, len(times))}
 
 
+# BASELINE.json configurations 3 / 4 / 5 at their per-GPU sizes.  Forward MACs per image are SURVEY.md 8a / 8d's dense-as-written
+# figures (x 2 x 3 = training FLOP); the reference's own module configuration supplies loss and optimiser.
+OTHER_CONFIGS = {
+    "bts": {"batch": 16, "hw": (480, 640), "gmac": 121.48,
+            "workload": "BTS DenseNet-161 + LPG / atrous decoder (reference network/Bts.py, bts_size 512, max_depth 1), %dx3x480x640 per "
+                        "GPU -> 5 maps, train step = fwd + SILog(0.85) on the final depth + bwd + AdamW(eps 1e-3, wd 1e-2 / 0)"},
+    "midas": {"batch": 32, "hw": (384, 384), "gmac": 103.47,
+              "workload": "MiDaS ResNeXt-101 32x8d (reference network/MiDaS.py, features 256), %dx3x384x384 per GPU -> 7-channel sigmoid, "
+                          "train step = fwd + MidasLoss(0.5, ssimse) on channel 0 + bwd + Adam(0.1 lr encoder, lr decoder)"},
+    "vnl": {"batch": 16, "hw": (480, 640), "gmac": 348.42,
+            "workload": "VNL ResNeXt-50 32x4d stride 16, 150 bins (reference network/VNL.py), %dx3x480x640 per GPU -> logits + softmax, "
+                        "train step = fwd + ModelLoss (WCEL + 6 x virtual-normal loss) + bwd + SGD(momentum 0.9, wd 5e-4)"},
+}
+
+
+def build_other(name, n, dev):
+    """-> (net, step(): one training step through the drop-in nn.Module path).  Mirrors tools/config_bench.py."""
+    import numpy as np
+    from mono_depth_estimation_amd import criteria
+    h, w = OTHER_CONFIGS[name]["hw"]
+    g = torch.Generator(device=dev)
+    g.manual_seed(1234 + int(os.environ.get("RANK", "0")))
+    x = torch.rand(n, 3, h, w, generator=g, device=dev)
+    gt = 0.05 + 0.95 * torch.rand(n, 1, h, w, generator=g, device=dev)
+    gt = gt.masked_fill(torch.rand(n, 1, h, w, generator=g, device=dev) < 0.10, 0.0)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if name == "bts":
+        from mono_depth_estimation_amd.network import Bts
+        net = Bts.BtsModel(max_depth=1.0, bts_size=512, encoder_version="densenet161_bts", out_channels=1).to(dev).train()
+        crit = criteria.silog_loss(0.85)
+        fwd_loss = lambda: crit(net(x)[4], gt)
+        opt = lambda: net._store.adam_step(1e-4, 1e-4, eps=1e-3, weight_decay=(1e-2, 0.0), decoupled=True, grad_scale=1.0 / world)
+    elif name == "midas":
+        from mono_depth_estimation_amd.network import MiDaS
+        net = MiDaS.MidasNet(features=256).to(dev).train()
+        crit = criteria.MidasLoss(alpha=0.5, loss="ssimse")
+        fwd_loss = lambda: crit(net(x)[:, :1], gt)
+        opt = lambda: net._store.adam_step(1e-5, 1e-4, grad_scale=1.0 / world)
+    else:
+        from types import SimpleNamespace
+        from mono_depth_estimation_amd.network import VNL
+        C, dmin, dmax = 150, 0.01, 1.1
+        interval = (np.log10(dmax) - np.log10(dmin)) / C
+        p = SimpleNamespace(depth_min=dmin, encoder="resnext50_32x4d_body_stride16", pretrained=0, freeze_backbone=False, init_type="xavier",
+                            enc_dim_in=[64, 256, 512, 1024, 2048], enc_dim_out=[512, 256, 256, 256], dec_dim_in=[512, 256, 256, 256, 256, 256],
+                            dec_dim_out=[256, 256, 256, 256, 256], dec_out_c=C, focal_x=519.0, focal_y=519.0, crop_size=(h, w), diff_loss_weight=6,
+                            depth_min_log=np.log10(dmin), depth_bin_interval=interval,
+                            wce_loss_weight=[[np.exp(-0.2 * (i - j) ** 2) for i in range(C)] for j in np.arange(C)],
+                            depth_bin_border=np.array([np.log10(dmin) + interval * (i + 0.5) for i in range(C)]))
+        net = VNL.MetricDepthModel(p).to(dev).train()
+        crit = criteria.ModelLoss(p)
+        bins = criteria.depth_to_bins(gt, dmin, dmax, C)
+
+        def fwd_loss():
+            logit, prob = net(x)
+            return crit(criteria.bins_to_depth(prob, p.depth_bin_border), logit, bins, gt)
+        opt = lambda: net._store.sgd_step(1e-4, 1e-5, momentum=0.9, weight_decay=5e-4, grad_scale=1.0 / world)
+    return net, fwd_loss, opt
+
+
+def run_other_config(args, dev, rank, world, use_dist, t_start):
+    """The same contract (warm-up, K timed steps between barriers, max over ranks, one JSON line with a roofline leg) for
+    BASELINE.json configurations 3 / 4 / 5.  The gradient exchange (N > 1) is one flat all-reduce per bucket after backward:
+    the tape engine's backward does not report its progress, so it is not overlapped here."""
+    import torch.distributed as dist
+    from mono_depth_estimation_amd import dp, ops
+    cfg = OTHER_CONFIGS[args.config]
+    net, fwd_loss, opt = build_other(args.config, args.batch, dev)
+    state = {}
+
+    def step():
+        net.zero_grad(set_to_none=True)
+        loss = fwd_loss()
+        loss.backward()
+        store = net._store
+        if use_dist:
+            if "red" not in state:
+                dist.broadcast(store.P, 0)
+                state["red"] = dp.FlatGradReducer(store.grad_buffer(), store.layer_boundaries(), target_bytes=64 << 20,
+                                                  wire_dtype=torch.bfloat16 if args.grad_dtype == "bf16" else None)
+            state["red"].flat = store.grad_buffer()          # the flat buffer this backward's .grad views live in
+            state["red"].ready(0)
+            state["red"].finish()
+        opt()
+        state["loss"] = loss
+
+    def log(msg):
+        if rank == 0:
+            print("[bench %.1fs] %s" % (time.perf_counter() - t_start, msg), file=sys.stderr, flush=True)
+
+    def fence():
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step()
+        torch.cuda.synchronize()
+        log("warm-up step %d done" % i)
+    fence()
+    timer = None if args.no_launch_timing else ops.LaunchTimer()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        if timer is not None and i == args.steps - 1:
+            ops.TIMER = timer            # per-launch HIP events in ONE step (they serialise neighbouring kernels)
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    ops.TIMER = None
+    tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if use_dist:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = float(tt)
+    log("timed region done: %.1f ms/step" % (1e3 * dt / args.steps))
+    if rank == 0:
+        ips = args.batch * world * args.steps / dt
+        gflop = cfg["gmac"] * 6.0
+        out = {
+            "metric": "training images/sec, %s, bf16" % args.config.upper(), "value": round(ips, 2), "unit": "images/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": cfg["workload"] % args.batch + (" + flat-gradient all-reduce after backward (RCCL, %s)" % args.grad_dtype
+                                                                   if world > 1 else ""),
+                       "global_batch": args.batch * world, "per_gpu_batch": args.batch, "parallelism": "dp%d" % world,
+                       "final_loss": round(float(state["loss"]), 5), "algorithmic_gflop_per_image": round(gflop, 1)},
+            "step_mfma_frac": round(ips * gflop / 1e3 / (world * PEAK_BF16_TFLOPS), 4),
+        }
+        if timer is not None:
+            if args.per_shape:
+                print_per_shape(timer, 1)
+            summ = timer.summary()
+            n, fl, sec = summ.get("conv_gemm_nt", (0, 0.0, 1.0))
+            ach = fl / sec / 1e12 if n else 0.0
+            out["roofline"] = {"bound": "mfma", "kernel": "conv_gemm_nt (implicit-GEMM conv fwd / input gradient, bf16 MFMA)",
+                               "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
+                               "traffic": None, "launches": n, "avg_launch_us": round(1e6 * sec / max(n, 1), 2),
+                               "avg_launch_gflop": round(fl / max(n, 1) / 1e9, 3),
+                               "share_of_step_time": round(sec / (dt / args.steps), 4), "timed_launch_steps": 1}
+            if "conv_wgrad_tn" in summ:
+                n2, fl2, sec2 = summ["conv_wgrad_tn"]
+                out["roofline"]["wgrad_kernel"] = {"achieved": round(fl2 / sec2 / 1e12, 2), "launches": n2,
+                                                   "avg_launch_us": round(1e6 * sec2 / n2, 2),
+                                                   "share_of_step_time": round(sec2 / (dt / args.steps), 4)}
+        print(json.dumps(out), flush=True)
+    if use_dist:
+        dist.destroy_process_group()
+
+
+def print_per_shape(timer, timed_launch_steps):
+    tab = {}
+    for kind, flops, e0, e1, tag in timer.records:
+        n, t = tab.get((kind, tag, flops), (0, 0.0))
+        tab[(kind, tag, flops)] = (n + 1, t + e0.elapsed_time(e1) * 1e-3)
+    for (kind, tag, flops), (n, t) in sorted(tab.items(), key=lambda kv: -kv[1][1]):
+        print("%-14s %-46s x%-3d %8.1f us  %7.1f TF/s  %5.2f ms/step" % (
+            kind, tag, n // timed_launch_steps, 1e6 * t / n, flops / (t / n) / 1e12, 1e3 * t / timed_launch_steps), file=sys.stderr)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=BATCH, help="images per GPU (weak scaling) / global batch (strong scaling)")
+    ap.add_argument("--batch", type=int, default=None, help="images per GPU (weak scaling) / global batch (strong scaling); "
+                                                            "default: the configuration's own (fcrn 32, bts 16, midas 32, vnl 16)")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="weak: --batch images on EVERY GPU; strong: --batch images split over the GPUs (SURVEY 8e)")
     ap.add_argument("--grad-dtype", choices=("bf16", "fp32"), default=os.environ.get("MDE_DP_GRAD_DTYPE", "fp32"),
                     help="wire format of the gradient all-reduce buckets (N > 1).  fp32 is what the reference's DDP sums in and the "
                          "default; bf16 halves the bytes on xGMI, is opt-in and is named in config.grad_wire_dtype")
+    ap.add_argument("--config", choices=("fcrn", "bts", "midas", "vnl"), default="fcrn",
+                    help="BASELINE.json configuration: fcrn = the headline (configuration 2, the default); bts / midas / vnl = "
+                         "configurations 3 / 4 / 5 at their per-GPU sizes (16x480x640, 32x384x384, 16x480x640), module path")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-launch-timing", action="store_true")
     ap.add_argument("--per-shape", action="store_true", help="print a per-shape table of the GEMM launches to stderr")
@@ -138,6 +301,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.batch is None:
+        args.batch = OTHER_CONFIGS[args.config]["batch"] if args.config != "fcrn" else BATCH
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
@@ -166,6 +331,8 @@ def main():
     from mono_depth_estimation_amd.network import FCRN
 
     torch.manual_seed(0)                                  # identical initial weights on every rank
+    if args.config != "fcrn":
+        return run_other_config(args, dev, rank, world, use_dist, t_start)
     net = FCRN.ResNet(layers=50, decoder="upproj", output_size=(H, W), out_channels=1, pretrained=False)
     net.conv3.weight.data.mul_(0.05)                      # keep the sigmoid unsaturated at init (see tests/golden)
     net = net.to(dev).train()
@@ -252,13 +419,7 @@ def main():
             "step_mfma_frac": round(ips * ALGO_GFLOP_PER_IMAGE / 1e3 / (world * PEAK_BF16_TFLOPS), 4),
         }
         if timer is not None and args.per_shape:
-            tab = {}
-            for kind, flops, e0, e1, tag in timer.records:
-                n, t = tab.get((kind, tag, flops), (0, 0.0))
-                tab[(kind, tag, flops)] = (n + 1, t + e0.elapsed_time(e1) * 1e-3)
-            for (kind, tag, flops), (n, t) in sorted(tab.items(), key=lambda kv: -kv[1][1]):
-                print("%-14s %-46s x%-3d %8.1f us  %7.1f TF/s  %5.2f ms/step" % (
-                    kind, tag, n // timed_launch_steps, 1e6 * t / n, flops / (t / n) / 1e12, 1e3 * t / timed_launch_steps), file=sys.stderr)
+            print_per_shape(timer, timed_launch_steps)
         if timer is not None:
             summ = timer.summary()
             n, fl, sec = summ.get("conv_gemm_nt", (0, 0.0, 1.0))
@@ -267,7 +428,12 @@ def main():
             out["roofline"] = {
                 "bound": "mfma", "kernel": "conv_gemm_nt (implicit-GEMM conv fwd/dgrad/up-projection, bf16 MFMA)",
                 "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
-                "traffic": traffic, "traffic_source": traffic_src, "launches": n, "avg_launch_us": round(1e6 * sec / max(n, 1), 2),
+                "traffic": traffic, "traffic_source": traffic_src,
+                # algorithmic HBM bytes of an average call (its input + output + weights, bf16, once each: DESIGN.md section 3)
+                # and the measured traffic over it -- the waste ratio the reviews track
+                "algorithmic_bytes": ALGO_CONV_BYTES_PER_CALL,
+                "traffic_over_algorithmic": round(traffic / ALGO_CONV_BYTES_PER_CALL, 3) if traffic else None,
+                "launches": n, "avg_launch_us": round(1e6 * sec / max(n, 1), 2),
                 "avg_launch_gflop": round(fl / max(n, 1) / 1e9, 3),
                 "share_of_step_time": round(sec / timed_launch_steps / (dt / args.steps), 4),
                 "timed_launch_steps": timed_launch_steps,

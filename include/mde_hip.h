@@ -497,6 +497,13 @@ int mde_stdepth_bwd(const float* pred, const float* targ, const float* rgba, int
 size_t mde_metrics_ws_bytes(void);
 int mde_depth_metrics(const float* pred, const float* target, int64_t n, void* ws, float* out,
                       void* stream);
+/* The 'ssim' entry of the reference's metric list (metrics.py:63,123: torchmetrics 0.7.3
+ * structural_similarity_index_measure with its defaults, on clamp_min(pred, 1e-7) and the unmasked target): 11 x 11
+ * Gaussian window (sigma 1.5), data_range from the two tensors' extrema, mean over the pixels whose window lies inside
+ * the image.  pred / target: fp32 [planes][H][W] (planes = N * C), H, W > 10; ws >= mde_ssim_metric_ws_bytes(), 8-byte
+ * aligned; out: one float. */
+size_t mde_ssim_metric_ws_bytes(void);
+int mde_ssim_metric(const float* pred, const float* target, int planes, int H, int W, void* ws, float* out, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Optimiser / parameter plumbing (torch.optim.Adam as configured at modules/laina.py:51-57).

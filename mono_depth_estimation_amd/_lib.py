@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MDE_LIB_PATH") or os.path.join(_HERE, "libmde_hip.so")   # override: diagnostic builds only
-ABI_VERSION = 6
+ABI_VERSION = 7
 MAX_TAPS = 32
 
 
@@ -146,6 +146,8 @@ SIGNATURES = {
     "mde_stdepth_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _U, _F, _F, _F, _F, _F, _P, _P, _P, _P, _P, _P]),
     "mde_metrics_ws_bytes": (_Z, []),
     "mde_depth_metrics": (_I, [_P, _P, _L, _P, _P, _P]),
+    "mde_ssim_metric_ws_bytes": (_Z, []),
+    "mde_ssim_metric": (_I, [_P, _P, _I, _I, _I, _P, _P, _P]),
     "mde_adam_step": (_I, [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _F, _I, _P]),
     "mde_adamw_step": (_I, [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _F, _I, _P]),
     "mde_sgd_step": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _P]),

@@ -77,6 +77,13 @@ struct KArgs {
     int32_t vec_ok;   // 16-byte stores allowed
     int32_t col_fastest;  // tile order: 1 = all column tiles of a pixel tile are neighbours (activation tile reused from L2)
     int32_t det;          // deterministic mode: BatchNorm partial sums leave the workgroup as integer atomics (mde_common.h)
+    // halo-tiled form (HALO kernels): the workgroup's 128 pixels are a th x tw block of ONE image (tw = 1 << h_tws), whose
+    // input window (th + dy span) x (tw + dx span) is staged ONCE per 64-channel chunk and read by every tap
+    int32_t h_tws, h_th;          // log2(tile width), tile height
+    int32_t h_nty, h_ntx;         // tiles per image
+    int32_t h_hw, h_rows;         // halo width (pixels), halo rows (pixels) in all
+    int32_t h_dy0, h_dx0;         // smallest tap offsets: halo pixel (0, 0) is input (gy0 + dy0, gx0 + dx0)
+    int32_t h_step_y, h_step_x;   // a wave's next window instruction is (waves x 8) rows on: that many / hw lines down, % hw pixels right (+ one carry)
 };
 
 // byte offset of the 16-byte chunk (row, kslot8) inside a swizzled tile
@@ -97,8 +104,17 @@ __device__ __forceinline__ int chunk_off(int row, int kslot8) {
 // so one of them is always in its MFMA cluster while the other issues its LDS reads and DMA pieces (guide: the 8-phase
 // template's stagger; MI355X_MICROARCH "Two waves per SIMD" item 9).  In the lockstep loop both waves read together (LDS
 // saturated, matrix pipe idle) and then compute together (pipe shared): MFMA busy measured 41 %.
-template <int BP, int BC, int NT, bool DMA, int NBUF, bool PP = false>
-__global__ __launch_bounds__(NT, (NT == 256 && BP * BC >= 256 * 256) ? 1 : (NBUF == 1 ? 4 : 2)) void conv_gemm_nt(const KArgs a) {
+//
+// HALO = true (single staging buffer, stride-1 gathers, >= 2 taps): the pixel operand of a K-step is not gathered per tap.
+// The 128 pixels of a tile form a th x tw block of one image; the block's input window is staged once per 64-channel chunk
+// ("LDS-staged im2col": (th + 2) x (tw + 2) rows of 128 B for a 3x3) and the taps of that chunk read it at shifted
+// rows.  Why: the 128x128 tile moves 32 KB through the L2 -> LDS DMA path per K-step for 2 MFLOP (64 FLOP/B); that path
+// delivers ~70 GB/s per CU (MI355X_MICROARCH.md, "Indexed rows: gather into LDS"), i.e. it caps the tile near 1.1 PFLOP/s
+// -- where the best 9- and 25-tap layers sit.  With the window shared by the taps a 3x3 K-step moves 18.6 KB instead.
+constexpr int HALO_MAX_Q = 8;    // halo DMA instructions per wave and chunk (4 waves x 8 x 8 rows = 256 halo rows)
+template <int BP, int BC, int NT, bool DMA, int NBUF, bool PP = false, bool HALO = false>
+__global__ __launch_bounds__(NT, HALO ? (NT == 512 ? 4 : BC <= 64 ? 5 : 4)
+                                     : (NT == 256 && BP * BC >= 256 * 256) ? 1 : (NBUF == 1 ? 4 : 2)) void conv_gemm_nt(const KArgs a) {
     constexpr int NW = NT / 64;
     constexpr int RPL = NT / 8;          // tile rows covered by one load pass (8 chunks per row)
     constexpr int XP = BP / RPL;         // X chunks per thread per K-step
@@ -112,7 +128,8 @@ __global__ __launch_bounds__(NT, (NT == 256 && BP * BC >= 256 * 256) ? 1 : (NBUF
     constexpr int BUF_BYTES = XT_BYTES + WT_BYTES;
     constexpr int ROWB = BC * 2 + 16;    // epilogue tile row pitch (bytes)
     // the epilogue re-tiles through LDS; when the whole tile does not fit, in EPASS pixel slabs
-    constexpr int STG_BYTES = (NBUF < 2 ? NBUF : 2) * BUF_BYTES;         // LDS the epilogue may stage through
+    // LDS the epilogue may stage through (HALO: the smallest window, one row per tile pixel, + the weight buffers)
+    constexpr int STG_BYTES = HALO ? XT_BYTES + NBUF * WT_BYTES : (NBUF < 2 ? NBUF : 2) * BUF_BYTES;
     constexpr int EPASS = (BP * ROWB <= STG_BYTES) ? 1 : (BP * ROWB <= 2 * STG_BYTES) ? 2 : 4;
     constexpr int EROWS = BP / EPASS;    // pixel rows per epilogue pass
     static_assert(WAVES_P * WAVES_C == NW && PF * 16 * WAVES_P == BP && CF * 16 * WAVES_C == BC && PF >= 2 && PF <= 8, "wave tiling");
@@ -120,15 +137,25 @@ __global__ __launch_bounds__(NT, (NT == 256 && BP * BC >= 256 * 256) ? 1 : (NBUF
     static_assert(EROWS * ROWB <= STG_BYTES && (WAVES_P % EPASS) == 0, "epilogue slab fits in the staging buffers");
     static_assert(NBUF == 2 || (DMA && (NBUF == 1 || NBUF == 3)), "register staging uses two LDS buffers");
     static_assert(NBUF != 1 || !PP, "the single-buffer loop has no ping-pong form");
+    static_assert(!HALO || (DMA && !PP && ((NBUF == 1 && BP == 128 && NT == 256) || (NBUF == 2 && BP == 256 && NT == 512))),
+                  "the halo form: 128-pixel single-buffer tiles (4 waves) or 256-pixel tiles with a two-deep weight ring (8 waves)");
     constexpr int XR = BP / 8 / NW, WR = BC / 8 / NW;   // DMA regions (8 rows) per wave per K-step
     static_assert(!DMA || (XR >= 1 && WR >= 1 && XR * NW * 8 == BP && WR * NW * 8 == BC && NW % 2 == 0), "DMA tiling");
 
+#ifdef MDE_SB_STAMP
+    const uint64_t sb_k0 = __builtin_amdgcn_s_memtime(), sb_r0 = __builtin_amdgcn_s_memrealtime();
+    uint64_t sb_loop0 = 0, sb_loop1 = 0;
+#endif
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    int* s_inbase = reinterpret_cast<int*>(smem + NBUF * BUF_BYTES);
-    int* s_yx = s_inbase + BP;
-    int* s_out = s_yx + BP;
-    float* s_stat = reinterpret_cast<float*>(s_out + BP);  // [WAVES_P][2][BC]
-    int* s_tap = reinterpret_cast<int*>(s_stat + WAVES_P * 2 * BC);   // [3][MDE_MAX_TAPS]: x offset, w offset, dy|dx
+    // HALO: [halo window: ceil(rows / 8) KiB][weight tile][s_out][s_tap]; the BatchNorm partial sums (epilogue only) live
+    // in the staging area behind the first epilogue slab, so that four (128 columns) / five (64) workgroups fit a CU
+    const int halo_bytes = HALO ? ((a.h_rows + 7) >> 3) * 1024 : 0;
+    static_assert(!HALO || EROWS * ROWB + WAVES_P * 2 * BC * 4 <= STG_BYTES, "statistics fit behind the epilogue slab");
+    int* s_inbase = reinterpret_cast<int*>(smem + (HALO ? halo_bytes + NBUF * WT_BYTES : NBUF * BUF_BYTES));
+    int* s_yx = HALO ? s_inbase : s_inbase + BP;                      // (HALO: no per-row gather tables)
+    int* s_out = HALO ? s_inbase : s_yx + BP;
+    float* s_stat = HALO ? reinterpret_cast<float*>(smem + EROWS * ROWB) : reinterpret_cast<float*>(s_out + BP);  // [WAVES_P][2][BC]
+    int* s_tap = HALO ? s_out + BP : reinterpret_cast<int*>(s_stat + WAVES_P * 2 * BC);   // [3][MDE_MAX_TAPS]: x offset, w offset, dy|dx
 
     const mde_conv_desc& d = a.d;
     const int tid = threadIdx.x;
@@ -142,6 +169,23 @@ __global__ __launch_bounds__(NT, (NT == 256 && BP * BC >= 256 * 256) ? 1 : (NBUF
     const int ci = a.col_fastest ? bid % a.nC : bid / a.nP;
     const int m0 = a.m_begin + pi * BP, n0 = ci * BC;
 
+    // HALO: tile pi = (image, tile row, tile column); pixel r of the tile = (r >> tws, r & (tw - 1)) of the block
+    int h_n = 0, h_gy0 = 0, h_gx0 = 0;
+    if constexpr (HALO) {
+        const int tpi = a.h_nty * a.h_ntx;
+        h_n = pi / tpi;
+        const int trem = pi - h_n * tpi, ty = trem / a.h_ntx;
+        h_gy0 = ty * a.h_th;
+        h_gx0 = (trem - ty * a.h_ntx) << a.h_tws;
+        for (int r = tid; r < BP; r += NT) {
+            const int gy = h_gy0 + (r >> a.h_tws), gx = h_gx0 + (r & ((1 << a.h_tws) - 1));
+            s_out[r] = (gy < d.GH && gx < d.GW) ? ((h_n * d.OH + gy * d.osy + d.ooy) * d.OW + gx * d.osx + d.oox) * d.ld_out : -1;
+        }
+        if (tid < d.ntaps) {
+            s_tap[tid] = (d.dy[tid] - a.h_dy0) * a.h_hw + (d.dx[tid] - a.h_dx0);     // halo-row offset of the tap
+            s_tap[MDE_MAX_TAPS + tid] = d.wtap[tid] * d.C;
+        }
+    } else {
     // ---- per-row decode, once per workgroup
     for (int r = tid; r < BP; r += NT) {
         const int m = m0 + r;
@@ -168,6 +212,7 @@ __global__ __launch_bounds__(NT, (NT == 256 && BP * BC >= 256 * 256) ? 1 : (NBUF
         s_tap[MDE_MAX_TAPS + tid] = d.wtap[tid] * d.C;
         s_tap[2 * MDE_MAX_TAPS + tid] = (tdy << 16) | (tdx & 0xFFFF);
     }
+    }   // !HALO
     __syncthreads();
 
     const int kslot8 = tid & 7;
@@ -178,8 +223,8 @@ __global__ __launch_bounds__(NT, (NT == 256 && BP * BC >= 256 * 256) ? 1 : (NBUF
     int x_base[XP], x_yx[XP];
 #pragma unroll
     for (int p = 0; p < XP; ++p) {
-        x_base[p] = s_inbase[p * RPL + lrow] + goff + kslot8 * 8;
-        x_yx[p] = s_yx[p * RPL + lrow];
+        x_base[p] = HALO ? 0 : s_inbase[p * RPL + lrow] + goff + kslot8 * 8;
+        x_yx[p] = HALO ? 0 : s_yx[p * RPL + lrow];
     }
     const int wrow_len = d.wtaps_total * d.C;
     int w_base[WP];
@@ -212,6 +257,9 @@ __global__ __launch_bounds__(NT, (NT == 256 && BP * BC >= 256 * 256) ? 1 : (NBUF
 
     // C need not be a multiple of BK: the last K-step of a tap is zero-filled past C (both operands) by sending
     // the 16-byte chunks beyond it to an out-of-range buffer offset (C % 8 == 0)
+    // K-steps run chunk-major in EVERY form of the loop: (64-channel chunk, tap), taps fastest.  The halo-tiled form needs that
+    // order (one window per chunk); the plain forms follow it so that a layer's result does not depend on which form its grid
+    // size selects: same operands into the same sequence of MFMAs = bit-identical output (eval outputs stay batch-invariant).
     const int csteps = (d.C + BK - 1) / BK;
     const int nsteps = d.ntaps * csteps;
     // two register staging sets: loads are issued TWO K-steps ahead of their use, so each has
@@ -238,7 +286,7 @@ __global__ __launch_bounds__(NT, (NT == 256 && BP * BC >= 256 * 256) ? 1 : (NBUF
 #pragma unroll
         for (int p = 0; p < WP; ++p)
             wr[p] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, kin ? (uint32_t)(w_base[p] + woff) * 2u : MDE_OOB_OFFSET, 0, 0);
-        if (++lcs == csteps) { lcs = 0; ++ltap; }
+        if (++ltap == d.ntaps) { ltap = 0; ++lcs; }
     };
     auto stage_write = [&](int buf, const i32x4_t (&xr)[XP], const i32x4_t (&wr)[WP]) {
         char* xbuf = smem + buf * BUF_BYTES;
@@ -299,8 +347,30 @@ __global__ __launch_bounds__(NT, (NT == 256 && BP * BC >= 256 * 256) ? 1 : (NBUF
         // per row: byte offset of the tap-origin pixel and a bitmask of the taps that stay inside
         // the image, computed once per tile so the K-loop spends ~3 VALU per DMA, not ~9
         uint32_t dx_base[XR], dx_ok[XR], dw_base[WR];
+        // HALO: byte offset of this lane's chunk of halo row h = (q * NW + wv) * 8 + lr (MDE_OOB_OFFSET: outside the image
+        // or past the window -> the DMA writes zeros = the convolution's padding); the window's fragment-read bases and
+        // the validity of this lane's pixels (a tile may hang over the image's edge)
+        // (the offsets are re-derived for every chunk by walking the window 32 rows at a time: eight of them held in registers
+        //  across the K-loop pushed the 128-column kernel over its 128-VGPR budget at four workgroups per CU)
+        int hb[PF];
+        uint32_t pvalid = 0;
+        int h_iy0 = 0, h_ix0 = 0;                   // input pixel of this lane's first halo row (q = 0)
+        if constexpr (HALO) {
+            const int h = wv * 8 + lr;
+            const int hy = h / a.h_hw;
+            h_iy0 = h_gy0 + a.h_dy0 + hy;
+            h_ix0 = h_gx0 + a.h_dx0 + (h - hy * a.h_hw);
+#pragma unroll
+            for (int j = 0; j < PF; ++j) {
+                const int p = wp * (PF * 16) + j * 16 + (lane & 15);
+                const int py = p >> a.h_tws, px = p & ((1 << a.h_tws) - 1);
+                hb[j] = py * a.h_hw + px;
+                pvalid |= (uint32_t)((h_gy0 + py < d.GH) & (h_gx0 + px < d.GW)) << j;
+            }
+        }
 #pragma unroll
         for (int q = 0; q < XR; ++q) {
+            if constexpr (HALO) { dx_base[q] = 0; dx_ok[q] = 0; continue; }
             const int row = (wv + q * NW) * 8 + lr;
             dx_base[q] = (uint32_t)(s_inbase[row] + goff + k8 * 8) * 2u;
             const int yx = s_yx[row];
@@ -339,7 +409,7 @@ __global__ __launch_bounds__(NT, (NT == 256 && BP * BC >= 256 * 256) ? 1 : (NBUF
                 const uint32_t offw = dw_base[q] + woff;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr)(xbuf + XT_BYTES + q * NW * 1024), 16, offw, 0, 0, 0);
             }
-            if (++lcs == csteps) { lcs = 0; ++ltap; }
+            if (++ltap == d.ntaps) { ltap = 0; ++lcs; }
         };
         constexpr int IPS = XR + WR;          // DMA instructions per wave per K-step
         constexpr int DIST = NBUF - 1;        // prefetch distance in K-steps
@@ -365,7 +435,7 @@ __global__ __launch_bounds__(NT, (NT == 256 && BP * BC >= 256 * 256) ? 1 : (NBUF
             constexpr int NEARLY = XE + 2;                      // pieces per early batch
             const bool grpB = wv >= NW / 2;
             int etap = 0, ecs = 0, ltap2 = 0, lcs2 = 0;        // load cursors of the early / late batch streams
-            auto advance = [&](int& tap, int& cs) { if (++cs == csteps) { cs = 0; ++tap; } };
+            auto advance = [&](int& tap, int& cs) { if (++tap == d.ntaps) { tap = 0; ++cs; } };
             auto issue_part = [&](int buf, int tap, int cs, int x0, int x1, int wpar) {
                 const uint32_t c0b = (uint32_t)(cs * BK) * 2u;
                 const bool kin = c0b < klimb;
@@ -492,19 +562,166 @@ __global__ __launch_bounds__(NT, (NT == 256 && BP * BC >= 256 * 256) ? 1 : (NBUF
 #undef PP_BARRIER
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
+        } else if constexpr (HALO) {
+            // K-steps run chunk-major: (64-channel chunk cc, tap t); the window of chunk cc is fetched once, ahead of its
+            // first tap.  The window's rows are read at ANY row offset (tile row x tap), so its bank swizzle is
+            // k-slot ^ (h & 7): every run of 16 consecutive rows then covers the 16 16-byte bank groups once whatever its
+            // start (with the weight tile's (row >> 1) & 7 only runs starting at a multiple of 4 do).
+            const int ninstr = (a.h_rows + 7) >> 3;
+            const int ks4 = lane >> 4;
+            const int k8h = (lane & 7) ^ lr;                   // h & 7 == lr: an instruction starts at a multiple of 8 rows
+            const uint32_t klimbh = (uint32_t)max(d.C - k8h * 8, 0) * 2u;
+#ifdef MDE_SB_STAMP
+#define SB_T() __builtin_amdgcn_s_memtime()
+#else
+#define SB_T() 0
+#endif
+            auto issue_window = [&](int cc) {
+                const uint32_t c0b = (uint32_t)(cc * BK) * 2u;
+                const bool kinh = c0b < klimbh;
+                int iy = h_iy0, ix = h_ix0, hrow = wv * 8 + lr;
+                const int xlim = h_gx0 + a.h_dx0 + a.h_hw;              // one past the window's last input column
+#pragma unroll
+                for (int q = 0; q < HALO_MAX_Q; ++q) {
+                    if (q * NW + wv < ninstr) {               // wave-uniform
+                        const bool ok = kinh & (hrow < a.h_rows) & ((uint32_t)iy < (uint32_t)d.H) & ((uint32_t)ix < (uint32_t)d.W);
+                        const uint32_t off = ok ? (uint32_t)(((h_n * d.H + iy) * d.W + ix) * d.ld_in + k8h * 8) * 2u + c0b : MDE_OOB_OFFSET;
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr)(smem + (q * NW + wv) * 1024), 16, off, 0, 0, 0);
+                    }
+                    hrow += NW * 8;                           // the next instruction of this wave: NW x 8 window rows on
+                    ix += a.h_step_x;
+                    iy += a.h_step_y;
+                    if (ix >= xlim) { ix -= a.h_hw; ++iy; }
+                }
+            };
+            auto issue_weights = [&](int buf, int cc, int t) {
+                const uint32_t c0b = (uint32_t)(cc * BK) * 2u;
+                const uint32_t woff = c0b < klimb ? (uint32_t)s_tap[MDE_MAX_TAPS + t] * 2u + c0b : MDE_OOB_OFFSET;
+                char* wdst = smem + halo_bytes + buf * WT_BYTES + wv * 1024;
+#pragma unroll
+                for (int q = 0; q < WR; ++q) {
+                    const uint32_t offw = dw_base[q] + woff;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr)(wdst + q * NW * 1024), 16, offw, 0, 0, 0);
+                }
+            };
+            auto window_addr = [&](int t, int (&ha)[PF]) {    // row h of the window, k-slot XORed with h & 7 (the DMA's swizzle)
+                const int toff = s_tap[t];
+#pragma unroll
+                for (int j = 0; j < PF; ++j) {
+                    const int h = hb[j] + toff;
+                    ha[j] = h * 128 + ((ks4 ^ (h & 7)) << 4);
+                }
+            };
+            auto compute_step = [&](int buf, const int (&ha)[PF]) {
+                const char* wbuf = smem + halo_bytes + buf * WT_BYTES + wc * (CF * 2048);
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
+                    bf16x8_t fa[CF], fb[PF];
+#pragma unroll
+                    for (int i = 0; i < CF; ++i) fa[i] = *reinterpret_cast<const bf16x8_t*>(wbuf + i * 2048 + rd_off[kb]);
+#pragma unroll
+                    for (int j = 0; j < PF; ++j) fb[j] = *reinterpret_cast<const bf16x8_t*>(smem + (ha[j] ^ (kb << 6)));
+#pragma unroll
+                    for (int i = 0; i < CF; ++i)
+#pragma unroll
+                        for (int j = 0; j < PF; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                }
+            };
+            int cc = 0, t = 0;
+#ifdef MDE_SB_STAMP
+            sb_loop0 = SB_T();
+#endif
+            if constexpr (NBUF == 1) {
+                for (int s = 0; s < nsteps; ++s) {
+                    if (s) __builtin_amdgcn_s_barrier();      // every wave is done reading step s-1 (weights; window if t == 0)
+                    if (t == 0) issue_window(cc);
+                    issue_weights(0, cc, t);
+                    int ha[PF];
+                    window_addr(t, ha);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                    compute_step(0, ha);
+                    if (++t == d.ntaps) { t = 0; ++cc; }
+                }
+            } else {
+                // 8 waves, 256 pixels, a two-deep ring for the weight tiles: the weights of step s+1 are fetched under the
+                // MFMAs of step s (a wave issues 2 weight pieces per 32 MFMAs here, against 8 pieces in the plain 128x128
+                // tile: the wave's issue slot, ~180 cycles per LDS-DMA instruction, was what the plain loop spent half its
+                // K-step in).  The window has ONE buffer: at a chunk boundary every wave must have finished the old chunk's
+                // last tap before the new window is fetched, so that fetch is exposed once per chunk (ntaps steps); the
+                // other workgroup of the CU runs meanwhile.
+                issue_window(0);
+                issue_weights(0, 0, 0);
+                for (int s = 0; s < nsteps; ++s) {
+                    const int cur = s & 1;
+                    int tn = t + 1, cn = cc;
+                    if (tn == d.ntaps) { tn = 0; ++cn; }
+                    int ha[PF];
+                    window_addr(t, ha);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of step s (and of a new window)
+                    __builtin_amdgcn_s_barrier();                         // everyone's are in; everyone left step s-1
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (s + 1 < nsteps) issue_weights(cur ^ 1, cn, tn);
+                    compute_step(cur, ha);
+                    if (tn == 0 && s + 1 < nsteps) {
+                        __builtin_amdgcn_s_barrier();                     // the old window is dead
+                        issue_window(cn);
+                    }
+                    t = tn;
+                    cc = cn;
+                }
+            }
+#ifdef MDE_SB_STAMP
+            sb_loop1 = SB_T();
+#endif
+            __syncthreads();
+            // a tile may hang over the image's edge: those pixels' results are never stored and must not reach the
+            // BatchNorm sums (their window rows are real pixels of the image)
+            if (a.stats) {
+#pragma unroll
+                for (int j = 0; j < PF; ++j)
+                    if (!((pvalid >> j) & 1u))
+#pragma unroll
+                        for (int i = 0; i < CF; ++i) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            }
         } else if constexpr (NBUF == 1) {
             // Short-K shapes (1x1 convolutions over 64 ... 256 channels are one to four K-steps: all prologue and
             // epilogue, HBM-bound): ONE staging buffer, so that twice as many workgroups fit a CU and one workgroup's
             // operand fetch overlaps its neighbours' epilogue stores — the overlap a ring inside one workgroup cannot give
             // a loop this short.
+#ifdef MDE_SB_STAMP
+            // diagnostic build: cycles of wave 0 of one mid-grid workgroup per loop phase, into the `stats` buffer (uint64):
+            // [0] top barrier, [1] DMA issue, [3] vmcnt wait, [4] barrier after the wait, [5] LDS reads + MFMA issue, [6] K-steps
+            uint64_t tacc[7] = {0, 0, 0, 0, 0, 0, 0};
+#define SB_ADD(i, tt) tacc[i] += SB_T() - (tt)
+            sb_loop0 = SB_T();
+#else
+#define SB_ADD(i, tt)
+#endif
             for (int s = 0; s < nsteps; ++s) {
+                [[maybe_unused]] uint64_t t0 = SB_T();
                 if (s) __builtin_amdgcn_s_barrier();          // every wave is done reading step s-1
+                SB_ADD(0, t0); t0 = SB_T();
                 issue_dma(0);
+                SB_ADD(1, t0); t0 = SB_T();
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                SB_ADD(3, t0); t0 = SB_T();
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
+                SB_ADD(4, t0); t0 = SB_T();
                 compute(0);
+                SB_ADD(5, t0);
             }
+#ifdef MDE_SB_STAMP
+            sb_loop1 = SB_T();
+            if (a.stats && blockIdx.x == gridDim.x / 2 && tid == 0) {
+                uint64_t* o = reinterpret_cast<uint64_t*>(a.stats + MDE_STAT_SLOTS * 2 * d.ncols);   // behind the partial sums
+                for (int i = 0; i < 6; ++i) o[i] = tacc[i];
+                o[6] = (uint64_t)nsteps;
+            }
+#endif
             __syncthreads();
         } else {
 #pragma unroll
@@ -620,7 +837,7 @@ __global__ __launch_bounds__(NT, (NT == 256 && BP * BC >= 256 * 256) ? 1 : (NBUF
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 if (more) {
-                    if (++lcs == csteps) { lcs = 0; ++ltap; }
+                    if (++ltap == d.ntaps) { ltap = 0; ++lcs; }
                     lbuf = lbuf + 1 == NBUF ? 0 : lbuf + 1;
                 }
                 cbuf = cbuf + 1 == NBUF ? 0 : cbuf + 1;
@@ -816,6 +1033,17 @@ __global__ __launch_bounds__(NT, (NT == 256 && BP * BC >= 256 * 256) ? 1 : (NBUF
             }
         }
     }
+#ifdef MDE_SB_STAMP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (a.stats && blockIdx.x == gridDim.x / 2 && tid == 0) {
+        uint64_t* o = reinterpret_cast<uint64_t*>(a.stats + MDE_STAT_SLOTS * 2 * d.ncols);
+        const uint64_t k1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+        o[7] = sb_loop0 - sb_k0;      // prologue
+        o[8] = sb_loop1 - sb_loop0;   // K-loop
+        o[9] = k1 - sb_loop1;         // epilogue (stores drained)
+        o[10] = r1 - sb_r0;           // the same span in 100 MHz ticks
+    }
+#endif
 }
 
 template <int BP, int BC, int NT, int NBUF>
@@ -844,6 +1072,77 @@ int launch(KArgs& ka, int64_t M, hipStream_t st) {
     return MDE_OK;
 }
 
+// ---- the halo-tiled form: eligibility, tile shape, launch
+// Eligible: stride-1 gathers (forward 3x3 / dilated 3x3, stride-1 input gradients, the up-projection's and the strided
+// input gradient's output phases), >= 2 taps, not grouped, and a window of at most 256 pixels for some 128-pixel block shape.
+struct HaloPlan {
+    int ok;
+    int tws, th, nty, ntx, hw, rows, dy0, dx0;
+    double dma_rows;      // 128-byte rows through the DMA path per 64-channel chunk, whole launch (what the form is chosen by)
+    int64_t tiles;
+};
+HaloPlan halo_plan(const mde_conv_desc& d, int bp, int bc) {
+    HaloPlan best{};
+    if (d.sy != 1 || d.sx != 1 || d.grouped || d.ntaps < 2) return best;
+    int dy0 = d.dy[0], dy1 = d.dy[0], dx0 = d.dx[0], dx1 = d.dx[0];
+    for (int t = 1; t < d.ntaps; ++t) {
+        dy0 = d.dy[t] < dy0 ? d.dy[t] : dy0;
+        dy1 = d.dy[t] > dy1 ? d.dy[t] : dy1;
+        dx0 = d.dx[t] < dx0 ? d.dx[t] : dx0;
+        dx1 = d.dx[t] > dx1 ? d.dx[t] : dx1;
+    }
+    const int nw = bp / 32;                                   // waves: 4 for the 128-pixel tile, 8 for the 256-pixel one
+    for (int tws = 1; (bp >> tws) >= 2; ++tws) {
+        const int tw = 1 << tws, th = bp >> tws;
+        const int hw = tw + (dx1 - dx0), rows = (th + (dy1 - dy0)) * hw;
+        if (rows > HALO_MAX_Q * nw * 8) continue;
+        const int nty = mde_cdiv(d.GH, th), ntx = mde_cdiv(d.GW, tw);
+        const int64_t tiles = (int64_t)d.N * nty * ntx * mde_cdiv(d.ncols, bc);
+        const double cost = (double)tiles * (((rows + 7) & ~7) + d.ntaps * bc);
+        if (!best.ok || cost < best.dma_rows) best = HaloPlan{1, tws, th, nty, ntx, hw, rows, dy0, dx0, cost, tiles};
+    }
+    return best;
+}
+
+template <int BP, int BC>
+int launch_halo(KArgs& ka, const HaloPlan& hp, hipStream_t st) {
+    constexpr int NT = BP * 2, NBUF = BP == 128 ? 1 : 2, NW = NT / 64;
+    static bool attr_done = false;
+    constexpr size_t fixed = (size_t)NBUF * BC * BK * 2 + BP * sizeof(int) + 3 * MDE_MAX_TAPS * sizeof(int);
+    const void* fn = reinterpret_cast<const void*>(&conv_gemm_nt<BP, BC, NT, true, NBUF, false, true>);
+    if (!attr_done) {
+        int rc = mde_check_hip(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)HALO_MAX_Q * NW * 1024 + fixed)),
+                               "hipFuncSetAttribute(conv_gemm_nt halo)");
+        if (rc) return rc;
+        attr_done = true;
+    }
+    ka.h_tws = hp.tws; ka.h_th = hp.th; ka.h_nty = hp.nty; ka.h_ntx = hp.ntx;
+    ka.h_hw = hp.hw; ka.h_rows = hp.rows; ka.h_dy0 = hp.dy0; ka.h_dx0 = hp.dx0;
+    ka.h_step_y = (NW * 8) / hp.hw; ka.h_step_x = (NW * 8) % hp.hw;
+    ka.nP = ka.d.N * hp.nty * hp.ntx;
+    ka.nC = mde_cdiv(ka.d.ncols, BC);
+    const size_t smem = (size_t)((hp.rows + 7) >> 3) * 1024 + fixed;
+    if (getenv("MDE_CONV_OCC")) {       // diagnostics: resident workgroups per CU the runtime computes for this launch
+        int nb = 0;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, NT, smem);
+        fprintf(stderr, "conv_gemm_nt<%d,%d,halo>: %zu B LDS, %d workgroups per CU, window %d rows (tile %dx%d), grid %d\n", BP, BC, smem, nb,
+                hp.rows, hp.th, 1 << hp.tws, ka.nP * ka.nC);
+    }
+    conv_gemm_nt<BP, BC, NT, true, NBUF, false, true><<<dim3(ka.nP * ka.nC), dim3(NT), smem, st>>>(ka);
+    MDE_LAUNCH_CHECK("conv_gemm_nt(halo)");
+    return MDE_OK;
+}
+
+int cus_() {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+    }
+    return cus;
+}
+
 // Tile choice: the biggest workgroup tile whose grid still fills the chip about twice over
 // (one 8-wave workgroup per CU for the 256-pixel tiles).  Diagnostics: MDE_CONV_TILE=<BP>x<BC>
 // forces a tile, MDE_CONV_PATH=reg selects the register-staged main loop instead of LDS-DMA.
@@ -861,6 +1160,31 @@ int pick_and_launch(KArgs& ka, int64_t M, hipStream_t st) {
         reg = q && !strcmp(q, "reg");
     }
     const int n = ka.d.ncols;
+    {
+        // MDE_CONV_HALO: 1 = the halo-tiled form wherever it is eligible (diagnostics / tests), 0 = never
+        // MDE_CONV_HALO (read per call: the tests switch it between launches): 0 = never the halo-tiled form; 1 / 2 = the
+        // 128-pixel single-buffer / the 256-pixel two-deep-weight-ring form wherever eligible (diagnostics, tests); unset =
+        // the 256-pixel form where it measured faster in-network (tools/per_shape_diff.py over `bench.py --per-shape` runs
+        // with the form forced): >= 4 taps (2-tap phases lost 7-24 %), a grid of at least two workgroups per CU for each of the
+        // two resident slots (150 x 2 tiles lost 3-12 %, 600 tiles won 4-9 %), and tiles that mostly lie inside the image (a
+        // 15 x 20 map covers 59 % of its two 16 x 16 blocks: -10 %).  The 128-pixel form lost to the plain tiles on most
+        // shapes (its K-step still waits out a full DMA latency) and is never chosen.
+        const char* he = getenv("MDE_CONV_HALO");
+        const int halo = !he ? -1 : atoi(he);
+        if (halo != 0 && forced == 0 && !reg) {
+            const int bc = n <= 64 ? 64 : 128, bp = halo == 1 ? 128 : 256;
+            const HaloPlan hp = halo_plan(ka.d, bp, bc);
+            bool take = hp.ok;
+            if (take && halo < 0) {
+                const double fill = (double)M / ((double)ka.d.N * hp.nty * hp.ntx * bp);
+                take = ka.d.ntaps >= 4 && hp.tiles >= 2 * cus_() && fill >= 0.75;
+            }
+            if (take) {
+                if (bp == 128) return bc == 64 ? launch_halo<128, 64>(ka, hp, st) : launch_halo<128, 128>(ka, hp, st);
+                return bc == 64 ? launch_halo<256, 64>(ka, hp, st) : launch_halo<256, 128>(ka, hp, st);
+            }
+        }
+    }
     const bool pp = gpp == 1 || (gpp == 2 && ka.d.ntaps * ((ka.d.C + BK - 1) / BK) >= 18);
     if (forced == 10 && !ka.d.grouped) return launch<128, 64, 256, true, 1>(ka, M, st);      // diagnostics: 64-column single-buffer tile everywhere
     if (n <= 64 || ka.d.grouped) {
@@ -877,12 +1201,7 @@ int pick_and_launch(KArgs& ka, int64_t M, hipStream_t st) {
         if (reg) return launch<128, 64, 256, false, 2>(ka, M, st);
         return (ring64 || forced == 6) ? launch<128, 64, 256, true, 2>(ka, M, st) : launch<128, 64, 256, true, 1>(ka, M, st);
     }
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
-    }
+    const int cus = cus_();
     // Cost model fitted to in-network timings: kernel time = rounds x work per resident
     // slot per round / per-flop rate; a CU hosts one 8-wave workgroup (256x256: rate 1.15, 192x256: 1.10)
     // or two 4-wave 128x128 workgroups (rate 1.0).  What decides between them is the tail round.
@@ -1013,6 +1332,7 @@ extern "C" int mde_conv_gemm(const mde_conv_desc* d, const void* in, const void*
         ka.col_fastest = order;
     }
     ka.det = g_mde_det.on;
+    ka.h_tws = ka.h_th = ka.h_nty = ka.h_ntx = ka.h_hw = ka.h_rows = ka.h_dy0 = ka.h_dx0 = ka.h_step_y = ka.h_step_x = 0;
     ka.vec_ok = (d->ld_out % 8 == 0) && (((uintptr_t)out % 16) == 0);
     return pick_and_launch(ka, M, reinterpret_cast<hipStream_t>(stream));
 }

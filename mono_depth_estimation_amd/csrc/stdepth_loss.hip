@@ -484,7 +484,121 @@ inline int grid_for(int64_t n) {
     return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
 }
 
+// ------------------------------------------------------------------------------------------ the 'ssim' metric
+// metrics.py:123 maps 'ssim' to torchmetrics.functional.structural_similarity_index_measure (torchmetrics 0.7.3, absent from
+// the image; restated from its published definition, functional/image/ssim.py): 11 x 11 Gaussian window (sigma 1.5),
+// data_range = max(max p - min p, max t - min t), c1 = (0.01 R)^2, c2 = (0.03 R)^2, the map of
+//   (2 mu_p mu_t + c1)(2 s_pt + c2) / ((mu_p^2 + mu_t^2 + c1)(s_p + s_t + c2))
+// computed on the reflect-padded planes and then CROPPED by the 5-pixel pad, so what is averaged is exactly the pixels
+// whose window lies inside the image (the padding never reaches them): mean over [5, H-5) x [5, W-5) of every plane.
+// The reference hands it clamp_min(pred, 1e-7) and the unmasked target (metrics.py:58-63).
+struct SsimMetricWs {
+    unsigned lo_p, hi_p, lo_t, hi_t;   // order-preserving integer images of the extrema (float_key)
+    unsigned pad0, pad1;
+    double sum;
+};
+__device__ __forceinline__ unsigned float_key(float v) {
+    const unsigned u = __float_as_uint(v);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key_float(unsigned k) {
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
+}
+__global__ __launch_bounds__(NT) void ssim_metric_range_k(const float* __restrict__ P, const float* __restrict__ T, int64_t n,
+                                                          SsimMetricWs* __restrict__ ws) {
+    float lp = __builtin_inff(), hp = -__builtin_inff(), lt = lp, ht = hp;
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
+        const float p = fmaxf(P[i], 1e-7f), t = T[i];
+        lp = fminf(lp, p); hp = fmaxf(hp, p); lt = fminf(lt, t); ht = fmaxf(ht, t);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        lp = fminf(lp, __shfl_xor(lp, o, 64)); hp = fmaxf(hp, __shfl_xor(hp, o, 64));
+        lt = fminf(lt, __shfl_xor(lt, o, 64)); ht = fmaxf(ht, __shfl_xor(ht, o, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMin(&ws->lo_p, float_key(lp)); atomicMax(&ws->hi_p, float_key(hp));
+        atomicMin(&ws->lo_t, float_key(lt)); atomicMax(&ws->hi_t, float_key(ht));
+    }
+}
+__global__ __launch_bounds__(NT) void ssim_metric_k(const float* __restrict__ P, const float* __restrict__ T, int H, int W, int tiles_x,
+                                                    Gauss gw, SsimMetricWs* __restrict__ ws) {
+    __shared__ float sp[SH][SWP], st[SH][SWP];
+    __shared__ float hz[5][SH][TW];
+    __shared__ double sh[NT / 64];
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int y0 = ty * TH, x0 = tx * TW;
+    const int64_t plane = (int64_t)blockIdx.y * H * W;
+    const float R = fmaxf(key_float(ws->hi_p) - key_float(ws->lo_p), key_float(ws->hi_t) - key_float(ws->lo_t));
+    const float C1 = (0.01f * R) * (0.01f * R), C2 = (0.03f * R) * (0.03f * R);
+    for (int i = threadIdx.x; i < SH * SW; i += NT) {
+        const int r = i / SW, c = i - r * SW;
+        const int y = y0 + r - HALO, x = x0 + c - HALO;
+        const bool in = y >= 0 && y < H && x >= 0 && x < W;     // (windows that leave the image are never averaged)
+        sp[r][c] = in ? fmaxf(P[plane + (int64_t)y * W + x], 1e-7f) : 0.f;
+        st[r][c] = in ? T[plane + (int64_t)y * W + x] : 0.f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < SH * TW; i += NT) {
+        const int r = i / TW, x = i - r * TW;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 11; ++k) {
+            const float p = sp[r][x + k], t = st[r][x + k], w = gw.w[k];
+            a0 += w * p; a1 += w * t; a2 += w * (p * p); a3 += w * (t * t); a4 += w * (p * t);
+        }
+        hz[0][r][x] = a0; hz[1][r][x] = a1; hz[2][r][x] = a2; hz[3][r][x] = a3; hz[4][r][x] = a4;
+    }
+    __syncthreads();
+    const int x = threadIdx.x & 63, rb = (threadIdx.x >> 6) * 4;
+    double part = 0.0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = rb + j, y = y0 + r, xx = x0 + x;
+        float mu1 = 0.f, mu2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 11; ++k) {
+            const float w = gw.w[k];
+            mu1 += w * hz[0][r + k][x]; mu2 += w * hz[1][r + k][x]; e11 += w * hz[2][r + k][x];
+            e22 += w * hz[3][r + k][x]; e12 += w * hz[4][r + k][x];
+        }
+        if (y >= HALO && y < H - HALO && xx >= HALO && xx < W - HALO) {
+            const float s1 = e11 - mu1 * mu1, s2 = e22 - mu2 * mu2, s12 = e12 - mu1 * mu2;
+            part += (double)(((2.f * mu1 * mu2 + C1) * (2.f * s12 + C2)) / ((mu1 * mu1 + mu2 * mu2 + C1) * (s1 + s2 + C2)));
+        }
+    }
+    const double r = block_sum_d(part, sh);
+    if (threadIdx.x == 0) atomicAdd(&ws->sum, r);
+}
+__global__ void ssim_metric_init_k(SsimMetricWs* ws) {
+    ws->lo_p = ws->lo_t = 0xFFFFFFFFu;
+    ws->hi_p = ws->hi_t = 0u;
+    ws->sum = 0.0;
+}
+__global__ void ssim_metric_finish_k(const SsimMetricWs* ws, double count, float* out) { out[0] = (float)(ws->sum / count); }
 }  // namespace
+
+extern "C" size_t mde_ssim_metric_ws_bytes(void) { return sizeof(SsimMetricWs); }
+
+extern "C" int mde_ssim_metric(const float* pred, const float* target, int planes, int H, int W, void* ws, float* out, void* stream) {
+    MDE_REQUIRE(pred && target && ws && out && planes > 0, "mde_ssim_metric: bad argument");
+    MDE_REQUIRE(H > 2 * HALO && W > 2 * HALO, "mde_ssim_metric: the 11 x 11 window needs maps larger than 10 x 10 (got %d x %d)", H, W);
+    MDE_REQUIRE(((uintptr_t)ws % 8) == 0, "mde_ssim_metric: ws must be 8-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    SsimMetricWs* w = reinterpret_cast<SsimMetricWs*>(ws);
+    const int64_t n = (int64_t)planes * H * W;
+    ssim_metric_init_k<<<1, 1, 0, st>>>(w);
+    MDE_LAUNCH_CHECK("ssim_metric_init_k");
+    const int64_t nb = (n + NT * 8 - 1) / (NT * 8);
+    ssim_metric_range_k<<<(int)(nb > 2048 ? 2048 : nb), NT, 0, st>>>(pred, target, n, w);
+    MDE_LAUNCH_CHECK("ssim_metric_range_k");
+    const int tiles_x = (W + TW - 1) / TW, tiles = tiles_x * ((H + TH - 1) / TH);
+    ssim_metric_k<<<dim3(tiles, planes), NT, 0, st>>>(pred, target, H, W, tiles_x, make_gauss(), w);
+    MDE_LAUNCH_CHECK("ssim_metric_k");
+    ssim_metric_finish_k<<<1, 1, 0, st>>>(w, (double)planes * (H - 2 * HALO) * (W - 2 * HALO), out);
+    MDE_LAUNCH_CHECK("ssim_metric_finish_k");
+    return MDE_OK;
+}
 
 extern "C" size_t mde_stdepth_ws_bytes(void) { return sizeof(StHead); }
 

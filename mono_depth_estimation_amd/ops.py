@@ -677,6 +677,14 @@ def depth_metrics(pred, target, ws, out):
           "mde_depth_metrics")
 
 
+def ssim_metric(pred, target, out):
+    """torchmetrics-0.7.3-style SSIM of clamp_min(pred, 1e-7) against target (fp32 [N][C][H][W]) into out[0]."""
+    lib = _lib.load()
+    ws = torch.zeros((lib.mde_ssim_metric_ws_bytes() + 7) // 8, dtype=torch.float64, device=pred.device)
+    check(lib.mde_ssim_metric(_p(pred), _p(target), pred.numel() // (pred.shape[-1] * pred.shape[-2]), pred.shape[-2], pred.shape[-1],
+                              _p(ws), _p(out), _stream()), "mde_ssim_metric")
+
+
 # ------------------------------------------------------------------------------ optimiser plumbing
 def fingerprint_state(device="cuda"):
     return torch.zeros((_lib.load().mde_param_fingerprint_state_bytes() + 7) // 8, dtype=torch.int64, device=device)

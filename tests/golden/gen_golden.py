@@ -260,6 +260,25 @@ def gen_metrics(metrics):
     print("metrics.npz", {k: float(out[k]) for k in mc.names})
 
 
+def gen_ssim():
+    """Anchor for the 'ssim' metric.  The reference maps that name to torchmetrics' structural_similarity_index_measure
+    (metrics.py:123; torchmetrics is absent from the image), so its value cannot be minted here.  What CAN be taken from the
+    reference is its own in-tree SSIM (stdepth_utils.py:90-121, imports as is): the same 11-tap sigma-1.5 Gaussian window
+    and the same index.  It differs from torchmetrics' in three conventions only -- zero 'same' padding instead of reflect
+    padding + crop, a fixed data_range, the clamp of the contrast term -- none of which touches a pixel whose window lies
+    inside the image when data_range is passed in and the clamp is off.  So: the reference's SSIM map with the tensors'
+    own data_range, unclamped, averaged over the interior [5, H-5) x [5, W-5) = what torchmetrics' definition averages."""
+    import stdepth_utils
+    noise, tgt = depth_pair(17, (3, 2, 40, 56))
+    pred = 0.8 * tgt + 0.6 * (noise - 0.5)            # a prediction correlated with its target (SSIM around one half), some of it < 0
+    p = torch.clamp_min(pred, 1e-7)
+    R = max(float(p.max() - p.min()), float(tgt.max() - tgt.min()))
+    m = stdepth_utils.ssim(p, tgt, dim=2, data_range=R, nonnegative_ssim=False, reduction="none")
+    out = {"pred": _np(pred), "tgt": _np(tgt), "data_range": np.float64(R), "ssim_interior": _np(m[..., 5:-5, 5:-5].mean())}
+    np.savez_compressed(os.path.join(HERE, "ssim.npz"), **out)
+    print("ssim.npz", float(out["ssim_interior"]), "data_range", R)
+
+
 def gen_upproj(FCRN):
     """G4: reference Unpool and UpProjModule(16), fwd + input/weight grads, train-mode BN."""
     torch.manual_seed(0)
@@ -763,6 +782,8 @@ def main():
         gen_stdepth(criteria)
     if want("metrics"):
         gen_metrics(metrics)
+    if want("ssim"):
+        gen_ssim()
     if want("upproj"):
         gen_upproj(FCRN)
     if want("fcrn"):

@@ -37,3 +37,44 @@ def test_bench_two_ranks_on_one_gpu(extra, port, exchange):
         assert d["config"]["replica_drift"] == 0.0, d["config"]
     else:
         assert d["config"]["replica_drift"] > 0.0, "the drift check cannot tell a working exchange from none"
+
+
+@pytest.mark.parametrize("dtype,algo,port", [("fp32", "allreduce", 29651), ("bf16", "allreduce", 29652),
+                                             ("fp32", "rs_ag", 29653), ("bf16", "rs_ag", 29654)])
+def test_bench_one_rank_over_rccl(dtype, algo, port):
+    """The RCCL path itself (backend `nccl`: exchange stream, events, async collectives, wire buffers), which the two-rank
+    rehearsal above cannot reach on one GPU: ONE rank launched the way the driver launches N, collectives forced although the
+    world is 1 (a sum over one rank is the identity), both wire formats and both algorithms.  The loss must come out as in a
+    run without any process group (fp32 wire: the same arithmetic; bf16 wire: gradients rounded once to 8 bits)."""
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--batch", "2", "--no-cpu-baseline",
+            "--no-launch-timing"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r0 = subprocess.run(base, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r0.returncode == 0, r0.stderr[-3000:]
+    ref = json.loads([l for l in r0.stdout.splitlines() if l.startswith("{")][0])
+    env.update(MDE_DP_FORCE="1", MDE_DP_ALGO=algo, MDE_DP_BUCKET_MB="64")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port)] + base[1:] + ["--gpus", "1", "--grad-dtype", dtype]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 1 and d["config"]["replica_drift"] == 0.0
+    a, b = d["config"]["final_loss"], ref["config"]["final_loss"]
+    assert a == a and abs(a - b) <= (5e-3 if dtype == "fp32" else 2e-2) * abs(b), (a, b)
+
+
+@pytest.mark.parametrize("config", ["bts", "midas", "vnl"])
+def test_bench_other_configurations_print_the_contract_line(config):
+    """`bench.py --config` runs BASELINE.json configurations 3 / 4 / 5 through the same contract (here at batch 2)."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--config", config, "--steps", "2", "--warmup", "1", "--batch", "2"]
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["value"] > 0 and d["config"]["per_gpu_batch"] == 2
+    assert d["config"]["final_loss"] == d["config"]["final_loss"]
+    assert d["roofline"]["launches"] > 0 and 0.0 < d["roofline"]["frac"] < 1.0 and config.upper()[:3] in d["config"]["workload"].upper()

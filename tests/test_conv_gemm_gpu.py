@@ -10,6 +10,26 @@ from oracle import weights as W
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["auto", "plain", "halo128", "halo256"])
+def conv_form(request):
+    """Every test of this file runs four times: with the library's own choice between the plain tiles and the halo-tiled
+    form (a 2-D pixel block whose input window is staged once per 64-channel chunk and shared by the taps), with the halo
+    form switched off, and with each of its two kernels forced wherever the geometry is eligible (MDE_CONV_HALO is read on
+    every call)."""
+    import os
+    old = os.environ.get("MDE_CONV_HALO")
+    val = {"auto": None, "plain": "0", "halo128": "1", "halo256": "2"}[request.param]
+    if val is None:
+        os.environ.pop("MDE_CONV_HALO", None)
+    else:
+        os.environ["MDE_CONV_HALO"] = val
+    yield request.param
+    if old is None:
+        os.environ.pop("MDE_CONV_HALO", None)
+    else:
+        os.environ["MDE_CONV_HALO"] = old
+
+
 def _bf(t):
     return t.to(torch.bfloat16).to(torch.float32)
 

@@ -309,3 +309,15 @@ def test_fcrn_in_channels(golden, cin):
     loss.backward()
     _close(loss.detach(), g[tag + "_train_silog"], rtol=1e-4)
     _close(net.conv1.weight.grad, g[tag + "_conv1_grad"], rtol=2e-3, atol=2e-3 * float(np.abs(g[tag + "_conv1_grad"]).max()))
+
+
+def test_ssim_metric_restatement_against_the_reference_window(golden):
+    """'ssim' is a torchmetrics call in the reference (metrics.py:123; absent here): the oracle restates torchmetrics 0.7.3's
+    published definition, and tests/golden/ssim.npz anchors it to the reference's OWN SSIM code (stdepth_utils.ssim, same
+    window and index) on the pixels where the two definitions coincide -- see gen_golden.gen_ssim."""
+    g = golden("ssim")
+    got = M.ssim(_t(g["pred"]), _t(g["tgt"]))
+    assert 0.2 < float(g["ssim_interior"]) < 0.9
+    _close(got, g["ssim_interior"], rtol=2e-5)
+    x = _t(g["tgt"]) + 0.5
+    assert abs(float(M.ssim(x, x)) - 1.0) < 1e-6
