@@ -83,6 +83,8 @@ struct KArgs {
     int32_t h_nty, h_ntx;         // tiles per image
     int32_t h_hw, h_rows;         // halo width (pixels), halo rows (pixels) in all
     int32_t h_dy0, h_dx0;         // smallest tap offsets: halo pixel (0, 0) is input (gy0 + dy0, gx0 + dx0)
+    int32_t h_dil;                // dilation D: the tile is a block of ONE parity class (rows % D, columns % D) of the output grid,
+                                  // in whose own coordinates the taps are D times closer (a dilated 3x3 has a (th + 2) x (tw + 2) window)
     int32_t h_step_y, h_step_x;   // a wave's next window instruction is (waves x 8) rows on: that many / hw lines down, % hw pixels right (+ one carry)
 };
 
@@ -170,19 +172,23 @@ __global__ __launch_bounds__(NT, HALO ? (NT == 512 ? 4 : BC <= 64 ? 5 : 4)
     const int m0 = a.m_begin + pi * BP, n0 = ci * BC;
 
     // HALO: tile pi = (image, tile row, tile column); pixel r of the tile = (r >> tws, r & (tw - 1)) of the block
-    int h_n = 0, h_gy0 = 0, h_gx0 = 0;
+    int h_n = 0, h_gy0 = 0, h_gx0 = 0, h_ry = 0, h_rx = 0;
     if constexpr (HALO) {
-        const int tpi = a.h_nty * a.h_ntx;
+        // tile pi = (image, parity class, tile row, tile column); h_gy0 / h_gx0 are in the class's own coordinates: class pixel
+        // (y, x) is grid pixel (y * D + ry, x * D + rx)
+        const int tpc = a.h_nty * a.h_ntx, D = a.h_dil, tpi = tpc * D * D;
         h_n = pi / tpi;
-        const int trem = pi - h_n * tpi, ty = trem / a.h_ntx;
+        const int irem = pi - h_n * tpi, cls = irem / tpc, trem = irem - cls * tpc, ty = trem / a.h_ntx;
+        h_ry = cls / D;
+        h_rx = cls - h_ry * D;
         h_gy0 = ty * a.h_th;
         h_gx0 = (trem - ty * a.h_ntx) << a.h_tws;
         for (int r = tid; r < BP; r += NT) {
-            const int gy = h_gy0 + (r >> a.h_tws), gx = h_gx0 + (r & ((1 << a.h_tws) - 1));
+            const int gy = (h_gy0 + (r >> a.h_tws)) * D + h_ry, gx = (h_gx0 + (r & ((1 << a.h_tws) - 1))) * D + h_rx;
             s_out[r] = (gy < d.GH && gx < d.GW) ? ((h_n * d.OH + gy * d.osy + d.ooy) * d.OW + gx * d.osx + d.oox) * d.ld_out : -1;
         }
         if (tid < d.ntaps) {
-            s_tap[tid] = (d.dy[tid] - a.h_dy0) * a.h_hw + (d.dx[tid] - a.h_dx0);     // halo-row offset of the tap
+            s_tap[tid] = (d.dy[tid] / D - a.h_dy0) * a.h_hw + (d.dx[tid] / D - a.h_dx0);     // halo-row offset of the tap (class coordinates)
             s_tap[MDE_MAX_TAPS + tid] = d.wtap[tid] * d.C;
         }
     } else {
@@ -365,7 +371,7 @@ __global__ __launch_bounds__(NT, HALO ? (NT == 512 ? 4 : BC <= 64 ? 5 : 4)
                 const int p = wp * (PF * 16) + j * 16 + (lane & 15);
                 const int py = p >> a.h_tws, px = p & ((1 << a.h_tws) - 1);
                 hb[j] = py * a.h_hw + px;
-                pvalid |= (uint32_t)((h_gy0 + py < d.GH) & (h_gx0 + px < d.GW)) << j;
+                pvalid |= (uint32_t)(((h_gy0 + py) * a.h_dil + h_ry < d.GH) & ((h_gx0 + px) * a.h_dil + h_rx < d.GW)) << j;
             }
         }
 #pragma unroll
@@ -584,8 +590,9 @@ __global__ __launch_bounds__(NT, HALO ? (NT == 512 ? 4 : BC <= 64 ? 5 : 4)
 #pragma unroll
                 for (int q = 0; q < HALO_MAX_Q; ++q) {
                     if (q * NW + wv < ninstr) {               // wave-uniform
-                        const bool ok = kinh & (hrow < a.h_rows) & ((uint32_t)iy < (uint32_t)d.H) & ((uint32_t)ix < (uint32_t)d.W);
-                        const uint32_t off = ok ? (uint32_t)(((h_n * d.H + iy) * d.W + ix) * d.ld_in + k8h * 8) * 2u + c0b : MDE_OOB_OFFSET;
+                        const int py = iy * a.h_dil + h_ry, px = ix * a.h_dil + h_rx;       // class coordinates -> input pixel
+                        const bool ok = kinh & (hrow < a.h_rows) & ((uint32_t)py < (uint32_t)d.H) & ((uint32_t)px < (uint32_t)d.W);
+                        const uint32_t off = ok ? (uint32_t)(((h_n * d.H + py) * d.W + px) * d.ld_in + k8h * 8) * 2u + c0b : MDE_OOB_OFFSET;
                         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr)(smem + (q * NW + wv) * 1024), 16, off, 0, 0, 0);
                     }
                     hrow += NW * 8;                           // the next instruction of this wave: NW x 8 window rows on
@@ -1077,7 +1084,7 @@ int launch(KArgs& ka, int64_t M, hipStream_t st) {
 // input gradient's output phases), >= 2 taps, not grouped, and a window of at most 256 pixels for some 128-pixel block shape.
 struct HaloPlan {
     int ok;
-    int tws, th, nty, ntx, hw, rows, dy0, dx0;
+    int tws, th, nty, ntx, hw, rows, dy0, dx0, dil;
     double dma_rows;      // 128-byte rows through the DMA path per 64-channel chunk, whole launch (what the form is chosen by)
     int64_t tiles;
 };
@@ -1091,15 +1098,28 @@ HaloPlan halo_plan(const mde_conv_desc& d, int bp, int bc) {
         dx0 = d.dx[t] < dx0 ? d.dx[t] : dx0;
         dx1 = d.dx[t] > dx1 ? d.dx[t] : dx1;
     }
+    // Dilation: when every tap offset is a multiple of D (an atrous 3x3: D = its dilation), the output grid splits into D x D
+    // parity classes that never share an input pixel; a tile is a block of ONE class, in whose coordinates the taps are D
+    // times closer -- the window of a dilated 3x3 is (th + 2) x (tw + 2) pixels like a plain one's, not (th + 2 D) x (tw + 2 D).
+    auto gcd = [](int a, int b) { a = a < 0 ? -a : a; b = b < 0 ? -b : b; while (b) { const int t = a % b; a = b; b = t; } return a; };
+    int D = 0;
+    for (int t = 0; t < d.ntaps; ++t) D = gcd(gcd(D, d.dy[t]), d.dx[t]);
+    if (D < 1) D = 1;
+    if (D > 8) return best;
+    dy0 /= D; dy1 /= D; dx0 /= D; dx1 /= D;
     const int nw = bp / 32;                                   // waves: 4 for the 128-pixel tile, 8 for the 256-pixel one
+    const int gh = mde_cdiv(d.GH, D), gw = mde_cdiv(d.GW, D); // a class's grid
+    // LDS: the window must leave room for the resident workgroups the form is built for (two 8-wave / four 4-wave per CU)
+    const int fixed = (bp == 128 ? 1 : 2) * bc * BK * 2 + bp * 4 + 3 * MDE_MAX_TAPS * 4;
+    const int max_rows = ((bp == 128 ? (bc <= 64 ? 32768 : 40960) : 81920) - fixed) / 128;
     for (int tws = 1; (bp >> tws) >= 2; ++tws) {
         const int tw = 1 << tws, th = bp >> tws;
         const int hw = tw + (dx1 - dx0), rows = (th + (dy1 - dy0)) * hw;
-        if (rows > HALO_MAX_Q * nw * 8) continue;
-        const int nty = mde_cdiv(d.GH, th), ntx = mde_cdiv(d.GW, tw);
-        const int64_t tiles = (int64_t)d.N * nty * ntx * mde_cdiv(d.ncols, bc);
+        if (rows > HALO_MAX_Q * nw * 8 || ((rows + 7) & ~7) > max_rows) continue;
+        const int nty = mde_cdiv(gh, th), ntx = mde_cdiv(gw, tw);
+        const int64_t tiles = (int64_t)d.N * D * D * nty * ntx * mde_cdiv(d.ncols, bc);
         const double cost = (double)tiles * (((rows + 7) & ~7) + d.ntaps * bc);
-        if (!best.ok || cost < best.dma_rows) best = HaloPlan{1, tws, th, nty, ntx, hw, rows, dy0, dx0, cost, tiles};
+        if (!best.ok || cost < best.dma_rows) best = HaloPlan{1, tws, th, nty, ntx, hw, rows, dy0, dx0, D, cost, tiles};
     }
     return best;
 }
@@ -1117,9 +1137,9 @@ int launch_halo(KArgs& ka, const HaloPlan& hp, hipStream_t st) {
         attr_done = true;
     }
     ka.h_tws = hp.tws; ka.h_th = hp.th; ka.h_nty = hp.nty; ka.h_ntx = hp.ntx;
-    ka.h_hw = hp.hw; ka.h_rows = hp.rows; ka.h_dy0 = hp.dy0; ka.h_dx0 = hp.dx0;
+    ka.h_hw = hp.hw; ka.h_rows = hp.rows; ka.h_dy0 = hp.dy0; ka.h_dx0 = hp.dx0; ka.h_dil = hp.dil;
     ka.h_step_y = (NW * 8) / hp.hw; ka.h_step_x = (NW * 8) % hp.hw;
-    ka.nP = ka.d.N * hp.nty * hp.ntx;
+    ka.nP = ka.d.N * hp.dil * hp.dil * hp.nty * hp.ntx;
     ka.nC = mde_cdiv(ka.d.ncols, BC);
     const size_t smem = (size_t)((hp.rows + 7) >> 3) * 1024 + fixed;
     if (getenv("MDE_CONV_OCC")) {       // diagnostics: resident workgroups per CU the runtime computes for this launch
@@ -1127,6 +1147,7 @@ int launch_halo(KArgs& ka, const HaloPlan& hp, hipStream_t st) {
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, NT, smem);
         fprintf(stderr, "conv_gemm_nt<%d,%d,halo>: %zu B LDS, %d workgroups per CU, window %d rows (tile %dx%d), grid %d\n", BP, BC, smem, nb,
                 hp.rows, hp.th, 1 << hp.tws, ka.nP * ka.nC);
+        if (hp.dil > 1) fprintf(stderr, "   dilation %d: %d parity classes\n", hp.dil, hp.dil * hp.dil);
     }
     conv_gemm_nt<BP, BC, NT, true, NBUF, false, true><<<dim3(ka.nP * ka.nC), dim3(NT), smem, st>>>(ka);
     MDE_LAUNCH_CHECK("conv_gemm_nt(halo)");
@@ -1172,11 +1193,15 @@ int pick_and_launch(KArgs& ka, int64_t M, hipStream_t st) {
         const char* he = getenv("MDE_CONV_HALO");
         const int halo = !he ? -1 : atoi(he);
         if (halo != 0 && forced == 0 && !reg) {
-            const int bc = n <= 64 ? 64 : 128, bp = halo == 1 ? 128 : 256;
+            // (diagnostics: 3 / 4 = the 128- / 256-pixel form with 64-column tiles whatever the layer's width)
+            // 64-column tiles for <= 64 columns, and where 128-column tiles would be mostly padding (VNL's 150-bin
+            // prediction conv: 152 columns = 3 x 64 at 79 % against 2 x 128 at 59 %)
+            const bool narrow = n <= 64 || mde_cdiv(n, 64) * 64 * 10 <= mde_cdiv(n, 128) * 128 * 8;
+            const int bc = (narrow || halo == 3 || halo == 4) ? 64 : 128, bp = (halo == 1 || halo == 3) ? 128 : 256;
             const HaloPlan hp = halo_plan(ka.d, bp, bc);
             bool take = hp.ok;
             if (take && halo < 0) {
-                const double fill = (double)M / ((double)ka.d.N * hp.nty * hp.ntx * bp);
+                const double fill = (double)M / ((double)ka.d.N * hp.dil * hp.dil * hp.nty * hp.ntx * bp);
                 take = ka.d.ntaps >= 4 && hp.tiles >= 2 * cus_() && fill >= 0.75;
             }
             if (take) {
@@ -1333,6 +1358,7 @@ extern "C" int mde_conv_gemm(const mde_conv_desc* d, const void* in, const void*
     }
     ka.det = g_mde_det.on;
     ka.h_tws = ka.h_th = ka.h_nty = ka.h_ntx = ka.h_hw = ka.h_rows = ka.h_dy0 = ka.h_dx0 = ka.h_step_y = ka.h_step_x = 0;
+    ka.h_dil = 1;
     ka.vec_ok = (d->ld_out % 8 == 0) && (((uintptr_t)out % 16) == 0);
     return pick_and_launch(ka, M, reinterpret_cast<hipStream_t>(stream));
 }

@@ -606,6 +606,31 @@ def gen_bts_net(criteria):
         len(out["keys"]), sum(p.numel() for p in ref.parameters()), out["eval_final"].min(), out["eval_final"].max(), float(loss)))
 
 
+def gen_bts_conditioned(criteria, metrics):
+    """C2 on a WELL-CONDITIONED state (oracle/weights.bts_conditioned_state: the north-star bound |dAbsRel| <= 1e-4 is only
+    meaningful where the fp32 reference itself is stable under bf16 storage): the reference's own network/Bts.py, eval
+    outputs, the metrics of the final depth from the reference's metrics.py, the SILog of one train-mode forward."""
+    from network import Bts
+    torch.manual_seed(0)
+    ref = Bts.BtsModel(bts_size=512, max_depth=10, out_channels=1, encoder_version="densenet161_bts")
+    W.bts_conditioned_state(ref, 53)
+    H, Wd = BTS_SIZE
+    rgb, tgt = W.synthetic_batch(53, 2, H, Wd)
+    W.calibrate_running_stats(ref, rgb)
+    ref.eval()
+    with torch.no_grad():
+        ys = ref(rgb)
+    out = {"eval_" + nme: _np(y) for nme, y in zip(("d8", "d4", "d2", "r1", "final"), ys)}
+    mc = metrics.MetricComputation(["absrel", "rmse", "delta1", "log10"])
+    for n, v in zip(mc.names, mc.compute(ys[4], tgt * 10.0)):
+        out["eval_" + n] = _np(v)
+    ref.train()
+    out["train_loss"] = _np(criteria.silog_loss(0.85)(ref(rgb)[4], tgt * 10.0))
+    np.savez_compressed(os.path.join(HERE, "bts_cond.npz"), **out)
+    print("bts_cond.npz: eval final range %.4f..%.4f, AbsRel %.6f, train SILog %.5f" % (
+        out["eval_final"].min(), out["eval_final"].max(), float(out["eval_absrel"]), float(out["train_loss"])))
+
+
 def gen_eigen(criteria):
     """C1 / BASELINE configuration 1 (CPU plumbing): the reference's own network/Eigen.py (Eigen, Scale2, Scale3, VGG) over
     the vgg19_bn stand-in, 4 x 3 x 240 x 320 (the two Linear layers fix that input size; 64 x 64 is rejected by the
@@ -798,6 +823,8 @@ def main():
         gen_midas_net(criteria)
     if want("bts_net"):
         gen_bts_net(criteria)
+    if want("bts_cond"):
+        gen_bts_conditioned(criteria, metrics)
     if want("eigen"):
         gen_eigen(criteria)
     if want("dorn_net"):

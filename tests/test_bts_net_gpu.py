@@ -151,6 +151,100 @@ def test_bts_train_step_against_oracle_and_reference(setup, golden):
     assert _rel(sd["decoder.bn4_2.running_var"].cpu(), torch.from_numpy(g["rv_bn4_2"])) < 5e-2
 
 
+def _conditioned():
+    from mono_depth_estimation_amd.network import Bts
+    torch.manual_seed(0)
+    net = Bts.BtsModel(bts_size=512, max_depth=10, out_channels=1, encoder_version="densenet161_bts")
+    sd = W.bts_conditioned_state(net, 53)
+    rgb, tgt = W.synthetic_batch(53, 2, *SIZE)
+    P = nets.leaf_state(sd)
+    with torch.no_grad():
+        nets.bts_forward(P, rgb, True, momentum=1.0)          # running statistics = this batch's (as the golden's generator)
+    return net, P, rgb, tgt
+
+
+def test_bts_conditioned_absrel_within_1e4_of_the_reference(golden):
+    """The north-star bound on BTS: on a state where the fp32 reference itself is stable under bf16 storage
+    (oracle/weights.bts_conditioned_state: the BatchNorms that read a dense block's concatenation damp the channels the
+    block produced, so rounding noise does not compound over the 78 layers; the oracle's own AbsRel moves by 2.4e-5 when
+    its activations are rounded) the HIP path's AbsRel of the final depth is within 1e-4 of the REFERENCE's
+    (tests/golden/bts_cond.npz, minted from network/Bts.py + metrics.py), 'rmse' / log10 / delta1 likewise, and each of the
+    five outputs within 1.5x the rounding noise."""
+    from mono_depth_estimation_amd import metrics
+    net, P, rgb, tgt = _conditioned()
+    g = golden("bts_cond")
+    net.load_state_dict({k: v.clone() for k, v in P.items()})
+    net = net.cuda().eval()
+    with torch.no_grad():
+        ys = net(rgb.cuda())
+        yo = nets.bts_forward(P, rgb, False)
+        yq = nets.bts_forward(P, rgb, False, q=nets.bf16_round)
+    for nme, y, o, q in zip(NAMES, ys, yo, yq):
+        noise, e_ref = _rel(q, o), _rel(y.cpu(), torch.from_numpy(g["eval_" + nme]))
+        print("BTS conditioned eval %-5s: HIP vs reference %.3e; the oracle's rounding noise %.3e" % (nme, e_ref, noise))
+        assert _rel(o, torch.from_numpy(g["eval_" + nme])) < 1e-5, nme            # the oracle IS the reference on this state too
+        assert e_ref < 1.5 * noise + 1e-3, nme
+    names = ["absrel", "rmse", "delta1", "log10"]
+    vals = metrics.MetricComputation(names).compute(ys[4], (tgt * 10.0).cuda())
+    for n, v in zip(names, vals):
+        print("BTS conditioned %-7s reference %.6f HIP %.6f (delta %.2e)" % (n, float(g["eval_" + n]), float(v), abs(float(v) - float(g["eval_" + n]))))
+    assert abs(float(vals[0]) - float(g["eval_absrel"])) <= 1e-4
+    assert abs(float(vals[1]) - float(g["eval_rmse"])) <= 1e-4 and abs(float(vals[3]) - float(g["eval_log10"])) <= 1e-4
+    assert abs(float(vals[2]) - float(g["eval_delta1"])) <= 1e-3
+
+
+def test_bts_loss_curves_agree_with_the_oracle(golden):
+    """Convergence parity for the DenseNet network (tests/test_tape_convergence_gpu.py does it for MiDaS,
+    tests/test_fcrn_convergence_gpu.py for FCRN): 20 AdamW steps as modules/bts.py:139-152 configures them (eps 1e-3, weight
+    decay 1e-2 on the encoder / 0 on the decoder) on one batch from the conditioned state -- the HIP path through its fused
+    flat-range step, the fp32 functional oracle through torch.optim.AdamW.  The SILog curves stay within 1 % of each other
+    at every step, both fall, and on the state the ORACLE reached the two eval paths agree in AbsRel to 2e-4."""
+    from mono_depth_estimation_amd import criteria, metrics
+    net, P0, rgb, tgt = _conditioned()
+    g = golden("bts_cond")
+    P = nets.leaf_state(P0, requires_grad=True)
+    net.load_state_dict({k: v.detach().clone() for k, v in P.items()})
+    net = net.cuda().train()
+    x, t = rgb.cuda(), (tgt * 10.0).cuda()
+    crit = criteria.silog_loss(0.85)
+    steps, lr = 20, 1e-4
+    lh = []
+    for _ in range(steps):
+        net.zero_grad(set_to_none=True)
+        loss = crit(net(x)[4], t)
+        loss.backward()
+        net._store.adam_step(lr, lr, eps=1e-3, weight_decay=(1e-2, 0.0), decoupled=True)
+        lh.append(float(loss))
+    enc = [v for k, v in P.items() if v.requires_grad and k.startswith("encoder.")]
+    dec = [v for k, v in P.items() if v.requires_grad and not k.startswith("encoder.")]
+    opt = torch.optim.AdamW([{"params": enc, "weight_decay": 1e-2}, {"params": dec, "weight_decay": 0.0}], lr=lr, eps=1e-3)
+    lo = []
+    for _ in range(steps):
+        opt.zero_grad()
+        loss = L.silog(nets.bts_forward(P, rgb, True)[4], tgt * 10.0, 0.85)
+        loss.backward()
+        opt.step()
+        lo.append(float(loss))
+    lh, lo = np.array(lh), np.array(lo)
+    assert abs(lo[0] - float(g["train_loss"])) <= 1e-4 * lo[0]                 # step 0 of the oracle = the reference's own loss
+    print("BTS SILog, HIP   :", np.round(lh[[0, 1, 2, 4, 9, 14, 19]], 4))
+    print("BTS SILog, oracle:", np.round(lo[[0, 1, 2, 4, 9, 14, 19]], 4))
+    band = np.abs(lh - lo) / lo
+    print("relative gap between the curves: max %.4f mean %.4f; fall HIP %.4f oracle %.4f" % (band.max(), band.mean(), lh[-1] / lh[0], lo[-1] / lo[0]))
+    assert np.isfinite(lh).all() and lh[-1] < 0.97 * lh[0] and lo[-1] < 0.97 * lo[0]
+    assert band.max() < 1e-2 and band.mean() < 4e-3
+    trained = {k: v.detach().clone() for k, v in P.items()}
+    net.load_state_dict(trained)
+    net.eval()
+    with torch.no_grad():
+        yh = net(x)[4]
+        yo = nets.bts_forward(trained, rgb, False)[4]
+    mc = metrics.MetricComputation(["absrel"])
+    a_h, a_o = float(mc.compute(yh, t)[0]), float(mc.compute(yo.cuda(), t)[0])
+    print("trained-like state, eval AbsRel: HIP %.6f oracle %.6f (delta %.2e)" % (a_h, a_o, abs(a_h - a_o)))
+    assert abs(a_h - a_o) <= 2e-4
+
+
 def test_shallow_densenet_trunk_gradients():
     """The DenseNet machinery (7x7/2 image stem on the GEMM kernel, max-pool, dense layers writing into the block's
     concatenation, batch moments reduced once per channel group and shared by every later BatchNorm, transition with 2x2

@@ -178,6 +178,31 @@ def test_bts_oracle_matches_the_reference(bts_fixture):
     assert np.allclose(P["decoder.bn4_2.running_var"].numpy(), g["rv_bn4_2"], rtol=1e-4, atol=1e-7)
 
 
+def test_bts_oracle_matches_the_reference_on_the_conditioned_state():
+    """tests/golden/bts_cond.npz (the reference's network/Bts.py + metrics.py on oracle/weights.bts_conditioned_state): the
+    oracle reproduces its five eval outputs, its AbsRel and its train-mode SILog; and the state is what it is there for --
+    rounding the oracle's own activations to bf16 moves its AbsRel by less than 1e-4."""
+    from mono_depth_estimation_amd.network import Bts
+    from oracle import metrics as OM
+    g = _golden("bts_cond")
+    torch.manual_seed(0)
+    net = Bts.BtsModel(bts_size=512, max_depth=10, out_channels=1, encoder_version="densenet161_bts")
+    P = nets.leaf_state(W.bts_conditioned_state(net, 53))
+    rgb, tgt = W.synthetic_batch(53, 2, *BTS_SIZE)
+    with torch.no_grad():
+        nets.bts_forward(P, rgb, True, momentum=1.0)
+        ys = nets.bts_forward(P, rgb, False)
+        yq = nets.bts_forward(P, rgb, False, q=nets.bf16_round)
+        loss = L.silog(nets.bts_forward(P, rgb, True)[4], tgt * 10.0, 0.85)
+    for nme, y in zip(("d8", "d4", "d2", "r1", "final"), ys):
+        assert np.allclose(y.numpy(), g["eval_" + nme], rtol=2e-4, atol=2e-6), nme
+    m = OM.compute(ys[4], tgt * 10.0)
+    for k in ("absrel", "rmse", "delta1", "log10"):
+        assert np.allclose(float(m[k]), float(g["eval_" + k]), rtol=2e-5), k
+    assert np.allclose(float(loss), float(g["train_loss"]), rtol=2e-5)
+    assert abs(float(OM.compute(yq[4], tgt * 10.0)["absrel"]) - float(m["absrel"])) < 1e-4
+
+
 # ---------------------------------------------------------------------------------------------- Eigen (SURVEY 8a row C1, BASELINE config 1)
 def test_config1_eigen_cpu_forward_silog_matches_the_reference():
     """BASELINE.json configuration 1: Eigen on the CPU, forward + SILog (plumbing, no GPU) — at 4 x 3 x 240 x 320, the only
