@@ -96,6 +96,13 @@ typedef struct mde_conv_desc {
  * into the conv epilogue; feed it to mde_bn_finalize as `part`. */
 int mde_conv_gemm(const mde_conv_desc* d, const void* in, const void* w, void* out,
                   float* stats, void* stream);
+/* The same launch with a fused epilogue: out = act(bf16(result) + bias + residual) -- a conv bias (Conv2d(bias=True):
+ * MiDaS.py:163-229, VNL.py:331-350, Dorn.py:58-80), an activation (act: 0 none, 1 ReLU, 2 ELU (Bts.py:69-80), 3 sigmoid) and a
+ * residual sum (ResidualConvUnit, FTB_block) without the extra pass over the conv's output.  The result is rounded to bf16
+ * BEFORE bias / residual / activation, so the output equals conv + mde_pw_fwd bit for bit.  bias: fp32 [ncols] or NULL;
+ * residual: bf16, laid out and addressed exactly like `out` (same N, OH, OW, ld_out), or NULL; d->accumulate must be 0. */
+int mde_conv_gemm_act(const mde_conv_desc* d, const void* in, const void* w, void* out, const float* bias,
+                      const void* residual, int act, void* stream);
 
 /* Weight gradient ("TN" GEMM over pixels), fp32 output accumulated with atomics:
  *   dw[r][otap[t]][c] += sum_{pix in grid} direct[pix][.] x gathered[src(pix,t)][.]

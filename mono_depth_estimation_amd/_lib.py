@@ -55,6 +55,7 @@ SIGNATURES = {
     "mde_deterministic": (_I, []),
     "mde_det_flush": (_I, [_P]),
     "mde_conv_gemm": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P]),
+    "mde_conv_gemm_act": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _I, _P]),
     "mde_conv_wgrad": (_I, [C.POINTER(WgradDesc), _P, _P, _P, _P]),
     "mde_stem_conv_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "mde_stem_conv_wgrad": (_I, [_P, _P, _P, _I, _I, _I, _P]),

@@ -77,6 +77,11 @@ struct KArgs {
     int32_t vec_ok;   // 16-byte stores allowed
     int32_t col_fastest;  // tile order: 1 = all column tiles of a pixel tile are neighbours (activation tile reused from L2)
     int32_t det;          // deterministic mode: BatchNorm partial sums leave the workgroup as integer atomics (mde_common.h)
+    // fused epilogue (mde_conv_gemm_act): out = act(bf16(result) + bias + residual) -- the pass a biased / activated conv
+    // would otherwise make over its own output (pointwise.hip pw_fwd_k, whose arithmetic this repeats bit for bit)
+    const float* bias;    // [ncols] or nullptr
+    const void* resid;    // bf16, addressed exactly like `out` (same offsets), or nullptr
+    int32_t act;          // 0 none, 1 ReLU, 2 ELU, 3 sigmoid
     // halo-tiled form (HALO kernels): the workgroup's 128 pixels are a th x tw block of ONE image (tw = 1 << h_tws), whose
     // input window (th + dy span) x (tw + dx span) is staged ONCE per 64-channel chunk and read by every tap
     int32_t h_tws, h_th;          // log2(tile width), tile height
@@ -87,6 +92,15 @@ struct KArgs {
                                   // in whose own coordinates the taps are D times closer (a dilated 3x3 has a (th + 2) x (tw + 2) window)
     int32_t h_step_y, h_step_x;   // a wave's next window instruction is (waves x 8) rows on: that many / hw lines down, % hw pixels right (+ one carry)
 };
+
+__device__ __forceinline__ float epi_act(float v, int act) {      // == pointwise.hip act_fwd
+    switch (act) {
+        case 1: return fmaxf(v, 0.f);
+        case 2: return v > 0.f ? v : expm1f(v);
+        case 3: return 1.f / (1.f + expf(-v));
+        default: return v;
+    }
+}
 
 // byte offset of the 16-byte chunk (row, kslot8) inside a swizzled tile
 __device__ __forceinline__ int chunk_off(int row, int kslot8) {
@@ -996,8 +1010,16 @@ __global__ __launch_bounds__(NT, HALO ? (NT == 512 ? 4 : BC <= 64 ? 5 : 4)
                 constexpr int ROWS_PT = EROWS / RPP;                 // rows per thread per pass
                 constexpr int RB = ROWS_PT % 4 == 0 ? 4 : ROWS_PT % 3 == 0 ? 3 : ROWS_PT % 2 == 0 ? 2 : 1;   // bounded by registers
                 static_assert(ROWS_PT * RPP == EROWS && ROWS_PT % RB == 0, "store batches");
+                // ACC 0: plain store; 1: out += result (read-modify-write); 2: out = act(result + bias + residual), the
+                // residual read like ACC 1 reads the old output (same offsets, loads ahead of the stores)
                 auto store_rows = [&](auto acc_tag) {
-                    constexpr bool ACC = decltype(acc_tag)::value;
+                    constexpr int ACC = decltype(acc_tag)::value;
+                    const bf16_t* resp = reinterpret_cast<const bf16_t*>(a.resid);
+                    float bv[8];
+                    if constexpr (ACC == 2) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) bv[e] = a.bias ? a.bias[col + e] : 0.f;
+                    }
 #pragma unroll 1
                     for (int rb = 0; rb < ROWS_PT; rb += RB) {
                         int oo[RB];
@@ -1005,25 +1027,33 @@ __global__ __launch_bounds__(NT, HALO ? (NT == 512 ? 4 : BC <= 64 ? 5 : 4)
 #pragma unroll
                         for (int q = 0; q < RB; ++q) {
                             oo[q] = s_out[ep * EROWS + r0 + (rb + q) * RPP];
-                            if constexpr (ACC) oldv[q] = *reinterpret_cast<const i32x4_t*>(outp + (size_t)max(oo[q], 0) + col);
+                            if constexpr (ACC == 1) oldv[q] = *reinterpret_cast<const i32x4_t*>(outp + (size_t)max(oo[q], 0) + col);
+                            if constexpr (ACC == 2) oldv[q] = resp ? *reinterpret_cast<const i32x4_t*>(resp + (size_t)max(oo[q], 0) + col) : i32x4_t{0, 0, 0, 0};
                         }
 #pragma unroll
                         for (int q = 0; q < RB; ++q) {
                             const int r = r0 + (rb + q) * RPP;
                             bf16x8_t v = *reinterpret_cast<const bf16x8_t*>(smem + r * ROWB + chunk * 16);
-                            if constexpr (ACC) {
+                            if constexpr (ACC == 1) {
                                 const bf16x8_t old = __builtin_bit_cast(bf16x8_t, oldv[q]);
 #pragma unroll
                                 for (int e = 0; e < 8; ++e) v[e] = (bf16_t)((float)v[e] + (float)old[e]);
+                            }
+                            if constexpr (ACC == 2) {
+                                const bf16x8_t rv = __builtin_bit_cast(bf16x8_t, oldv[q]);
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) v[e] = (bf16_t)epi_act((float)v[e] + bv[e] + (resp ? (float)rv[e] : 0.f), a.act);
                             }
                             if (oo[q] >= 0) *reinterpret_cast<bf16x8_t*>(outp + (size_t)oo[q] + col) = v;
                         }
                     }
                 };
-                if (d.accumulate)
-                    store_rows(std::true_type{});
+                if (a.bias || a.resid || a.act)
+                    store_rows(std::integral_constant<int, 2>{});
+                else if (d.accumulate)
+                    store_rows(std::integral_constant<int, 1>{});
                 else
-                    store_rows(std::false_type{});
+                    store_rows(std::integral_constant<int, 0>{});
             } else {
                 for (int r = r0; r < EROWS; r += RPP) {
                     const int oo = s_out[ep * EROWS + r];
@@ -1031,9 +1061,15 @@ __global__ __launch_bounds__(NT, HALO ? (NT == 512 ? 4 : BC <= 64 ? 5 : 4)
                     const bf16x8_t v = *reinterpret_cast<const bf16x8_t*>(smem + r * ROWB + chunk * 16);
                     bf16_t* dst = outp + (size_t)oo + col;
                     const int nv = min(8, d.ncols - col);
+                    const bool fused = a.bias || a.resid || a.act;
                     for (int e = 0; e < nv; ++e) {
                         float x = (float)v[e];
-                        if (d.accumulate) x += (float)dst[e];
+                        if (fused) {
+                            const bf16_t* resp = reinterpret_cast<const bf16_t*>(a.resid);
+                            x = epi_act(x + (a.bias ? a.bias[col + e] : 0.f) + (resp ? (float)resp[(size_t)oo + col + e] : 0.f), a.act);
+                        } else if (d.accumulate) {
+                            x += (float)dst[e];
+                        }
                         dst[e] = (bf16_t)x;
                     }
                 }
@@ -1312,8 +1348,24 @@ int pick_and_launch(KArgs& ka, int64_t M, hipStream_t st) {
 
 }  // namespace
 
+static int conv_gemm_impl(const mde_conv_desc* d, const void* in, const void* w, void* out, float* stats, const float* bias,
+                          const void* resid, int act, void* stream);
+
 extern "C" int mde_conv_gemm(const mde_conv_desc* d, const void* in, const void* w, void* out,
                              float* stats, void* stream) {
+    return conv_gemm_impl(d, in, w, out, stats, nullptr, nullptr, 0, stream);
+}
+
+extern "C" int mde_conv_gemm_act(const mde_conv_desc* d, const void* in, const void* w, void* out, const float* bias,
+                                 const void* residual, int act, void* stream) {
+    MDE_REQUIRE(d && !d->accumulate, "mde_conv_gemm_act: an accumulating launch has no fused epilogue");
+    MDE_REQUIRE(act >= 0 && act <= 3, "mde_conv_gemm_act: act=%d (0 none, 1 ReLU, 2 ELU, 3 sigmoid)", act);
+    MDE_REQUIRE(!residual || ((uintptr_t)residual % 16) == 0, "mde_conv_gemm_act: residual must be 16-byte aligned");
+    return conv_gemm_impl(d, in, w, out, nullptr, bias, residual, act, stream);
+}
+
+static int conv_gemm_impl(const mde_conv_desc* d, const void* in, const void* w, void* out, float* stats, const float* bias,
+                          const void* resid, int act, void* stream) {
     MDE_REQUIRE(d && in && w && out, "mde_conv_gemm: null argument");
     MDE_REQUIRE(d->C > 0 && d->C % 8 == 0, "mde_conv_gemm: C=%d must be a positive multiple of 8", d->C);
     MDE_REQUIRE(!d->grouped || (d->C == BK && d->ncols % BK == 0),
@@ -1357,6 +1409,9 @@ extern "C" int mde_conv_gemm(const mde_conv_desc* d, const void* in, const void*
         ka.col_fastest = order;
     }
     ka.det = g_mde_det.on;
+    ka.bias = bias;
+    ka.resid = resid;
+    ka.act = act;
     ka.h_tws = ka.h_th = ka.h_nty = ka.h_ntx = ka.h_hw = ka.h_rows = ka.h_dy0 = ka.h_dx0 = ka.h_step_y = ka.h_step_x = 0;
     ka.h_dil = 1;
     ka.vec_ok = (d->ld_out % 8 == 0) && (((uintptr_t)out % 16) == 0);

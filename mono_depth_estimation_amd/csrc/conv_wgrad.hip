@@ -17,6 +17,8 @@
 
 #include "mde_common.h"
 
+int mde_conv_wgrad_windowed(const mde_wgrad_desc* d, const void* direct, const void* gathered, float* dw, hipStream_t st, int force);
+
 namespace {
 
 constexpr int BKP = 64;   // pixels per K-step
@@ -356,6 +358,16 @@ extern "C" int mde_conv_wgrad(const mde_wgrad_desc* d, const void* direct, const
     MDE_REQUIRE(M < (1ll << 31) && M * d->ld_d < (1ll << 30) && (int64_t)d->N * d->H * d->W * d->ld_g < (1ll << 30),
                 "mde_conv_wgrad: tensor too large for 32-bit indexing");
 
+    {
+        // the windowed form (conv_wgrad_win.hip): one workgroup per kernel ROW of taps.  MDE_WGRAD_WIN=1 wherever the geometry
+        // is eligible (diagnostics, tests), 0 never; read per call
+        const char* we = getenv("MDE_WGRAD_WIN");
+        const int win = !we ? 0 : atoi(we);
+        if (win) {
+            const int rc = mde_conv_wgrad_windowed(d, direct, gathered, dw, reinterpret_cast<hipStream_t>(stream), win == 1);
+            if (rc != 0) return rc < 0 ? rc : MDE_OK;
+        }
+    }
     KArgs ka;
     ka.d = *d;
     ka.direct = direct;

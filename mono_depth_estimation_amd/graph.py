@@ -155,6 +155,26 @@ class Conv(Op):
             ks = eng._ksplit(M, O, Cin, k * k)
         self.wdesc = ops.conv_wgrad_desc(n, x.H, x.W, x.ld, x.C, xb, OH, OW, o.ld, O, ob, k, stride, pad, ks, dil=dil)
         self.wdesc.group_size = G
+        self.groups = groups
+        # fused epilogue (TapeEngine.pw): out = act(conv + bias + res) written by the conv launch itself
+        self.f_bias = self.f_boff = self.f_res = self.f_act = self.f_part = self.pre_g = None
+        self.fused = False
+
+    def fuse(self, bias, b_off, res, act, out):
+        """Take over the pointwise pass that would follow this conv: the launch writes act(conv + bias + res) into `out`
+        (mde_conv_gemm_act; bit-identical to conv + mde_pw_fwd) and the pre-activation tensor is never materialised.  Its
+        GRADIENT still is (pre_g): the weight- and input-gradient GEMMs contract with d(pre-activation)."""
+        o = self.out
+        assert (out.N, out.H, out.W, out.C) == (o.N, o.H, o.W, o.C) and self.site is None and self.groups == 1
+        old_ld = o.ld
+        o.t = None                                   # (anything that still reads the pre-activation fails loudly)
+        self.out, self.own_out = out, out.parent is None and out is not o
+        self.f_bias, self.f_boff, self.f_res, self.f_act, self.fused = bias, b_off, res, act, True
+        self.f_part = ops.new_stat_buffer(out.C, self.eng.dev) if bias is not None else None
+        assert old_ld == o.C, "only a conv that owns a dense output is fused (its gradient descriptors address pre_g, stride C)"
+        self.fdesc.ld_out = out.ld                   # the forward descriptor carries the NEW output's pixel stride
+        self.pre_g = torch.empty(out.N, out.H, out.W, out.C, dtype=torch.bfloat16, device=self.eng.dev)
+        return self
 
     def acts(self):
         return (self.out,) if self.own_out else ()
@@ -165,12 +185,26 @@ class Conv(Op):
     def fwd(self, train):
         stats = self.site.part if (train and self.site is not None) else None
         n = self.chunk
+        if self.fused:
+            r = self.f_res
+            for i in self._chunks():
+                ops.conv_gemm(self.fdesc, self.x.t[i:i + n], self.conv.wf, self.out.t[i:i + n], bias=self.f_bias,
+                              res=r.t[i:i + n] if r is not None else None, act=self.f_act)
+            return
         for i in self._chunks():
             ops.conv_gemm(self.fdesc, self.x.t[i:i + n], self.conv.wf, self.out.t[i:i + n], stats)
 
     def bwd(self):
         x, o, eng, n = self.x, self.out, self.eng, self.chunk
         og = o.g
+        if self.fused:
+            # g = dout * act'(out): the conv's own output gradient; the bias gradient and the residual's ride along
+            r = self.f_res
+            acc_r = _take(r) if r is not None else False
+            dbias = eng.store.Gcur[self.f_boff:self.f_boff + o.C] if self.f_bias is not None else None
+            ops.pw_bwd(og, _ldg(o), o.t, o.ld, self.pre_g, o.C, False, r.g if r is not None else None, _ldg(r) if r is not None else 0,
+                       acc_r, dbias, o.M, o.C, self.f_act, bias_part=self.f_part)
+            og = self.pre_g
         for i in self._chunks():
             eng.wgrad(self.wdesc, og[i:i + n], x.t[i:i + n], self.conv.dw)
         if not self.need_dgrad:
@@ -860,6 +894,8 @@ class TapeEngine(EngineCore):
         self._plan()
         self._acts = [a for op in self.tape for a in op.acts()] + self._bufs
 
+    _fuse_pw = os.environ.get("MDE_FUSE_PW", "1") != "0"
+
     def add(self, op):
         self.tape.append(op)
         return op
@@ -873,6 +909,28 @@ class TapeEngine(EngineCore):
         return a
 
     # ---- building blocks shared by the plans
+    def pw(self, x, bias=None, r=None, act=None, out=None):
+        """out = act(x + bias + r) (Pw).  When x is the dense output of the convolution just added to the tape and nothing else
+        has read it, the pass is folded into that convolution's epilogue instead (Conv.fuse): one launch and one tensor
+        less per biased / activated conv (MiDaS' ResidualConvUnits and output head, BTS' conv + ELU chains, VNL's FTB
+        blocks, DORN's and MyNet's biased convs).  MDE_FUSE_PW=0 keeps the separate pass (A/B, tests)."""
+        last = self.tape[-1] if self.tape else None
+        ok = (self._fuse_pw and isinstance(last, Conv) and last.out is x and last.own_out and last.site is None and last.groups == 1
+              and not last.fused and x.parent is None and (bias is not None or r is not None or act is not None))
+        if ok and r is not None:
+            o_ld = out.ld if out is not None else x.C
+            ok = (r.N, r.H, r.W, r.C) == (x.N, x.H, x.W, x.C) and r.ld == o_ld and r is not x
+        if ok and out is not None:
+            ok = (out.N, out.H, out.W, out.C) == (x.N, x.H, x.W, x.C)
+        if not ok:
+            return self.add(Pw(self, x, bias=bias, r=r, act=act, out=out)).out
+        b, b_off = (None, None)
+        if bias is not None:
+            b, b_off = self.store.vec(bias)
+            assert b.numel() == x.C, (b.numel(), x.C)
+        dst = out if out is not None else Act(self.dev, x.N, x.H, x.W, x.C)
+        return last.fuse(b, b_off, r, act, dst).out
+
     def conv_bn(self, x, conv, bn, relu, out=None):
         """nn.Conv2d (its own stride / padding / dilation / groups) -> nn.BatchNorm2d -> [ReLU]."""
         k, s, p, d, g = conv.kernel_size[0], conv.stride[0], conv.padding[0], conv.dilation[0], conv.groups

@@ -238,7 +238,7 @@ class BtsEngine(G.TapeEngine):
 
     def _conv_elu(self, x, conv, out=None, **kw):
         c = self.add(G.Conv(self, x, conv.weight, conv.kernel_size[0], 1, conv.padding[0], conv.dilation[0], **kw)).out
-        return self.add(G.Pw(self, c, act="elu", out=out)).out
+        return self.pw(c, act="elu", out=out)
 
     def _upconv(self, x, up, out=None):
         return self._conv_elu(self.add(G.Nearest2(self, x)).out, up.conv, out=out)
@@ -249,7 +249,7 @@ class BtsEngine(G.TapeEngine):
         return self.add(G.BN(self, x, s, False, out=out)).out
 
     def _copy(self, x, out):
-        return self.add(G.Pw(self, x, out=out)).out
+        return self.pw(x, out=out)
 
     def _atrous(self, x, ac, out):
         seq = ac.atrous_conv.aconv_sequence
@@ -258,7 +258,7 @@ class BtsEngine(G.TapeEngine):
             self.add(G.StatsPass(self, x, s))
             r = self.add(G.BN(self, x, s, True)).out
         else:
-            r = self.add(G.Pw(self, x, act="relu")).out
+            r = self.pw(x, act="relu")
         a = self.conv_bn(r, seq[1], seq[2], True)
         return self.add(G.Conv(self, a, seq[4].weight, 3, 1, ac.dilation, ac.dilation, out=out)).out
 

@@ -188,7 +188,7 @@ class DORNEngine(G.TapeEngine):
             return self.conv_bn(x, conv, seq[1], True, out=out)
         k, s, p, d = conv.kernel_size[0], conv.stride[0], conv.padding[0], conv.dilation[0]
         c = self.add(G.Conv(self, x, conv.weight, k, s, p, d)).out
-        return self.add(G.Pw(self, c, bias=conv.bias, act="relu", out=out)).out
+        return self.pw(c, bias=conv.bias, act="relu", out=out)
 
     def _plan(self):
         m, N, H, W = self.m, self.N, self.H, self.W
@@ -214,9 +214,9 @@ class DORNEngine(G.TapeEngine):
         self.dropouts.append(pooled)
         cat = self.buf(N, x.H, x.W, 5 * 512)
         f = self.add(G.Conv(self, pooled.out, enc.global_fc.weight, 1)).out
-        f = self.add(G.Pw(self, f, bias=enc.global_fc.bias, act="relu")).out
+        f = self.pw(f, bias=enc.global_fc.bias, act="relu")
         f = self.add(G.Conv(self, f, enc.conv1.weight, 1)).out
-        f = self.add(G.Pw(self, f, bias=enc.conv1.bias)).out
+        f = self.pw(f, bias=enc.conv1.bias)
         self.add(G.Broadcast(self, f, cat.slice(0, 512)))             # bilinear(align_corners) of a 1x1 map
         for i in range(4):
             aspp = getattr(su, "aspp%d" % (i + 1))
@@ -228,7 +228,7 @@ class DORNEngine(G.TapeEngine):
         d = self.add(G.ChannelDropout(self, t, cp[2].p))
         self.dropouts.append(d)
         c = self.add(G.Conv(self, d.out, cp[3].weight, 1)).out
-        c = self.add(G.Pw(self, c, bias=cp[3].bias)).out
+        c = self.pw(c, bias=cp[3].bias)
         K = cp[3].out_channels // 2
         up = self.add(G.Resize(self, c, int(su.size[0]), int(su.size[1]), True)).out     # (c.C = 2K rounded up to 8, the padding is zero)
         self.heads = [self.add(G.OrdinalHead(self, up, K))]

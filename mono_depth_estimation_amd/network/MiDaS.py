@@ -104,16 +104,16 @@ class MidasEngine(G.TapeEngine):
     def _rcu(self, a, rcu, r2=None):
         """ResidualConvUnit on a = relu(x) (the unit's ReLU is in place, MiDaS.py:196: the skip is relu(x))."""
         c1 = self.add(G.Conv(self, a, rcu.conv1.weight, 3, 1, 1)).out
-        h = self.add(G.Pw(self, c1, bias=rcu.conv1.bias, act="relu")).out
+        h = self.pw(c1, bias=rcu.conv1.bias, act="relu")
         c2 = self.add(G.Conv(self, h, rcu.conv2.weight, 3, 1, 1)).out
-        return self.add(G.Pw(self, c2, bias=rcu.conv2.bias, r=a)).out
+        return self.pw(c2, bias=rcu.conv2.bias, r=a)
 
     def _ffb(self, ffb, x0, x1=None):
         if x1 is not None:
-            t = self._rcu(self.add(G.Pw(self, x1, act="relu")).out, ffb.resConfUnit1)
-            a = self.add(G.Pw(self, x0, r=t, act="relu")).out          # relu(x0 + rcu1(x1)), the in-place ReLU of unit 2
+            t = self._rcu(self.pw(x1, act="relu"), ffb.resConfUnit1)
+            a = self.pw(x0, r=t, act="relu")          # relu(x0 + rcu1(x1)), the in-place ReLU of unit 2
         else:
-            a = self.add(G.Pw(self, x0, act="relu")).out
+            a = self.pw(x0, act="relu")
         y = self._rcu(a, ffb.resConfUnit2)
         return self.add(G.Resize(self, y, 2 * y.H, 2 * y.W, True)).out
 
@@ -138,10 +138,10 @@ class MidasEngine(G.TapeEngine):
         p = self._ffb(sc.refinenet1, p, rn[0])
         oc = sc.output_conv
         c = self.add(G.Conv(self, p, oc[0].weight, 3, 1, 1)).out
-        c = self.add(G.Pw(self, c, bias=oc[0].bias)).out                # (the bias before the resize: padding of the next conv sees it)
+        c = self.pw(c, bias=oc[0].bias)                # (the bias before the resize: padding of the next conv sees it)
         u = self.add(G.Resize(self, c, 2 * c.H, 2 * c.W, False)).out
         c = self.add(G.Conv(self, u, oc[2].weight, 3, 1, 1)).out
-        h = self.add(G.Pw(self, c, bias=oc[2].bias, act="relu")).out
+        h = self.pw(c, bias=oc[2].bias, act="relu")
         c = self.add(G.Conv(self, h, oc[4].weight, 1)).out
         self.heads = [self.add(G.ToNCHW(self, c, oc[4].bias, oc[4].out_channels, "sigmoid"))]
 

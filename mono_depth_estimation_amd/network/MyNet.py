@@ -115,15 +115,15 @@ class MyEngine(BtsEngine):
     """The tape of MyModel.forward (MyNet.py:270-272 -> encoder.forward :181-192 -> my_decoder.forward :135-157)."""
 
     def _rcu(self, x, u, out=None):
-        r = self.add(G.Pw(self, x, act="relu")).out
+        r = self.pw(x, act="relu")
         c = self.add(G.Conv(self, r, u.conv1.weight, 3, 1, 1)).out
-        t = self.add(G.Pw(self, c, bias=u.conv1.bias, act="relu")).out
+        t = self.pw(c, bias=u.conv1.bias, act="relu")
         c = self.add(G.Conv(self, t, u.conv2.weight, 3, 1, 1)).out
-        return self.add(G.Pw(self, c, bias=u.conv2.bias, r=x, out=out)).out
+        return self.pw(c, bias=u.conv2.bias, r=x, out=out)
 
     def _pre(self, x, blk, out=None):
         """Conv2d.forward (MyNet.py:11-15)."""
-        a = self.add(G.Pw(self, x, act="elu")).out
+        a = self.pw(x, act="elu")
         b = self._bn_after_elu(a, blk.bn, None)
         cv = blk.conv
         return self.add(G.Conv(self, b, cv.weight, cv.kernel_size[0], cv.stride[0], cv.padding[0], out=out)).out
@@ -132,12 +132,12 @@ class MyEngine(BtsEngine):
         k, p = tc.kernel_size[0], tc.padding[0]
         assert tc.stride == (2, 2) and tc.output_padding == (0, 0)
         y = self.add(G.ConvT(self, x, tc.weight, k, p)).out
-        return self.add(G.Pw(self, y, bias=tc.bias, out=out)).out
+        return self.pw(y, bias=tc.bias, out=out)
 
     def _up_conv_relu(self, x, seq):
         u = self.add(G.Nearest2(self, x)).out
         c = self.add(G.Conv(self, u, seq[1].weight, 3, 1, 1)).out
-        return self.add(G.Pw(self, c, bias=seq[1].bias, act="relu")).out
+        return self.pw(c, bias=seq[1].bias, act="relu")
 
     def _plan(self):
         m, N, H, W = self.m, self.N, self.H, self.W

@@ -286,7 +286,7 @@ class VNLEngine(G.TapeEngine):
         c1 = self.add(G.Conv(self, x, ftb.conv1.weight, 1)).out                 # also the residual
         t = self.conv_bn(c1, ftb.conv2, ftb.bn1, True)
         c3 = self.add(G.Conv(self, t, ftb.conv3.weight, 3, 1, 2, 2)).out
-        return self.add(G.Pw(self, c3, r=c1, act="relu")).out
+        return self.pw(c3, r=c1, act="relu")
 
     def _afa(self, afa, lat, top):
         C = lat.C
@@ -294,9 +294,9 @@ class VNLEngine(G.TapeEngine):
         self.add(G.GlobalAvgPool(self, lat, out=pooled.slice(0, C)))
         self.add(G.GlobalAvgPool(self, top, out=pooled.slice(C, C)))
         h = self.add(G.Conv(self, pooled, afa.conv1.weight, 1)).out
-        h = self.add(G.Pw(self, h, act="relu")).out
+        h = self.pw(h, act="relu")
         w = self.add(G.Conv(self, h, afa.conv2.weight, 1)).out
-        w = self.add(G.Pw(self, w, act="sigmoid")).out
+        w = self.pw(w, act="sigmoid")
         return self.add(G.Gate(self, w, lat, top)).out
 
     def _plan(self):

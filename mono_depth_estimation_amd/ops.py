@@ -159,16 +159,25 @@ def det_flush():
     check(_lib.load().mde_det_flush(_stream()), "mde_det_flush")
 
 
-def conv_gemm(desc, x, w, out, stats=None):
+ACT_CODE = {None: 0, "none": 0, "relu": 1, "elu": 2, "sigmoid": 3}
+
+
+def conv_gemm(desc, x, w, out, stats=None, bias=None, res=None, act=None):
+    """bias / res / act: the fused epilogue out = act(conv + bias + res) (mde_conv_gemm_act; no statistics with it)."""
     lib = _lib.load()
+    if bias is not None or res is not None or ACT_CODE[act]:
+        assert stats is None, "BatchNorm statistics and a fused activation epilogue do not combine"
+        call = lambda: check(lib.mde_conv_gemm_act(C.byref(desc), _p(x), _p(w), _p(out), _p(bias), _p(res), ACT_CODE[act], _stream()),
+                             "mde_conv_gemm_act")
+    else:
+        call = lambda: check(lib.mde_conv_gemm(C.byref(desc), _p(x), _p(w), _p(out), _p(stats), _stream()), "mde_conv_gemm")
     if TIMER is None:
-        check(lib.mde_conv_gemm(C.byref(desc), _p(x), _p(w), _p(out), _p(stats), _stream()), "mde_conv_gemm")
+        call()
         return
     flops = 2.0 * desc.N * desc.GH * desc.GW * desc.ncols * desc.ntaps * desc.C
-    _timed("conv_gemm_nt", flops, lambda: check(
-        lib.mde_conv_gemm(C.byref(desc), _p(x), _p(w), _p(out), _p(stats), _stream()), "mde_conv_gemm"),
-        "M=%d N=%d taps=%d C=%d s=%d%s" % (desc.N * desc.GH * desc.GW, desc.ncols, desc.ntaps, desc.C, desc.sy,
-                                          " acc" if desc.accumulate else ""))
+    _timed("conv_gemm_nt", flops, call,
+           "M=%d N=%d taps=%d C=%d s=%d%s" % (desc.N * desc.GH * desc.GW, desc.ncols, desc.ntaps, desc.C, desc.sy,
+                                              " acc" if desc.accumulate else ""))
 
 
 def stat_slots():

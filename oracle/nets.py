@@ -63,6 +63,12 @@ def bf16_round(t):
     return t.to(torch.bfloat16).to(torch.float32)
 
 
+def fp16_round(t):
+    """Storage rounding of the reference's own mixed-precision runs (train.py:139-140: precision=16, amp_level='O2'): 11 bits
+    of significand against bf16's 8, overflow to +-inf above 65504 and gradual underflow below 6e-5 as fp16 has them."""
+    return t.to(torch.float16).to(torch.float32)
+
+
 def vnl_forward(P, x, train, block_counts=(3, 4, 6, 3), momentum=None, q=None):
     """MetricDepthModel.forward (VNL.py:678-693) for the resnext*_32x4d_body_stride16 encoders -> (logits, softmax).
     momentum: override every BatchNorm's (1.0 = "running statistics := this batch's", weights.calibrate_running_stats).

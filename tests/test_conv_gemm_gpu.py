@@ -23,7 +23,14 @@ def conv_form(request):
         os.environ.pop("MDE_CONV_HALO", None)
     else:
         os.environ["MDE_CONV_HALO"] = val
+    old_w = os.environ.get("MDE_WGRAD_WIN")
+    if request.param == "halo256":            # ... and the weight gradients of these tests through the windowed kernel
+        os.environ["MDE_WGRAD_WIN"] = "1"
     yield request.param
+    if old_w is None:
+        os.environ.pop("MDE_WGRAD_WIN", None)
+    else:
+        os.environ["MDE_WGRAD_WIN"] = old_w
     if old is None:
         os.environ.pop("MDE_CONV_HALO", None)
     else:
@@ -251,3 +258,51 @@ def test_random_shapes_fwd_dgrad_wgrad():
                        dyd, xd, dw)
         torch.cuda.synchronize()
         _assert_close(dw.cpu(), wi.grad.permute(0, 2, 3, 1).reshape(Cout, k * k, Cin), tag + " wgrad", tol=2.0 ** -7)
+
+
+@pytest.mark.parametrize("N,H,Wd,Cin,Cout,k,act,with_bias,with_res", [
+    (2, 12, 20, 64, 128, 3, "relu", True, False),      # conv bias + ReLU (MiDaS ResidualConvUnit.conv1, DORN, MyNet)
+    (2, 12, 20, 64, 128, 3, None, True, True),         # conv bias + residual sum (ResidualConvUnit.conv2)
+    (1, 30, 40, 128, 64, 3, "elu", False, False),      # BTS conv + ELU, 64-column tile
+    (2, 9, 11, 192, 72, 1, "sigmoid", True, True),     # 1x1, ragged column tile: the scalar tail of the store loop
+    (2, 160, 241, 64, 256, 3, "relu", True, True),     # large grid: the 256-pixel halo form takes it when the library chooses
+])
+def test_fused_epilogue_equals_conv_plus_pointwise_pass(N, H, Wd, Cin, Cout, k, act, with_bias, with_res):
+    """mde_conv_gemm_act: out = act(bf16(conv) + bias + residual) written by the conv launch.  The header promises the result
+    of conv followed by mde_pw_fwd BIT FOR BIT (the conv result is rounded to bf16 before bias / residual / activation,
+    as the separate pass sees it), so this is torch.equal, not a tolerance -- in every form of the conv loop."""
+    from mono_depth_estimation_amd import ops
+    p = k // 2
+    x = _bf(W.normal(7, "x", (N, Cin, H, Wd)))
+    w = _bf(W.normal(7, "w", (Cout, Cin, k, k), std=(2.0 / (k * k * Cin)) ** 0.5))
+    xd, wd = _nhwc(x), _pack_fwd(w)
+    bias = W.normal(7, "b", (Cout,), 0.5).cuda() if with_bias else None
+    res = _nhwc(_bf(W.normal(7, "r", (N, Cout, H, Wd)))) if with_res else None
+    d = ops.fwd_desc(N, H, Wd, Cin, Cin, xd.numel() * 2, k, 1, p, Cout, Cout)
+    plain = torch.empty(N, H, Wd, Cout, dtype=torch.bfloat16, device="cuda")
+    ops.conv_gemm(d, xd, wd, plain)
+    want = torch.empty_like(plain)
+    ops.pw_fwd(plain, Cout, bias, res, Cout if with_res else 0, want, Cout, N * H * Wd, Cout, act)
+    got = torch.full_like(plain, 7.0)
+    ops.conv_gemm(d, xd, wd, got, bias=bias, res=res, act=act)
+    torch.cuda.synchronize()
+    assert torch.equal(got, want), float((got.float() - want.float()).abs().max())
+    # and against torch on the same operands, so that both are not wrong together
+    ref = F.conv2d(x, w, padding=p).to(torch.bfloat16).float()
+    if with_bias:
+        ref = ref + bias.cpu().view(1, -1, 1, 1)
+    if with_res:
+        ref = ref + _nchw(res)
+    ref = {"relu": torch.relu, "elu": F.elu, "sigmoid": torch.sigmoid, None: lambda t: t}[act](ref)
+    _assert_close(_nchw(got), ref, "fused epilogue", tol=2.0 ** -7)
+
+
+def test_fused_epilogue_rejects_an_accumulating_launch():
+    from mono_depth_estimation_amd import _lib, ops
+    x = torch.zeros(1, 4, 4, 64, dtype=torch.bfloat16, device="cuda")
+    w = torch.zeros(64, 1, 64, dtype=torch.bfloat16, device="cuda")
+    out = torch.zeros(1, 4, 4, 64, dtype=torch.bfloat16, device="cuda")
+    d = ops.fwd_desc(1, 4, 4, 64, 64, x.numel() * 2, 1, 1, 0, 64, 64)
+    d.accumulate = 1
+    with pytest.raises(_lib.MdeError, match="accumulating"):
+        ops.conv_gemm(d, x, w, out, act="relu")

@@ -10,6 +10,20 @@ from oracle import weights as W
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["per-tap", "windowed"])
+def wgrad_form(request):
+    """Every test runs with the per-tap kernel and with the windowed one forced wherever the geometry is eligible (one
+    workgroup per kernel row of taps over 4 x 16 pixel blocks; MDE_WGRAD_WIN is read on every call)."""
+    import os
+    old = os.environ.get("MDE_WGRAD_WIN")
+    os.environ["MDE_WGRAD_WIN"] = "1" if request.param == "windowed" else "0"
+    yield request.param
+    if old is None:
+        os.environ.pop("MDE_WGRAD_WIN", None)
+    else:
+        os.environ["MDE_WGRAD_WIN"] = old
+
+
 def _bf(t):
     return t.to(torch.bfloat16).to(torch.float32)
 
@@ -33,6 +47,9 @@ def _assert_close(got, ref, what, tol=1e-3):
     (1, 14, 18, 128, 192, 3, 2, 1, 2),    # stride 2; 192 rows -> one launch of 128-row tiles + one of 64-row tiles
     (2, 10, 12, 256, 128, 1, 2, 0, 1),    # 1x1 stride 2
     (1, 30, 40, 64, 64, 3, 1, 1, 4),
+    (2, 33, 50, 192, 136, 3, 1, 1, 2),    # blocks that hang over the grid (33 x 50), channel tails on both operands
+    (1, 20, 37, 72, 64, 5, 1, 2, 1),      # 5 taps per kernel row: groups of 3 + 2
+    (2, 17, 23, 64, 128, 3, 1, 2, 2),     # padding 2 (the window starts two pixels outside)
 ])
 def test_conv_wgrad(N, H, Wd, Cin, Cout, k, s, p, ksplit):
     from mono_depth_estimation_amd import ops
