@@ -36,7 +36,7 @@ def synthetic(n, seed, device):
     return rgb, depth.masked_fill(hole, 0.0)
 
 
-TRAFFIC_FILE = os.path.join("profiles", "r02_hbm_traffic.json")
+TRAFFIC_FILE = os.path.join("profiles", "r03_hbm_traffic.json")
 TRAFFIC_SOURCES = ("conv_gemm.hip", "conv_wgrad.hip", "mde_common.h")
 
 
@@ -186,7 +186,11 @@ def run_other_config(args, dev, rank, world, use_dist, t_start):
     import torch.distributed as dist
     from mono_depth_estimation_amd import dp, ops
     cfg = OTHER_CONFIGS[args.config]
-    net, fwd_loss, opt = build_other(args.config, args.batch, dev)
+    # the contract is ONE line on stdout: whatever a module prints while it is built (MidasNet reports the weight file it
+    # loads, as the reference's does: MiDaS.py) goes to stderr
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):
+        net, fwd_loss, opt = build_other(args.config, args.batch, dev)
     state = {}
 
     def step():

@@ -359,8 +359,9 @@ extern "C" int mde_conv_wgrad(const mde_wgrad_desc* d, const void* direct, const
                 "mde_conv_wgrad: tensor too large for 32-bit indexing");
 
     {
-        // the windowed form (conv_wgrad_win.hip): one workgroup per kernel ROW of taps.  MDE_WGRAD_WIN=1 wherever the geometry
-        // is eligible (diagnostics, tests), 0 never; read per call
+        // the windowed form (conv_wgrad_win.hip): one workgroup per kernel ROW of taps.  It measured slower than the per-tap
+        // kernel below on every shape (that file's header has the numbers), so it is never chosen: MDE_WGRAD_WIN=1 runs it
+        // wherever the geometry is eligible (diagnostics, tests); unset or 0 = never.  Read per call.
         const char* we = getenv("MDE_WGRAD_WIN");
         const int win = !we ? 0 : atoi(we);
         if (win) {

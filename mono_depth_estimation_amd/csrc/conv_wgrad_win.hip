@@ -10,6 +10,15 @@
 // shifted rows.  A 3x3 moves 25 KB per 3.1 MFLOP (128 direct x 64 gathered channels x 3 taps): half the bytes per flop.
 // 8 waves, two workgroups per CU, K-step s+1 fetched under the MFMAs of step s (two staging buffers).
 //
+// MEASURED (round 3, in-network, FCRN-50 step, `bench.py --per-shape` with MDE_WGRAD_WIN=0 against =1; gpurun_out/r3_ww*.txt):
+// this kernel is SLOWER than the per-tap one on every multi-tap shape of the step -- +22 % (614 400 px, 128 x 128 ch, 9 taps:
+// 261 -> 318 us) to +110 % (9 600 px, 1024 x 1024 ch, 25 taps: 622 -> 1 309 us); weight-gradient time 8.00 -> 11.59 ms per
+// step, no shape faster.  The byte argument above holds and did not decide it: a wave here issues 8 T MFMAs per 16
+// transposed-read pairs where the per-tap kernel's 128 x 128 tile issues 32 (the DMA bytes were traded for LDS reads), the
+// stride-2 windows of the up-projection layers take 2-way bank conflicts on every read, and a 5-tap row runs as 3 + 2 with
+// the third slot of the short group computed and thrown away.  It is correct (tests/test_conv_wgrad_gpu.py runs every case
+// through both kernels) and is kept as a diagnostic: mde_conv_wgrad calls it only under MDE_WGRAD_WIN=1.
+//
 // Tiles are row-major [pixel][channel] and consumed with ds_read_b64_tr_b16 exactly as in conv_wgrad.hip (same swizzles);
 // the window's rows are addressed through per-lane offsets computed once per workgroup (they do not depend on the K-step).
 #include <stdlib.h>

@@ -74,7 +74,8 @@ def test_bench_other_configurations_print_the_contract_line(config):
         env.pop(k, None)
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
-    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert len(r.stdout.strip().splitlines()) == 1, "bench.py must print exactly one line on stdout: %r" % r.stdout[:300]
+    d = json.loads(r.stdout)
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["value"] > 0 and d["config"]["per_gpu_batch"] == 2
     assert d["config"]["final_loss"] == d["config"]["final_loss"]
     assert d["roofline"]["launches"] > 0 and 0.0 < d["roofline"]["frac"] < 1.0 and config.upper()[:3] in d["config"]["workload"].upper()

@@ -287,14 +287,23 @@ def test_fused_epilogue_equals_conv_plus_pointwise_pass(N, H, Wd, Cin, Cout, k, 
     ops.conv_gemm(d, xd, wd, got, bias=bias, res=res, act=act)
     torch.cuda.synchronize()
     assert torch.equal(got, want), float((got.float() - want.float()).abs().max())
-    # and against torch on the same operands, so that both are not wrong together
-    ref = F.conv2d(x, w, padding=p).to(torch.bfloat16).float()
+    # and against torch on the same operands, so that both are not wrong together.  The kernel rounds the CONV result to bf16
+    # before bias / residual / activation; torch's conv sums in another order, so a few results in 20 M land on the other side
+    # of a bf16 rounding boundary.  That is one ulp of the conv value, and where the residual cancels the conv value it is
+    # large against the small sum (first version of this check, bound relative to the sum: 4 of 19 742 720 elements out, the
+    # same four in every form of the loop).  The bound is therefore taken against |conv|, the quantity that was rounded;
+    # all three activations are 1-Lipschitz, so the error cannot grow behind them.
+    conv = F.conv2d(x, w, padding=p)
+    ref = conv.to(torch.bfloat16).float()
     if with_bias:
         ref = ref + bias.cpu().view(1, -1, 1, 1)
     if with_res:
         ref = ref + _nchw(res)
     ref = {"relu": torch.relu, "elu": F.elu, "sigmoid": torch.sigmoid, None: lambda t: t}[act](ref)
-    _assert_close(_nchw(got), ref, "fused epilogue", tol=2.0 ** -7)
+    err = (_nchw(got) - ref).abs()
+    bound = 2.0 ** -7 * (conv.abs() + ref.abs()) + 2.0 ** -7 * conv.pow(2).mean().sqrt()
+    bad = int((~(err <= bound)).sum())
+    assert bad == 0, "fused epilogue vs torch: %d/%d outside tolerance, max err %.4g" % (bad, ref.numel(), float(err.max()))
 
 
 def test_fused_epilogue_rejects_an_accumulating_launch():

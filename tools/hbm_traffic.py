@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
-"""Turn two rocprofv3 PMC passes over bench.py into profiles/r02_hbm_traffic.json (tagged with the hash of the kernel
+"""Turn two rocprofv3 PMC passes over bench.py into profiles/r03_hbm_traffic.json (tagged with the hash of the kernel
 sources it was collected on: bench.py quotes it only for those).
 
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_fetch -o p -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-launch-timing
   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_write -o p -- python3 bench.py ... (same)
-  python tools/hbm_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write <steps incl. warm-up> <conv calls/step> <wgrad calls/step> > profiles/r02_hbm_traffic.json
+  python tools/hbm_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write <steps incl. warm-up> <conv calls/step> <wgrad calls/step> > profiles/r03_hbm_traffic.json
 
 Counters are in KiB; FETCH_SIZE is doubled on gfx950 (it tallies 128-byte read requests as 64 bytes,
 MI355X_MICROARCH.md, HBM/rocprofv3 section); WRITE_SIZE is exact.  Bytes are reported per conv CALL (the
@@ -22,8 +22,8 @@ def totals(d, counter):
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] != counter:
             continue
-        for k in ("conv_gemm_nt", "conv_wgrad_tn"):
-            if k in r["Kernel_Name"]:
+        for k, names in (("conv_gemm_nt", ("conv_gemm_nt",)), ("conv_wgrad_tn", ("conv_wgrad_tn", "conv_wgrad_win"))):
+            if any(nm in r["Kernel_Name"] for nm in names):     # (the windowed weight-gradient kernel counts as a weight-gradient call)
                 tot[k] += float(r["Counter_Value"])
                 n[k] += 1
     return tot, n
