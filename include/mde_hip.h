@@ -317,6 +317,16 @@ int mde_pack_grouped(const float* src, void* fwd, void* dgrad, int O, int T, int
 /* nn.MaxPool2d(3, 2, 1, ceil_mode=True) (Dorn.py:235): as mde_maxpool_fwd / _bwd with the output size of ATen's ceil rule
  * (OH = ceil((H - 1) / 2) + 1, minus one if the last window would start beyond the padded input); out / idx are
  * [N][OH][OW][C].  ceil_mode == 0 is exactly mde_maxpool_fwd / _bwd. */
+/* nn.MaxPool2d(k, s) without padding over a spatial VIEW of an NHWC tensor: VGG-19-BN's MaxPool2d(2, 2) (Eigen.py:74) and the
+ * cropped pools of Eigen's scale 2 / 3 (`pool(x)[:, :, 1:-1, 1:-1]`, Eigen.py:23,41; `conv(img)[:, :, 2:-3, 2:-3]` then
+ * MaxPool2d(3, 1), Eigen.py:52,65-67) -- the crop is the view.  x / dx point at the view's first pixel inside the producing
+ * tensor; ld = its channel stride, wpitch / ipitch = its pixels per row / per image, Hv x Wv = the view.  out: bf16
+ * [N][OH][OW][ldo >= C] with OH = (Hv - k) / s + 1; idx: uint8 [N][OH][OW][C] (argmax inside the window, ATen's tie rule).
+ * The backward pass writes (accumulate != 0: adds onto) the VIEW of dx only: the caller zeroes what a crop leaves out. */
+int mde_maxpool_view_fwd(const void* x, int ldx, int wpitch, int64_t ipitch, int Hv, int Wv, void* out, int ldo, uint8_t* idx,
+                         int N, int C, int k, int s, void* stream);
+int mde_maxpool_view_bwd(const void* dout, int ldd, const uint8_t* idx, void* dx, int lddx, int wpitch, int64_t ipitch, int Hv, int Wv,
+                         int N, int C, int k, int s, int accumulate, void* stream);
 int mde_maxpool_fwd2(const void* x, void* out, uint8_t* idx, int N, int H, int W, int C, int ceil_mode, void* stream);
 int mde_maxpool_bwd2(const void* dout, const uint8_t* idx, void* dx, int N, int H, int W, int C, int ceil_mode, void* stream);
 /* nn.Dropout2d as data (Dorn.py:59,107,109): out[n][p][c] = x[n][p][c] * m[n][c] (+ out when accumulate), m fp32 [N][C] holding

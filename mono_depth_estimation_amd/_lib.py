@@ -98,6 +98,8 @@ SIGNATURES = {
     "mde_map_to_slot": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "mde_slot_to_map_add": (_I, [_P, _I, _P, _I, _I, _I, _I, _P]),
     "mde_pack_grouped": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "mde_maxpool_view_fwd": (_I, [_P, _I, _I, _L, _I, _I, _P, _I, _P, _I, _I, _I, _I, _P]),
+    "mde_maxpool_view_bwd": (_I, [_P, _I, _P, _P, _I, _I, _L, _I, _I, _I, _I, _I, _I, _I, _P]),
     "mde_maxpool_fwd2": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "mde_maxpool_bwd2": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "mde_chan_scale": (_I, [_P, _I, _P, _P, _I, _I, _L, _I, _I, _P]),

@@ -92,6 +92,93 @@ __global__ __launch_bounds__(NT) void maxpool_bwd_k(const bf16_t* __restrict__ d
     }
 }
 
+// ------------------------------------------------------------------ maxpool k x k, stride s, no padding, over a spatial VIEW
+// nn.MaxPool2d(2, 2) of VGG-19-BN and the cropped pools of Eigen's scale-2 / scale-3 stacks (Eigen.py:23,41 `pool(x)[:, :,
+// 1:-1, 1:-1]`; :52,65 `conv(img)[:, :, 2:-3, 2:-3]` then MaxPool2d(3, 1)): the crop is folded into the view -- x points at
+// the view's first pixel inside the producing tensor, whose own row / image pitches (in pixels) are passed in.
+struct PoolView { int ld, wpitch; int64_t ipitch; int H, W; };     // channel stride, pixels per row, pixels per image, view size
+
+__global__ __launch_bounds__(NT) void maxpool_g_fwd_k(const bf16_t* __restrict__ x, PoolView v, bf16_t* __restrict__ out, int ldo,
+                                                      uint8_t* __restrict__ idx, int N, int C, int OH, int OW, int k, int s) {
+    const int cpr = C >> 3;
+    const int64_t total = (int64_t)N * OH * OW * cpr;
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
+        const int col = (int)(i % cpr);
+        int64_t p = i / cpr;
+        const int ow = (int)(p % OW); p /= OW;
+        const int oh = (int)(p % OH);
+        const int n = (int)(p / OH);
+        float best[8];
+        int bi[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { best[e] = -INFINITY; bi[e] = -1; }
+        for (int kh = 0; kh < k; ++kh)
+            for (int kw = 0; kw < k; ++kw) {
+                const int ih = oh * s + kh, iw = ow * s + kw;              // (inside the view by the definition of OH / OW)
+                const bf16x8_t t = *reinterpret_cast<const bf16x8_t*>(x + ((int64_t)n * v.ipitch + (int64_t)ih * v.wpitch + iw) * v.ld + col * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float val = (float)t[e];
+                    if (bi[e] < 0 || val > best[e] || val != val) { best[e] = val; bi[e] = kh * k + kw; }     // ATen's tie / NaN rule
+                }
+            }
+        bf16x8_t o;
+        uint64_t packed = 0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            o[e] = (bf16_t)best[e];
+            packed |= (uint64_t)(uint8_t)bi[e] << (8 * e);
+        }
+        const int64_t opix = ((int64_t)n * OH + oh) * OW + ow;
+        *reinterpret_cast<bf16x8_t*>(out + opix * ldo + col * 8) = o;
+        *reinterpret_cast<uint64_t*>(idx + opix * C + col * 8) = packed;
+    }
+}
+
+// gather form (no atomics): a view pixel sums dout of the windows whose argmax it is; dx (+)= that
+__global__ __launch_bounds__(NT) void maxpool_g_bwd_k(const bf16_t* __restrict__ dout, int ldd, const uint8_t* __restrict__ idx,
+                                                      bf16_t* __restrict__ dx, PoolView v, int N, int C, int OH, int OW, int k, int s,
+                                                      int accumulate) {
+    const int cpr = C >> 3;
+    const int64_t total = (int64_t)N * v.H * v.W * cpr;
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
+        const int col = (int)(i % cpr);
+        int64_t p = i / cpr;
+        const int iw = (int)(p % v.W); p /= v.W;
+        const int ih = (int)(p % v.H);
+        const int n = (int)(p / v.H);
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        // windows oh with oh * s <= ih <= oh * s + k - 1
+        const int oh1 = min(ih / s, OH - 1), ow1 = min(iw / s, OW - 1);
+        const int oh0 = max(0, (ih - k + s) / s), ow0 = max(0, (iw - k + s) / s);       // ceil((ih - k + 1) / s) for ih - k + 1 > -s
+        for (int oh = oh0; oh <= oh1; ++oh) {
+            const int kh = ih - oh * s;
+            if (kh < 0 || kh >= k) continue;
+            for (int ow = ow0; ow <= ow1; ++ow) {
+                const int kw = iw - ow * s;
+                if (kw < 0 || kw >= k) continue;
+                const int64_t opix = ((int64_t)n * OH + oh) * OW + ow;
+                const uint64_t packed = *reinterpret_cast<const uint64_t*>(idx + opix * C + col * 8);
+                const bf16x8_t g = *reinterpret_cast<const bf16x8_t*>(dout + opix * ldd + col * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if ((int)((packed >> (8 * e)) & 0xFF) == kh * k + kw) acc[e] += (float)g[e];
+            }
+        }
+        bf16_t* dst = dx + ((int64_t)n * v.ipitch + (int64_t)ih * v.wpitch + iw) * v.ld + col * 8;
+        bf16x8_t o;
+        if (accumulate) {
+            const bf16x8_t old = *reinterpret_cast<const bf16x8_t*>(dst);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (bf16_t)(acc[e] + (float)old[e]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (bf16_t)acc[e];
+        }
+        *reinterpret_cast<bf16x8_t*>(dst) = o;
+    }
+}
+
 // ------------------------------------------------------------------ bilinear (align_corners) + sigmoid
 // source coordinate exactly as ATen computes it in float: src = dst * ((in-1)/(out-1)).
 struct Lerp { int i0, i1; float l0, l1; };
@@ -285,6 +372,38 @@ extern "C" int mde_maxpool_bwd2(const void* dout, const uint8_t* idx, void* dx, 
     maxpool_bwd_k<<<grid_for((int64_t)N * H * W * (C / 8)), NT, 0, (hipStream_t)stream>>>(
         (const bf16_t*)dout, idx, (bf16_t*)dx, N, H, W, C, OH, OW);
     MDE_LAUNCH_CHECK("maxpool_bwd_k");
+    return MDE_OK;
+}
+
+static int pool_view_check(const char* who, const void* x, int ldx, int wpitch, int64_t ipitch, int Hv, int Wv, int N, int C, int k, int s) {
+    MDE_REQUIRE(x && N > 0 && C > 0 && C % 8 == 0 && ldx % 8 == 0 && ldx >= C && ((uintptr_t)x % 16) == 0,
+                "%s: channels (C=%d, ld=%d) must be multiples of 8 on a 16-byte aligned base", who, C, ldx);
+    MDE_REQUIRE(k >= 1 && k <= 15 && s >= 1 && Hv >= k && Wv >= k && wpitch >= Wv && ipitch >= (int64_t)(Hv - 1) * wpitch + Wv,
+                "%s: window %d / stride %d over a %d x %d view (row pitch %d)", who, k, s, Hv, Wv, wpitch);
+    return MDE_OK;
+}
+
+extern "C" int mde_maxpool_view_fwd(const void* x, int ldx, int wpitch, int64_t ipitch, int Hv, int Wv, void* out, int ldo, uint8_t* idx,
+                                    int N, int C, int k, int s, void* stream) {
+    if (int rc = pool_view_check("mde_maxpool_view_fwd", x, ldx, wpitch, ipitch, Hv, Wv, N, C, k, s)) return rc;
+    MDE_REQUIRE(out && idx && ldo % 8 == 0 && ldo >= C && ((uintptr_t)out % 16) == 0 && ((uintptr_t)idx % 8) == 0,
+                "mde_maxpool_view_fwd: output alignment");
+    const int OH = (Hv - k) / s + 1, OW = (Wv - k) / s + 1;
+    maxpool_g_fwd_k<<<grid_for((int64_t)N * OH * OW * (C / 8)), NT, 0, (hipStream_t)stream>>>(
+        (const bf16_t*)x, PoolView{ldx, wpitch, ipitch, Hv, Wv}, (bf16_t*)out, ldo, idx, N, C, OH, OW, k, s);
+    MDE_LAUNCH_CHECK("maxpool_g_fwd_k");
+    return MDE_OK;
+}
+
+extern "C" int mde_maxpool_view_bwd(const void* dout, int ldd, const uint8_t* idx, void* dx, int lddx, int wpitch, int64_t ipitch, int Hv, int Wv,
+                                    int N, int C, int k, int s, int accumulate, void* stream) {
+    if (int rc = pool_view_check("mde_maxpool_view_bwd", dx, lddx, wpitch, ipitch, Hv, Wv, N, C, k, s)) return rc;
+    MDE_REQUIRE(dout && idx && ldd % 8 == 0 && ldd >= C && ((uintptr_t)dout % 16) == 0 && ((uintptr_t)idx % 8) == 0,
+                "mde_maxpool_view_bwd: gradient alignment");
+    const int OH = (Hv - k) / s + 1, OW = (Wv - k) / s + 1;
+    maxpool_g_bwd_k<<<grid_for((int64_t)N * Hv * Wv * (C / 8)), NT, 0, (hipStream_t)stream>>>(
+        (const bf16_t*)dout, ldd, idx, (bf16_t*)dx, PoolView{lddx, wpitch, ipitch, Hv, Wv}, N, C, OH, OW, k, s, accumulate);
+    MDE_LAUNCH_CHECK("maxpool_g_bwd_k");
     return MDE_OK;
 }
 

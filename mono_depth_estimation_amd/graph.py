@@ -445,14 +445,18 @@ class ImageStem(Op):
     run as launches of the GEMM kernel of at most 32 taps each (7x7: 32 + 17, the second accumulating), the BatchNorm
     statistics come from a stand-alone reduction.  No input gradient."""
 
-    def __init__(self, eng, conv, site, N, H, W):
+    def __init__(self, eng, conv, site, N, H, W, xin=None):
+        """xin: the converted image of another ImageStem of the same plan (Eigen reads the image with three convs): shared,
+        and converted once by the stem that owns it."""
         self.eng, self.site = eng, site
         self.w = eng._conv([conv.weight], need_dgrad=False)
         O, Cp = self.w.O, self.w.I
         k, st, pd = conv.kernel_size[0], conv.stride[0], conv.padding[0]
         assert Cp == 8 and conv.kernel_size == (k, k) and conv.stride == (st, st) and conv.padding == (pd, pd) and conv.dilation == (1, 1)
         H2, W2 = ops.out_size(H, k, st, pd), ops.out_size(W, k, st, pd)
-        self.xin = Act(eng.dev, N, H, W, Cp)
+        self.owns_xin = xin is None
+        self.xin = Act(eng.dev, N, H, W, Cp) if xin is None else xin
+        assert (self.xin.N, self.xin.H, self.xin.W, self.xin.C) == (N, H, W, Cp)
         self.out = Act(eng.dev, N, H2, W2, O)
         taps = [(i - pd, j - pd, i * k + j) for i in range(k) for j in range(k)]
         ks = eng._ksplit(N * H2 * W2, O, Cp, min(32, k * k))
@@ -467,10 +471,11 @@ class ImageStem(Op):
         return (self.out,)
 
     def fwd(self, train):
-        ops.nchw_to_nhwc_bf16_pad(self.x, self.xin.t, self.xin.C)
+        if self.owns_xin:
+            ops.nchw_to_nhwc_bf16_pad(self.x, self.xin.t, self.xin.C)
         for d in self.fd:
             ops.conv_gemm(d, self.xin.t, self.w.wf, self.out.t)
-        if train:
+        if train and self.site is not None:               # (Eigen's 9 x 9 / 2 image convs have no BatchNorm: Eigen.py:22,51)
             ops.bn_stats(self.out.t, self.out.M, self.out.C, self.out.ld, self.site.part)
 
     def bwd(self):
@@ -507,6 +512,69 @@ class MaxPool(Op):
             self.tmp = torch.empty_like(x.t)
         ops.maxpool_bwd(self.out.g, self.idx, self.tmp, x.N, x.H, x.W, x.C, self.ceil)
         ops.pw_fwd(self.tmp, x.C, None, x.g, _ldg(x), x.g, _ldg(x), x.M, x.C, None)
+
+
+class MaxPoolView(Op):
+    """nn.MaxPool2d(k, s) (no padding) over the spatial view x[:, y0:y0 + Hv, x0:x0 + Wv] of an NHWC tensor, the crops of
+    Eigen's stacks folded into the view: VGG-19-BN's MaxPool2d(2, 2) (whole tensor), scale 2's `pool(x)[:, :, 1:-1, 1:-1]`
+    (Eigen.py:41: MaxPool2d(3, 2), output rows 1 .. OH - 2 = windows starting at 2, 4, ...: view origin (2, 2)) and scale 3's
+    `conv(img)[:, :, 2:-3, 2:-3]` -> ReLU -> MaxPool2d(3, 1) (Eigen.py:65-67: the ReLU commutes with the crop).  `out` may be
+    a channel slice of a concatenation.  Pixels the view leaves out receive a zero gradient."""
+
+    def __init__(self, eng, x, k, s, y0=0, x0=0, Hv=None, Wv=None, out=None):
+        assert x.parent is None, "the view is taken on a tensor of its own"
+        self.x, self.k, self.s, self.y0, self.x0 = x, k, s, y0, x0
+        self.Hv, self.Wv = (x.H - y0 if Hv is None else Hv), (x.W - x0 if Wv is None else Wv)
+        assert 0 <= y0 and 0 <= x0 and y0 + self.Hv <= x.H and x0 + self.Wv <= x.W and self.Hv >= k and self.Wv >= k
+        OH, OW = (self.Hv - k) // s + 1, (self.Wv - k) // s + 1
+        self.out = out if out is not None else Act(eng.dev, x.N, OH, OW, x.C)
+        assert (self.out.N, self.out.H, self.out.W, self.out.C) == (x.N, OH, OW, x.C)
+        self.own_out = out is None
+        self.idx = torch.empty(x.N, OH, OW, x.C, dtype=torch.uint8, device=eng.dev)
+        self.partial = (y0, x0, self.Hv, self.Wv) != (0, 0, x.H, x.W) or (OH - 1) * s + k < self.Hv or (OW - 1) * s + k < self.Wv
+
+    def acts(self):
+        return (self.out,) if self.own_out else ()
+
+    def _view(self, t):
+        return t[:, self.y0:, self.x0:]
+
+    def fwd(self, train):
+        x, o = self.x, self.out
+        ops.maxpool_view_fwd(self._view(x.t), x.ld, x.W, x.H * x.W, self.Hv, self.Wv, o.t, o.ld, self.idx, x.N, x.C, self.k, self.s)
+
+    def bwd(self):
+        x, o = self.x, self.out
+        acc = _take(x)
+        if self.partial and not acc:
+            x.g.zero_()                                  # what the view (or a stride that does not reach the edge) leaves out
+            acc = True
+        ops.maxpool_view_bwd(o.g, _ldg(o), self.idx, self._view(x.g), _ldg(x), x.W, x.H * x.W, self.Hv, self.Wv, x.N, x.C, self.k, self.s,
+                             accumulate=acc)
+
+
+class Unflatten(Op):
+    """`x.reshape(-1, C, h, w)` of a Linear layer's output row (Eigen.py:87): the [N][1][1][C h w] row is in the NCHW order of
+    the reference's reshape, the convolutions want [N][h][w][C].  The inverse of PooledFlat's layout change (pool 1 x 1, no
+    dropout), so it is that op's two kernels with forward and backward exchanged."""
+
+    def __init__(self, eng, x, C, h, w):
+        assert (x.H, x.W) == (1, 1) and x.C == C * h * w and x.parent is None
+        self.x = x
+        self.out = Act(eng.dev, x.N, h, w, C)
+        self.ones = torch.ones(x.N, C, device=eng.dev)
+
+    def acts(self):
+        return (self.out,)
+
+    def fwd(self, train):
+        o = self.out
+        ops.avgpool_flat_bwd(self.x.t, self.ones, o.t, o.ld, o.N, o.H, o.W, o.C, 1, 1, 0)
+
+    def bwd(self):
+        o, x = self.out, self.x
+        assert not _take(x), "the Linear layer's output row has one consumer"
+        ops.avgpool_flat_fwd(o.g, _ldg(o), self.ones, x.g, o.N, o.H, o.W, o.C, 1, 1, 0)
 
 
 class Nearest2(Op):
@@ -779,17 +847,21 @@ class ConvT(Op):
     over the transposed packing, input gradient = that convolution's forward over d(out), weight gradient = its weight
     gradient with activation and output gradient exchanged."""
 
-    def __init__(self, eng, x, w, k, pad):
+    def __init__(self, eng, x, w, k, pad, stride=2):
+        """stride 2 with k = 2 pad + 2 doubles the size (MyNet); Eigen.py:79 upsamples by stride 4 with k 3 (14 x 19 -> 55 x 75:
+        sixteen output phases, seven of them without a tap: bias only) and Eigen.py:34 ends scale 2 in k 5 / stride 2 /
+        pad 2 (h -> 2 h - 1).  Output size (h - 1) stride - 2 pad + k, as nn.ConvTranspose2d without output_padding."""
         self.eng, self.x = eng, x
         self.w = eng.store.conv([w])                       # O = Cin, I = Cout (storage, possibly padded to 8)
         Cin, C = self.w.O, self.w.I
-        assert x.C == Cin and ops.out_size(2 * x.H, k, 2, pad) == x.H and ops.out_size(2 * x.W, k, 2, pad) == x.W, (x.C, Cin, k, pad)
-        N, h, wd = x.N, x.H, x.W
-        self.out = Act(eng.dev, N, 2 * h, 2 * wd, C)
+        N, h, wd, st = x.N, x.H, x.W, stride
+        H2, W2 = (h - 1) * st - 2 * pad + k, (wd - 1) * st - 2 * pad + k
+        assert x.C == Cin and ops.out_size(H2, k, st, pad) == h and ops.out_size(W2, k, st, pad) == wd, (x.C, Cin, k, pad, st)
+        self.out = Act(eng.dev, N, H2, W2, C)
         o = self.out
-        self.fdescs, self.fzero = ops.dgrad_descs(N, 2 * h, 2 * wd, o.ld, C, h, wd, x.ld, Cin, x.nbytes, k, 2, pad)
-        self.ddesc = ops.fwd_desc(N, 2 * h, 2 * wd, o.ld, C, o.nbytes, k, 2, pad, Cin, x.ld)
-        self.wdesc = ops.conv_wgrad_desc(N, 2 * h, 2 * wd, o.ld, C, o.nbytes, h, wd, x.ld, Cin, x.nbytes, k, 2, pad,
+        self.fdescs, self.fzero = ops.dgrad_descs(N, H2, W2, o.ld, C, h, wd, x.ld, Cin, x.nbytes, k, st, pad)
+        self.ddesc = ops.fwd_desc(N, H2, W2, o.ld, C, o.nbytes, k, st, pad, Cin, x.ld)
+        self.wdesc = ops.conv_wgrad_desc(N, H2, W2, o.ld, C, o.nbytes, h, wd, x.ld, Cin, x.nbytes, k, st, pad,
                                          eng._ksplit(x.M, Cin, C, k * k))
 
     def acts(self):

@@ -349,6 +349,16 @@ def pixel_shuffle2(src, ld_src, dst, ld_dst, N, h, w, C_, inverse=False):
           "mde_pixel_shuffle2")
 
 
+def maxpool_view_fwd(x, ldx, wpitch, ipitch, Hv, Wv, out, ldo, idx, N, C_, k, s):
+    check(_lib.load().mde_maxpool_view_fwd(_p(x), ldx, wpitch, ipitch, Hv, Wv, _p(out), ldo, _p(idx), N, C_, k, s, _stream()),
+          "mde_maxpool_view_fwd")
+
+
+def maxpool_view_bwd(dout, ldd, idx, dx, lddx, wpitch, ipitch, Hv, Wv, N, C_, k, s, accumulate=False):
+    check(_lib.load().mde_maxpool_view_bwd(_p(dout), ldd, _p(idx), _p(dx), lddx, wpitch, ipitch, Hv, Wv, N, C_, k, s, int(accumulate),
+                                           _stream()), "mde_maxpool_view_bwd")
+
+
 def maxpool_fwd(x, out, idx, N, H, W, C_, ceil_mode=False):
     check(_lib.load().mde_maxpool_fwd2(_p(x), _p(out), _p(idx), N, H, W, C_, int(ceil_mode), _stream()), "mde_maxpool_fwd2")
 

@@ -606,3 +606,31 @@ def test_pixel_shuffle2_matches_torch():
     assert float(back[..., :8].float().abs().max()) == 0.0 and float(back[..., 8 + 4 * C:].float().abs().max()) == 0.0
 
 
+
+
+@pytest.mark.parametrize("N,H,Wd,C,k,s,y0,x0,Hv,Wv", [
+    (2, 12, 20, 64, 2, 2, 0, 0, 12, 20),       # VGG's MaxPool2d(2, 2)
+    (1, 15, 21, 16, 2, 2, 0, 0, 15, 21),       # odd sizes: the last row / column is outside every window
+    (2, 17, 23, 32, 3, 2, 2, 2, 11, 17),       # MaxPool2d(3, 2) cropped [1:-1]: a view at (2, 2) (Eigen scale 2)
+    (2, 16, 21, 24, 3, 1, 2, 2, 11, 16),       # [2:-3] then MaxPool2d(3, 1): overlapping windows (Eigen scale 3)
+])
+def test_maxpool_view(N, H, Wd, C, k, s, y0, x0, Hv, Wv):
+    """mde_maxpool_view_fwd / _bwd against torch's MaxPool2d on the cropped tensor, values exact (bf16 in, bf16 out) and the
+    gradient routed to the same argmax; pixels outside the view get exactly zero."""
+    from mono_depth_estimation_amd import ops
+    x = W.normal(11, "x", (N, C, H, Wd)).to(torch.bfloat16).float()
+    xi = x.clone().requires_grad_(True)
+    ref = F.max_pool2d(xi[:, :, y0:y0 + Hv, x0:x0 + Wv], k, s)
+    OH, OW = ref.shape[2:]
+    dy = W.normal(11, "dy", tuple(ref.shape)).to(torch.bfloat16).float()
+    ref.backward(dy)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).cuda()
+    out = torch.empty(N, OH, OW, C, dtype=torch.bfloat16, device="cuda")
+    idx = torch.empty(N, OH, OW, C, dtype=torch.uint8, device="cuda")
+    ops.maxpool_view_fwd(xd[:, y0:, x0:], C, Wd, H * Wd, Hv, Wv, out, C, idx, N, C, k, s)
+    assert torch.equal(out.float().cpu().permute(0, 3, 1, 2), ref.detach())
+    dyd = dy.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).cuda()
+    dx = torch.zeros(N, H, Wd, C, dtype=torch.bfloat16, device="cuda")
+    ops.maxpool_view_bwd(dyd, C, idx, dx[:, y0:, x0:], C, Wd, H * Wd, Hv, Wv, N, C, k, s, accumulate=True)
+    got = dx.float().cpu().permute(0, 3, 1, 2)
+    assert torch.allclose(got, xi.grad.to(torch.bfloat16).float(), rtol=2.0 ** -7, atol=1e-6), float((got - xi.grad).abs().max())
