@@ -208,6 +208,36 @@ def _densenet_features(growth, blocks, init, bn_size=4):
     return seq
 
 
+def _torchvision_resnet(blocks, groups=1, base_width=64):
+    """torchvision.models.resnet50 / resnet101 / resnext50_32x4d / resnext101_32x8d kept WHOLE, as Bts.py:293-307 keeps them:
+    conv1, bn1, relu, maxpool, layer1 .. layer4, avgpool, fc under torchvision's names (absent from the image and from
+    /root/reference; restated from the public definition).  The forward walk skips avgpool and fc (Bts.py:313-315), but their
+    parameters are part of the state_dict.  fc never receives a gradient: torch's optimisers skip it (grad is None); it is
+    frozen here so that the fused flat-range AdamW step, which decays every entry of a range, leaves it alone as well."""
+    from .MiDaS import _stage
+    m = _Container()
+    m.conv1 = nn.Conv2d(3, 64, kernel_size=7, stride=2, padding=3, bias=False)
+    m.bn1 = nn.BatchNorm2d(64)
+    m.relu = nn.ReLU(inplace=True)
+    m.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+    m.layer1 = _stage(64, 64, blocks[0], 1, groups, base_width)
+    m.layer2 = _stage(256, 128, blocks[1], 2, groups, base_width)
+    m.layer3 = _stage(512, 256, blocks[2], 2, groups, base_width)
+    m.layer4 = _stage(1024, 512, blocks[3], 2, groups, base_width)
+    m.avgpool = nn.AdaptiveAvgPool2d((1, 1))
+    m.fc = nn.Linear(2048, 1000)
+    for mod in m.modules():                          # torchvision's default initialisation of the trunk
+        if isinstance(mod, nn.Conv2d):
+            nn.init.kaiming_normal_(mod.weight, mode="fan_out", nonlinearity="relu")
+    for p in m.fc.parameters():
+        p.requires_grad_(False)
+    return m
+
+
+_RESNETS = {'resnet50_bts': ((3, 4, 6, 3), 1, 64), 'resnet101_bts': ((3, 4, 23, 3), 1, 64),
+            'resnext50_bts': ((3, 4, 6, 3), 32, 4), 'resnext101_bts': ((3, 4, 23, 3), 32, 8)}
+
+
 class encoder(_Container):
     """Bts.py:280-321.  `pretrained=True` there downloads torchvision weights; here the trunk keeps its random initialisation
     until a checkpoint is loaded (load_state_dict with the reference's keys)."""
@@ -216,14 +246,19 @@ class encoder(_Container):
         super(encoder, self).__init__()
         if version == 'densenet121_bts':
             self.base_model = _densenet_features(32, (6, 12, 24, 16), 64)
+            self.feat_names = ['relu0', 'pool0', 'transition1', 'transition2', 'norm5']
             self.feat_out_channels = [64, 64, 128, 256, 1024]
         elif version == 'densenet161_bts':
             self.base_model = _densenet_features(48, (6, 12, 36, 24), 96)
+            self.feat_names = ['relu0', 'pool0', 'transition1', 'transition2', 'norm5']
             self.feat_out_channels = [96, 96, 192, 384, 2208]
+        elif version in _RESNETS:
+            self.base_model = _torchvision_resnet(*_RESNETS[version])
+            self.feat_names = ['relu', 'layer1', 'layer2', 'layer3', 'layer4']
+            self.feat_out_channels = [64, 256, 512, 1024, 2048]
         else:
-            raise NotImplementedError("HIP BTS encoder: densenet121_bts / densenet161_bts (got %r; the ResNet / ResNeXt trunks of "
-                                      "Bts.py:293-307 have no plan here)" % (version,))
-        self.feat_names = ['relu0', 'pool0', 'transition1', 'transition2', 'norm5']
+            raise NotImplementedError("BTS encoder %r (the reference prints 'Not supported encoder' and builds nothing, Bts.py:306-307)"
+                                      % (version,))
         self.version = version
 
 
@@ -311,12 +346,30 @@ class BtsEngine(G.TapeEngine):
                 skips.append(self.add(G.PrefixBN(self, buf, feats.norm5, mean, var)).out)
         return skips
 
+    def _resnet_trunk(self, rn, N, H, W):
+        """encoder.forward (Bts.py:309-321) over a whole torchvision ResNet / ResNeXt: 'relu' (after conv1 / bn1), then
+        layer1 .. layer4 are the five features; the 3x3 convs of the ResNeXt variants run as block-diagonal grouped tiles."""
+        s0 = self._site([rn.bn1])
+        self.stem = self.add(G.ImageStem(self, rn.conv1, s0, N, H, W))
+        relu = self.add(G.BN(self, self.stem.out, s0, True)).out
+        x = self.add(G.MaxPool(self, relu)).out
+        skips = [relu]
+        for stage in (rn.layer1, rn.layer2, rn.layer3, rn.layer4):
+            for b in stage:
+                ds = b.downsample
+                x = self.bottleneck(x, b.conv1, b.bn1, b.conv2, b.bn2, b.conv3, b.bn3,
+                                    ds[0] if ds is not None else None, ds[1] if ds is not None else None)
+            skips.append(x)
+        return skips                                  # (layer4 ends in a ReLU: the decoder's ReLU on it, Bts.py:207, is the identity)
+
     def _plan(self):
         m, N, H, W = self.m, self.N, self.H, self.W
         if H % 32 or W % 32:
             raise ValueError("BtsModel: image sizes must be multiples of 32 (got %d x %d)" % (H, W))
         d, md = m.decoder, float(m.decoder.max_depth)
-        skip0, skip1, skip2, skip3, dense = self._dense_trunk(m.encoder.base_model, N, H, W)
+        base = m.encoder.base_model
+        trunk = self._resnet_trunk if hasattr(base, "layer1") else self._dense_trunk
+        skip0, skip1, skip2, skip3, dense = trunk(base, N, H, W)
         nf = d.bn5.num_features
         # 1/16: upconv5 -> bn5 | skip3 -> conv5
         cat5 = self.buf(N, skip3.H, skip3.W, nf + skip3.C)

@@ -248,11 +248,33 @@ def densenet_features(n, x, pfx, blocks=(6, 12, 36, 24)):
     return skips
 
 
+def resnet_features(n, x, pfx):
+    """encoder.forward (Bts.py:309-321) over a torchvision ResNet / ResNeXt kept whole as `base_model` (Bts.py:293-307): the walk
+    over `_modules` collects 'relu' (after conv1 / bn1) and layer1 .. layer4; block counts and the group count are read off
+    the state dict."""
+    P = n.P
+    y = n.q(F.relu(n.bn(n.conv(x, pfx + "conv1", 2, 3), pfx + "bn1")))
+    skips = [y]
+    y = F.max_pool2d(y, 3, 2, 1)
+    for L in range(1, 5):
+        i = 0
+        while pfx + "layer%d.%d.conv1.weight" % (L, i) in P:
+            k = pfx + "layer%d.%d" % (L, i)
+            w2 = P[k + ".conv2.weight"]
+            y = _tv_bottleneck(n, y, k, 2 if (i == 0 and L > 1) else 1, w2.shape[0] // w2.shape[1])
+            i += 1
+        skips.append(y)
+    return skips
+
+
 def bts_forward(P, x, train, max_depth=10.0, momentum=None, q=None):
-    """BtsModel.forward (Bts.py:324-333) with the densenet161_bts encoder -> the 5-tuple of bts.forward (Bts.py:205-278);
-    dataset 'nyu', no image residuals."""
+    """BtsModel.forward (Bts.py:324-333) with a densenet*_bts or a resnet*_bts / resnext*_bts encoder (told apart by the state
+    dict's keys) -> the 5-tuple of bts.forward (Bts.py:205-278); dataset 'nyu', no image residuals."""
     n = Net(P, train, q=q, momentum=momentum)
-    s0, s1, s2, s3, dense = densenet_features(n, x, "encoder.base_model.")
+    if "encoder.base_model.conv1.weight" in P:
+        s0, s1, s2, s3, dense = resnet_features(n, x, "encoder.base_model.")
+    else:
+        s0, s1, s2, s3, dense = densenet_features(n, x, "encoder.base_model.")
     d = "decoder."
     bnk = lambda t, k: n.bn(t, d + k, 0.01, 1.1e-5)
     dense = n.q(F.relu(dense))

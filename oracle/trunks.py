@@ -64,6 +64,33 @@ class ResNeXt(nn.Module):
         return nn.Sequential(*mods)
 
 
+class ResNetFull(ResNeXt):
+    """The WHOLE torchvision ResNet, avgpool and fc included: what `models.resnet50(pretrained=True)` returns and Bts.py:293-307
+    keeps as `encoder.base_model` (its forward walk skips 'avgpool' and 'fc', Bts.py:313-315, but their parameters stay in
+    the state_dict)."""
+
+    def __init__(self, layers, groups=1, width_per_group=64):
+        super().__init__(layers, groups, width_per_group)
+        self.avgpool = nn.AdaptiveAvgPool2d((1, 1))
+        self.fc = nn.Linear(2048, 1000)
+
+
+def resnet50_full(pretrained=False):
+    return ResNetFull([3, 4, 6, 3])
+
+
+def resnet101_full(pretrained=False):
+    return ResNetFull([3, 4, 23, 3])
+
+
+def resnext50_32x4d_full(pretrained=False):
+    return ResNetFull([3, 4, 6, 3], 32, 4)
+
+
+def resnext101_32x8d_full(pretrained=False):
+    return ResNetFull([3, 4, 23, 3], 32, 8)
+
+
 def resnext101_32x8d():
     return ResNeXt([3, 4, 23, 3], 32, 8)
 

@@ -170,6 +170,21 @@ def bts_fixture_state(model, seed):
     return sd
 
 
+def bts_resnet_fixture_state(model, seed):
+    """BTS over a ResNet / ResNeXt encoder: net_conditioned_state with the residual branches' last BatchNorm damped to 0.05 (as
+    the MiDaS / VNL trunks), and the decoder's head convs scaled as in bts_fixture_state so that no sigmoid saturates."""
+    sd = net_conditioned_state(model, seed, damp=(".bn3.",), damp_to=0.05)
+    for k in sd:
+        if k.endswith("plane_params.weight"):
+            sd[k] = (sd[k] * 0.02).to(torch.bfloat16).to(torch.float32)
+        if k.endswith("reduc.final.0.weight"):
+            sd[k] = (sd[k] * 0.05).to(torch.bfloat16).to(torch.float32)
+    k = "decoder.get_depth.0.weight"
+    sd[k] = (sd[k] * 0.02).to(torch.bfloat16).to(torch.float32)
+    model.load_state_dict(sd)
+    return sd
+
+
 def bts_conditioned_state(model, seed, damp=0.05):
     """A WELL-CONDITIONED BTS state, the counterpart of fcrn_conditioned_state for a DenseNet trunk.  bts_fixture_state's
     trunk amplifies storage rounding because every one of its 78 dense layers is computed from ALL the features before it

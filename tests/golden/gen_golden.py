@@ -606,6 +606,47 @@ def gen_bts_net(criteria):
         len(out["keys"]), sum(p.numel() for p in ref.parameters()), out["eval_final"].min(), out["eval_final"].max(), float(loss)))
 
 
+def gen_bts_resnet(criteria):
+    """C2's other encoders (Bts.py:293-307): the reference's BtsModel over a ResNet-50 and a ResNeXt-50 32x4d.  Bts.py keeps the
+    WHOLE torchvision model as `encoder.base_model` (fc included), so for this generator `torchvision.models.resnet50` /
+    `resnext50_32x4d` are the full stand-ins of oracle/trunks.py (the FCRN generators keep the trunk-only stand-in they were
+    minted with)."""
+    import torchvision.models as tvm
+    from network import Bts
+    from oracle import trunks
+    saved = {k: tvm.__dict__.get(k) for k in ("resnet50", "resnext50_32x4d")}
+    tvm.resnet50, tvm.resnext50_32x4d = trunks.resnet50_full, trunks.resnext50_32x4d_full
+    try:
+        for version, seed in (("resnet50_bts", 57), ("resnext50_bts", 59)):
+            torch.manual_seed(0)
+            ref = Bts.BtsModel(bts_size=512, max_depth=10, out_channels=1, encoder_version=version)
+            W.bts_resnet_fixture_state(ref, seed)
+            H, Wd = BTS_SIZE
+            rgb, tgt = W.synthetic_batch(seed, 2, H, Wd)
+            W.calibrate_running_stats(ref, rgb)
+            out = {"keys": np.array(list(ref.state_dict().keys())), "n_params": np.int64(sum(p.numel() for p in ref.parameters()))}
+            ref.eval()
+            with torch.no_grad():
+                ys = ref(rgb)
+            for nme, y in zip(("d8", "d4", "d2", "r1", "final"), ys):
+                out["eval_" + nme] = _np(y).astype(np.float16) if nme != "final" else _np(y)
+            ref.train()
+            ys = ref(rgb)
+            loss = criteria.silog_loss(0.85)(ys[4], tgt * 10.0)
+            loss.backward()
+            out["train_loss"] = _np(loss)
+            out["grad_names"], out["grad_norms"] = _grad_norms(ref)
+            np.savez_compressed(os.path.join(HERE, "bts_%s.npz" % version[:-4]), **out)
+            print("bts_%s.npz: %d keys, %d params, eval final range %.4f..%.4f, train loss %.5f" % (
+                version[:-4], len(out["keys"]), int(out["n_params"]), out["eval_final"].min(), out["eval_final"].max(), float(loss)))
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                tvm.__dict__.pop(k, None)
+            else:
+                tvm.__dict__[k] = v
+
+
 def gen_bts_conditioned(criteria, metrics):
     """C2 on a WELL-CONDITIONED state (oracle/weights.bts_conditioned_state: the north-star bound |dAbsRel| <= 1e-4 is only
     meaningful where the fp32 reference itself is stable under bf16 storage): the reference's own network/Bts.py, eval
@@ -825,6 +866,8 @@ def main():
         gen_bts_net(criteria)
     if want("bts_cond"):
         gen_bts_conditioned(criteria, metrics)
+    if want("bts_resnet"):
+        gen_bts_resnet(criteria)
     if want("eigen"):
         gen_eigen(criteria)
     if want("dorn_net"):

@@ -97,7 +97,7 @@ def test_eigen_train_step_against_the_reference(setup, golden):
         ratios[str(k)] = float(gh.norm()) / float(v)
     print("gradient-norm ratios HIP / reference:", {k: round(r, 4) for k, r in ratios.items()})
     for k, r in ratios.items():
-        assert abs(r - 1.0) < 0.06, (k, r)                  # measured 0.992 ... 1.032
+        assert abs(r - 1.0) < 0.08, (k, r)                  # measured 0.992 ... 1.032 (two runs; a train-mode step with float atomics)
     # modules/eigen.py:55-60: Adam over the three groups at one rate, through the fused flat-range step
     losses = []
     for _ in range(3):
