@@ -431,7 +431,10 @@ class BtsModel(G.TapeModule):
         self._init_runtime()
 
     def _make_store(self, device):
-        return G.NetStore(self, device, is_encoder=lambda n: n.startswith("encoder."))      # bts.py:140-141
+        # (the grouped 3x3 weights of the ResNeXt encoders, [O][G][3][3] with G = 4 or 8, keep their exact shape: their
+        #  block-diagonal packings are built from it)
+        raw = [n + ".weight" for n, m in self.named_modules() if isinstance(m, nn.Conv2d) and m.groups > 1]
+        return G.NetStore(self, device, is_encoder=lambda n: n.startswith("encoder."), raw=raw)      # bts.py:140-141
 
     def forward(self, x, focal=518.8579):
         return self._run(x)

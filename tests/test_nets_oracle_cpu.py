@@ -178,6 +178,36 @@ def test_bts_oracle_matches_the_reference(bts_fixture):
     assert np.allclose(P["decoder.bn4_2.running_var"].numpy(), g["rv_bn4_2"], rtol=1e-4, atol=1e-7)
 
 
+@pytest.mark.parametrize("version,seed", [("resnet50_bts", 57), ("resnext50_bts", 59)])
+def test_bts_resnet_encoders_match_the_reference(version, seed):
+    """Bts.py:293-307: BtsModel over a torchvision ResNet-50 / ResNeXt-50 32x4d kept whole as `encoder.base_model`
+    (tests/golden/bts_resnet50.npz, bts_resnext50.npz, minted from the reference): same keys and parameter count in the product
+    module, and the oracle's walk (nets.resnet_features) reproduces the five eval outputs, the SILog and the gradient norms."""
+    from mono_depth_estimation_amd.network import Bts
+    g = _golden("bts_" + version[:-4])
+    torch.manual_seed(0)
+    net = Bts.BtsModel(bts_size=512, max_depth=10, out_channels=1, encoder_version=version)
+    assert list(net.state_dict().keys()) == list(g["keys"]) and sum(p.numel() for p in net.parameters()) == int(g["n_params"])
+    assert net.encoder.feat_out_channels == [64, 256, 512, 1024, 2048] and net.encoder.feat_names[0] == "relu"
+    sd = W.bts_resnet_fixture_state(net, seed)
+    rgb, tgt = W.synthetic_batch(seed, 2, *BTS_SIZE)
+    P0 = nets.leaf_state(sd)
+    with torch.no_grad():
+        nets.bts_forward(P0, rgb, True, momentum=1.0)
+        ys = nets.bts_forward(P0, rgb, False)
+    for nme, y in zip(("d8", "d4", "d2", "r1", "final"), ys):
+        ref = g["eval_" + nme].astype(np.float32)                          # (the four auxiliary maps are stored as fp16)
+        assert np.allclose(y.numpy(), ref, rtol=2e-3 if nme != "final" else 2e-4, atol=2e-3 if nme != "final" else 2e-6), nme
+    P = nets.leaf_state(P0, requires_grad=True)
+    loss = L.silog(nets.bts_forward(P, rgb, True)[4], tgt * 10.0, 0.85)
+    assert np.allclose(float(loss.detach()), float(g["train_loss"]), rtol=2e-5)
+    loss.backward()
+    assert P["encoder.base_model.fc.weight"].grad is None                # never part of the forward walk (Bts.py:313-315)
+    for k, v in zip(g["grad_names"], g["grad_norms"]):
+        got = float(P[str(k)].grad.norm())
+        assert abs(got - v) <= 3e-3 * v + 1e-7, (k, got, v)
+
+
 def test_bts_oracle_matches_the_reference_on_the_conditioned_state():
     """tests/golden/bts_cond.npz (the reference's network/Bts.py + metrics.py on oracle/weights.bts_conditioned_state): the
     oracle reproduces its five eval outputs, its AbsRel and its train-mode SILog; and the state is what it is there for --
