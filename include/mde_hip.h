@@ -295,6 +295,11 @@ int mde_to_nchw_act_fwd(const void* x, int ldx, const float* bias, float* out, i
                         void* stream);
 int mde_to_nchw_act_bwd(const float* dout, const float* out, void* dx, int lddx, float* dbias, int N, int64_t HW, int C,
                         int act, float scale, void* stream);
+/* BTS' image-residual head (Bts.py:264-271; out_channels == 10 with image_residuals): d = the ten sigmoid channels of get_depth
+ * (two RGBA layers + two depths), fp32 [N][C][HW]; rgb = the input image fp32 [N][3][HW].  out[:, 0:3] = clamp(2 d - 1 + rgb, 0, 1),
+ * out[:, 3] = clamp(2 d - 1 + mean(rgb), 0, 1), [4:8] likewise, [8:] = d.  Backward: dd = d(loss)/d(d) (no gradient to the image). */
+int mde_image_residual_fwd(const float* d, const float* rgb, float* out, int N, int64_t HW, int C, void* stream);
+int mde_image_residual_bwd(const float* dout, const float* d, const float* rgb, float* dd, int N, int64_t HW, int C, void* stream);
 /* BTS plane heads (Bts.py:105-122 reduction_1x1's tail, :228-231 F.normalize, :124-146 local_planar_guidance): x bf16
  * [N][h][w][ldx] holds the three plane parameters in channels 0..2; theta = sigmoid(x0) pi/3, phi = sigmoid(x1) 2 pi,
  * dist = sigmoid(x2) max_depth, n = normalize(sin theta cos phi, sin theta sin phi, cos theta);

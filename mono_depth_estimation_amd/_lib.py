@@ -93,6 +93,8 @@ SIGNATURES = {
     "mde_softmax_head_bwd": (_I, [_P, _P, _P, _P, _I, _P, _I, _L, _I, _P]),
     "mde_to_nchw_act_fwd": (_I, [_P, _I, _P, _P, _I, _L, _I, _I, _F, _P]),
     "mde_to_nchw_act_bwd": (_I, [_P, _P, _P, _I, _P, _I, _L, _I, _I, _F, _P]),
+    "mde_image_residual_fwd": (_I, [_P, _P, _P, _I, _L, _I, _P]),
+    "mde_image_residual_bwd": (_I, [_P, _P, _P, _P, _I, _L, _I, _P]),
     "mde_plane_depth_fwd": (_I, [_P, _I, _P, _I, _I, _I, _I, _F, _P]),
     "mde_plane_depth_bwd": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
     "mde_map_to_slot": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),

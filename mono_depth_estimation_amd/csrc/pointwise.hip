@@ -858,6 +858,56 @@ extern "C" int mde_to_nchw_act_bwd(const float* dout, const float* out, void* dx
     return MDE_OK;
 }
 
+// ------------------------------------------------------------------ BTS' image-residual head (Bts.py:264-271)
+// depth = get_depth(iconv1): ten sigmoid channels = two RGBA layers + two depths.  The colour channels are RESIDUALS on the input
+// image: front = clamp(2 d[0:3] - 1 + rgb, 0, 1), front alpha = clamp(2 d[3] - 1 + mean(rgb), 0, 1), back likewise from d[4:8];
+// d[8:] passes through.  fp32 NCHW in and out.  torch.clamp hands the gradient on where min <= v <= max.
+__global__ __launch_bounds__(NT) void image_residual_fwd_k(const float* __restrict__ d, const float* __restrict__ rgb, float* __restrict__ out,
+                                                           int N, int64_t HW, int C) {
+    const int64_t total = (int64_t)N * HW;
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
+        const int64_t n = i / HW, p = i - n * HW;
+        const float r = rgb[(n * 3 + 0) * HW + p], g = rgb[(n * 3 + 1) * HW + p], b = rgb[(n * 3 + 2) * HW + p];
+        const float add[4] = {r, g, b, (r + g + b) / 3.0f};
+        for (int c = 0; c < C; ++c) {
+            const float v = d[(n * C + c) * HW + p];
+            out[(n * C + c) * HW + p] = c < 8 ? fminf(fmaxf(v * 2.0f - 1.0f + add[c & 3], 0.0f), 1.0f) : v;
+        }
+    }
+}
+__global__ __launch_bounds__(NT) void image_residual_bwd_k(const float* __restrict__ dout, const float* __restrict__ d,
+                                                           const float* __restrict__ rgb, float* __restrict__ dd, int N, int64_t HW, int C) {
+    const int64_t total = (int64_t)N * HW;
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
+        const int64_t n = i / HW, p = i - n * HW;
+        const float r = rgb[(n * 3 + 0) * HW + p], g = rgb[(n * 3 + 1) * HW + p], b = rgb[(n * 3 + 2) * HW + p];
+        const float add[4] = {r, g, b, (r + g + b) / 3.0f};
+        for (int c = 0; c < C; ++c) {
+            const int64_t o = (n * C + c) * HW + p;
+            float gsum = dout[o];
+            if (c < 8) {
+                const float v = d[o] * 2.0f - 1.0f + add[c & 3];
+                gsum = (v >= 0.0f && v <= 1.0f) ? 2.0f * gsum : 0.0f;
+            }
+            dd[o] = gsum;
+        }
+    }
+}
+
+extern "C" int mde_image_residual_fwd(const float* d, const float* rgb, float* out, int N, int64_t HW, int C, void* stream) {
+    MDE_REQUIRE(d && rgb && out && N > 0 && HW > 0 && C >= 8, "mde_image_residual_fwd: bad argument (C=%d >= 8: two RGBA layers)", C);
+    image_residual_fwd_k<<<grid_flat((int64_t)N * HW), NT, 0, (hipStream_t)stream>>>(d, rgb, out, N, HW, C);
+    MDE_LAUNCH_CHECK("image_residual_fwd_k");
+    return MDE_OK;
+}
+
+extern "C" int mde_image_residual_bwd(const float* dout, const float* d, const float* rgb, float* dd, int N, int64_t HW, int C, void* stream) {
+    MDE_REQUIRE(dout && d && rgb && dd && N > 0 && HW > 0 && C >= 8, "mde_image_residual_bwd: bad argument (C=%d >= 8)", C);
+    image_residual_bwd_k<<<grid_flat((int64_t)N * HW), NT, 0, (hipStream_t)stream>>>(dout, d, rgb, dd, N, HW, C);
+    MDE_LAUNCH_CHECK("image_residual_bwd_k");
+    return MDE_OK;
+}
+
 extern "C" int mde_pack_grouped(const float* src, void* fwd, void* dgrad, int O, int T, int G, void* stream) {
     MDE_REQUIRE(src && (fwd || dgrad) && O > 0 && T > 0 && G > 0 && O % 64 == 0 && 64 % G == 0,
                 "mde_pack_grouped: O=%d must be a multiple of 64 and the group size %d must divide 64", O, G);

@@ -438,6 +438,30 @@ class ToNCHW(Op):
         ops.to_nchw_act_bwd(self.douts[0], self.y, x.g, _ldg(x), dbias, x.N, x.H * x.W, self.C, self.act, self.scale)
 
 
+class ImageResidualHead(ToNCHW):
+    """BTS' final_depth with image_residuals (Bts.py:264-271): the sigmoid head's ten channels, the colour ones as residuals on
+    the input image.  The image is the plan's input (`eng.stem.x`), read as it is (fp32 NCHW)."""
+
+    def __init__(self, eng, x, C):
+        super().__init__(eng, x, None, C, "sigmoid", 1.0)
+        self.d = self.y                                   # the sigmoid channels
+        self.y = torch.empty_like(self.d)
+        self.outputs = (self.y,)
+        self.dd = torch.empty_like(self.d)
+
+    def fwd(self, train):
+        x = self.x
+        ops.to_nchw_act_fwd(x.t, x.ld, None, self.d, x.N, x.H * x.W, self.C, self.act, self.scale)
+        ops.image_residual_fwd(self.d, self.eng.stem.x, self.y)
+
+    def bwd(self):
+        x = self.x
+        assert not x.gw
+        x.gw = True
+        ops.image_residual_bwd(self.douts[0], self.d, self.eng.stem.x, self.dd)
+        ops.to_nchw_act_bwd(self.dd, self.d, x.g, _ldg(x), None, x.N, x.H * x.W, self.C, self.act, self.scale)
+
+
 # ---------------------------------------------------------------------------------------------- ops of the BTS / DenseNet plans
 class ImageStem(Op):
     """A k x k stem conv on the image with any number of output channels (densenet161's 7x7/2 conv0: 96 channels, Bts.py:289;

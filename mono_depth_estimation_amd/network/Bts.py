@@ -9,7 +9,9 @@ BN -> ReLU -> 3x3 dense layers whose 48 new channels are written straight into t
 batch moments of every channel group are reduced once and shared by all the BatchNorms that normalise it again), the
 decoder's nearest-x2 up-convolutions with ELU, dense ASPP (BN -> ReLU -> 1x1 -> BN -> ReLU -> dilated 3x3, dilations
 3 / 6 / 12 / 18 / 24), the reduction_1x1 chains down to three plane parameters, local planar guidance at 8x / 4x / 2x, and
-the sigmoid depth head.  The ResNet / ResNeXt encoder options of Bts.py:293-307 and `image_residuals` have no plan here.
+the sigmoid depth head, with `image_residuals` the colour channels as residuals on the input image (Bts.py:264-271).  Encoders:
+densenet121 / 161 and the whole-model ResNet-50 / -101, ResNeXt-50 32x4d / -101 32x8d of Bts.py:293-307 (grouped 3x3 convs as
+block-diagonal tiles); ResNet-50 and ResNeXt-50 are pinned by goldens, the 101-layer variants by their parameter tree only.
 """
 import math
 from collections import OrderedDict
@@ -131,8 +133,6 @@ class bts(_Container):
 
     def __init__(self, max_depth, feat_out_channels, out_channels=20, image_residuals=False, num_features=512, dataset='nyu'):
         super(bts, self).__init__()
-        if image_residuals:
-            raise NotImplementedError("HIP BTS: the image-residual head (Bts.py:264-271) has no plan")
         self.max_depth, self.image_residuals, self.dataset, self.out_channels = max_depth, image_residuals, dataset, out_channels
         nf, f = num_features, feat_out_channels
         bn = lambda c: nn.BatchNorm2d(c, momentum=0.01, affine=True, eps=1.1e-5)
@@ -414,7 +414,11 @@ class BtsEngine(G.TapeEngine):
             self.add(G.MapSlot(self, mp, cat1, s + j, 1))
         i1 = self._conv_elu(cat1, d.conv1[0])
         c = self.add(G.Conv(self, i1, d.get_depth[0].weight, 3, 1, 1)).out
-        final = self.add(G.ToNCHW(self, c, None, d.get_depth[0].out_channels, "sigmoid", md))
+        oc = d.get_depth[0].out_channels
+        if d.out_channels == 10 and d.image_residuals:          # Bts.py:264-271 (no max_depth factor on this branch)
+            final = self.add(G.ImageResidualHead(self, c, oc))
+        else:
+            final = self.add(G.ToNCHW(self, c, None, oc, "sigmoid", md))
         self.heads = [d8, d4, d2, r1, final]
 
 

@@ -524,6 +524,16 @@ def to_nchw_act_bwd(dout, out, dx, lddx, dbias, N, HW, C_, act, scale=1.0):
           "mde_to_nchw_act_bwd")
 
 
+def image_residual_fwd(d, rgb, out):
+    N, C_, H, W = d.shape
+    check(_lib.load().mde_image_residual_fwd(_p(d), _p(rgb), _p(out), N, H * W, C_, _stream()), "mde_image_residual_fwd")
+
+
+def image_residual_bwd(dout, d, rgb, dd):
+    N, C_, H, W = d.shape
+    check(_lib.load().mde_image_residual_bwd(_p(dout), _p(d), _p(rgb), _p(dd), N, H * W, C_, _stream()), "mde_image_residual_bwd")
+
+
 def plane_depth_fwd(x, ldx, out, N, h, w, up, max_depth):
     check(_lib.load().mde_plane_depth_fwd(_p(x), ldx, _p(out), N, h, w, up, max_depth, _stream()), "mde_plane_depth_fwd")
 

@@ -267,7 +267,7 @@ def resnet_features(n, x, pfx):
     return skips
 
 
-def bts_forward(P, x, train, max_depth=10.0, momentum=None, q=None):
+def bts_forward(P, x, train, max_depth=10.0, momentum=None, q=None, image_residuals=False):
     """BtsModel.forward (Bts.py:324-333) with a densenet*_bts or a resnet*_bts / resnext*_bts encoder (told apart by the state
     dict's keys) -> the 5-tuple of bts.forward (Bts.py:205-278); dataset 'nyu', no image residuals."""
     n = Net(P, train, q=q, momentum=momentum)
@@ -303,7 +303,17 @@ def bts_forward(P, x, train, max_depth=10.0, momentum=None, q=None):
     up1 = _bts_upconv(n, i2, d + "upconv1")
     r1 = _bts_reduc(n, up1, d + "reduc1x1", max_depth, final=True)
     i1 = n.q(F.elu(n.conv(torch.cat([up1, r1, d2, d4, d8], 1), d + "conv1.0", pad=1)))
-    final = max_depth * torch.sigmoid(n.conv(i1, d + "get_depth.0", pad=1))
+    depth = torch.sigmoid(n.conv(i1, d + "get_depth.0", pad=1))
+    if image_residuals and depth.shape[1] == 10:
+        # Bts.py:264-271: the colour channels of the two RGBA layers are residuals on the input image; no max_depth factor here
+        mean = x.mean(dim=1)
+        front = torch.clamp(depth[:, :3] * 2.0 - 1.0 + x, 0.0, 1.0)
+        back = torch.clamp(depth[:, 4:7] * 2.0 - 1.0 + x, 0.0, 1.0)
+        fronta = torch.clamp(depth[:, 3] * 2.0 - 1.0 + mean, 0.0, 1.0).unsqueeze(1)
+        backa = torch.clamp(depth[:, 7] * 2.0 - 1.0 + mean, 0.0, 1.0).unsqueeze(1)
+        final = torch.cat([front, fronta, back, backa, depth[:, 8:]], dim=1)
+    else:
+        final = max_depth * depth
     return d8, d4, d2, r1, final
 
 

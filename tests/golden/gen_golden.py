@@ -647,6 +647,31 @@ def gen_bts_resnet(criteria):
                 tvm.__dict__[k] = v
 
 
+def gen_bts_image_residuals(criteria):
+    """Bts.py:264-271: BtsModel(out_channels=10, image_residuals=True) -- final_depth = two RGBA layers as residuals on the input
+    image + two depths.  Eval output and, in train mode, a masked-L1-like scalar (mean |final - target|) with its gradient norms."""
+    from network import Bts
+    torch.manual_seed(0)
+    ref = Bts.BtsModel(bts_size=512, max_depth=10, out_channels=10, image_residuals=True, encoder_version="densenet161_bts")
+    W.bts_conditioned_state(ref, 61)
+    H, Wd = BTS_SIZE
+    rgb, _ = W.synthetic_batch(61, 2, H, Wd)
+    target = W.uniform(61, "layers", (2, 10, H, Wd), 0.0, 1.0)
+    W.calibrate_running_stats(ref, rgb)
+    ref.eval()
+    with torch.no_grad():
+        final = ref(rgb)[4]
+    out = {"eval_final": _np(final).astype(np.float16), "clamped_share": np.float64(((final[:, :8] <= 0) | (final[:, :8] >= 1)).float().mean())}
+    ref.train()
+    loss = (ref(rgb)[4] - target).abs().mean()
+    loss.backward()
+    out["train_loss"] = _np(loss)
+    out["grad_names"], out["grad_norms"] = _grad_norms(ref)
+    np.savez_compressed(os.path.join(HERE, "bts_imgres.npz"), **out)
+    print("bts_imgres.npz: final %s range %.3f..%.3f, %.1f %% of the colour values clamped, train loss %.5f" % (
+        tuple(final.shape), float(final.min()), float(final.max()), 100 * float(out["clamped_share"]), float(loss)))
+
+
 def gen_bts_conditioned(criteria, metrics):
     """C2 on a WELL-CONDITIONED state (oracle/weights.bts_conditioned_state: the north-star bound |dAbsRel| <= 1e-4 is only
     meaningful where the fp32 reference itself is stable under bf16 storage): the reference's own network/Bts.py, eval
@@ -868,6 +893,8 @@ def main():
         gen_bts_conditioned(criteria, metrics)
     if want("bts_resnet"):
         gen_bts_resnet(criteria)
+    if want("bts_imgres"):
+        gen_bts_image_residuals(criteria)
     if want("eigen"):
         gen_eigen(criteria)
     if want("dorn_net"):

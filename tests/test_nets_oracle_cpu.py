@@ -208,6 +208,33 @@ def test_bts_resnet_encoders_match_the_reference(version, seed):
         assert abs(got - v) <= 3e-3 * v + 1e-7, (k, got, v)
 
 
+def test_bts_image_residuals_oracle_matches_the_reference():
+    """Bts.py:264-271 (tests/golden/bts_imgres.npz, minted from BtsModel(out_channels=10, image_residuals=True)): two RGBA layers
+    as clamped residuals on the input image + two depth channels.  Keys of the product module, the oracle's eval output, the
+    scalar mean |final - target| in train mode and its gradient norms."""
+    from mono_depth_estimation_amd.network import Bts
+    g = _golden("bts_imgres")
+    torch.manual_seed(0)
+    net = Bts.BtsModel(bts_size=512, max_depth=10, out_channels=10, image_residuals=True, encoder_version="densenet161_bts")
+    assert net.decoder.get_depth[0].weight.shape[0] == 10 and net.decoder.image_residuals
+    P0 = nets.leaf_state(W.bts_conditioned_state(net, 61))
+    rgb, _ = W.synthetic_batch(61, 2, *BTS_SIZE)
+    target = W.uniform(61, "layers", (2, 10, *BTS_SIZE), 0.0, 1.0)
+    with torch.no_grad():
+        nets.bts_forward(P0, rgb, True, momentum=1.0, image_residuals=True)
+        final = nets.bts_forward(P0, rgb, False, image_residuals=True)[4]
+    assert final.shape == (2, 10, *BTS_SIZE)
+    assert np.allclose(final.numpy(), g["eval_final"].astype(np.float32), rtol=1e-3, atol=1e-3)          # (stored as fp16)
+    assert float(final[:, :8].min()) >= 0.0 and float(final[:, :8].max()) <= 1.0
+    P = nets.leaf_state(P0, requires_grad=True)
+    loss = (nets.bts_forward(P, rgb, True, image_residuals=True)[4] - target).abs().mean()
+    assert np.allclose(float(loss.detach()), float(g["train_loss"]), rtol=2e-5)
+    loss.backward()
+    for k, v in zip(g["grad_names"], g["grad_norms"]):
+        got = float(P[str(k)].grad.norm())
+        assert abs(got - v) <= 3e-3 * v + 1e-7, (k, got, v)
+
+
 def test_bts_oracle_matches_the_reference_on_the_conditioned_state():
     """tests/golden/bts_cond.npz (the reference's network/Bts.py + metrics.py on oracle/weights.bts_conditioned_state): the
     oracle reproduces its five eval outputs, its AbsRel and its train-mode SILog; and the state is what it is there for --
