@@ -103,6 +103,26 @@ int mde_conv_gemm(const mde_conv_desc* d, const void* in, const void* w, void* o
  * residual: bf16, laid out and addressed exactly like `out` (same N, OH, OW, ld_out), or NULL; d->accumulate must be 0. */
 int mde_conv_gemm_act(const mde_conv_desc* d, const void* in, const void* w, void* out, const float* bias,
                       const void* residual, int act, void* stream);
+/* An input-gradient launch whose output is the gradient g of a BatchNorm (+ ReLU) site's OUTPUT (torchvision Bottleneck:
+ * conv3's input gradient is d(relu(bn2(.))), FCRN.py:320-323): the epilogue also adds that site's backward sums
+ * sum(g') and sum(g' * xhat) -- g' = g under the ReLU mask, xhat = (x - save_mean) * save_rstd -- into `part`, so that
+ * mde_bn_bwd_reduce's pass over g and x is not made; continue with mde_bn_bwd_finalize / mde_bn_bwd_apply as after
+ * mde_bn_bwd_reduce.  With d->accumulate the sums are of the accumulated gradient: the launch must be its last writer.
+ * x: the site's input, bf16, the same pixels as `out`; x_ld its row stride in elements (0: ld_out; otherwise a multiple of
+ * ld_out -- the upper half of the up-projection's two-branch tensor, FCRN.py:181-188).  ReLU mask: mask_scale / mask_shift (recomputed as
+ * x * scale + shift > 0), or relu_bits (one byte per 8 channels, dense rows: ld_out == ncols), or neither (no ReLU).
+ * Several launches that together cover the gradient (the output phases of a strided conv) each add their part. */
+typedef struct mde_bn_red {
+    const void* x;
+    const float* save_mean;
+    const float* save_rstd;
+    const float* mask_scale;
+    const float* mask_shift;
+    const uint8_t* relu_bits;
+    float* part;               /* fp32 [mde_stat_slots()][2][ncols] */
+    int32_t x_ld;
+} mde_bn_red;
+int mde_conv_gemm_bnred(const mde_conv_desc* d, const void* in, const void* w, void* out, const mde_bn_red* r, void* stream);
 
 /* Weight gradient ("TN" GEMM over pixels), fp32 output accumulated with atomics:
  *   dw[r][otap[t]][c] += sum_{pix in grid} direct[pix][.] x gathered[src(pix,t)][.]

@@ -8,12 +8,18 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MDE_LIB_PATH") or os.path.join(_HERE, "libmde_hip.so")   # override: diagnostic builds only
-ABI_VERSION = 7
+ABI_VERSION = 8
 MAX_TAPS = 32
 
 
 class MdeError(RuntimeError):
     pass
+
+
+class BnRed(C.Structure):
+    """mde_bn_red (include/mde_hip.h)."""
+    _fields_ = [("x", C.c_void_p), ("save_mean", C.c_void_p), ("save_rstd", C.c_void_p), ("mask_scale", C.c_void_p),
+                ("mask_shift", C.c_void_p), ("relu_bits", C.c_void_p), ("part", C.c_void_p), ("x_ld", C.c_int32)]
 
 
 class ConvDesc(C.Structure):
@@ -56,6 +62,7 @@ SIGNATURES = {
     "mde_det_flush": (_I, [_P]),
     "mde_conv_gemm": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P]),
     "mde_conv_gemm_act": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _I, _P]),
+    "mde_conv_gemm_bnred": (_I, [C.POINTER(ConvDesc), _P, _P, _P, C.POINTER(BnRed), _P]),
     "mde_conv_wgrad": (_I, [C.POINTER(WgradDesc), _P, _P, _P, _P]),
     "mde_stem_conv_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "mde_stem_conv_wgrad": (_I, [_P, _P, _P, _I, _I, _I, _P]),

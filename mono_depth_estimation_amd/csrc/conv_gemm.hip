@@ -82,6 +82,17 @@ struct KArgs {
     const float* bias;    // [ncols] or nullptr
     const void* resid;    // bf16, addressed exactly like `out` (same offsets), or nullptr
     int32_t act;          // 0 none, 1 ReLU, 2 ELU, 3 sigmoid
+    // fused BatchNorm-backward sums (mde_conv_gemm_bnred): this launch writes the gradient g of a BatchNorm (+ ReLU) site's
+    // OUTPUT; its epilogue also adds that site's sum(g') and sum(g' * xhat) (g' = g under the ReLU mask, xhat the site's
+    // normalised input) into the site's partial-sum buffer -- the pass bn.hip's bn_bwd_reduce_k would make over g and x
+    const void* red_x;        // the site's input (bf16, addressed exactly like `out`), nullptr = off
+    const float* red_mu;      // saved batch mean / 1 / std of the site [ncols]
+    const float* red_rs;
+    const float* red_msc;     // ReLU mask recomputed as x * msc + msh > 0 (the site's scale / shift), or
+    const float* red_msh;
+    const uint8_t* red_bits;  // packed mask bits, one byte per 8 channels of a dense row (residual joins), or neither: no ReLU
+    float* red_part;          // [MDE_STAT_SLOTS][2][ncols]
+    int32_t red_ldmul;        // the site's input has row stride red_ldmul * ld_out
     // halo-tiled form (HALO kernels): the workgroup's 128 pixels are a th x tw block of ONE image (tw = 1 << h_tws), whose
     // input window (th + dy span) x (tw + dx span) is staged ONCE per 64-channel chunk and read by every tap
     int32_t h_tws, h_th;          // log2(tile width), tile height
@@ -128,7 +139,9 @@ __device__ __forceinline__ int chunk_off(int row, int kslot8) {
 // delivers ~70 GB/s per CU (MI355X_MICROARCH.md, "Indexed rows: gather into LDS"), i.e. it caps the tile near 1.1 PFLOP/s
 // -- where the best 9- and 25-tap layers sit.  With the window shared by the taps a 3x3 K-step moves 18.6 KB instead.
 constexpr int HALO_MAX_Q = 8;    // halo DMA instructions per wave and chunk (4 waves x 8 x 8 rows = 256 halo rows)
-template <int BP, int BC, int NT, bool DMA, int NBUF, bool PP = false, bool HALO = false>
+// RED = true: the instances behind mde_conv_gemm_bnred (the epilogue also reduces a BatchNorm site's backward sums); kept apart
+// so that the registers that epilogue needs do not cost the other launches their occupancy
+template <int BP, int BC, int NT, bool DMA, int NBUF, bool PP = false, bool HALO = false, bool RED = false>
 __global__ __launch_bounds__(NT, HALO ? (NT == 512 ? 4 : BC <= 64 ? 5 : 4)
                                      : (NT == 256 && BP * BC >= 256 * 256) ? 1 : (NBUF == 1 ? 4 : 2)) void conv_gemm_nt(const KArgs a) {
     constexpr int NW = NT / 64;
@@ -966,7 +979,20 @@ __global__ __launch_bounds__(NT, HALO ? (NT == 512 ? 4 : BC <= 64 ? 5 : 4)
     constexpr int CPR = BC / 8;          // 16-byte chunks per pixel row
     constexpr int RPP = NT / CPR;        // rows per store pass
     static_assert(RPP >= 1 && RPP * CPR == NT, "store tiling");
+    static_assert(RPP * 2 * BC * 4 <= STG_BYTES, "the fused BatchNorm-backward sums are combined in the staging area");
     bf16_t* outp = reinterpret_cast<bf16_t*>(a.out);
+    // fused BatchNorm-backward sums: every thread stores (and sums) the same 8 channels of every row it handles
+    float red1[RED ? 8 : 1] = {}, red2[RED ? 8 : 1] = {};
+    if constexpr (RED) {
+        // the site's per-channel constants [mean | 1/std | mask scale | mask shift][BC] wait in the statistics area (no
+        // forward statistics in such a launch) and are read per row: held in registers they cost the 64-column tiles a workgroup per CU
+        static_assert(WAVES_P >= 2, "the statistics area holds four vectors");
+        for (int e = tid; e < 4 * BC; e += NT) {
+            const int which = e / BC, c = n0 + (e - which * BC);
+            const float* src = which == 0 ? a.red_mu : which == 1 ? a.red_rs : which == 2 ? a.red_msc : a.red_msh;
+            s_stat[e] = (src && c < d.ncols) ? src[c] : 0.f;
+        }
+    }
 #pragma unroll
     for (int ep = 0; ep < EPASS; ++ep) {
         if (ep) __syncthreads();         // previous slab fully stored before it is overwritten
@@ -1012,26 +1038,35 @@ __global__ __launch_bounds__(NT, HALO ? (NT == 512 ? 4 : BC <= 64 ? 5 : 4)
                 static_assert(ROWS_PT * RPP == EROWS && ROWS_PT % RB == 0, "store batches");
                 // ACC 0: plain store; 1: out += result (read-modify-write); 2: out = act(result + bias + residual), the
                 // residual read like ACC 1 reads the old output (same offsets, loads ahead of the stores)
-                auto store_rows = [&](auto acc_tag) {
+                // RED 1 / 2 / 3: also the BatchNorm-backward sums of the site this gradient belongs to (mask recomputed from the
+                // site's input / packed mask bits / no ReLU); the site's input is read like ACC 1 reads the old output
+                auto store_rows = [&](auto acc_tag, auto red_tag) {
                     constexpr int ACC = decltype(acc_tag)::value;
+                    constexpr int RM = decltype(red_tag)::value;        // mask mode of the fused sums, 0 = off
+                    constexpr int RBL = (RM != 0 && RB > 2) ? 2 : RB;   // (the sums' constants take the registers of two rows in flight)
                     const bf16_t* resp = reinterpret_cast<const bf16_t*>(a.resid);
+                    const bf16_t* redx = reinterpret_cast<const bf16_t*>(a.red_x);
                     float bv[8];
                     if constexpr (ACC == 2) {
 #pragma unroll
                         for (int e = 0; e < 8; ++e) bv[e] = a.bias ? a.bias[col + e] : 0.f;
                     }
 #pragma unroll 1
-                    for (int rb = 0; rb < ROWS_PT; rb += RB) {
-                        int oo[RB];
-                        i32x4_t oldv[ACC ? RB : 1];
+                    for (int rb = 0; rb < ROWS_PT; rb += RBL) {
+                        int oo[RBL];
+                        i32x4_t oldv[ACC ? RBL : 1];
+                        i32x4_t xin[RM ? RBL : 1];
+                        uint32_t mb[RM == 2 ? RBL : 1];
 #pragma unroll
-                        for (int q = 0; q < RB; ++q) {
+                        for (int q = 0; q < RBL; ++q) {
                             oo[q] = s_out[ep * EROWS + r0 + (rb + q) * RPP];
                             if constexpr (ACC == 1) oldv[q] = *reinterpret_cast<const i32x4_t*>(outp + (size_t)max(oo[q], 0) + col);
                             if constexpr (ACC == 2) oldv[q] = resp ? *reinterpret_cast<const i32x4_t*>(resp + (size_t)max(oo[q], 0) + col) : i32x4_t{0, 0, 0, 0};
+                            if constexpr (RM != 0) xin[q] = *reinterpret_cast<const i32x4_t*>(redx + (size_t)max(oo[q], 0) * a.red_ldmul + col);
+                            if constexpr (RM == 2) mb[q] = a.red_bits[((size_t)max(oo[q], 0) + col) >> 3];
                         }
 #pragma unroll
-                        for (int q = 0; q < RB; ++q) {
+                        for (int q = 0; q < RBL; ++q) {
                             const int r = r0 + (rb + q) * RPP;
                             bf16x8_t v = *reinterpret_cast<const bf16x8_t*>(smem + r * ROWB + chunk * 16);
                             if constexpr (ACC == 1) {
@@ -1045,15 +1080,57 @@ __global__ __launch_bounds__(NT, HALO ? (NT == 512 ? 4 : BC <= 64 ? 5 : 4)
                                 for (int e = 0; e < 8; ++e) v[e] = (bf16_t)epi_act((float)v[e] + bv[e] + (resp ? (float)rv[e] : 0.f), a.act);
                             }
                             if (oo[q] >= 0) *reinterpret_cast<bf16x8_t*>(outp + (size_t)oo[q] + col) = v;
+                            if constexpr (RM != 0) {
+                                // (bn.hip bn_bwd_reduce_k's arithmetic on the value just stored)
+                                const bf16x8_t xv = __builtin_bit_cast(bf16x8_t, xin[q]);
+                                if (oo[q] >= 0) {
+#pragma unroll
+                                    for (int h = 0; h < 8; h += 4) {
+                                        int cofs = chunk * 8 + h;
+                                        asm volatile("" : "+v"(cofs));           // (keeps the constants' loads inside the row loop)
+                                        const f32x4_t mu = *reinterpret_cast<const f32x4_t*>(s_stat + cofs);
+                                        const f32x4_t rs = *reinterpret_cast<const f32x4_t*>(s_stat + BC + cofs);
+                                        f32x4_t ms = {0.f, 0.f, 0.f, 0.f}, mh = {0.f, 0.f, 0.f, 0.f};
+                                        if constexpr (RM == 1) {
+                                            ms = *reinterpret_cast<const f32x4_t*>(s_stat + 2 * BC + cofs);
+                                            mh = *reinterpret_cast<const f32x4_t*>(s_stat + 3 * BC + cofs);
+                                        }
+#pragma unroll
+                                        for (int e = 0; e < 4; ++e) {
+                                            const float xe = (float)xv[h + e];
+                                            bool on = true;
+                                            if constexpr (RM == 1) on = xe * ms[e] + mh[e] > 0.f;
+                                            if constexpr (RM == 2) on = (mb[q] >> (h + e)) & 1u;
+                                            const float ge = on ? (float)v[h + e] : 0.f;
+                                            red1[h + e] += ge;
+                                            red2[h + e] += ge * ((xe - mu[e]) * rs[e]);
+                                        }
+                                    }
+                                }
+                            }
                         }
                     }
                 };
-                if (a.bias || a.resid || a.act)
-                    store_rows(std::integral_constant<int, 2>{});
-                else if (d.accumulate)
-                    store_rows(std::integral_constant<int, 1>{});
-                else
-                    store_rows(std::integral_constant<int, 0>{});
+                using T0 = std::integral_constant<int, 0>;
+                using T1 = std::integral_constant<int, 1>;
+                using T2 = std::integral_constant<int, 2>;
+                using T3 = std::integral_constant<int, 3>;
+                if constexpr (RED) {
+                    if (a.red_bits) {
+                        if (d.accumulate) store_rows(T1{}, T2{}); else store_rows(T0{}, T2{});
+                    } else if (a.red_msc) {
+                        if (d.accumulate) store_rows(T1{}, T1{}); else store_rows(T0{}, T1{});
+                    } else {
+                        if (d.accumulate) store_rows(T1{}, T3{}); else store_rows(T0{}, T3{});
+                    }
+                } else {
+                    if (a.bias || a.resid || a.act)
+                        store_rows(T2{}, T0{});
+                    else if (d.accumulate)
+                        store_rows(T1{}, T0{});
+                    else
+                        store_rows(T0{}, T0{});
+                }
             } else {
                 for (int r = r0; r < EROWS; r += RPP) {
                     const int oo = s_out[ep * EROWS + r];
@@ -1073,6 +1150,26 @@ __global__ __launch_bounds__(NT, HALO ? (NT == 512 ? 4 : BC <= 64 ? 5 : 4)
                         dst[e] = (bf16_t)x;
                     }
                 }
+            }
+        }
+    }
+    if constexpr (RED) {
+        // row lanes combined in a fixed order (as bn.hip's deterministic flush does), one addend per column and workgroup
+        __syncthreads();                 // the last slab has been read out of the staging area
+        float* red = reinterpret_cast<float*>(smem);     // [RPP][2][BC]
+        const int chunk = tid % CPR, rl = tid / CPR;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            red[(rl * 2 + 0) * BC + chunk * 8 + e] = red1[e];
+            red[(rl * 2 + 1) * BC + chunk * 8 + e] = red2[e];
+        }
+        __syncthreads();
+        for (int e = tid; e < 2 * BC; e += NT) {
+            const int which = e / BC, ch = e - which * BC;
+            if (n0 + ch < d.ncols) {
+                float sum = 0.f;
+                for (int q = 0; q < RPP; ++q) sum += red[(q * 2 + which) * BC + ch];
+                mde_stat_add(a.red_part, d.ncols, (uint32_t)pi, which, n0 + ch, sum, a.det);
             }
         }
     }
@@ -1110,7 +1207,19 @@ int launch(KArgs& ka, int64_t M, hipStream_t st) {
     (void)M;
     ka.nP = mde_cdiv(ka.m_end - ka.m_begin, BP);
     ka.nC = mde_cdiv(ka.d.ncols, BC);
-    conv_gemm_nt<BP, BC, NT, DMA, NBUF, PP><<<dim3(ka.nP * ka.nC), dim3(NT), smem, st>>>(ka);
+    if (ka.red_x) {
+        static bool red_attr_done = false;
+        if (!red_attr_done) {
+            int rc = mde_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_nt<BP, BC, NT, DMA, NBUF, PP, false, true>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem),
+                                   "hipFuncSetAttribute(conv_gemm_nt, fused BatchNorm-backward sums)");
+            if (rc) return rc;
+            red_attr_done = true;
+        }
+        conv_gemm_nt<BP, BC, NT, DMA, NBUF, PP, false, true><<<dim3(ka.nP * ka.nC), dim3(NT), smem, st>>>(ka);
+    } else {
+        conv_gemm_nt<BP, BC, NT, DMA, NBUF, PP><<<dim3(ka.nP * ka.nC), dim3(NT), smem, st>>>(ka);
+    }
     MDE_LAUNCH_CHECK("conv_gemm_nt");
     return MDE_OK;
 }
@@ -1163,14 +1272,16 @@ HaloPlan halo_plan(const mde_conv_desc& d, int bp, int bc) {
 template <int BP, int BC>
 int launch_halo(KArgs& ka, const HaloPlan& hp, hipStream_t st) {
     constexpr int NT = BP * 2, NBUF = BP == 128 ? 1 : 2, NW = NT / 64;
-    static bool attr_done = false;
+    static bool attr_done[2] = {false, false};
     constexpr size_t fixed = (size_t)NBUF * BC * BK * 2 + BP * sizeof(int) + 3 * MDE_MAX_TAPS * sizeof(int);
-    const void* fn = reinterpret_cast<const void*>(&conv_gemm_nt<BP, BC, NT, true, NBUF, false, true>);
-    if (!attr_done) {
+    const int red = ka.red_x != nullptr;
+    const void* fn = red ? reinterpret_cast<const void*>(&conv_gemm_nt<BP, BC, NT, true, NBUF, false, true, true>)
+                         : reinterpret_cast<const void*>(&conv_gemm_nt<BP, BC, NT, true, NBUF, false, true>);
+    if (!attr_done[red]) {
         int rc = mde_check_hip(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)HALO_MAX_Q * NW * 1024 + fixed)),
                                "hipFuncSetAttribute(conv_gemm_nt halo)");
         if (rc) return rc;
-        attr_done = true;
+        attr_done[red] = true;
     }
     ka.h_tws = hp.tws; ka.h_th = hp.th; ka.h_nty = hp.nty; ka.h_ntx = hp.ntx;
     ka.h_hw = hp.hw; ka.h_rows = hp.rows; ka.h_dy0 = hp.dy0; ka.h_dx0 = hp.dx0; ka.h_dil = hp.dil;
@@ -1185,7 +1296,10 @@ int launch_halo(KArgs& ka, const HaloPlan& hp, hipStream_t st) {
                 hp.rows, hp.th, 1 << hp.tws, ka.nP * ka.nC);
         if (hp.dil > 1) fprintf(stderr, "   dilation %d: %d parity classes\n", hp.dil, hp.dil * hp.dil);
     }
-    conv_gemm_nt<BP, BC, NT, true, NBUF, false, true><<<dim3(ka.nP * ka.nC), dim3(NT), smem, st>>>(ka);
+    if (red)
+        conv_gemm_nt<BP, BC, NT, true, NBUF, false, true, true><<<dim3(ka.nP * ka.nC), dim3(NT), smem, st>>>(ka);
+    else
+        conv_gemm_nt<BP, BC, NT, true, NBUF, false, true><<<dim3(ka.nP * ka.nC), dim3(NT), smem, st>>>(ka);
     MDE_LAUNCH_CHECK("conv_gemm_nt(halo)");
     return MDE_OK;
 }
@@ -1349,7 +1463,7 @@ int pick_and_launch(KArgs& ka, int64_t M, hipStream_t st) {
 }  // namespace
 
 static int conv_gemm_impl(const mde_conv_desc* d, const void* in, const void* w, void* out, float* stats, const float* bias,
-                          const void* resid, int act, void* stream);
+                          const void* resid, int act, void* stream, const mde_bn_red* red = nullptr);
 
 extern "C" int mde_conv_gemm(const mde_conv_desc* d, const void* in, const void* w, void* out,
                              float* stats, void* stream) {
@@ -1364,8 +1478,20 @@ extern "C" int mde_conv_gemm_act(const mde_conv_desc* d, const void* in, const v
     return conv_gemm_impl(d, in, w, out, nullptr, bias, residual, act, stream);
 }
 
+extern "C" int mde_conv_gemm_bnred(const mde_conv_desc* d, const void* in, const void* w, void* out, const mde_bn_red* r, void* stream) {
+    MDE_REQUIRE(d && r && r->x && r->save_mean && r->save_rstd && r->part, "mde_conv_gemm_bnred: null argument");
+    MDE_REQUIRE((r->mask_scale == nullptr) == (r->mask_shift == nullptr), "mde_conv_gemm_bnred: mask_scale / mask_shift come in pairs");
+    MDE_REQUIRE(!(r->mask_scale && r->relu_bits), "mde_conv_gemm_bnred: the ReLU mask is either recomputed or read from bits");
+    MDE_REQUIRE(d->ncols % 8 == 0 && d->ld_out % 8 == 0 && ((uintptr_t)out % 16) == 0 && ((uintptr_t)r->x % 16) == 0,
+                "mde_conv_gemm_bnred: ncols=%d and ld_out=%d must be multiples of 8, out and x 16-byte aligned", d->ncols, d->ld_out);
+    MDE_REQUIRE(r->x_ld >= 0 && r->x_ld % d->ld_out == 0, "mde_conv_gemm_bnred: x_ld=%d must be a multiple of ld_out=%d", r->x_ld, d->ld_out);
+    MDE_REQUIRE(!r->relu_bits || d->ld_out == d->ncols, "mde_conv_gemm_bnred: packed mask bits address dense rows (ld_out=%d, ncols=%d)",
+                d->ld_out, d->ncols);
+    return conv_gemm_impl(d, in, w, out, nullptr, nullptr, nullptr, 0, stream, r);
+}
+
 static int conv_gemm_impl(const mde_conv_desc* d, const void* in, const void* w, void* out, float* stats, const float* bias,
-                          const void* resid, int act, void* stream) {
+                          const void* resid, int act, void* stream, const mde_bn_red* red) {
     MDE_REQUIRE(d && in && w && out, "mde_conv_gemm: null argument");
     MDE_REQUIRE(d->C > 0 && d->C % 8 == 0, "mde_conv_gemm: C=%d must be a positive multiple of 8", d->C);
     MDE_REQUIRE(!d->grouped || (d->C == BK && d->ncols % BK == 0),
@@ -1412,6 +1538,14 @@ static int conv_gemm_impl(const mde_conv_desc* d, const void* in, const void* w,
     ka.bias = bias;
     ka.resid = resid;
     ka.act = act;
+    ka.red_x = red ? red->x : nullptr;
+    ka.red_mu = red ? red->save_mean : nullptr;
+    ka.red_rs = red ? red->save_rstd : nullptr;
+    ka.red_msc = red ? red->mask_scale : nullptr;
+    ka.red_msh = red ? red->mask_shift : nullptr;
+    ka.red_bits = red ? red->relu_bits : nullptr;
+    ka.red_part = red ? red->part : nullptr;
+    ka.red_ldmul = (red && red->x_ld) ? red->x_ld / d->ld_out : 1;
     ka.h_tws = ka.h_th = ka.h_nty = ka.h_ntx = ka.h_hw = ka.h_rows = ka.h_dy0 = ka.h_dx0 = ka.h_step_y = ka.h_step_x = 0;
     ka.h_dil = 1;
     ka.vec_ok = (d->ld_out % 8 == 0) && (((uintptr_t)out % 16) == 0);

@@ -23,6 +23,9 @@ import torch
 from . import ops
 
 _ALIGN = 64
+# BatchNorm-backward sums from the epilogue of the input-gradient launch that writes the site's output gradient
+# (mde_conv_gemm_bnred) instead of mde_bn_bwd_reduce's pass over gradient and input; MDE_FUSE_BN_RED=0: the separate pass (A/B)
+FUSE_BN_RED = os.environ.get("MDE_FUSE_BN_RED", "1") != "0"
 
 
 def _round_up(n, a=_ALIGN):
@@ -43,6 +46,8 @@ class Act:
             self.t = parent.t[..., c0 - parent.c0:c0 - parent.c0 + C]
         self._g = None
         self._gw = False         # gradient already written during the current backward (slices share their root's flag)
+        self.producer = None     # the ConvBN whose BatchNorm (+ residual, ReLU) writes this activation
+        self.reduced = False     # this backward: the producer site's sums have been added by the launch that completed .g
         self.concat_root = False  # TapeEngine.buf(): gradient zeroed and flagged written before every backward
 
     @property
@@ -135,18 +140,29 @@ class BNSite:
         else:
             ops.bn_eval_scale_shift(self.gamma, self.beta, self.rmean, self.rvar, self.eps, self.C, self.scale, self.shift)
 
-    def backward(self, dout, out, x, relu, dx, accumulate=False, dres=None, mask_from_x=False, relu_bits=None):
+    def backward(self, dout, out, x, relu, dx, accumulate=False, dres=None, mask_from_x=False, relu_bits=None, reduced=False):
         """g = dout*(out>0 if relu); writes dgamma/dbeta (+=), dx (bf16) and optionally dres = g.
         mask_from_x: out == relu(x*scale+shift) exactly (no residual), so the mask is recomputed
-        from x with this site's scale/shift and `out` is never read."""
+        from x with this site's scale/shift and `out` is never read.
+        reduced: the sums are in `part` already (red_spec: added by the launch that wrote dout)."""
         M, C = x.M, self.C
         ms, mh = (self.scale, self.shift) if (relu and mask_from_x) else (None, None)
-        ops.bn_bwd_reduce(dout, _ld(dout, out), out.t if out is not None else None, out.ld if out is not None else 0,
-                          x.t, x.ld, self.smean, self.srstd, M, C, relu, self.part, ms, mh, relu_bits)
+        if not reduced:
+            ops.bn_bwd_reduce(dout, _ld(dout, out), out.t if out is not None else None, out.ld if out is not None else 0,
+                              x.t, x.ld, self.smean, self.srstd, M, C, relu, self.part, ms, mh, relu_bits)
         ops.bn_bwd_finalize(self.part, M, C, self.gamma, self.srstd, self.dgamma, self.dbeta, self.coef)
         ops.bn_bwd_apply(dout, _ld(dout, out), out.t if out is not None else None, out.ld if out is not None else 0,
                          x.t, x.ld, self.smean, self.srstd, self.coef, M, C, relu, dx, _ld(dx, x), accumulate,
                          dres, _ld(dres, x) if dres is not None else 0, ms, mh, relu_bits)
+
+
+    def red_spec(self, x, relu, mask_from_x=False, relu_bits=None):
+        """What an input-gradient launch needs to add this site's backward sums from its epilogue (ops.conv_gemm(red=)):
+        the arguments of backward() that decide the mask.  None where that launch cannot (a mask read from `out`)."""
+        if not FUSE_BN_RED or self.C % 8 or (relu and not mask_from_x and relu_bits is None):
+            return None
+        ms, mh = (self.scale, self.shift) if (relu and mask_from_x) else (None, None)
+        return ops.bn_red(x.t, self.smean, self.srstd, self.part, ms, mh, relu_bits if (relu and not mask_from_x) else None, x_ld=x.ld)
 
 
 def bn_join_backward(sa, sb, dout, out, xa, xb, dxa, dxb, relu_bits):
@@ -758,6 +774,7 @@ class FCRNEngine(EngineCore):
             x = L.out
         L = ConvBN(self, x, self._conv([m.conv2.weight]), self._site([m.bn2]), 1, 1, 0, relu=False)
         L.conv_weight0 = m.conv2.weight
+        L.last_writer = True                       # the trunk's output feeds conv2 only
         self.layers.append(L)
         x = L.out
         for name in ("layer1", "layer2", "layer3", "layer4"):
@@ -872,6 +889,10 @@ class ConvBN:
         # residual joins keep a bit-packed ReLU mask (1 byte per 8 channels) for the backward passes
         self.bits = (torch.empty(x.N * OH * OW * (Cout // 8), dtype=torch.uint8, device=dev)
                      if (relu and res is not None and has_out) else None)
+        if has_out:
+            self.out.producer = self
+        self._red = False
+        self.last_writer = False      # set by the owner where x feeds this unit only: see conv_bwd
         self.fdesc = ops.fwd_desc(x.N, x.H, x.W, x.ld, x.C, x.nbytes, k, stride, pad, Cout, Cout)
         self.ddescs, self.dzero = ops.dgrad_descs(x.N, x.H, x.W, x.ld, x.C, OH, OW, Cout, Cout, self.c.nbytes, k, stride, pad)
         ks = eng._ksplit(self.c.M, Cout, x.C, k * k)
@@ -903,6 +924,15 @@ class ConvBN:
             ops.bn_apply(c.t, c.ld, s.scale, s.shift, o.t, o.ld, c.M, c.C, self.relu, r=self.res.t, ldr=self.res.ld,
                          rscale=rs.scale, rshift=rs.shift, relu_bits=self.bits if train else None)
 
+    def red_spec(self):
+        """For the launch that completes d(out): this unit's BatchNorm-backward sums from that launch's epilogue (None: a
+        join of two sites, whose sums stay with bn_join_backward)."""
+        if self._red is False:
+            self._red = None
+            if self.out is not None and self.res_site is None and self.out.ld == self.c.ld:
+                self._red = self.site.red_spec(self.c, self.relu, mask_from_x=self.res is None, relu_bits=self.bits)
+        return self._red
+
     def bn_bwd(self, dres_to=None):
         """d(out) -> d(c) (in self.c.g); optionally routes the masked gradient to an identity residual."""
         dres = None
@@ -910,24 +940,30 @@ class ConvBN:
             assert not dres_to.gw, "identity-residual gradient must be the first writer"
             dres = dres_to.g
             dres_to.gw = True
+        reduced, self.out.reduced = self.out.reduced, False
         self.site.backward(self.out.g, self.out, self.c, self.relu, self.c.g, dres=dres, mask_from_x=self.res is None,
-                           relu_bits=self.bits)
+                           relu_bits=self.bits, reduced=reduced)
         self.c.gw = True
 
-    def conv_bwd(self):
+    def conv_bwd(self, last_writer=False, red=None):
+        """last_writer: no other gradient reaches x after this one, so the unit that produced x gets its BatchNorm-backward sums
+        from these launches' epilogues (red: the same for a site that is not a ConvBN's, given by the caller)."""
         x, eng = self.x, self.eng
         eng.wgrad(self.wdesc, self.c.g, x.t, self.conv.dw)
         acc = x.gw
         if self.dzero and not acc:
             x.g.zero_()
+        if red is None and last_writer and x.producer is not None and x.parent is None:
+            red = x.producer.red_spec()
         for d in self.ddescs:
             d.accumulate = int(acc)
-            ops.conv_gemm(d, self.c.g, self.conv.wd, x.g)
+            ops.conv_gemm(d, self.c.g, self.conv.wd, x.g, red=red)
         x.gw = True
+        x.reduced = red is not None
 
     def bwd(self):
         self.bn_bwd()
-        self.conv_bwd()
+        self.conv_bwd(last_writer=self.last_writer)
 
 
 class Bottleneck:
@@ -972,9 +1008,11 @@ class Bottleneck:
             bn_join_backward(c.site, ds.site, c.out.g, c.out, c.c, ds.c, c.c.g, ds.c.g, c.bits)
             c.c.gw = ds.c.gw = True
             ds.conv_bwd()
-        c.conv_bwd()
-        self.b.bwd()
-        self.a.bwd()
+        c.conv_bwd(last_writer=True)         # (b.out and a.out feed one conv each; x: the shortcut's gradient is in already)
+        self.b.bn_bwd()
+        self.b.conv_bwd(last_writer=True)
+        self.a.bn_bwd()
+        self.a.conv_bwd(last_writer=True)
 
 
 class BasicBlock:
@@ -1044,6 +1082,7 @@ class UpProjLayer:
         self.c2 = ConvBN(eng, self.a1, eng._conv([ub.conv2.weight]), eng._site([ub.batchnorm2]), 3, 1, 1, True,
                          res=self.y_b, res_site=self.site_b)
         self.out = self.c2.out
+        self._red_u = False
 
     def first_param_offset(self):
         return self.eng.store.p_off[id(self.mod.upper_branch.conv1.weight)]
@@ -1068,12 +1107,17 @@ class UpProjLayer:
         # join of bn2(conv3x3) and bn(bottom 5x5): d(out) -> d(c2.c) and d(y55 lower half) in one pair of passes
         bn_join_backward(c2.site, self.site_b, c2.out.g, c2.out, c2.c, self.y_b, c2.c.g, yg[..., C:], c2.bits)
         c2.c.gw = True
-        c2.conv_bwd()                                                       # -> d(a1), dW(conv2)
-        self.site_u.backward(self.a1.g, self.a1, self.y_u, True, yg[..., :C], mask_from_x=True)
+        if self._red_u is False:
+            self._red_u = self.site_u.red_spec(self.y_u, True, mask_from_x=True)
+        c2.conv_bwd(red=self._red_u)                                        # -> d(a1) (+ site_u's sums), dW(conv2)
+        self.site_u.backward(self.a1.g, self.a1, self.y_u, True, yg[..., :C], mask_from_x=True, reduced=self._red_u is not None)
+        self.a1.reduced = False
         self.eng.wgrad(self.wdesc, x.t, yg, self.w55.dw)
         self.ddesc.accumulate = int(x.gw)
-        ops.conv_gemm(self.ddesc, yg, self.w55.wd, x.g)
+        red = x.producer.red_spec() if (x.producer is not None and x.parent is None) else None   # (x feeds this layer only)
+        ops.conv_gemm(self.ddesc, yg, self.w55.wd, x.g, red=red)
         x.gw = True
+        x.reduced = red is not None
 
 
 class UpConvLayer:

@@ -162,10 +162,23 @@ def det_flush():
 ACT_CODE = {None: 0, "none": 0, "relu": 1, "elu": 2, "sigmoid": 3}
 
 
-def conv_gemm(desc, x, w, out, stats=None, bias=None, res=None, act=None):
-    """bias / res / act: the fused epilogue out = act(conv + bias + res) (mde_conv_gemm_act; no statistics with it)."""
+def bn_red(x, save_mean, save_rstd, part, mask_scale=None, mask_shift=None, relu_bits=None, x_ld=0):
+    """mde_bn_red: the BatchNorm site whose backward sums an input-gradient launch adds from its epilogue (conv_gemm(red=...)).
+    The returned object keeps the tensors alive."""
+    r = _lib.BnRed(*[t.data_ptr() if t is not None else None for t in (x, save_mean, save_rstd, mask_scale, mask_shift, relu_bits, part)], x_ld)
+    r._keep = (x, save_mean, save_rstd, part, mask_scale, mask_shift, relu_bits)
+    return r
+
+
+def conv_gemm(desc, x, w, out, stats=None, bias=None, res=None, act=None, red=None):
+    """bias / res / act: the fused epilogue out = act(conv + bias + res) (mde_conv_gemm_act; no statistics with it).
+    red (ops.bn_red): the launch writes the gradient of a BatchNorm site's output and adds that site's backward sums
+    (mde_conv_gemm_bnred)."""
     lib = _lib.load()
-    if bias is not None or res is not None or ACT_CODE[act]:
+    if red is not None:
+        assert stats is None and bias is None and res is None and not ACT_CODE[act]
+        call = lambda: check(lib.mde_conv_gemm_bnred(C.byref(desc), _p(x), _p(w), _p(out), C.byref(red), _stream()), "mde_conv_gemm_bnred")
+    elif bias is not None or res is not None or ACT_CODE[act]:
         assert stats is None, "BatchNorm statistics and a fused activation epilogue do not combine"
         call = lambda: check(lib.mde_conv_gemm_act(C.byref(desc), _p(x), _p(w), _p(out), _p(bias), _p(res), ACT_CODE[act], _stream()),
                              "mde_conv_gemm_act")

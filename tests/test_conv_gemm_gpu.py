@@ -315,3 +315,71 @@ def test_fused_epilogue_rejects_an_accumulating_launch():
     d.accumulate = 1
     with pytest.raises(_lib.MdeError, match="accumulating"):
         ops.conv_gemm(d, x, w, out, act="relu")
+
+
+@pytest.mark.parametrize("N,H,Wd,Cin,Cout,k,s,mode,acc,xmul", [
+    (2, 24, 40, 256, 64, 1, 1, "scale", False, 1),     # conv3's input gradient -> bn2's sums (64-column tile)
+    (2, 24, 40, 128, 128, 3, 1, "scale", False, 1),    # conv2's -> bn1's
+    (1, 26, 30, 128, 128, 3, 2, "scale", False, 1),    # strided: four output phases, each adds its pixels
+    (2, 24, 40, 64, 256, 1, 1, "bits", True, 1),       # the next block's conv1, accumulating onto the shortcut's gradient -> bn3's
+    (2, 24, 40, 64, 256, 1, 1, "none", False, 1),      # no ReLU (conv2 / bn2 under the decoder)
+    (2, 32, 48, 64, 64, 3, 1, "scale", False, 2),      # the up-projection's 3x3: the site's input is the upper half of a 2C tensor
+    (2, 160, 241, 256, 64, 3, 1, "scale", True, 1),    # split launch (256x256 rounds + 128x128 tail), accumulating
+])
+def test_dgrad_with_fused_batchnorm_backward_sums(N, H, Wd, Cin, Cout, k, s, mode, acc, xmul):
+    """mde_conv_gemm_bnred: the input-gradient launch also adds the BatchNorm-backward sums of the site whose output gradient it
+    writes.  (a) the gradient equals the plain launch's bit for bit; (b) the sums equal mde_bn_bwd_reduce's over that
+    gradient and the same site input -- the same arithmetic per element, summed in another order -- and a float64 torch
+    evaluation of sum(g') and sum(g' * xhat)."""
+    from mono_depth_estimation_amd import ops
+    p = k // 2
+    w = _bf(W.normal(5, "w", (Cout, Cin, k, k), std=(2.0 / (k * k * Cout)) ** 0.5))
+    OH, OW = ops.out_size(H, k, s, p), ops.out_size(Wd, k, s, p)
+    dyd, wd = _nhwc(_bf(W.normal(5, "dy", (N, Cout, OH, OW)))), _pack_dgrad(w)
+    M = N * H * Wd
+    xfull = W.normal(5, "x", (N, H, Wd, Cin * xmul), std=1.5).add_(0.3).to(torch.bfloat16).cuda()     # the site's input (pre-BN)
+    xs = xfull[..., :Cin]
+    mean, rstd = W.normal(5, "mu", (Cin,), std=0.5).cuda(), W.uniform(5, "rs", (Cin,), 0.5, 2.0).cuda()
+    gamma, beta = W.normal(5, "g", (Cin,)).cuda(), W.normal(5, "b", (Cin,), std=0.3).cuda()
+    scale = gamma * rstd
+    shift = beta - mean * scale
+    bits = None
+    if mode == "bits":
+        mask = torch.from_numpy((W.uniform(5, "m", (N, H, Wd, Cin)) > 0.4).numpy()).cuda()
+        weights = (2 ** torch.arange(8, device="cuda")).view(1, 1, 1, 1, 8)
+        bits = (mask.view(N, H, Wd, Cin // 8, 8).long() * weights).sum(-1).to(torch.uint8).contiguous()
+    elif mode == "scale":
+        mask = (xs.float() * scale + shift) > 0
+    else:
+        mask = torch.ones(N, H, Wd, Cin, dtype=torch.bool, device="cuda")
+    base = _nhwc(_bf(W.normal(5, "skip", (N, Cin, H, Wd)))) if acc else None
+    descs, zero = ops.dgrad_descs(N, H, Wd, Cin, Cin, OH, OW, Cout, Cout, dyd.numel() * 2, k, s, p)
+
+    def run(red):
+        dx = base.clone() if acc else torch.full((N, H, Wd, Cin), 3.0, dtype=torch.bfloat16, device="cuda")
+        if zero and not acc:
+            dx.zero_()
+        for d in descs:
+            d.accumulate = int(acc)
+            ops.conv_gemm(d, dyd, wd, dx, red=red)
+        return dx
+
+    part = ops.new_stat_buffer(Cin)
+    red = ops.bn_red(xs, mean, rstd, part, scale if mode == "scale" else None, shift if mode == "scale" else None, bits,
+                     x_ld=Cin * xmul)
+    plain, fused = run(None), run(red)
+    torch.cuda.synchronize()
+    assert torch.equal(plain, fused), "the gradient itself must not change"
+    sums = part.double().sum(0)
+    part2 = ops.new_stat_buffer(Cin)
+    ops.bn_bwd_reduce(fused, Cin, None, 0, xs, Cin * xmul, mean, rstd, M, Cin, mode != "none", part2,
+                      scale if mode == "scale" else None, shift if mode == "scale" else None, bits)
+    torch.cuda.synchronize()
+    sums2 = part2.double().sum(0)
+    g = torch.where(mask, fused.double(), torch.zeros((), dtype=torch.float64, device="cuda"))
+    xhat = ((xs.float() - mean) * rstd).double()
+    ref = torch.stack([g.sum((0, 1, 2)), (g * xhat).sum((0, 1, 2))])
+    mag = torch.stack([g.abs().sum((0, 1, 2)), (g * xhat).abs().sum((0, 1, 2))]) + 1e-30
+    e_ref, e_red = float(((sums - ref).abs() / mag).max()), float(((sums - sums2).abs() / mag).max())
+    assert e_ref < 2e-6 and e_red < 2e-6, (e_ref, e_red)
+    assert float(mask.float().mean()) < 0.95 or mode == "none"
