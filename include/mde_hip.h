@@ -121,6 +121,14 @@ typedef struct mde_bn_red {
     const uint8_t* relu_bits;
     float* part;               /* fp32 [mde_stat_slots()][2][ncols] */
     int32_t x_ld;
+    /* a residual join out = relu(bn(x) + bn2(x2)) (Bottleneck with a projection shortcut; the up-projection's two branches,
+     * FCRN.py:190-197): the gradient reaches both sites under the same mask (relu_bits, or none); the launch adds the sums of
+     * both, as mde_bn_bwd_reduce2 does.  x2 == NULL: one site. */
+    const void* x2;
+    const float* save_mean2;
+    const float* save_rstd2;
+    float* part2;
+    int32_t x2_ld;
 } mde_bn_red;
 int mde_conv_gemm_bnred(const mde_conv_desc* d, const void* in, const void* w, void* out, const mde_bn_red* r, void* stream);
 

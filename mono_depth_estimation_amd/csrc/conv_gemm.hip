@@ -93,6 +93,12 @@ struct KArgs {
     const uint8_t* red_bits;  // packed mask bits, one byte per 8 channels of a dense row (residual joins), or neither: no ReLU
     float* red_part;          // [MDE_STAT_SLOTS][2][ncols]
     int32_t red_ldmul;        // the site's input has row stride red_ldmul * ld_out
+    // a residual join out = relu(bn_a(x) + bn_b(x2)): one masked gradient (bits), the sums of both sites (bn.hip bn_bwd_reduce2_k)
+    const void* red_x2;       // nullptr = one site
+    const float* red_mu2;
+    const float* red_rs2;
+    float* red_part2;
+    int32_t red_ldmul2;
     // halo-tiled form (HALO kernels): the workgroup's 128 pixels are a th x tw block of ONE image (tw = 1 << h_tws), whose
     // input window (th + dy span) x (tw + dx span) is staged ONCE per 64-channel chunk and read by every tap
     int32_t h_tws, h_th;          // log2(tile width), tile height
@@ -139,9 +145,9 @@ __device__ __forceinline__ int chunk_off(int row, int kslot8) {
 // delivers ~70 GB/s per CU (MI355X_MICROARCH.md, "Indexed rows: gather into LDS"), i.e. it caps the tile near 1.1 PFLOP/s
 // -- where the best 9- and 25-tap layers sit.  With the window shared by the taps a 3x3 K-step moves 18.6 KB instead.
 constexpr int HALO_MAX_Q = 8;    // halo DMA instructions per wave and chunk (4 waves x 8 x 8 rows = 256 halo rows)
-// RED = true: the instances behind mde_conv_gemm_bnred (the epilogue also reduces a BatchNorm site's backward sums); kept apart
-// so that the registers that epilogue needs do not cost the other launches their occupancy
-template <int BP, int BC, int NT, bool DMA, int NBUF, bool PP = false, bool HALO = false, bool RED = false>
+// RED = 1 / 2: the instances behind mde_conv_gemm_bnred (the epilogue also reduces the backward sums of a BatchNorm site / of the
+// two sites of a residual join); kept apart so that the registers that epilogue needs do not cost the other launches their occupancy
+template <int BP, int BC, int NT, bool DMA, int NBUF, bool PP = false, bool HALO = false, int RED = 0>
 __global__ __launch_bounds__(NT, HALO ? (NT == 512 ? 4 : BC <= 64 ? 5 : 4)
                                      : (NT == 256 && BP * BC >= 256 * 256) ? 1 : (NBUF == 1 ? 4 : 2)) void conv_gemm_nt(const KArgs a) {
     constexpr int NW = NT / 64;
@@ -982,14 +988,16 @@ __global__ __launch_bounds__(NT, HALO ? (NT == 512 ? 4 : BC <= 64 ? 5 : 4)
     static_assert(RPP * 2 * BC * 4 <= STG_BYTES, "the fused BatchNorm-backward sums are combined in the staging area");
     bf16_t* outp = reinterpret_cast<bf16_t*>(a.out);
     // fused BatchNorm-backward sums: every thread stores (and sums) the same 8 channels of every row it handles
-    float red1[RED ? 8 : 1] = {}, red2[RED ? 8 : 1] = {};
+    float red1[RED ? 8 : 1] = {}, red2[RED ? 8 : 1] = {}, red3[RED == 2 ? 8 : 1] = {};
     if constexpr (RED) {
-        // the site's per-channel constants [mean | 1/std | mask scale | mask shift][BC] wait in the statistics area (no
-        // forward statistics in such a launch) and are read per row: held in registers they cost the 64-column tiles a workgroup per CU
+        // the site's per-channel constants [mean | 1/std | mask scale | mask shift][BC] (a join: [mean | 1/std] of both sites) wait
+        // in the statistics area (no forward statistics in such a launch) and are read per row: held in registers they cost the
+        // 64-column tiles a workgroup per CU
         static_assert(WAVES_P >= 2, "the statistics area holds four vectors");
         for (int e = tid; e < 4 * BC; e += NT) {
             const int which = e / BC, c = n0 + (e - which * BC);
-            const float* src = which == 0 ? a.red_mu : which == 1 ? a.red_rs : which == 2 ? a.red_msc : a.red_msh;
+            const float* src = which == 0 ? a.red_mu : which == 1 ? a.red_rs : which == 2 ? (a.red_x2 ? a.red_mu2 : a.red_msc)
+                                                                                            : (a.red_x2 ? a.red_rs2 : a.red_msh);
             s_stat[e] = (src && c < d.ncols) ? src[c] : 0.f;
         }
     }
@@ -1046,6 +1054,7 @@ __global__ __launch_bounds__(NT, HALO ? (NT == 512 ? 4 : BC <= 64 ? 5 : 4)
                     constexpr int RBL = (RM != 0 && RB > 2) ? 2 : RB;   // (the sums' constants take the registers of two rows in flight)
                     const bf16_t* resp = reinterpret_cast<const bf16_t*>(a.resid);
                     const bf16_t* redx = reinterpret_cast<const bf16_t*>(a.red_x);
+                    const bf16_t* redx2 = reinterpret_cast<const bf16_t*>(a.red_x2);
                     float bv[8];
                     if constexpr (ACC == 2) {
 #pragma unroll
@@ -1056,14 +1065,16 @@ __global__ __launch_bounds__(NT, HALO ? (NT == 512 ? 4 : BC <= 64 ? 5 : 4)
                         int oo[RBL];
                         i32x4_t oldv[ACC ? RBL : 1];
                         i32x4_t xin[RM ? RBL : 1];
-                        uint32_t mb[RM == 2 ? RBL : 1];
+                        i32x4_t xin2[RM == 4 ? RBL : 1];
+                        uint32_t mb[(RM == 2 || RM == 4) ? RBL : 1];
 #pragma unroll
                         for (int q = 0; q < RBL; ++q) {
                             oo[q] = s_out[ep * EROWS + r0 + (rb + q) * RPP];
                             if constexpr (ACC == 1) oldv[q] = *reinterpret_cast<const i32x4_t*>(outp + (size_t)max(oo[q], 0) + col);
                             if constexpr (ACC == 2) oldv[q] = resp ? *reinterpret_cast<const i32x4_t*>(resp + (size_t)max(oo[q], 0) + col) : i32x4_t{0, 0, 0, 0};
                             if constexpr (RM != 0) xin[q] = *reinterpret_cast<const i32x4_t*>(redx + (size_t)max(oo[q], 0) * a.red_ldmul + col);
-                            if constexpr (RM == 2) mb[q] = a.red_bits[((size_t)max(oo[q], 0) + col) >> 3];
+                            if constexpr (RM == 2 || RM == 4) mb[q] = a.red_bits[((size_t)max(oo[q], 0) + col) >> 3];
+                            if constexpr (RM == 4) xin2[q] = *reinterpret_cast<const i32x4_t*>(redx2 + (size_t)max(oo[q], 0) * a.red_ldmul2 + col);
                         }
 #pragma unroll
                         for (int q = 0; q < RBL; ++q) {
@@ -1083,6 +1094,7 @@ __global__ __launch_bounds__(NT, HALO ? (NT == 512 ? 4 : BC <= 64 ? 5 : 4)
                             if constexpr (RM != 0) {
                                 // (bn.hip bn_bwd_reduce_k's arithmetic on the value just stored)
                                 const bf16x8_t xv = __builtin_bit_cast(bf16x8_t, xin[q]);
+                                const bf16x8_t xv2 = __builtin_bit_cast(bf16x8_t, xin2[RM == 4 ? q : 0]);
                                 if (oo[q] >= 0) {
 #pragma unroll
                                     for (int h = 0; h < 8; h += 4) {
@@ -1091,7 +1103,7 @@ __global__ __launch_bounds__(NT, HALO ? (NT == 512 ? 4 : BC <= 64 ? 5 : 4)
                                         const f32x4_t mu = *reinterpret_cast<const f32x4_t*>(s_stat + cofs);
                                         const f32x4_t rs = *reinterpret_cast<const f32x4_t*>(s_stat + BC + cofs);
                                         f32x4_t ms = {0.f, 0.f, 0.f, 0.f}, mh = {0.f, 0.f, 0.f, 0.f};
-                                        if constexpr (RM == 1) {
+                                        if constexpr (RM == 1 || RM == 4) {      // (a join: the second site's mean and 1 / std)
                                             ms = *reinterpret_cast<const f32x4_t*>(s_stat + 2 * BC + cofs);
                                             mh = *reinterpret_cast<const f32x4_t*>(s_stat + 3 * BC + cofs);
                                         }
@@ -1100,10 +1112,11 @@ __global__ __launch_bounds__(NT, HALO ? (NT == 512 ? 4 : BC <= 64 ? 5 : 4)
                                             const float xe = (float)xv[h + e];
                                             bool on = true;
                                             if constexpr (RM == 1) on = xe * ms[e] + mh[e] > 0.f;
-                                            if constexpr (RM == 2) on = (mb[q] >> (h + e)) & 1u;
+                                            if constexpr (RM == 2 || RM == 4) on = (mb[q] >> (h + e)) & 1u;
                                             const float ge = on ? (float)v[h + e] : 0.f;
                                             red1[h + e] += ge;
                                             red2[h + e] += ge * ((xe - mu[e]) * rs[e]);
+                                            if constexpr (RM == 4) red3[h + e] += ge * (((float)xv2[h + e] - ms[e]) * mh[e]);
                                         }
                                     }
                                 }
@@ -1115,7 +1128,10 @@ __global__ __launch_bounds__(NT, HALO ? (NT == 512 ? 4 : BC <= 64 ? 5 : 4)
                 using T1 = std::integral_constant<int, 1>;
                 using T2 = std::integral_constant<int, 2>;
                 using T3 = std::integral_constant<int, 3>;
-                if constexpr (RED) {
+                using T4 = std::integral_constant<int, 4>;
+                if constexpr (RED == 2) {
+                    if (d.accumulate) store_rows(T1{}, T4{}); else store_rows(T0{}, T4{});
+                } else if constexpr (RED == 1) {
                     if (a.red_bits) {
                         if (d.accumulate) store_rows(T1{}, T2{}); else store_rows(T0{}, T2{});
                     } else if (a.red_msc) {
@@ -1170,6 +1186,20 @@ __global__ __launch_bounds__(NT, HALO ? (NT == 512 ? 4 : BC <= 64 ? 5 : 4)
                 float sum = 0.f;
                 for (int q = 0; q < RPP; ++q) sum += red[(q * 2 + which) * BC + ch];
                 mde_stat_add(a.red_part, d.ncols, (uint32_t)pi, which, n0 + ch, sum, a.det);
+                if (which == 0 && RED == 2) mde_stat_add(a.red_part2, d.ncols, (uint32_t)pi, 0, n0 + ch, sum, a.det);
+            }
+        }
+        if constexpr (RED == 2) {        // the second site's sum(g' * xhat), through the same area
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < 8; ++e) red[rl * BC + chunk * 8 + e] = red3[e];
+            __syncthreads();
+            for (int ch = tid; ch < BC; ch += NT) {
+                if (n0 + ch < d.ncols) {
+                    float sum = 0.f;
+                    for (int q = 0; q < RPP; ++q) sum += red[q * BC + ch];
+                    mde_stat_add(a.red_part2, d.ncols, (uint32_t)pi, 1, n0 + ch, sum, a.det);
+                }
             }
         }
     }
@@ -1208,15 +1238,20 @@ int launch(KArgs& ka, int64_t M, hipStream_t st) {
     ka.nP = mde_cdiv(ka.m_end - ka.m_begin, BP);
     ka.nC = mde_cdiv(ka.d.ncols, BC);
     if (ka.red_x) {
-        static bool red_attr_done = false;
-        if (!red_attr_done) {
-            int rc = mde_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_nt<BP, BC, NT, DMA, NBUF, PP, false, true>),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem),
+        static bool red_attr_done[2] = {false, false};
+        const int join = ka.red_x2 != nullptr;
+        const void* fn = join ? reinterpret_cast<const void*>(&conv_gemm_nt<BP, BC, NT, DMA, NBUF, PP, false, 2>)
+                              : reinterpret_cast<const void*>(&conv_gemm_nt<BP, BC, NT, DMA, NBUF, PP, false, 1>);
+        if (!red_attr_done[join]) {
+            int rc = mde_check_hip(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem),
                                    "hipFuncSetAttribute(conv_gemm_nt, fused BatchNorm-backward sums)");
             if (rc) return rc;
-            red_attr_done = true;
+            red_attr_done[join] = true;
         }
-        conv_gemm_nt<BP, BC, NT, DMA, NBUF, PP, false, true><<<dim3(ka.nP * ka.nC), dim3(NT), smem, st>>>(ka);
+        if (join)
+            conv_gemm_nt<BP, BC, NT, DMA, NBUF, PP, false, 2><<<dim3(ka.nP * ka.nC), dim3(NT), smem, st>>>(ka);
+        else
+            conv_gemm_nt<BP, BC, NT, DMA, NBUF, PP, false, 1><<<dim3(ka.nP * ka.nC), dim3(NT), smem, st>>>(ka);
     } else {
         conv_gemm_nt<BP, BC, NT, DMA, NBUF, PP><<<dim3(ka.nP * ka.nC), dim3(NT), smem, st>>>(ka);
     }
@@ -1272,11 +1307,12 @@ HaloPlan halo_plan(const mde_conv_desc& d, int bp, int bc) {
 template <int BP, int BC>
 int launch_halo(KArgs& ka, const HaloPlan& hp, hipStream_t st) {
     constexpr int NT = BP * 2, NBUF = BP == 128 ? 1 : 2, NW = NT / 64;
-    static bool attr_done[2] = {false, false};
+    static bool attr_done[3] = {false, false, false};
     constexpr size_t fixed = (size_t)NBUF * BC * BK * 2 + BP * sizeof(int) + 3 * MDE_MAX_TAPS * sizeof(int);
-    const int red = ka.red_x != nullptr;
-    const void* fn = red ? reinterpret_cast<const void*>(&conv_gemm_nt<BP, BC, NT, true, NBUF, false, true, true>)
-                         : reinterpret_cast<const void*>(&conv_gemm_nt<BP, BC, NT, true, NBUF, false, true>);
+    const int red = !ka.red_x ? 0 : ka.red_x2 ? 2 : 1;
+    const void* fn = red == 2 ? reinterpret_cast<const void*>(&conv_gemm_nt<BP, BC, NT, true, NBUF, false, true, 2>)
+                     : red  ? reinterpret_cast<const void*>(&conv_gemm_nt<BP, BC, NT, true, NBUF, false, true, 1>)
+                            : reinterpret_cast<const void*>(&conv_gemm_nt<BP, BC, NT, true, NBUF, false, true>);
     if (!attr_done[red]) {
         int rc = mde_check_hip(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)HALO_MAX_Q * NW * 1024 + fixed)),
                                "hipFuncSetAttribute(conv_gemm_nt halo)");
@@ -1296,8 +1332,10 @@ int launch_halo(KArgs& ka, const HaloPlan& hp, hipStream_t st) {
                 hp.rows, hp.th, 1 << hp.tws, ka.nP * ka.nC);
         if (hp.dil > 1) fprintf(stderr, "   dilation %d: %d parity classes\n", hp.dil, hp.dil * hp.dil);
     }
-    if (red)
-        conv_gemm_nt<BP, BC, NT, true, NBUF, false, true, true><<<dim3(ka.nP * ka.nC), dim3(NT), smem, st>>>(ka);
+    if (red == 2)
+        conv_gemm_nt<BP, BC, NT, true, NBUF, false, true, 2><<<dim3(ka.nP * ka.nC), dim3(NT), smem, st>>>(ka);
+    else if (red)
+        conv_gemm_nt<BP, BC, NT, true, NBUF, false, true, 1><<<dim3(ka.nP * ka.nC), dim3(NT), smem, st>>>(ka);
     else
         conv_gemm_nt<BP, BC, NT, true, NBUF, false, true><<<dim3(ka.nP * ka.nC), dim3(NT), smem, st>>>(ka);
     MDE_LAUNCH_CHECK("conv_gemm_nt(halo)");
@@ -1485,6 +1523,10 @@ extern "C" int mde_conv_gemm_bnred(const mde_conv_desc* d, const void* in, const
     MDE_REQUIRE(d->ncols % 8 == 0 && d->ld_out % 8 == 0 && ((uintptr_t)out % 16) == 0 && ((uintptr_t)r->x % 16) == 0,
                 "mde_conv_gemm_bnred: ncols=%d and ld_out=%d must be multiples of 8, out and x 16-byte aligned", d->ncols, d->ld_out);
     MDE_REQUIRE(r->x_ld >= 0 && r->x_ld % d->ld_out == 0, "mde_conv_gemm_bnred: x_ld=%d must be a multiple of ld_out=%d", r->x_ld, d->ld_out);
+    MDE_REQUIRE(!r->x2 || (r->save_mean2 && r->save_rstd2 && r->part2 && !r->mask_scale && ((uintptr_t)r->x2 % 16) == 0 &&
+                           r->x2_ld >= 0 && r->x2_ld % d->ld_out == 0),
+                "mde_conv_gemm_bnred: a join needs the second site's mean, 1 / std and partial sums, takes its mask from bits, and "
+                "x2 16-byte aligned with x2_ld a multiple of ld_out");
     MDE_REQUIRE(!r->relu_bits || d->ld_out == d->ncols, "mde_conv_gemm_bnred: packed mask bits address dense rows (ld_out=%d, ncols=%d)",
                 d->ld_out, d->ncols);
     return conv_gemm_impl(d, in, w, out, nullptr, nullptr, nullptr, 0, stream, r);
@@ -1546,6 +1588,11 @@ static int conv_gemm_impl(const mde_conv_desc* d, const void* in, const void* w,
     ka.red_bits = red ? red->relu_bits : nullptr;
     ka.red_part = red ? red->part : nullptr;
     ka.red_ldmul = (red && red->x_ld) ? red->x_ld / d->ld_out : 1;
+    ka.red_x2 = red ? red->x2 : nullptr;
+    ka.red_mu2 = red ? red->save_mean2 : nullptr;
+    ka.red_rs2 = red ? red->save_rstd2 : nullptr;
+    ka.red_part2 = red ? red->part2 : nullptr;
+    ka.red_ldmul2 = (red && red->x2_ld) ? red->x2_ld / d->ld_out : 1;
     ka.h_tws = ka.h_th = ka.h_nty = ka.h_ntx = ka.h_hw = ka.h_rows = ka.h_dy0 = ka.h_dx0 = ka.h_step_y = ka.h_step_x = 0;
     ka.h_dil = 1;
     ka.vec_ok = (d->ld_out % 8 == 0) && (((uintptr_t)out % 16) == 0);

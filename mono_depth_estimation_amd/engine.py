@@ -167,11 +167,14 @@ class BNSite:
 
 def bn_join_backward(sa, sb, dout, out, xa, xb, dxa, dxb, relu_bits):
     """Backward of out = relu(bn_a(xa) + bn_b(xb)) for both sites at once: dout and the mask are read once
-    per pass (ops.bn_bwd_reduce2 / bn_bwd_apply2) instead of once per site."""
+    per pass (ops.bn_bwd_reduce2 / bn_bwd_apply2) instead of once per site.  `out.reduced`: the sums of both sites came with
+    the launch that completed dout (ConvBN.red_spec)."""
     M, C = xa.M, sa.C
     ldd = _ld(dout, out)
-    ops.bn_bwd_reduce2(dout, ldd, xa.t, xa.ld, xb.t, xb.ld, sa.smean, sa.srstd, sb.smean, sb.srstd, relu_bits, M, C,
-                       sa.part, sb.part)
+    reduced, out.reduced = out.reduced, False
+    if not reduced:
+        ops.bn_bwd_reduce2(dout, ldd, xa.t, xa.ld, xb.t, xb.ld, sa.smean, sa.srstd, sb.smean, sb.srstd, relu_bits, M, C,
+                           sa.part, sb.part)
     ops.bn_bwd_finalize(sa.part, M, C, sa.gamma, sa.srstd, sa.dgamma, sa.dbeta, sa.coef)
     ops.bn_bwd_finalize(sb.part, M, C, sb.gamma, sb.srstd, sb.dgamma, sb.dbeta, sb.coef)
     ops.bn_bwd_apply2(dout, ldd, xa.t, xa.ld, xb.t, xb.ld, sa.smean, sa.srstd, sb.smean, sb.srstd, relu_bits, sa.coef,
@@ -925,12 +928,17 @@ class ConvBN:
                          rscale=rs.scale, rshift=rs.shift, relu_bits=self.bits if train else None)
 
     def red_spec(self):
-        """For the launch that completes d(out): this unit's BatchNorm-backward sums from that launch's epilogue (None: a
-        join of two sites, whose sums stay with bn_join_backward)."""
+        """For the launch that completes d(out): this unit's BatchNorm-backward sums (a join: both sites') from that launch's
+        epilogue; None where it cannot."""
         if self._red is False:
             self._red = None
-            if self.out is not None and self.res_site is None and self.out.ld == self.c.ld:
-                self._red = self.site.red_spec(self.c, self.relu, mask_from_x=self.res is None, relu_bits=self.bits)
+            s, rs = self.site, self.res_site
+            if self.out is not None and self.out.ld == self.c.ld and rs is None:
+                self._red = s.red_spec(self.c, self.relu, mask_from_x=self.res is None, relu_bits=self.bits)
+            elif self.out is not None and self.out.ld == self.c.ld and FUSE_BN_RED and self.bits is not None and s.C % 8 == 0:
+                # a join: the sums of both sites under the one mask (what bn_join_backward's first pass computes)
+                self._red = ops.bn_red(self.c.t, s.smean, s.srstd, s.part, relu_bits=self.bits, x_ld=self.c.ld,
+                                       second=(self.res.t, rs.smean, rs.srstd, rs.part, self.res.ld))
         return self._red
 
     def bn_bwd(self, dres_to=None):

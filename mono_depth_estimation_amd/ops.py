@@ -162,11 +162,16 @@ def det_flush():
 ACT_CODE = {None: 0, "none": 0, "relu": 1, "elu": 2, "sigmoid": 3}
 
 
-def bn_red(x, save_mean, save_rstd, part, mask_scale=None, mask_shift=None, relu_bits=None, x_ld=0):
+def bn_red(x, save_mean, save_rstd, part, mask_scale=None, mask_shift=None, relu_bits=None, x_ld=0, second=None):
     """mde_bn_red: the BatchNorm site whose backward sums an input-gradient launch adds from its epilogue (conv_gemm(red=...)).
-    The returned object keeps the tensors alive."""
-    r = _lib.BnRed(*[t.data_ptr() if t is not None else None for t in (x, save_mean, save_rstd, mask_scale, mask_shift, relu_bits, part)], x_ld)
-    r._keep = (x, save_mean, save_rstd, part, mask_scale, mask_shift, relu_bits)
+    second = (x2, save_mean2, save_rstd2, part2, x2_ld): the other site of a residual join.  The returned object keeps the
+    tensors alive."""
+    dp = lambda t: t.data_ptr() if t is not None else None
+    r = _lib.BnRed(*[dp(t) for t in (x, save_mean, save_rstd, mask_scale, mask_shift, relu_bits, part)], x_ld)
+    r._keep = (x, save_mean, save_rstd, part, mask_scale, mask_shift, relu_bits, second)
+    if second is not None:
+        r.x2, r.save_mean2, r.save_rstd2, r.part2 = (dp(t) for t in second[:4])
+        r.x2_ld = second[4]
     return r
 
 

@@ -325,6 +325,9 @@ def test_fused_epilogue_rejects_an_accumulating_launch():
     (2, 24, 40, 64, 256, 1, 1, "none", False, 1),      # no ReLU (conv2 / bn2 under the decoder)
     (2, 32, 48, 64, 64, 3, 1, "scale", False, 2),      # the up-projection's 3x3: the site's input is the upper half of a 2C tensor
     (2, 160, 241, 256, 64, 3, 1, "scale", True, 1),    # split launch (256x256 rounds + 128x128 tail), accumulating
+    (2, 24, 40, 64, 256, 1, 1, "join", True, 1),       # a block with a projection shortcut: bn3's and the shortcut BN's sums
+    (2, 12, 20, 128, 64, 3, 1, "join", False, 2),      # the up-projection's join: the second site's input is the lower half of 2C
+    (2, 160, 241, 128, 128, 3, 1, "join", True, 1),    # 8-wave tiles
 ])
 def test_dgrad_with_fused_batchnorm_backward_sums(N, H, Wd, Cin, Cout, k, s, mode, acc, xmul):
     """mde_conv_gemm_bnred: the input-gradient launch also adds the BatchNorm-backward sums of the site whose output gradient it
@@ -344,7 +347,14 @@ def test_dgrad_with_fused_batchnorm_backward_sums(N, H, Wd, Cin, Cout, k, s, mod
     scale = gamma * rstd
     shift = beta - mean * scale
     bits = None
-    if mode == "bits":
+    second = None
+    if mode == "join":
+        x2full = W.normal(5, "x2", (N, H, Wd, Cin * xmul), std=0.7).add_(-0.2).to(torch.bfloat16).cuda()
+        x2 = x2full[..., Cin * (xmul - 1):]
+        mean2, rstd2 = W.normal(5, "mu2", (Cin,), std=0.5).cuda(), W.uniform(5, "rs2", (Cin,), 0.5, 2.0).cuda()
+        part_b = ops.new_stat_buffer(Cin)
+        second = (x2, mean2, rstd2, part_b, Cin * xmul)
+    if mode in ("bits", "join"):
         mask = torch.from_numpy((W.uniform(5, "m", (N, H, Wd, Cin)) > 0.4).numpy()).cuda()
         weights = (2 ** torch.arange(8, device="cuda")).view(1, 1, 1, 1, 8)
         bits = (mask.view(N, H, Wd, Cin // 8, 8).long() * weights).sum(-1).to(torch.uint8).contiguous()
@@ -366,20 +376,30 @@ def test_dgrad_with_fused_batchnorm_backward_sums(N, H, Wd, Cin, Cout, k, s, mod
 
     part = ops.new_stat_buffer(Cin)
     red = ops.bn_red(xs, mean, rstd, part, scale if mode == "scale" else None, shift if mode == "scale" else None, bits,
-                     x_ld=Cin * xmul)
+                     x_ld=Cin * xmul, second=second)
     plain, fused = run(None), run(red)
     torch.cuda.synchronize()
     assert torch.equal(plain, fused), "the gradient itself must not change"
     sums = part.double().sum(0)
     part2 = ops.new_stat_buffer(Cin)
-    ops.bn_bwd_reduce(fused, Cin, None, 0, xs, Cin * xmul, mean, rstd, M, Cin, mode != "none", part2,
-                      scale if mode == "scale" else None, shift if mode == "scale" else None, bits)
+    if mode == "join":
+        part2b = ops.new_stat_buffer(Cin)
+        ops.bn_bwd_reduce2(fused, Cin, xs, Cin * xmul, x2, Cin * xmul, mean, rstd, mean2, rstd2, bits, M, Cin, part2, part2b)
+    else:
+        ops.bn_bwd_reduce(fused, Cin, None, 0, xs, Cin * xmul, mean, rstd, M, Cin, mode != "none", part2,
+                          scale if mode == "scale" else None, shift if mode == "scale" else None, bits)
     torch.cuda.synchronize()
     sums2 = part2.double().sum(0)
     g = torch.where(mask, fused.double(), torch.zeros((), dtype=torch.float64, device="cuda"))
-    xhat = ((xs.float() - mean) * rstd).double()
-    ref = torch.stack([g.sum((0, 1, 2)), (g * xhat).sum((0, 1, 2))])
-    mag = torch.stack([g.abs().sum((0, 1, 2)), (g * xhat).abs().sum((0, 1, 2))]) + 1e-30
-    e_ref, e_red = float(((sums - ref).abs() / mag).max()), float(((sums - sums2).abs() / mag).max())
-    assert e_ref < 2e-6 and e_red < 2e-6, (e_ref, e_red)
+
+    def check(sums, sums2, x, mean, rstd):
+        xhat = ((x.float() - mean) * rstd).double()
+        ref = torch.stack([g.sum((0, 1, 2)), (g * xhat).sum((0, 1, 2))])
+        mag = torch.stack([g.abs().sum((0, 1, 2)), (g * xhat).abs().sum((0, 1, 2))]) + 1e-30
+        e_ref, e_red = float(((sums - ref).abs() / mag).max()), float(((sums - sums2).abs() / mag).max())
+        assert e_ref < 2e-6 and e_red < 2e-6, (e_ref, e_red)
+
+    check(sums, sums2, xs, mean, rstd)
+    if mode == "join":
+        check(part_b.double().sum(0), part2b.double().sum(0), x2, mean2, rstd2)
     assert float(mask.float().mean()) < 0.95 or mode == "none"
