@@ -108,8 +108,8 @@ int mde_conv_gemm_act(const mde_conv_desc* d, const void* in, const void* w, voi
  * sum(g') and sum(g' * xhat) -- g' = g under the ReLU mask, xhat = (x - save_mean) * save_rstd -- into `part`, so that
  * mde_bn_bwd_reduce's pass over g and x is not made; continue with mde_bn_bwd_finalize / mde_bn_bwd_apply as after
  * mde_bn_bwd_reduce.  With d->accumulate the sums are of the accumulated gradient: the launch must be its last writer.
- * x: the site's input, bf16, the same pixels as `out`; x_ld its row stride in elements (0: ld_out; otherwise a multiple of
- * ld_out -- the upper half of the up-projection's two-branch tensor, FCRN.py:181-188).  ReLU mask: mask_scale / mask_shift (recomputed as
+ * x: the site's input, bf16, the same pixels as `out`; x_ld its row stride in elements (0: ld_out; the upper half of the
+ * up-projection's two-branch tensor, FCRN.py:181-188; a prefix of a DenseNet block's concatenation, Bts.py:283-292).  ReLU mask: mask_scale / mask_shift (recomputed as
  * x * scale + shift > 0), or relu_bits (one byte per 8 channels, dense rows: ld_out == ncols), or neither (no ReLU).
  * Several launches that together cover the gradient (the output phases of a strided conv) each add their part. */
 typedef struct mde_bn_red {

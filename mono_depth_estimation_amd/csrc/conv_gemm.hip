@@ -92,13 +92,14 @@ struct KArgs {
     const float* red_msh;
     const uint8_t* red_bits;  // packed mask bits, one byte per 8 channels of a dense row (residual joins), or neither: no ReLU
     float* red_part;          // [MDE_STAT_SLOTS][2][ncols]
-    int32_t red_ldmul;        // the site's input has row stride red_ldmul * ld_out
+    int32_t red_ldmul;        // the site's input has row stride red_ldmul * ld_out, or (0) any stride red_ldx: the row index is
+    int32_t red_ldx;          // then recovered from the output offset by a division (DenseNet: a prefix of a wider concatenation)
     // a residual join out = relu(bn_a(x) + bn_b(x2)): one masked gradient (bits), the sums of both sites (bn.hip bn_bwd_reduce2_k)
     const void* red_x2;       // nullptr = one site
     const float* red_mu2;
     const float* red_rs2;
     float* red_part2;
-    int32_t red_ldmul2;
+    int32_t red_ldmul2, red_ldx2;
     // halo-tiled form (HALO kernels): the workgroup's 128 pixels are a th x tw block of ONE image (tw = 1 << h_tws), whose
     // input window (th + dy span) x (tw + dx span) is staged ONCE per 64-channel chunk and read by every tap
     int32_t h_tws, h_th;          // log2(tile width), tile height
@@ -1048,6 +1049,10 @@ __global__ __launch_bounds__(NT, HALO ? (NT == 512 ? 4 : BC <= 64 ? 5 : 4)
                 // residual read like ACC 1 reads the old output (same offsets, loads ahead of the stores)
                 // RED 1 / 2 / 3: also the BatchNorm-backward sums of the site this gradient belongs to (mask recomputed from the
                 // site's input / packed mask bits / no ReLU); the site's input is read like ACC 1 reads the old output
+                auto red_off = [&](int oo_, int ldmul, int ldx) -> size_t {      // offset of the row in the site's input
+                    const uint32_t o = (uint32_t)max(oo_, 0);
+                    return ldmul ? (size_t)o * ldmul : (size_t)(o / (uint32_t)d.ld_out) * ldx;
+                };
                 auto store_rows = [&](auto acc_tag, auto red_tag) {
                     constexpr int ACC = decltype(acc_tag)::value;
                     constexpr int RM = decltype(red_tag)::value;        // mask mode of the fused sums, 0 = off
@@ -1072,9 +1077,9 @@ __global__ __launch_bounds__(NT, HALO ? (NT == 512 ? 4 : BC <= 64 ? 5 : 4)
                             oo[q] = s_out[ep * EROWS + r0 + (rb + q) * RPP];
                             if constexpr (ACC == 1) oldv[q] = *reinterpret_cast<const i32x4_t*>(outp + (size_t)max(oo[q], 0) + col);
                             if constexpr (ACC == 2) oldv[q] = resp ? *reinterpret_cast<const i32x4_t*>(resp + (size_t)max(oo[q], 0) + col) : i32x4_t{0, 0, 0, 0};
-                            if constexpr (RM != 0) xin[q] = *reinterpret_cast<const i32x4_t*>(redx + (size_t)max(oo[q], 0) * a.red_ldmul + col);
+                            if constexpr (RM != 0) xin[q] = *reinterpret_cast<const i32x4_t*>(redx + red_off(oo[q], a.red_ldmul, a.red_ldx) + col);
                             if constexpr (RM == 2 || RM == 4) mb[q] = a.red_bits[((size_t)max(oo[q], 0) + col) >> 3];
-                            if constexpr (RM == 4) xin2[q] = *reinterpret_cast<const i32x4_t*>(redx2 + (size_t)max(oo[q], 0) * a.red_ldmul2 + col);
+                            if constexpr (RM == 4) xin2[q] = *reinterpret_cast<const i32x4_t*>(redx2 + red_off(oo[q], a.red_ldmul2, a.red_ldx2) + col);
                         }
 #pragma unroll
                         for (int q = 0; q < RBL; ++q) {
@@ -1522,11 +1527,12 @@ extern "C" int mde_conv_gemm_bnred(const mde_conv_desc* d, const void* in, const
     MDE_REQUIRE(!(r->mask_scale && r->relu_bits), "mde_conv_gemm_bnred: the ReLU mask is either recomputed or read from bits");
     MDE_REQUIRE(d->ncols % 8 == 0 && d->ld_out % 8 == 0 && ((uintptr_t)out % 16) == 0 && ((uintptr_t)r->x % 16) == 0,
                 "mde_conv_gemm_bnred: ncols=%d and ld_out=%d must be multiples of 8, out and x 16-byte aligned", d->ncols, d->ld_out);
-    MDE_REQUIRE(r->x_ld >= 0 && r->x_ld % d->ld_out == 0, "mde_conv_gemm_bnred: x_ld=%d must be a multiple of ld_out=%d", r->x_ld, d->ld_out);
+    MDE_REQUIRE(r->x_ld >= 0 && r->x_ld % 8 == 0 && (r->x_ld == 0 || r->x_ld >= d->ncols),
+                "mde_conv_gemm_bnred: x_ld=%d must be 0 or a multiple of 8 that holds the %d columns", r->x_ld, d->ncols);
     MDE_REQUIRE(!r->x2 || (r->save_mean2 && r->save_rstd2 && r->part2 && !r->mask_scale && ((uintptr_t)r->x2 % 16) == 0 &&
-                           r->x2_ld >= 0 && r->x2_ld % d->ld_out == 0),
+                           r->x2_ld >= 0 && r->x2_ld % 8 == 0),
                 "mde_conv_gemm_bnred: a join needs the second site's mean, 1 / std and partial sums, takes its mask from bits, and "
-                "x2 16-byte aligned with x2_ld a multiple of ld_out");
+                "x2 16-byte aligned with x2_ld a multiple of 8");
     MDE_REQUIRE(!r->relu_bits || d->ld_out == d->ncols, "mde_conv_gemm_bnred: packed mask bits address dense rows (ld_out=%d, ncols=%d)",
                 d->ld_out, d->ncols);
     return conv_gemm_impl(d, in, w, out, nullptr, nullptr, nullptr, 0, stream, r);
@@ -1587,12 +1593,14 @@ static int conv_gemm_impl(const mde_conv_desc* d, const void* in, const void* w,
     ka.red_msh = red ? red->mask_shift : nullptr;
     ka.red_bits = red ? red->relu_bits : nullptr;
     ka.red_part = red ? red->part : nullptr;
-    ka.red_ldmul = (red && red->x_ld) ? red->x_ld / d->ld_out : 1;
+    ka.red_ldmul = !(red && red->x_ld) ? 1 : (red->x_ld % d->ld_out == 0) ? red->x_ld / d->ld_out : 0;
+    ka.red_ldx = red ? red->x_ld : 0;
     ka.red_x2 = red ? red->x2 : nullptr;
     ka.red_mu2 = red ? red->save_mean2 : nullptr;
     ka.red_rs2 = red ? red->save_rstd2 : nullptr;
     ka.red_part2 = red ? red->part2 : nullptr;
-    ka.red_ldmul2 = (red && red->x2_ld) ? red->x2_ld / d->ld_out : 1;
+    ka.red_ldmul2 = !(red && red->x2_ld) ? 1 : (red->x2_ld % d->ld_out == 0) ? red->x2_ld / d->ld_out : 0;
+    ka.red_ldx2 = red ? red->x2_ld : 0;
     ka.h_tws = ka.h_th = ka.h_nty = ka.h_ntx = ka.h_hw = ka.h_rows = ka.h_dy0 = ka.h_dx0 = ka.h_step_y = ka.h_step_x = 0;
     ka.h_dil = 1;
     ka.vec_ok = (d->ld_out % 8 == 0) && (((uintptr_t)out % 16) == 0);

@@ -26,6 +26,7 @@ _ALIGN = 64
 # BatchNorm-backward sums from the epilogue of the input-gradient launch that writes the site's output gradient
 # (mde_conv_gemm_bnred) instead of mde_bn_bwd_reduce's pass over gradient and input; MDE_FUSE_BN_RED=0: the separate pass (A/B)
 FUSE_BN_RED = os.environ.get("MDE_FUSE_BN_RED", "1") != "0"
+_CHECK_FUSED_SUMS = os.environ.get("MDE_FUSE_BN_RED_CHECK", "0") == "1"    # (tests switch it on in-process)
 
 
 def _round_up(n, a=_ALIGN):
@@ -150,6 +151,13 @@ class BNSite:
         if not reduced:
             ops.bn_bwd_reduce(dout, _ld(dout, out), out.t if out is not None else None, out.ld if out is not None else 0,
                               x.t, x.ld, self.smean, self.srstd, M, C, relu, self.part, ms, mh, relu_bits)
+        elif _CHECK_FUSED_SUMS:
+            # diagnostics (MDE_FUSE_BN_RED_CHECK=1): the sums that came with the conv launch against the reduction pass
+            tmp = torch.zeros_like(self.part)
+            ops.bn_bwd_reduce(dout, _ld(dout, out), out.t if out is not None else None, out.ld if out is not None else 0,
+                              x.t, x.ld, self.smean, self.srstd, M, C, relu, tmp, ms, mh, relu_bits)
+            _check_fused_sums(self.part, tmp, "M=%d C=%d x.ld=%d relu=%s mask_from_x=%s bits=%s" % (M, C, x.ld, relu, mask_from_x,
+                                                                                                 relu_bits is not None))
         ops.bn_bwd_finalize(self.part, M, C, self.gamma, self.srstd, self.dgamma, self.dbeta, self.coef)
         ops.bn_bwd_apply(dout, _ld(dout, out), out.t if out is not None else None, out.ld if out is not None else 0,
                          x.t, x.ld, self.smean, self.srstd, self.coef, M, C, relu, dx, _ld(dx, x), accumulate,
@@ -165,6 +173,16 @@ class BNSite:
         return ops.bn_red(x.t, self.smean, self.srstd, self.part, ms, mh, relu_bits if (relu and not mask_from_x) else None, x_ld=x.ld)
 
 
+FUSED_SUM_CHECKS = []      # diagnostics: (site description, largest relative difference) per checked site and backward
+
+
+def _check_fused_sums(part, ref_part, what):
+    """|fused - reduction pass| per (sum, channel) relative to the reduction pass's value + 1e-3 of its largest."""
+    a, b = part.double().sum(0), ref_part.double().sum(0)
+    scale = b.abs() + 1e-3 * b.abs().amax(dim=1, keepdim=True) + 1e-30
+    FUSED_SUM_CHECKS.append((what, float(((a - b).abs() / scale).max())))
+
+
 def bn_join_backward(sa, sb, dout, out, xa, xb, dxa, dxb, relu_bits):
     """Backward of out = relu(bn_a(xa) + bn_b(xb)) for both sites at once: dout and the mask are read once
     per pass (ops.bn_bwd_reduce2 / bn_bwd_apply2) instead of once per site.  `out.reduced`: the sums of both sites came with
@@ -175,6 +193,11 @@ def bn_join_backward(sa, sb, dout, out, xa, xb, dxa, dxb, relu_bits):
     if not reduced:
         ops.bn_bwd_reduce2(dout, ldd, xa.t, xa.ld, xb.t, xb.ld, sa.smean, sa.srstd, sb.smean, sb.srstd, relu_bits, M, C,
                            sa.part, sb.part)
+    elif _CHECK_FUSED_SUMS:
+        ta, tb = torch.zeros_like(sa.part), torch.zeros_like(sb.part)
+        ops.bn_bwd_reduce2(dout, ldd, xa.t, xa.ld, xb.t, xb.ld, sa.smean, sa.srstd, sb.smean, sb.srstd, relu_bits, M, C, ta, tb)
+        _check_fused_sums(sa.part, ta, "join a: M=%d C=%d" % (M, C))
+        _check_fused_sums(sb.part, tb, "join b: M=%d C=%d xb.ld=%d" % (M, C, xb.ld))
     ops.bn_bwd_finalize(sa.part, M, C, sa.gamma, sa.srstd, sa.dgamma, sa.dbeta, sa.coef)
     ops.bn_bwd_finalize(sb.part, M, C, sb.gamma, sb.srstd, sb.dgamma, sb.dbeta, sb.coef)
     ops.bn_bwd_apply2(dout, ldd, xa.t, xa.ld, xb.t, xb.ld, sa.smean, sa.srstd, sb.smean, sb.srstd, relu_bits, sa.coef,

@@ -14,7 +14,7 @@ import os
 import torch
 
 from . import ops
-from .engine import Act, BNSite, EngineCore, FlatStore, bn_join_backward
+from .engine import FUSE_BN_RED, Act, BNSite, EngineCore, FlatStore, bn_join_backward
 
 
 # ---------------------------------------------------------------------------------------------- parameter storage
@@ -60,8 +60,18 @@ class Op:
         return ()
 
 
+# The first backward of a plan records, per activation, the op that took its gradient LAST (every accumulating writer asks
+# _take for its flag; the few writers that do not are asserted first writers).  Where that op is a Conv reading the output of a
+# BatchNorm op, the conv's input-gradient launches add that BatchNorm's backward sums from their epilogue from then on
+# (TapeEngine._plan_fused_sums, mde_conv_gemm_bnred) and the BatchNorm op skips its reduction pass.
+_TRACE = None
+_CUR_OP = None
+
+
 def _take(x):
     """-> accumulate flag for a write into x.g, marking it written."""
+    if _TRACE is not None:
+        _TRACE[id(x.root())] = _CUR_OP
     if x.parent is not None and not x.root().concat_root:
         # the written-flag is shared by a root and all its slices: a first writer that covers only part of the channels
         # would make the writers of the other channels accumulate onto uninitialised memory, unless the root is a
@@ -159,6 +169,7 @@ class Conv(Op):
         # fused epilogue (TapeEngine.pw): out = act(conv + bias + res) written by the conv launch itself
         self.f_bias = self.f_boff = self.f_res = self.f_act = self.f_part = self.pre_g = None
         self.fused = False
+        self.red = None        # ops.bn_red of the BatchNorm op that wrote x, when this conv completes d(x) (see _TRACE)
 
     def fuse(self, bias, b_off, res, act, out):
         """Take over the pointwise pass that would follow this conv: the launch writes act(conv + bias + res) into `out`
@@ -216,7 +227,7 @@ class Conv(Op):
         for d in self.ddescs:
             d.accumulate = int(acc)
             for i in self._chunks():
-                ops.conv_gemm(d, og[i:i + n], self.conv.wd, xg[i:i + n])
+                ops.conv_gemm(d, og[i:i + n], self.conv.wd, xg[i:i + n], red=self.red)
 
 
 class BN(Op):
@@ -232,6 +243,20 @@ class BN(Op):
         self.bits = (torch.empty(c.M * (c.C // 8), dtype=torch.uint8, device=eng.dev) if (relu and res is not None) else None)
         if res is not None and res_site is None and not relu:
             raise NotImplementedError("BN + identity residual without ReLU")
+        self.reduced = False   # the backward sums come with the launch that completes d(out) (see _TRACE)
+
+    def red_spec(self):
+        s, c, rs = self.site, self.c, self.res_site
+        if not self.own_out or self.out.parent is not None or s.C % 8:
+            return None
+        if self.res is None:
+            return s.red_spec(c, self.relu, mask_from_x=self.relu)
+        if rs is None:
+            return s.red_spec(c, self.relu, relu_bits=self.bits)
+        if self.bits is None:
+            return None
+        return ops.bn_red(c.t, s.smean, s.srstd, s.part, relu_bits=self.bits, x_ld=c.ld,
+                          second=(self.res.t, rs.smean, rs.srstd, rs.part, self.res.ld))
 
     def acts(self):
         return (self.out,) if self.own_out else ()
@@ -262,16 +287,17 @@ class BN(Op):
         c, o, res = self.c, self.out, self.res
         acc = _take(c)
         if res is None:
-            self.site.backward(o.g, o, c, self.relu, c.g, accumulate=acc, mask_from_x=self.relu)
+            self.site.backward(o.g, o, c, self.relu, c.g, accumulate=acc, mask_from_x=self.relu, reduced=self.reduced)
             return
         assert not acc, "a pre-BN tensor joined with a residual has one consumer"
         if self.res_site is None:
             assert not res.gw, "identity-residual gradient must be the first writer"
             res.gw = True
-            self.site.backward(o.g, o, c, self.relu, c.g, dres=res.g, relu_bits=self.bits)
+            self.site.backward(o.g, o, c, self.relu, c.g, dres=res.g, relu_bits=self.bits, reduced=self.reduced)
         else:
             assert not res.gw
             res.gw = True
+            o.reduced = self.reduced
             bn_join_backward(self.site, self.res_site, o.g, o, c, res, c.g, res.g, self.bits)
 
 
@@ -694,6 +720,13 @@ class PrefixBN(Op):
         for c0 in range(0, C, step):
             cn = min(step, C - c0)
             self.chunks.append((eng._site_chunk(bn, c0, cn), x.slice(c0, cn), self.out.slice(c0, cn), mean[c0:c0 + cn], var[c0:c0 + cn]))
+        self.reduced = False
+
+    def red_spec(self):
+        if len(self.chunks) != 1 or not self.own_out or self.out.parent is not None or self.x.C % 8:
+            return None
+        s, xs = self.chunks[0][:2]
+        return s.red_spec(xs, self.relu, mask_from_x=self.relu)
 
     def acts(self):
         return (self.out,) if self.own_out else ()
@@ -706,7 +739,7 @@ class PrefixBN(Op):
     def bwd(self):
         acc = _take(self.x)
         for s, xs, os_, _, _ in self.chunks:
-            s.backward(os_.g, os_, xs, self.relu, xs.g, accumulate=acc, mask_from_x=self.relu)
+            s.backward(os_.g, os_, xs, self.relu, xs.g, accumulate=acc, mask_from_x=self.relu, reduced=self.reduced)
 
 
 class F32Map:
@@ -987,6 +1020,7 @@ class TapeEngine(EngineCore):
     def __init__(self, module, store, N, H, W):
         super().__init__(module, store, N, H, W)
         self.tape, self.heads, self.stem, self._bufs = [], [], None, []
+        self._sums_planned = False
         self._plan()
         self._acts = [a for op in self.tape for a in op.acts()] + self._bufs
 
@@ -1073,10 +1107,43 @@ class TapeEngine(EngineCore):
                 d = douts[i]
                 h.douts[k] = d.contiguous() if d is not None else None
                 i += 1
-        for op in reversed(self.tape):
-            op.bwd()
+        global _TRACE, _CUR_OP
+        tracing = FUSE_BN_RED and not self._sums_planned
+        if tracing:
+            _TRACE = {}
+        try:
+            for op in reversed(self.tape):
+                _CUR_OP = op
+                op.bwd()
+        finally:
+            trace, _TRACE, _CUR_OP = _TRACE, None, None
+        if tracing:
+            self._plan_fused_sums(trace)
         self.join_side()
         self.store.det_end()
+
+    def _plan_fused_sums(self, last_taker):
+        """After the first backward: every BatchNorm op whose output gradient is completed by a convolution's input-gradient
+        launch hands that launch its backward sums (Conv.red) and drops its own reduction pass."""
+        self._sums_planned = True
+        self.fused_sums = 0
+        self._fused_pairs = []
+        for op in self.tape:
+            if not isinstance(op, (BN, PrefixBN)):
+                continue
+            conv = last_taker.get(id(op.out))
+            if (isinstance(conv, Conv) and conv.x is op.out and conv.need_dgrad and conv.red is None and len(conv._chunks()) == 1
+                    and op.out.parent is None):
+                spec = op.red_spec()
+                if spec is not None:
+                    conv.red, op.reduced = spec, True
+                    self._fused_pairs.append((conv, op, spec))
+                    self.fused_sums += 1
+
+    def set_fused_sums(self, on):
+        """Diagnostics / tests: switch the planned fusions off (every BatchNorm runs its own reduction pass again) and back on."""
+        for conv, op, spec in self._fused_pairs:
+            conv.red, op.reduced = (spec, True) if on else (None, False)
 
     def grad_boundaries(self):
         return [0, self.store.encoder_numel]

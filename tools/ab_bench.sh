@@ -11,7 +11,8 @@ for r in $(seq 1 $R); do
     env $VAR=$v python bench.py --steps 10 --warmup 3 --no-cpu-baseline "$@" 2>>$LOG | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
-print('$VAR=$v', 'ms/step', d['ms_per_step'], 'img/s', d['value'], 'conv frac', d['roofline']['frac'], 'conv us', d['roofline']['avg_launch_us'], 'wgrad', d['roofline']['wgrad_kernel']['achieved'])
+r=d['roofline']
+print('$VAR=$v', 'ms/step', d['ms_per_step'], 'img/s', d['value'], 'conv frac', r['frac'], 'conv us', r.get('avg_launch_us'), 'wgrad', r.get('wgrad_kernel',{}).get('achieved'))
 " | tee -a $LOG
   done
 done
