@@ -145,6 +145,12 @@ __device__ __forceinline__ int chunk_off(int row, int kslot8) {
 // rows.  Why: the 128x128 tile moves 32 KB through the L2 -> LDS DMA path per K-step for 2 MFLOP (64 FLOP/B); that path
 // delivers ~70 GB/s per CU (MI355X_MICROARCH.md, "Indexed rows: gather into LDS"), i.e. it caps the tile near 1.1 PFLOP/s
 // -- where the best 9- and 25-tap layers sit.  With the window shared by the taps a 3x3 K-step moves 18.6 KB instead.
+#ifndef MDE_RING3_MAX_TILES_PER_CU
+#define MDE_RING3_MAX_TILES_PER_CU 1
+#endif
+#ifndef MDE_DEEP_RING
+#define MDE_DEEP_RING 4
+#endif
 constexpr int HALO_MAX_Q = 8;    // halo DMA instructions per wave and chunk (4 waves x 8 x 8 rows = 256 halo rows)
 // RED = 1 / 2: the instances behind mde_conv_gemm_bnred (the epilogue also reduces the backward sums of a BatchNorm site / of the
 // two sites of a residual join); kept apart so that the registers that epilogue needs do not cost the other launches their occupancy
@@ -171,7 +177,7 @@ __global__ __launch_bounds__(NT, HALO ? (NT == 512 ? 4 : BC <= 64 ? 5 : 4)
     static_assert(WAVES_P * WAVES_C == NW && PF * 16 * WAVES_P == BP && CF * 16 * WAVES_C == BC && PF >= 2 && PF <= 8, "wave tiling");
     static_assert(XP >= 1 && WP >= 1 && XP * RPL == BP && WP * RPL == BC, "load tiling");
     static_assert(EROWS * ROWB <= STG_BYTES && (WAVES_P % EPASS) == 0, "epilogue slab fits in the staging buffers");
-    static_assert(NBUF == 2 || (DMA && (NBUF == 1 || NBUF == 3)), "register staging uses two LDS buffers");
+    static_assert(NBUF == 2 || (DMA && (NBUF == 1 || (NBUF >= 3 && NBUF <= 6 && !PP && !HALO))), "register staging uses two LDS buffers");
     static_assert(NBUF != 1 || !PP, "the single-buffer loop has no ping-pong form");
     static_assert(!HALO || (DMA && !PP && ((NBUF == 1 && BP == 128 && NT == 256) || (NBUF == 2 && BP == 256 && NT == 512))),
                   "the halo form: 128-pixel single-buffer tiles (4 waves) or 256-pixel tiles with a two-deep weight ring (8 waves)");
@@ -886,11 +892,16 @@ __global__ __launch_bounds__(NT, HALO ? (NT == 512 ? 4 : BC <= 64 ? 5 : 4)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the trailing (zero) DMA must land before the epilogue reuses LDS
         } else
         for (int s = 0; s < nsteps; ++s) {
-            // step s landed once only the younger group(s) remain outstanding
-            if (DIST == 2 && s + 1 < nsteps)
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IPS) : "memory");
-            else
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // step s landed once only the younger groups remain outstanding: min(DIST - 1, steps still to come) of them
+            {
+                const int rem = nsteps - 1 - s;
+                static_assert(IPS * (DIST > 1 ? DIST - 1 : 1) <= 63, "vmcnt is a 6-bit count");
+                if (DIST >= 2 && rem >= DIST - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IPS * (DIST > 1 ? DIST - 1 : 0)) : "memory");
+                else if (DIST >= 5 && rem == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IPS * 3 <= 63 ? IPS * 3 : 0) : "memory");
+                else if (DIST >= 4 && rem == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IPS * 2 <= 63 ? IPS * 2 : 0) : "memory");
+                else if (DIST >= 3 && rem == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IPS) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
             __builtin_amdgcn_s_barrier();     // every wave's DMA of step s is in; everyone left step s-1
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (MDE_DMA_MID) {
@@ -1414,10 +1425,19 @@ int pick_and_launch(KArgs& ka, int64_t M, hipStream_t st) {
         static int ring64 = -1;
         if (ring64 < 0) {
             const char* e = getenv("MDE_CONV_RING64");
-            ring64 = e && !strcmp(e, "1");
+            ring64 = !e ? -2 : atoi(e);          // diagnostics: 0 never a ring, 1 the 2-deep ring everywhere, 3 the 3-deep ring everywhere
         }
         if (reg) return launch<128, 64, 256, false, 2>(ka, M, st);
-        return (ring64 || forced == 6) ? launch<128, 64, 256, true, 2>(ka, M, st) : launch<128, 64, 256, true, 1>(ka, M, st);
+        // A grid that leaves CUs with one workgroup or none (DenseNet's 3x3 192 -> 48 on 19 200 or 4 800 pixels: 150 or 38
+        // tiles of 27 K-steps) is a chain of DMA latencies: no neighbour overlaps them, so the tile prefetches two K-steps
+        // ahead itself (3-deep ring, 72 KB).
+        const int64_t tiles64 = (int64_t)mde_cdiv(M, 128) * mde_cdiv(n, 64);
+        if (ring64 == 3) return launch<128, 64, 256, true, 3>(ka, M, st);
+        const char* de = getenv("MDE_CONV_DEEP");
+        const int deep64 = !(de && !strcmp(de, "0"));
+        if (ring64 == 4 || (ring64 == -2 && deep64 && forced == 0 && tiles64 <= MDE_RING3_MAX_TILES_PER_CU * cus_() && ka.d.ntaps * ((ka.d.C + BK - 1) / BK) >= 4))
+            return launch<128, 64, 256, true, MDE_DEEP_RING>(ka, M, st);
+        return (ring64 == 1 || forced == 6) ? launch<128, 64, 256, true, 2>(ka, M, st) : launch<128, 64, 256, true, 1>(ka, M, st);
     }
     const int cus = cus_();
     // Cost model fitted to in-network timings: kernel time = rounds x work per resident
@@ -1443,6 +1463,15 @@ int pick_and_launch(KArgs& ka, int64_t M, hipStream_t st) {
         const int nst = ka.d.ntaps * ((ka.d.C + BK - 1) / BK);
         if (sk && forced == 0 && !reg && nst <= 8 && (int64_t)mde_cdiv(M, 128) * nc128 >= 2 * cus)
             return launch<128, 128, 256, true, 1>(ka, M, st);
+    }
+    {
+        // a grid of at most one 128x128 tile per CU (DenseNet's 3x3 input gradients, 48 -> 192 channels on 19 200 or 4 800 pixels):
+        // a chain of DMA latencies, see the 64-column rule above -- the deep ring (MDE_CONV_DEEP=0: off)
+        const char* de = getenv("MDE_CONV_DEEP");              // (read per call: the tests switch it between launches)
+        const int deep = !(de && !strcmp(de, "0"));
+        const int nst = ka.d.ntaps * ((ka.d.C + BK - 1) / BK);
+        if (deep && forced == 0 && !reg && nst >= 4 && (int64_t)mde_cdiv(M, 128) * nc128 <= MDE_RING3_MAX_TILES_PER_CU * cus)
+            return launch<128, 128, 256, true, MDE_DEEP_RING>(ka, M, st);
     }
     const int64_t p256 = mde_cdiv(M, 256), t256 = p256 * nc256;
     auto rounds = [](int64_t tiles, int64_t slots) { return (tiles + slots - 1) / slots; };

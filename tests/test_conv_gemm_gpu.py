@@ -10,15 +10,19 @@ from oracle import weights as W
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["auto", "plain", "halo128", "halo256"])
+@pytest.fixture(autouse=True, params=["auto", "plain", "halo128", "halo256", "shallow"])
 def conv_form(request):
-    """Every test of this file runs four times: with the library's own choice between the plain tiles and the halo-tiled
+    """Every test of this file runs five times: with the library's own choice between the plain tiles and the halo-tiled
     form (a 2-D pixel block whose input window is staged once per 64-channel chunk and shared by the taps), with the halo
-    form switched off, and with each of its two kernels forced wherever the geometry is eligible (MDE_CONV_HALO is read on
-    every call)."""
+    form switched off, with each of its two kernels forced wherever the geometry is eligible, and with neither the halo form
+    nor the deep staging ring that grids of at most one tile per CU -- most shapes here -- otherwise get (MDE_CONV_HALO and
+    MDE_CONV_DEEP are read on every call)."""
     import os
     old = os.environ.get("MDE_CONV_HALO")
-    val = {"auto": None, "plain": "0", "halo128": "1", "halo256": "2"}[request.param]
+    old_d = os.environ.get("MDE_CONV_DEEP")
+    if request.param == "shallow":
+        os.environ["MDE_CONV_DEEP"] = "0"
+    val = {"auto": None, "plain": "0", "halo128": "1", "halo256": "2", "shallow": "0"}[request.param]
     if val is None:
         os.environ.pop("MDE_CONV_HALO", None)
     else:
@@ -35,6 +39,10 @@ def conv_form(request):
         os.environ.pop("MDE_CONV_HALO", None)
     else:
         os.environ["MDE_CONV_HALO"] = old
+    if old_d is None:
+        os.environ.pop("MDE_CONV_DEEP", None)
+    else:
+        os.environ["MDE_CONV_DEEP"] = old_d
 
 
 def _bf(t):
