@@ -154,6 +154,15 @@ typedef struct mde_wgrad_desc {
 
 int mde_conv_wgrad(const mde_wgrad_desc* d, const void* direct, const void* gathered,
                    float* dw, void* stream);
+/* The same with a workspace for a two-stage split-K reduction: every workgroup stores its partial tile (fp32
+ * [slices][rows][ntaps][cols]) and a second kernel adds the slices into dw -- plain stores and one streaming pass instead of
+ * slices x |dw| fp32 atomics (the L2 atomic units add one dword per clock and channel).  ws: fp32, 16-byte aligned, ws_bytes
+ * >= mde_conv_wgrad_ws_bytes(d), otherwise (or ws == NULL, a grouped weight, deterministic mode) the atomic path runs.  The
+ * second kernel updates dw with plain read-modify-writes: launches into the same dw, and launches that share a workspace,
+ * must be ordered on one stream. */
+int64_t mde_conv_wgrad_ws_bytes(const mde_wgrad_desc* d);
+int mde_conv_wgrad_ws(const mde_wgrad_desc* d, const void* direct, const void* gathered, float* dw, float* ws, int64_t ws_bytes,
+                      void* stream);
 
 /* Stem 7x7/2 convolution on the raw image (torchvision conv1, used at FCRN.py:308,353).
  * x: fp32 NCHW [N][3][H][W] (the tensor the LightningModule hands to model(x), laina.py:18)

@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MDE_LIB_PATH") or os.path.join(_HERE, "libmde_hip.so")   # override: diagnostic builds only
-ABI_VERSION = 8
+ABI_VERSION = 9
 MAX_TAPS = 32
 
 
@@ -65,6 +65,8 @@ SIGNATURES = {
     "mde_conv_gemm_act": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _I, _P]),
     "mde_conv_gemm_bnred": (_I, [C.POINTER(ConvDesc), _P, _P, _P, C.POINTER(BnRed), _P]),
     "mde_conv_wgrad": (_I, [C.POINTER(WgradDesc), _P, _P, _P, _P]),
+    "mde_conv_wgrad_ws": (_I, [C.POINTER(WgradDesc), _P, _P, _P, _P, _L, _P]),
+    "mde_conv_wgrad_ws_bytes": (_L, [C.POINTER(WgradDesc)]),
     "mde_stem_conv_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "mde_stem_conv_wgrad": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "mde_head_conv_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),

@@ -20,7 +20,7 @@ int mde_check_hip(hipError_t e, const char* what) {
 
 extern "C" const char* mde_last_error(void) { return g_err; }
 
-extern "C" int mde_abi_version(void) { return 8; }
+extern "C" int mde_abi_version(void) { return 9; }
 
 extern "C" int mde_device_cu_count(int* out) {
     MDE_REQUIRE(out, "mde_device_cu_count: null argument");

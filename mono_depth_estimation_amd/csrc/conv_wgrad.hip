@@ -38,6 +38,10 @@ struct KArgs {
     uint32_t inv_gw, inv_ghw;
     int32_t row_off;      // first row of this launch's tile grid (a row range may be split over two launches with different tile heights)
     int32_t skip_store;   // diagnostics (MDE_WGRAD_NOSTORE=1): the epilogue's atomics are skipped (timing only: results are wrong)
+    // two-stage reduction (mde_conv_wgrad_ws): every workgroup STORES its partial tile into slice `ks` of the workspace,
+    // fp32 [kslices][Crows][ntaps][Ccols] (tap index of this launch, not the output slot), and wgrad_reduce_k adds the slices
+    // into dw.  nullptr: fp32 atomics straight into dw.
+    float* ws;
 };
 
 // byte offset of 16-byte chunk `ch` of row `row` in a [64][CH] bf16 tile, CH = 128 or 64
@@ -271,6 +275,25 @@ __global__ __launch_bounds__(NT, NBUF == 1 ? 4 : 2) void conv_wgrad_tn(const KAr
         if (keep == 123456.789f) a.dw[0] = keep;      // (keeps the accumulators alive)
         return;
     }
+    if (a.ws) {
+        // plain stores: the L2 atomic units add one dword per clock and channel (~1.1 TB/s chip-wide), stores
+        // and the summing pass run at the streaming rate
+        float* wsl = a.ws + ((size_t)ks * a.Crows * d.ntaps + tap) * a.Ccols;
+        const size_t wstride = (size_t)d.ntaps * a.Ccols;
+#pragma unroll
+        for (int i = 0; i < FA; ++i)
+#pragma unroll
+            for (int j = 0; j < FB; ++j) {
+                const int col = col0 + wb * (BB / 2) + j * 16 + (lane & 15);
+                const int rbase = row0 + wa * (BA / 2) + i * 16 + (lane >> 4) * 4;
+                if (col < a.Ccols) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (rbase + r < a.Crows) wsl[(size_t)(rbase + r) * wstride + col] = acc[i][j][r];
+                }
+            }
+        return;
+    }
     const int otap = d.otap[tap];
     const size_t rstride = (size_t)d.otaps_total * a.Ccols;
 #pragma unroll
@@ -335,10 +358,79 @@ int dispatch(const KArgs& ka, int ba, int bb, int nblk, hipStream_t st) {
 
 inline uint32_t inv32(uint32_t dv) { return dv <= 1 ? 0xFFFFFFFFu : (uint32_t)((1ull << 32) / dv); }
 
+// Second stage of the two-stage reduction: dw[row][otap[t]][col] += sum_k ws[k][row][t][col].  One thread per four columns;
+// the k loop keeps four slices in flight.  Plain read-modify-write of dw: the caller's launches into one dw are ordered
+// on one stream (mde_conv_wgrad_ws).
+struct RedArgs {
+    const float* ws;
+    float* dw;
+    int32_t ks, Crows, ntaps, Ccols, otaps_total;
+    int16_t otap[MDE_MAX_TAPS];
+};
+// KG: slices are dealt to KG thread groups of a workgroup (32 x KG float4 columns x groups per 256 threads) and combined through
+// LDS -- a small dw split many ways (64 x 256 weights, 384 slices) would otherwise be a few thousand threads walking hundreds of
+// slices one after the other.
+template <int KG>
+__global__ __launch_bounds__(256) void wgrad_reduce_k(const RedArgs a) {
+    constexpr int EPB = 256 / KG;                                  // float4 elements per workgroup pass
+    __shared__ f32x4_t sh[KG > 1 ? 256 : 1];
+    const int c4 = a.Ccols >> 2;
+    const int64_t per = (int64_t)a.Crows * a.ntaps * c4;           // float4 elements per slice
+    const int64_t slice = per * 4;
+    const int el = threadIdx.x % EPB, kg = threadIdx.x / EPB;
+    for (int64_t i0 = (int64_t)blockIdx.x * EPB; i0 < per; i0 += (int64_t)gridDim.x * EPB) {
+        const int64_t i = i0 + el;
+        f32x4_t s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+        if (i < per) {
+            const float* src = a.ws + i * 4;
+            int k = kg;
+            for (; k + 3 * KG < a.ks; k += 4 * KG) {
+                s0 += *reinterpret_cast<const f32x4_t*>(src + (size_t)(k + 0 * KG) * slice);
+                s1 += *reinterpret_cast<const f32x4_t*>(src + (size_t)(k + 1 * KG) * slice);
+                s2 += *reinterpret_cast<const f32x4_t*>(src + (size_t)(k + 2 * KG) * slice);
+                s3 += *reinterpret_cast<const f32x4_t*>(src + (size_t)(k + 3 * KG) * slice);
+            }
+            for (; k < a.ks; k += KG) s0 += *reinterpret_cast<const f32x4_t*>(src + (size_t)k * slice);
+        }
+        f32x4_t sum = (s0 + s1) + (s2 + s3);
+        if constexpr (KG > 1) {
+            __syncthreads();                                       // (the previous pass has been read out)
+            sh[threadIdx.x] = sum;
+            __syncthreads();
+            if (kg == 0) {
+#pragma unroll
+                for (int g = 1; g < KG; ++g) sum += sh[g * EPB + el];
+            }
+        }
+        if (kg == 0 && i < per) {
+            const int c = (int)(i % c4);
+            const int64_t rt = i / c4;
+            const int t = (int)(rt % a.ntaps);
+            const int64_t row = rt / a.ntaps;
+            f32x4_t* dst = reinterpret_cast<f32x4_t*>(a.dw + ((size_t)row * a.otaps_total + a.otap[t]) * a.Ccols + c * 4);
+            *dst = *dst + sum;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int mde_conv_wgrad(const mde_wgrad_desc* d, const void* direct, const void* gathered,
                               float* dw, void* stream) {
+    return mde_conv_wgrad_ws(d, direct, gathered, dw, nullptr, 0, stream);
+}
+
+extern "C" int64_t mde_conv_wgrad_ws_bytes(const mde_wgrad_desc* d) {
+    if (!d || d->group_size || d->Cd <= 0 || d->Cg <= 0 || d->ntaps < 1 || d->ksplit < 1) return 0;
+    const int64_t M = (int64_t)d->N * d->GH * d->GW;
+    int64_t chunk = (M + d->ksplit - 1) / d->ksplit;
+    chunk = (chunk + BKP - 1) / BKP * BKP;
+    const int64_t kslices = (M + chunk - 1) / chunk;
+    return kslices * d->Cd * d->Cg * d->ntaps * 4;
+}
+
+extern "C" int mde_conv_wgrad_ws(const mde_wgrad_desc* d, const void* direct, const void* gathered,
+                                 float* dw, float* ws, int64_t ws_bytes, void* stream) {
     MDE_REQUIRE(d && direct && gathered && dw, "mde_conv_wgrad: null argument");
     MDE_REQUIRE(d->Cd > 0 && d->Cg > 0 && d->Cd % 8 == 0 && d->Cg % 8 == 0,
                 "mde_conv_wgrad: channel counts (%d, %d) must be positive multiples of 8", d->Cd, d->Cg);
@@ -403,6 +495,54 @@ extern "C" int mde_conv_wgrad(const mde_wgrad_desc* d, const void* direct, const
     ka.inv_gw = inv32((uint32_t)d->GW);
     ka.inv_ghw = inv32((uint32_t)(d->GH * d->GW));
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    // Two-stage reduction where a workspace is given and holds every partial tile (MDE_WGRAD_TWOSTAGE=0: never).  Not in
+    // deterministic mode (its integer atomics are order-free already), not for grouped weights (block-diagonal dw).
+    ka.ws = nullptr;
+    {
+        const char* e = getenv("MDE_WGRAD_TWOSTAGE");           // (read per call: the tests switch it between launches)
+        const int two = !e ? 1 : atoi(e);
+        static int ncu = 0;
+        if (!ncu) {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+        }
+        const int64_t need = (int64_t)kslices * ka.Crows * ka.Ccols * d->ntaps * 4;
+        // Where it pays (in-network, tools/per_shape_diff.py over `bench.py --per-shape` with MDE_WGRAD_TWOSTAGE=0 / 2): what the
+        // atomics cost is the burst at the END of a launch whose workgroups all finish together -- one round of short workgroups
+        // (512 x 128 weights split 128 ways: 92 -> 67 us; 1024 x 256 split 32: 63 -> 50; 256 x 256 x 9 split 14: 87 -> 77).  A grid
+        // of several rounds, or workgroups of hundreds of K-steps, hides its atomics under the other workgroups' MFMAs and
+        // only pays for the extra pass (1024 x 1024 x 25 split 2: +3 %; 128 x 128 x 9 over 614 400 pixels: +5 %); below ~20 MB
+        // of partial tiles the second launch costs more than the burst (64 x 64 x 9 split 113: +6 %).
+        // MDE_WGRAD_TWOSTAGE=2: wherever possible (tests, measurements).
+        const int64_t blocks = (int64_t)d->ntaps * mde_cdiv(ka.Crows, ba) * ka.nB * kslices;
+        const bool pays = two == 2 || (need >= (20ll << 20) && blocks <= 5 * (int64_t)ncu && chunk / BKP <= 96);
+        if (two && pays && ws && !ka.gsize && !ka.det.scratch && !ka.skip_store && need <= ws_bytes && ka.Ccols % 4 == 0 &&
+            ((uintptr_t)ws % 16) == 0 && ((uintptr_t)dw % 16) == 0)
+            ka.ws = ws;
+    }
+    auto reduce = [&]() -> int {
+        if (!ka.ws) return MDE_OK;
+        RedArgs ra;
+        ra.ws = ka.ws;
+        ra.dw = dw;
+        ra.ks = kslices;
+        ra.Crows = ka.Crows;
+        ra.ntaps = d->ntaps;
+        ra.Ccols = ka.Ccols;
+        ra.otaps_total = d->otaps_total;
+        for (int t = 0; t < MDE_MAX_TAPS; ++t) ra.otap[t] = t < d->ntaps ? d->otap[t] : 0;
+        const int64_t per = (int64_t)ka.Crows * d->ntaps * (ka.Ccols / 4);
+        if (kslices >= 32 && per < (1 << 20)) {
+            const int64_t nb = (per + 31) / 32;
+            wgrad_reduce_k<8><<<dim3((unsigned)(nb < 8192 ? nb : 8192)), dim3(256), 0, st>>>(ra);
+        } else {
+            const int64_t nb = (per + 255) / 256;
+            wgrad_reduce_k<1><<<dim3((unsigned)(nb < 4096 ? nb : 4096)), dim3(256), 0, st>>>(ra);
+        }
+        MDE_LAUNCH_CHECK("wgrad_reduce_k");
+        return MDE_OK;
+    };
     auto go = [&](int tile_a, int row_off, int rows) -> int {
         ka.row_off = row_off;
         ka.nA = mde_cdiv(rows, tile_a);
@@ -422,7 +562,9 @@ extern "C" int mde_conv_wgrad(const mde_wgrad_desc* d, const void* direct, const
     if (mixed && ba == 64 && !ka.gsize && ka.Crows > 128 && ka.Crows % 128 > 32) {
         const int head = ka.Crows / 128 * 128;
         if (int rc = go(128, 0, head)) return rc;
-        return go(64, head, ka.Crows - head);
+        if (int rc = go(64, head, ka.Crows - head)) return rc;
+        return reduce();
     }
-    return go(ba, 0, ka.Crows);
+    if (int rc = go(ba, 0, ka.Crows)) return rc;
+    return reduce();
 }

@@ -738,14 +738,32 @@ class EngineCore:
         input-gradient GEMM of the same layer: on a second stream its workgroups fill the CUs that the other
         kernel leaves idle and its MFMAs overlap the HBM-bound BatchNorm passes (MDE_WGRAD_STREAM=0 turns it off; a step that
         is being timed per launch — ops.TIMER — stays on one stream so that each duration describes one kernel)."""
+        ws = self._wgrad_ws(desc)
         if self.side is None or ops.TIMER is not None:
-            ops.conv_wgrad(desc, a, b, dw)
+            ops.conv_wgrad(desc, a, b, dw, ws)
             return
         cur = torch.cuda.current_stream()
         self.side.wait_stream(cur)                  # dY (and everything before it) is ready
         with torch.cuda.stream(self.side):
-            ops.conv_wgrad(desc, a, b, dw)
+            ops.conv_wgrad(desc, a, b, dw, ws)
         self.side_busy = True
+
+    _WS_MIN, _WS_MAX = 256 << 20, 2 << 30
+
+    def _wgrad_ws(self, desc):
+        """The workspace of the two-stage split-K reduction (ops.conv_wgrad): ONE buffer per engine, shared by all of its
+        weight-gradient launches -- they are ordered on one stream (the side stream, or the main one without it).  Grown on
+        demand after a device synchronisation; launches that would need more than 2 GiB keep the atomic path."""
+        need = getattr(desc, "_ws_need", None)
+        if need is None:
+            need = desc._ws_need = ops.wgrad_ws_bytes(desc)
+        if need == 0 or need > self._WS_MAX:
+            return None
+        ws = getattr(self, "_ws", None)
+        if ws is None or ws.numel() < need:
+            torch.cuda.synchronize(self.dev)
+            self._ws = ws = torch.empty(max(need, self._WS_MIN), dtype=torch.uint8, device=self.dev)
+        return ws
 
     def join_side(self):
         if self.side is not None and self.side_busy:

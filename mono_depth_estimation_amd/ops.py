@@ -233,15 +233,23 @@ def upproj_wgrad_desc(N, h, w, ld_x, Cin, x_bytes, ld_dy, Cdy, dy_bytes, ksplit)
     return wgrad_desc(N, h, w, ld_x, Cin, x_bytes, 2 * h, 2 * w, ld_dy, Cdy, dy_bytes, 2, 2, taps, 25, True, ksplit)
 
 
-def conv_wgrad(desc, direct, gathered, dw):
+def wgrad_ws_bytes(desc):
+    """Bytes of workspace the two-stage split-K reduction of this launch needs (0: no such form)."""
+    return int(_lib.load().mde_conv_wgrad_ws_bytes(C.byref(desc)))
+
+
+def conv_wgrad(desc, direct, gathered, dw, ws=None):
+    """ws: a workspace (any dtype, 16-byte aligned) for the two-stage split-K reduction (mde_conv_wgrad_ws); launches that
+    share it, or add into the same dw, must be ordered on one stream.  None: fp32 atomics into dw."""
     lib = _lib.load()
+    nb = ws.numel() * ws.element_size() if ws is not None else 0
+    call = lambda: check(lib.mde_conv_wgrad_ws(C.byref(desc), _p(direct), _p(gathered), _p(dw), _p(ws), nb, _stream()), "mde_conv_wgrad_ws")
     if TIMER is None:
-        check(lib.mde_conv_wgrad(C.byref(desc), _p(direct), _p(gathered), _p(dw), _stream()), "mde_conv_wgrad")
+        call()
         return
     flops = 2.0 * desc.N * desc.GH * desc.GW * desc.Cd * desc.Cg * desc.ntaps
-    _timed("conv_wgrad_tn", flops, lambda: check(
-        lib.mde_conv_wgrad(C.byref(desc), _p(direct), _p(gathered), _p(dw), _stream()), "mde_conv_wgrad"),
-        "K=%d Cd=%d Cg=%d taps=%d ks=%d" % (desc.N * desc.GH * desc.GW, desc.Cd, desc.Cg, desc.ntaps, desc.ksplit))
+    _timed("conv_wgrad_tn", flops, call,
+           "K=%d Cd=%d Cg=%d taps=%d ks=%d" % (desc.N * desc.GH * desc.GW, desc.Cd, desc.Cg, desc.ntaps, desc.ksplit))
 
 
 def wgrad_time_model(pixels, row_tiles, col_tiles, ntaps, ks, cus=256, wg_per_cu=2, tile_elems=128 * 128):

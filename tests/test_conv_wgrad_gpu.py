@@ -10,14 +10,22 @@ from oracle import weights as W
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["per-tap", "windowed"])
+@pytest.fixture(autouse=True, params=["per-tap", "windowed", "two-stage"])
 def wgrad_form(request):
-    """Every test runs with the per-tap kernel and with the windowed one forced wherever the geometry is eligible (one
-    workgroup per kernel row of taps over 4 x 16 pixel blocks; MDE_WGRAD_WIN is read on every call)."""
+    """Every test runs with the per-tap kernel adding its partial tiles with fp32 atomics, with the windowed kernel forced
+    wherever the geometry is eligible (one workgroup per kernel row of taps over 4 x 16 pixel blocks; MDE_WGRAD_WIN is read on
+    every call), and with the two-stage split-K reduction (partial tiles stored into a workspace, summed into dw by a second
+    kernel: `_run` hands ops.conv_wgrad a workspace and a dw that already holds values, since the second kernel ADDS)."""
     import os
     old = os.environ.get("MDE_WGRAD_WIN")
     os.environ["MDE_WGRAD_WIN"] = "1" if request.param == "windowed" else "0"
+    old_t = os.environ.get("MDE_WGRAD_TWOSTAGE")
+    os.environ["MDE_WGRAD_TWOSTAGE"] = "2"            # wherever a workspace is given, not only where the library expects a gain
     yield request.param
+    if old_t is None:
+        os.environ.pop("MDE_WGRAD_TWOSTAGE", None)
+    else:
+        os.environ["MDE_WGRAD_TWOSTAGE"] = old_t
     if old is None:
         os.environ.pop("MDE_WGRAD_WIN", None)
     else:
@@ -30,6 +38,24 @@ def _bf(t):
 
 def _nhwc(t):
     return t.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).cuda()
+
+
+def _run(ops, form, d, direct, gathered, shape):
+    """dw of one launch (a zeroed dw for the atomic forms; the two-stage form adds onto a seeded one, which is subtracted again)."""
+    if form != "two-stage":
+        dw = torch.zeros(shape, device="cuda")
+        ops.conv_wgrad(d, direct, gathered, dw)
+        torch.cuda.synchronize()
+        return dw.cpu()
+    need = ops.wgrad_ws_bytes(d)
+    assert need > 0
+    ws = torch.full((need // 4 + 64,), float("nan"), device="cuda")          # every slot the second kernel reads must be written
+    base = W.normal(6, "base", shape).cuda()
+    dw = base.clone()
+    ops.conv_wgrad(d, direct, gathered, dw, ws[:need // 4])
+    torch.cuda.synchronize()
+    assert torch.isnan(ws[need // 4:]).all()                                # ... and nothing beyond the stated size
+    return (dw - base).cpu()
 
 
 def _assert_close(got, ref, what, tol=1e-3):
@@ -51,7 +77,7 @@ def _assert_close(got, ref, what, tol=1e-3):
     (1, 20, 37, 72, 64, 5, 1, 2, 1),      # 5 taps per kernel row: groups of 3 + 2
     (2, 17, 23, 64, 128, 3, 1, 2, 2),     # padding 2 (the window starts two pixels outside)
 ])
-def test_conv_wgrad(N, H, Wd, Cin, Cout, k, s, p, ksplit):
+def test_conv_wgrad(N, H, Wd, Cin, Cout, k, s, p, ksplit, wgrad_form):
     from mono_depth_estimation_amd import ops
     x = _bf(W.normal(4, "x", (N, Cin, H, Wd)))
     w = torch.zeros(Cout, Cin, k, k, requires_grad=True)
@@ -62,10 +88,7 @@ def test_conv_wgrad(N, H, Wd, Cin, Cout, k, s, p, ksplit):
     xd, dyd = _nhwc(x), _nhwc(dy)
     OH, OW = y.shape[2:]
     d = ops.conv_wgrad_desc(N, H, Wd, Cin, Cin, xd.numel() * 2, OH, OW, Cout, Cout, dyd.numel() * 2, k, s, p, ksplit)
-    dw = torch.zeros(Cout, k * k, Cin, device="cuda")
-    ops.conv_wgrad(d, dyd, xd, dw)
-    torch.cuda.synchronize()
-    _assert_close(dw.cpu(), ref, "wgrad")
+    _assert_close(_run(ops, wgrad_form, d, dyd, xd, (Cout, k * k, Cin)), ref, "wgrad", tol=2e-3 if wgrad_form == "two-stage" else 1e-3)
 
 
 def _unpool(x):
@@ -76,7 +99,7 @@ def _unpool(x):
 
 
 @pytest.mark.parametrize("N,h,w,Cin,ksplit", [(2, 6, 8, 64, 1), (2, 9, 7, 128, 2)])
-def test_upproj_wgrad(N, h, w, Cin, ksplit):
+def test_upproj_wgrad(N, h, w, Cin, ksplit, wgrad_form):
     from mono_depth_estimation_amd import ops
     Cout2 = Cin  # both 5x5 branches fused: 2 * (Cin/2)
     x = _bf(W.normal(5, "x", (N, Cin, h, w)))
@@ -87,7 +110,4 @@ def test_upproj_wgrad(N, h, w, Cin, ksplit):
     ref = wcat.grad.permute(0, 2, 3, 1).reshape(Cout2, 25, Cin)
     xd, dyd = _nhwc(x), _nhwc(dy)
     d = ops.upproj_wgrad_desc(N, h, w, Cin, Cin, xd.numel() * 2, Cout2, Cout2, dyd.numel() * 2, ksplit)
-    dw = torch.zeros(Cout2, 25, Cin, device="cuda")
-    ops.conv_wgrad(d, xd, dyd, dw)
-    torch.cuda.synchronize()
-    _assert_close(dw.cpu(), ref, "upproj wgrad")
+    _assert_close(_run(ops, wgrad_form, d, xd, dyd, (Cout2, 25, Cin)), ref, "upproj wgrad", tol=2e-3 if wgrad_form == "two-stage" else 1e-3)
