@@ -23,6 +23,7 @@ sys.path.insert(0, ROOT)
 
 H, W, BATCH = 480, 640, 32
 PEAK_BF16_TFLOPS = 2500.0                 # dense MFMA bf16 (MI355X_MICROARCH.md)
+PEAK_HBM_TBS = 8.0                        # HBM3E (MI355X_MICROARCH.md)
 ALGO_GFLOP_PER_IMAGE = 410.9              # useful conv MACs x 2 x 3 (fwd+dgrad+wgrad)
 ALGO_CONV_BYTES_PER_CALL = 153.8e6        # 22.0 GB per step (in + out + weights of the 143 forward / input-gradient calls, bf16) / 143
 
@@ -266,9 +267,27 @@ def run_other_config(args, dev, rank, world, use_dist, t_start):
                 out["roofline"]["wgrad_kernel"] = {"achieved": round(fl2 / sec2 / 1e12, 2), "launches": n2,
                                                    "avg_launch_us": round(1e6 * sec2 / n2, 2),
                                                    "share_of_step_time": round(sec2 / (dt / args.steps), 4)}
+            add_binding_roofline(out["roofline"], timer)
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.destroy_process_group()
+
+
+def add_binding_roofline(roof, timer):
+    """`frac` above prices every launch of the kernel against the MFMA peak.  Many of them cannot get there: a 1x1 convolution
+    over 64 or 128 channels moves its tensors once and is done (64 -> 256 channels: 51 FLOP per byte; the chip's ridge is
+    2500 / 8 = 312).  `vs_binding_roofline` prices each launch against whichever of the two rooflines binds IT -- max(FLOP /
+    2.5 PFLOP/s, algorithmic bytes / 8 TB/s) -- and reports the sum of those floors over the measured time, with the count of
+    launches whose floor is the HBM one."""
+    bind = timer.binding(PEAK_BF16_TFLOPS * 1e12, PEAK_HBM_TBS * 1e12)
+    for kind, key in (("conv_gemm_nt", None), ("conv_wgrad_tn", "wgrad_kernel")):
+        if kind not in bind:
+            continue
+        lo, nh, t = bind[kind]
+        d = roof if key is None else roof.get(key)
+        if d is not None:
+            d["vs_binding_roofline"] = {"frac": round(lo / t, 4), "hbm_bound_launches": nh,
+                                        "peaks": "%.0f TFLOP/s bf16 dense, %.0f TB/s HBM" % (PEAK_BF16_TFLOPS, PEAK_HBM_TBS)}
 
 
 def print_per_shape(timer, timed_launch_steps):
@@ -449,6 +468,7 @@ def main():
                 out["roofline"]["wgrad_kernel"] = {"achieved": round(fl2 / sec2 / 1e12, 2), "launches": n2,
                                                    "avg_launch_us": round(1e6 * sec2 / n2, 2),
                                                    "share_of_step_time": round(sec2 / timed_launch_steps / (dt / args.steps), 4)}
+            add_binding_roofline(out["roofline"], timer)
         if world == 1 and not args.no_cpu_baseline:
             log("timing the CPU oracle baseline on %d host cores" % host_cores())
             out["cpu_baseline"] = cpu_baseline(host_cores())

@@ -129,6 +129,13 @@ typedef struct mde_bn_red {
     const float* save_rstd2;
     float* part2;
     int32_t x2_ld;
+    /* out = result + add under add_bits: the launch also brings in the gradient that reaches `out` through an identity shortcut
+     * (torchvision Bottleneck: out += identity) -- `add` is the gradient of the block's OUTPUT, bf16, addressed exactly like
+     * `out`, add_bits that output's ReLU mask (one byte per 8 channels; NULL: unmasked).  The BatchNorm-backward pass of the
+     * block then need not write that masked copy into `out` first (mde_bn_bwd_apply's dres).  d->accumulate must be 0; only
+     * with relu_bits or x2 (dense rows).  NULL: off. */
+    const void* add;
+    const uint8_t* add_bits;
 } mde_bn_red;
 int mde_conv_gemm_bnred(const mde_conv_desc* d, const void* in, const void* w, void* out, const mde_bn_red* r, void* stream);
 

@@ -20,7 +20,8 @@ class BnRed(C.Structure):
     """mde_bn_red (include/mde_hip.h)."""
     _fields_ = [("x", C.c_void_p), ("save_mean", C.c_void_p), ("save_rstd", C.c_void_p), ("mask_scale", C.c_void_p),
                 ("mask_shift", C.c_void_p), ("relu_bits", C.c_void_p), ("part", C.c_void_p), ("x_ld", C.c_int32),
-                ("x2", C.c_void_p), ("save_mean2", C.c_void_p), ("save_rstd2", C.c_void_p), ("part2", C.c_void_p), ("x2_ld", C.c_int32)]
+                ("x2", C.c_void_p), ("save_mean2", C.c_void_p), ("save_rstd2", C.c_void_p), ("part2", C.c_void_p), ("x2_ld", C.c_int32),
+                ("add", C.c_void_p), ("add_bits", C.c_void_p)]
 
 
 class ConvDesc(C.Structure):

@@ -100,6 +100,10 @@ struct KArgs {
     const float* red_rs2;
     float* red_part2;
     int32_t red_ldmul2, red_ldx2;
+    // with the sums (RED instances only): out = result + (add under its own mask bits) -- an identity shortcut's gradient taken
+    // straight from the block OUTPUT's gradient, which the BatchNorm-backward pass then need not copy into `out` first
+    const void* add_src;      // bf16, addressed exactly like `out`; nullptr = off
+    const uint8_t* add_bits;  // one byte per 8 channels of a dense row, or nullptr: unmasked
     // halo-tiled form (HALO kernels): the workgroup's 128 pixels are a th x tw block of ONE image (tw = 1 << h_tws), whose
     // input window (th + dy span) x (tw + dx span) is staged ONCE per 64-channel chunk and read by every tap
     int32_t h_tws, h_th;          // log2(tile width), tile height
@@ -1080,6 +1084,7 @@ __global__ __launch_bounds__(NT, HALO ? (NT == 512 ? 4 : BC <= 64 ? 5 : 4)
                     for (int rb = 0; rb < ROWS_PT; rb += RBL) {
                         int oo[RBL];
                         i32x4_t oldv[ACC ? RBL : 1];
+                        uint32_t ab[ACC == 3 ? RBL : 1];
                         i32x4_t xin[RM ? RBL : 1];
                         i32x4_t xin2[RM == 4 ? RBL : 1];
                         uint32_t mb[(RM == 2 || RM == 4) ? RBL : 1];
@@ -1087,6 +1092,10 @@ __global__ __launch_bounds__(NT, HALO ? (NT == 512 ? 4 : BC <= 64 ? 5 : 4)
                         for (int q = 0; q < RBL; ++q) {
                             oo[q] = s_out[ep * EROWS + r0 + (rb + q) * RPP];
                             if constexpr (ACC == 1) oldv[q] = *reinterpret_cast<const i32x4_t*>(outp + (size_t)max(oo[q], 0) + col);
+                            if constexpr (ACC == 3) {      // (ACC 3: the addend comes from another tensor, under that tensor's mask bits)
+                                oldv[q] = *reinterpret_cast<const i32x4_t*>(reinterpret_cast<const bf16_t*>(a.add_src) + (size_t)max(oo[q], 0) + col);
+                                ab[q] = a.add_bits ? a.add_bits[((size_t)max(oo[q], 0) + col) >> 3] : 0xFFu;
+                            }
                             if constexpr (ACC == 2) oldv[q] = resp ? *reinterpret_cast<const i32x4_t*>(resp + (size_t)max(oo[q], 0) + col) : i32x4_t{0, 0, 0, 0};
                             if constexpr (RM != 0) xin[q] = *reinterpret_cast<const i32x4_t*>(redx + red_off(oo[q], a.red_ldmul, a.red_ldx) + col);
                             if constexpr (RM == 2 || RM == 4) mb[q] = a.red_bits[((size_t)max(oo[q], 0) + col) >> 3];
@@ -1100,6 +1109,11 @@ __global__ __launch_bounds__(NT, HALO ? (NT == 512 ? 4 : BC <= 64 ? 5 : 4)
                                 const bf16x8_t old = __builtin_bit_cast(bf16x8_t, oldv[q]);
 #pragma unroll
                                 for (int e = 0; e < 8; ++e) v[e] = (bf16_t)((float)v[e] + (float)old[e]);
+                            }
+                            if constexpr (ACC == 3) {
+                                const bf16x8_t old = __builtin_bit_cast(bf16x8_t, oldv[q]);
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) v[e] = (bf16_t)((float)v[e] + (((ab[q] >> e) & 1u) ? (float)old[e] : 0.f));
                             }
                             if constexpr (ACC == 2) {
                                 const bf16x8_t rv = __builtin_bit_cast(bf16x8_t, oldv[q]);
@@ -1146,10 +1160,10 @@ __global__ __launch_bounds__(NT, HALO ? (NT == 512 ? 4 : BC <= 64 ? 5 : 4)
                 using T3 = std::integral_constant<int, 3>;
                 using T4 = std::integral_constant<int, 4>;
                 if constexpr (RED == 2) {
-                    if (d.accumulate) store_rows(T1{}, T4{}); else store_rows(T0{}, T4{});
+                    if (a.add_src) store_rows(T3{}, T4{}); else if (d.accumulate) store_rows(T1{}, T4{}); else store_rows(T0{}, T4{});
                 } else if constexpr (RED == 1) {
                     if (a.red_bits) {
-                        if (d.accumulate) store_rows(T1{}, T2{}); else store_rows(T0{}, T2{});
+                        if (a.add_src) store_rows(T3{}, T2{}); else if (d.accumulate) store_rows(T1{}, T2{}); else store_rows(T0{}, T2{});
                     } else if (a.red_msc) {
                         if (d.accumulate) store_rows(T1{}, T1{}); else store_rows(T0{}, T1{});
                     } else {
@@ -1562,6 +1576,9 @@ extern "C" int mde_conv_gemm_bnred(const mde_conv_desc* d, const void* in, const
                            r->x2_ld >= 0 && r->x2_ld % 8 == 0),
                 "mde_conv_gemm_bnred: a join needs the second site's mean, 1 / std and partial sums, takes its mask from bits, and "
                 "x2 16-byte aligned with x2_ld a multiple of 8");
+    MDE_REQUIRE(!r->add || (!d->accumulate && (r->relu_bits || r->x2) && d->ld_out == d->ncols && ((uintptr_t)r->add % 16) == 0),
+                "mde_conv_gemm_bnred: `add` goes with a launch that does not accumulate, takes its sums' mask from relu_bits (or is a "
+                "join), and addresses dense rows");
     MDE_REQUIRE(!r->relu_bits || d->ld_out == d->ncols, "mde_conv_gemm_bnred: packed mask bits address dense rows (ld_out=%d, ncols=%d)",
                 d->ld_out, d->ncols);
     return conv_gemm_impl(d, in, w, out, nullptr, nullptr, nullptr, 0, stream, r);
@@ -1628,6 +1645,8 @@ static int conv_gemm_impl(const mde_conv_desc* d, const void* in, const void* w,
     ka.red_mu2 = red ? red->save_mean2 : nullptr;
     ka.red_rs2 = red ? red->save_rstd2 : nullptr;
     ka.red_part2 = red ? red->part2 : nullptr;
+    ka.add_src = red ? red->add : nullptr;
+    ka.add_bits = red ? red->add_bits : nullptr;
     ka.red_ldmul2 = !(red && red->x2_ld) ? 1 : (red->x2_ld % d->ld_out == 0) ? red->x2_ld / d->ld_out : 0;
     ka.red_ldx2 = red ? red->x2_ld : 0;
     ka.h_tws = ka.h_th = ka.h_nty = ka.h_ntx = ka.h_hw = ka.h_rows = ka.h_dy0 = ka.h_dx0 = ka.h_step_y = ka.h_step_x = 0;

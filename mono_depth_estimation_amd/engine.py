@@ -26,6 +26,7 @@ _ALIGN = 64
 # BatchNorm-backward sums from the epilogue of the input-gradient launch that writes the site's output gradient
 # (mde_conv_gemm_bnred) instead of mde_bn_bwd_reduce's pass over gradient and input; MDE_FUSE_BN_RED=0: the separate pass (A/B)
 FUSE_BN_RED = os.environ.get("MDE_FUSE_BN_RED", "1") != "0"
+FUSE_DRES = FUSE_BN_RED and os.environ.get("MDE_FUSE_DRES", "1") != "0"      # identity shortcuts: see Bottleneck.bwd
 _CHECK_FUSED_SUMS = os.environ.get("MDE_FUSE_BN_RED_CHECK", "0") == "1"    # (tests switch it on in-process)
 
 
@@ -936,6 +937,7 @@ class ConvBN:
         if has_out:
             self.out.producer = self
         self._red = False
+        self._red_add = None
         self.last_writer = False      # set by the owner where x feeds this unit only: see conv_bwd
         self.fdesc = ops.fwd_desc(x.N, x.H, x.W, x.ld, x.C, x.nbytes, k, stride, pad, Cout, Cout)
         self.ddescs, self.dzero = ops.dgrad_descs(x.N, x.H, x.W, x.ld, x.C, OH, OW, Cout, Cout, self.c.nbytes, k, stride, pad)
@@ -994,9 +996,11 @@ class ConvBN:
                            relu_bits=self.bits, reduced=reduced)
         self.c.gw = True
 
-    def conv_bwd(self, last_writer=False, red=None):
+    def conv_bwd(self, last_writer=False, red=None, add=None):
         """last_writer: no other gradient reaches x after this one, so the unit that produced x gets its BatchNorm-backward sums
-        from these launches' epilogues (red: the same for a site that is not a ConvBN's, given by the caller)."""
+        from these launches' epilogues (red: the same for a site that is not a ConvBN's, given by the caller).
+        add = (gradient, mask bits): these launches are the FIRST writer of d(x) too and bring that gradient in themselves (an
+        identity shortcut's: Bottleneck.bwd)."""
         x, eng = self.x, self.eng
         eng.wgrad(self.wdesc, self.c.g, x.t, self.conv.dw)
         acc = x.gw
@@ -1004,6 +1008,11 @@ class ConvBN:
             x.g.zero_()
         if red is None and last_writer and x.producer is not None and x.parent is None:
             red = x.producer.red_spec()
+        if add is not None:
+            assert red is not None and not acc and not self.dzero and len(self.ddescs) == 1
+            if self._red_add is None:
+                self._red_add = ops.bn_red_with_add(red, add[0], add[1])
+            red = self._red_add
         for d in self.ddescs:
             d.accumulate = int(acc)
             ops.conv_gemm(d, self.c.g, self.conv.wd, x.g, red=red)
@@ -1049,9 +1058,16 @@ class Bottleneck:
         self.c.fwd(train)
 
     def bwd(self):
-        c, ds = self.c, self.ds
+        c, ds, x = self.c, self.ds, self.x
+        add = None
         if ds is None:
-            c.bn_bwd(dres_to=self.x)         # identity shortcut: d(x) = masked d(out)
+            # identity shortcut: d(x) = masked d(out) + conv1's input gradient.  Where conv1's launch can bring the masked d(out)
+            # in itself (it carries the producer's BatchNorm-backward sums anyway: mde_bn_red.add), bn3's pass does not write it
+            spec = x.producer.red_spec() if (FUSE_DRES and x.producer is not None and x.parent is None) else None
+            if (spec is not None and (spec.relu_bits or spec.x2) and not x.gw and c.bits is not None and c.out.ld == x.ld == x.C
+                    and len(self.a.ddescs) == 1 and not self.a.dzero):
+                add = (c.out.g, c.bits)
+            c.bn_bwd(dres_to=None if add is not None else x)
         else:
             # both BN sites of the join (conv3 and the shortcut conv) see the same masked gradient
             bn_join_backward(c.site, ds.site, c.out.g, c.out, c.c, ds.c, c.c.g, ds.c.g, c.bits)
@@ -1061,7 +1077,7 @@ class Bottleneck:
         self.b.bn_bwd()
         self.b.conv_bwd(last_writer=True)
         self.a.bn_bwd()
-        self.a.conv_bwd(last_writer=True)
+        self.a.conv_bwd(last_writer=True, add=add)
 
 
 class BasicBlock:

@@ -122,6 +122,17 @@ class LaunchTimer:
 
     def __init__(self):
         self.records = []          # (kind, flops, start_event, end_event, shape tag)
+        self.bytes = []            # algorithmic HBM bytes of the same launches (operands and results once each), same order
+
+    def binding(self, peak_flops, peak_bytes):
+        """kind -> (seconds at whichever roofline binds each launch -- max(flops / peak_flops, bytes / peak_bytes), summed --,
+        launches bound by HBM, measured seconds); call after a device synchronize."""
+        out = {}
+        for (kind, flops, e0, e1, _), nbytes in zip(self.records, self.bytes):
+            tf, tb = flops / peak_flops, nbytes / peak_bytes
+            lo, nh, t = out.get(kind, (0.0, 0, 0.0))
+            out[kind] = (lo + max(tf, tb), nh + int(tb > tf), t + e0.elapsed_time(e1) * 1e-3)
+        return out
 
     def summary(self):
         """kind -> (launches, total flops, total seconds); call after a device synchronize."""
@@ -135,7 +146,7 @@ class LaunchTimer:
 TIMER = None   # set to a LaunchTimer to time every conv_gemm / conv_wgrad launch
 
 
-def _timed(kind, flops, fn, tag=""):
+def _timed(kind, flops, fn, tag="", nbytes=0.0):
     if TIMER is None:
         return fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -143,6 +154,7 @@ def _timed(kind, flops, fn, tag=""):
     fn()
     e1.record()
     TIMER.records.append((kind, flops, e0, e1, tag))
+    TIMER.bytes.append(nbytes)
 
 
 def set_deterministic(on, gbase=None, scratch=None):
@@ -175,6 +187,16 @@ def bn_red(x, save_mean, save_rstd, part, mask_scale=None, mask_shift=None, relu
     return r
 
 
+def bn_red_with_add(red, add, add_bits):
+    """A copy of `red` whose launch also adds `add` (bf16, laid out like the launch's output) under `add_bits` to its result:
+    the gradient an identity shortcut hands to the block's input (mde_bn_red.add)."""
+    r = _lib.BnRed.from_buffer_copy(red)
+    r.add = add.data_ptr()
+    r.add_bits = add_bits.data_ptr() if add_bits is not None else None
+    r._keep = (red, add, add_bits)
+    return r
+
+
 def conv_gemm(desc, x, w, out, stats=None, bias=None, res=None, act=None, red=None):
     """bias / res / act: the fused epilogue out = act(conv + bias + res) (mde_conv_gemm_act; no statistics with it).
     red (ops.bn_red): the launch writes the gradient of a BatchNorm site's output and adds that site's backward sums
@@ -192,10 +214,14 @@ def conv_gemm(desc, x, w, out, stats=None, bias=None, res=None, act=None, red=No
     if TIMER is None:
         call()
         return
-    flops = 2.0 * desc.N * desc.GH * desc.GW * desc.ncols * desc.ntaps * desc.C
+    M = desc.N * desc.GH * desc.GW
+    flops = 2.0 * M * desc.ncols * desc.ntaps * desc.C
+    # algorithmic bytes: the input tensor, the weights and the output once each (bf16), + what the epilogue is asked to read:
+    # the old output (accumulate), a residual, the BatchNorm site input(s) of a launch that carries backward sums
+    extra = int(bool(desc.accumulate)) + int(res is not None) + (0 if red is None else (2 if red.x2 else 1) + int(bool(red.add)))
+    nbytes = 2.0 * (desc.N * desc.H * desc.W * desc.C + desc.ncols * desc.ntaps * desc.C + M * desc.ncols * (1 + extra))
     _timed("conv_gemm_nt", flops, call,
-           "M=%d N=%d taps=%d C=%d s=%d%s" % (desc.N * desc.GH * desc.GW, desc.ncols, desc.ntaps, desc.C, desc.sy,
-                                              " acc" if desc.accumulate else ""))
+           "M=%d N=%d taps=%d C=%d s=%d%s" % (M, desc.ncols, desc.ntaps, desc.C, desc.sy, " acc" if desc.accumulate else ""), nbytes)
 
 
 def stat_slots():
@@ -248,8 +274,9 @@ def conv_wgrad(desc, direct, gathered, dw, ws=None):
         call()
         return
     flops = 2.0 * desc.N * desc.GH * desc.GW * desc.Cd * desc.Cg * desc.ntaps
+    nbytes = 2.0 * (desc.N * desc.GH * desc.GW * desc.Cd + desc.N * desc.H * desc.W * desc.Cg) + 4.0 * desc.Cd * desc.Cg * desc.ntaps
     _timed("conv_wgrad_tn", flops, call,
-           "K=%d Cd=%d Cg=%d taps=%d ks=%d" % (desc.N * desc.GH * desc.GW, desc.Cd, desc.Cg, desc.ntaps, desc.ksplit))
+           "K=%d Cd=%d Cg=%d taps=%d ks=%d" % (desc.N * desc.GH * desc.GW, desc.Cd, desc.Cg, desc.ntaps, desc.ksplit), nbytes)
 
 
 def wgrad_time_model(pixels, row_tiles, col_tiles, ntaps, ks, cus=256, wg_per_cu=2, tile_elems=128 * 128):

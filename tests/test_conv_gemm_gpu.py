@@ -410,4 +410,31 @@ def test_dgrad_with_fused_batchnorm_backward_sums(N, H, Wd, Cin, Cout, k, s, mod
     check(sums, sums2, xs, mean, rstd)
     if mode == "join":
         check(part_b.double().sum(0), part2b.double().sum(0), x2, mean2, rstd2)
+    if acc and mode in ("bits", "join") and xmul == 1 and len(descs) == 1:
+        # mde_bn_red.add: the launch brings the identity shortcut's gradient in itself -- (block-output gradient under ITS mask
+        # bits) + result, instead of accumulating onto a copy of it that another pass wrote.  Same bits, same sums.
+        src = _nhwc(_bf(W.normal(5, "dout", (N, Cin, H, Wd))))
+        m2 = torch.from_numpy((W.uniform(5, "m2", (N, H, Wd, Cin)) > 0.3).numpy()).cuda()
+        bits2 = (m2.view(N, H, Wd, Cin // 8, 8).long() * (2 ** torch.arange(8, device="cuda")).view(1, 1, 1, 1, 8)).sum(-1).to(torch.uint8).contiguous()
+        masked = torch.where(m2, src, torch.zeros((), dtype=torch.bfloat16, device="cuda"))
+        ref_out = masked.clone()
+        descs[0].accumulate = 1
+        ops.conv_gemm(descs[0], dyd, wd, ref_out)
+        part.zero_()
+        if second is not None:
+            second[3].zero_()
+        out = torch.full((N, H, Wd, Cin), 3.0, dtype=torch.bfloat16, device="cuda")
+        descs[0].accumulate = 0
+        ops.conv_gemm(descs[0], dyd, wd, out, red=ops.bn_red_with_add(red, src, bits2))
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref_out)
+        part3 = ops.new_stat_buffer(Cin)
+        if mode == "join":
+            part3b = ops.new_stat_buffer(Cin)
+            ops.bn_bwd_reduce2(out, Cin, xs, Cin, x2, Cin, mean, rstd, mean2, rstd2, bits, M, Cin, part3, part3b)
+        else:
+            ops.bn_bwd_reduce(out, Cin, None, 0, xs, Cin, mean, rstd, M, Cin, True, part3, None, None, bits)
+        torch.cuda.synchronize()
+        a3, b3 = part.double().sum(0), part3.double().sum(0)
+        assert float(((a3 - b3).abs() / (b3.abs() + 1e-3 * b3.abs().amax(dim=1, keepdim=True))).max()) < 2e-3
     assert float(mask.float().mean()) < 0.95 or mode == "none"

@@ -86,6 +86,8 @@ def test_tape_weight_gradient_stream_changes_nothing_but_the_schedule():
             net.zero_grad(set_to_none=True)
             crit(net(x)[:, :1], t).backward()
             return torch.cat([p.grad.flatten() for p in net.parameters() if p.grad is not None]).clone()
+        grads()         # (the first backward of a plan traces who completes each BatchNorm's gradient and runs the separate
+        #                  reduction passes; from the second on the sums come from the conv epilogues: graph._plan_fused_sums)
         g_two = grads()
         eng = next(iter(net._engines.values()))
         if eng.side is None:
