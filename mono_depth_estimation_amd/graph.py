@@ -14,7 +14,7 @@ import os
 import torch
 
 from . import ops
-from .engine import FUSE_BN_RED, Act, BNSite, EngineCore, FlatStore, bn_join_backward
+from .engine import FUSE_BN_RED, FUSE_DRES, Act, BNSite, EngineCore, FlatStore, bn_join_backward
 
 
 # ---------------------------------------------------------------------------------------------- parameter storage
@@ -71,7 +71,7 @@ _CUR_OP = None
 def _take(x):
     """-> accumulate flag for a write into x.g, marking it written."""
     if _TRACE is not None:
-        _TRACE[id(x.root())] = _CUR_OP
+        _TRACE.setdefault(id(x.root()), []).append(_CUR_OP)
     if x.parent is not None and not x.root().concat_root:
         # the written-flag is shared by a root and all its slices: a first writer that covers only part of the channels
         # would make the writers of the other channels accumulate onto uninitialised memory, unless the root is a
@@ -170,6 +170,7 @@ class Conv(Op):
         self.f_bias = self.f_boff = self.f_res = self.f_act = self.f_part = self.pre_g = None
         self.fused = False
         self.red = None        # ops.bn_red of the BatchNorm op that wrote x, when this conv completes d(x) (see _TRACE)
+        self.first_writer = False   # ... and is its only writer: the identity shortcut's share comes in through red.add
 
     def fuse(self, bias, b_off, res, act, out):
         """Take over the pointwise pass that would follow this conv: the launch writes act(conv + bias + res) into `out`
@@ -221,6 +222,7 @@ class Conv(Op):
         if not self.need_dgrad:
             return
         acc = _take(x)
+        assert not (self.first_writer and acc), "a launch that brings the shortcut's gradient in itself is the first writer"
         xg = x.g
         if self.dzero and not acc:
             xg.zero_()
@@ -244,6 +246,7 @@ class BN(Op):
         if res is not None and res_site is None and not relu:
             raise NotImplementedError("BN + identity residual without ReLU")
         self.reduced = False   # the backward sums come with the launch that completes d(out) (see _TRACE)
+        self.skip_dres = False
 
     def red_spec(self):
         s, c, rs = self.site, self.c, self.res_site
@@ -292,6 +295,9 @@ class BN(Op):
         assert not acc, "a pre-BN tensor joined with a residual has one consumer"
         if self.res_site is None:
             assert not res.gw, "identity-residual gradient must be the first writer"
+            if self.skip_dres:           # the convolution that completes d(res) adds the masked d(out) itself (Conv.first_writer)
+                self.site.backward(o.g, o, c, self.relu, c.g, relu_bits=self.bits, reduced=self.reduced)
+                return
             res.gw = True
             self.site.backward(o.g, o, c, self.relu, c.g, dres=res.g, relu_bits=self.bits, reduced=self.reduced)
         else:
@@ -1131,7 +1137,7 @@ class TapeEngine(EngineCore):
         for op in self.tape:
             if not isinstance(op, (BN, PrefixBN)):
                 continue
-            conv = last_taker.get(id(op.out))
+            conv = (last_taker.get(id(op.out)) or [None])[-1]
             if (isinstance(conv, Conv) and conv.x is op.out and conv.need_dgrad and conv.red is None and len(conv._chunks()) == 1
                     and op.out.parent is None):
                 spec = op.red_spec()
@@ -1140,10 +1146,33 @@ class TapeEngine(EngineCore):
                     self._fused_pairs.append((conv, op, spec))
                     self.fused_sums += 1
 
+        # identity shortcuts (out = relu(bn(c) + x)): where x's gradient has exactly two writers -- this BatchNorm's backward pass
+        # (the masked d(out), first) and ONE convolution that already carries x's producer's sums -- that convolution's launch
+        # takes the masked d(out) from out.g itself (mde_bn_red.add) and the pass stops writing the copy
+        self._dres_pairs = []
+        if FUSE_DRES:
+            by_conv = {id(conv): i for i, (conv, _, _) in enumerate(self._fused_pairs)}
+            for op in self.tape:
+                if not (isinstance(op, BN) and op.res is not None and op.res_site is None and op.bits is not None):
+                    continue
+                x = op.res
+                takers = last_taker.get(id(x.root()), [])
+                if x.parent is not None or len(takers) != 1 or id(takers[0]) not in by_conv:
+                    continue
+                conv, prod, spec = self._fused_pairs[by_conv[id(takers[0])]]
+                if (conv.x is x and len(conv.ddescs) == 1 and not conv.dzero and (spec.relu_bits or spec.x2) and op.out.parent is None
+                        and op.out.ld == x.ld == x.C and (op.out.N, op.out.H, op.out.W, op.out.C) == (x.N, x.H, x.W, x.C)):
+                    spec2 = ops.bn_red_with_add(spec, op.out.g, op.bits)
+                    self._fused_pairs[by_conv[id(conv)]] = (conv, prod, spec2)
+                    self._dres_pairs.append((op, conv, spec, spec2))
+                    conv.red, conv.first_writer, op.skip_dres = spec2, True, True
+
     def set_fused_sums(self, on):
         """Diagnostics / tests: switch the planned fusions off (every BatchNorm runs its own reduction pass again) and back on."""
         for conv, op, spec in self._fused_pairs:
             conv.red, op.reduced = (spec, True) if on else (None, False)
+        for op, conv, _, _ in self._dres_pairs:
+            conv.first_writer = op.skip_dres = on
 
     def grad_boundaries(self):
         return [0, self.store.encoder_numel]
