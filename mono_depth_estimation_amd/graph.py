@@ -152,12 +152,16 @@ class Conv(Op):
         xb, ob = (n * x.H * x.W * x.ld - x.c0) * 2, (n * OH * OW * o.ld - o.c0) * 2       # bytes addressable from the first element
         self.fdesc = ops.fwd_desc(n, x.H, x.W, x.ld, Cin, xb, k, stride, pad, O, o.ld, dil=dil)
         self.fdesc.grouped = int(groups > 1)
+        if groups > 1:
+            self.fdesc._useful = G / 64.0                # (read by ops.conv_gemm's launch timer: algorithmic FLOP)
         if need_dgrad:
             # (grouped: every 64-column tile of dx contracts the matching 64-channel window of dY)
             self.ddescs, self.dzero = ops.dgrad_descs(n, x.H, x.W, x.ld, x.C, OH, OW, o.ld, O if groups == 1 else 64, ob,
                                                       k, stride, pad, dil=dil)
             for d in self.ddescs:
                 d.grouped = int(groups > 1)
+                if groups > 1:
+                    d._useful = G / 64.0
         M = n * OH * OW
         if groups > 1:
             ks = ops.choose_ksplit(M, O // 64, 1, k * k, eng.cus, wg_per_cu=4, tile_elems=64 * 64)

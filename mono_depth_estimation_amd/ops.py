@@ -215,7 +215,9 @@ def conv_gemm(desc, x, w, out, stats=None, bias=None, res=None, act=None, red=No
         call()
         return
     M = desc.N * desc.GH * desc.GW
-    flops = 2.0 * M * desc.ncols * desc.ntaps * desc.C
+    # algorithmic FLOP: a grouped launch contracts 64 channels per column tile of which only the group's own are the
+    # convolution's (graph.Conv sets `_useful` = group size / 64 on its descriptors); the rest are zeros of the block-diagonal packing
+    flops = 2.0 * M * desc.ncols * desc.ntaps * desc.C * getattr(desc, "_useful", 1.0)
     # algorithmic bytes: the input tensor, the weights and the output once each (bf16), + what the epilogue is asked to read:
     # the old output (accumulate), a residual, the BatchNorm site input(s) of a launch that carries backward sums
     extra = int(bool(desc.accumulate)) + int(res is not None) + (0 if red is None else (2 if red.x2 else 1) + int(bool(red.add)))
@@ -273,7 +275,7 @@ def conv_wgrad(desc, direct, gathered, dw, ws=None):
     if TIMER is None:
         call()
         return
-    flops = 2.0 * desc.N * desc.GH * desc.GW * desc.Cd * desc.Cg * desc.ntaps
+    flops = 2.0 * desc.N * desc.GH * desc.GW * desc.Cd * (desc.group_size if desc.group_size else desc.Cg) * desc.ntaps   # (grouped: the block diagonal)
     nbytes = 2.0 * (desc.N * desc.GH * desc.GW * desc.Cd + desc.N * desc.H * desc.W * desc.Cg) + 4.0 * desc.Cd * desc.Cg * desc.ntaps
     _timed("conv_wgrad_tn", flops, call,
            "K=%d Cd=%d Cg=%d taps=%d ks=%d" % (desc.N * desc.GH * desc.GW, desc.Cd, desc.Cg, desc.ntaps, desc.ksplit), nbytes)

@@ -22,8 +22,8 @@ def totals(d, counter):
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] != counter:
             continue
-        for k, names in (("conv_gemm_nt", ("conv_gemm_nt",)), ("conv_wgrad_tn", ("conv_wgrad_tn", "conv_wgrad_win"))):
-            if any(nm in r["Kernel_Name"] for nm in names):     # (the windowed weight-gradient kernel counts as a weight-gradient call)
+        for k, names in (("conv_gemm_nt", ("conv_gemm_nt",)), ("conv_wgrad_tn", ("conv_wgrad_tn", "conv_wgrad_win", "wgrad_reduce_k"))):
+            if any(nm in r["Kernel_Name"] for nm in names):     # (the windowed kernel and the two-stage reduction's second kernel count towards the weight-gradient call)
                 tot[k] += float(r["Counter_Value"])
                 n[k] += 1
     return tot, n
