@@ -24,6 +24,9 @@ sys.path.insert(0, ROOT)
 H, W, BATCH = 480, 640, 32
 PEAK_BF16_TFLOPS = 2500.0                 # dense MFMA bf16 (MI355X_MICROARCH.md)
 PEAK_HBM_TBS = 8.0                        # HBM3E (MI355X_MICROARCH.md)
+ACT_NAME = os.environ.get("MDE_ACT_DTYPE", "bf16").lower()          # the library build: bf16 (default) or fp16 storage
+ACT_NAME = "fp16" if ACT_NAME in ("fp16", "float16", "half", "f16") else "bf16"
+LOSS_SCALE = float(os.environ.get("MDE_LOSS_SCALE", "4096" if ACT_NAME == "fp16" else "1"))
 ALGO_GFLOP_PER_IMAGE = 410.9              # useful conv MACs x 2 x 3 (fwd+dgrad+wgrad)
 ALGO_CONV_BYTES_PER_CALL = 153.8e6        # 22.0 GB per step (in + out + weights of the 143 forward / input-gradient calls, bf16) / 143:
 #                                           the convolutions alone.  Since round 3 fifty-odd of those launches also carry a BatchNorm
@@ -154,13 +157,13 @@ def build_other(name, n, dev):
         net = Bts.BtsModel(max_depth=1.0, bts_size=512, encoder_version="densenet161_bts", out_channels=1).to(dev).train()
         crit = criteria.silog_loss(0.85)
         fwd_loss = lambda: crit(net(x)[4], gt)
-        opt = lambda: net._store.adam_step(1e-4, 1e-4, eps=1e-3, weight_decay=(1e-2, 0.0), decoupled=True, grad_scale=1.0 / world)
+        opt = lambda: net._store.adam_step(1e-4, 1e-4, eps=1e-3, weight_decay=(1e-2, 0.0), decoupled=True, grad_scale=1.0 / (world * LOSS_SCALE))
     elif name == "midas":
         from mono_depth_estimation_amd.network import MiDaS
         net = MiDaS.MidasNet(features=256).to(dev).train()
         crit = criteria.MidasLoss(alpha=0.5, loss="ssimse")
         fwd_loss = lambda: crit(net(x)[:, :1], gt)
-        opt = lambda: net._store.adam_step(1e-5, 1e-4, grad_scale=1.0 / world)
+        opt = lambda: net._store.adam_step(1e-5, 1e-4, grad_scale=1.0 / (world * LOSS_SCALE))
     else:
         from types import SimpleNamespace
         from mono_depth_estimation_amd.network import VNL
@@ -179,7 +182,7 @@ def build_other(name, n, dev):
         def fwd_loss():
             logit, prob = net(x)
             return crit(criteria.bins_to_depth(prob, p.depth_bin_border), logit, bins, gt)
-        opt = lambda: net._store.sgd_step(1e-4, 1e-5, momentum=0.9, weight_decay=5e-4, grad_scale=1.0 / world)
+        opt = lambda: net._store.sgd_step(1e-4, 1e-5, momentum=0.9, weight_decay=5e-4, grad_scale=1.0 / (world * LOSS_SCALE))
     return net, fwd_loss, opt
 
 
@@ -200,7 +203,7 @@ def run_other_config(args, dev, rank, world, use_dist, t_start):
     def step():
         net.zero_grad(set_to_none=True)
         loss = fwd_loss()
-        loss.backward()
+        (loss * LOSS_SCALE if LOSS_SCALE != 1.0 else loss).backward()      # (fp16 build: static loss scale, divided out by the optimiser step)
         store = net._store
         if use_dist:
             if "red" not in state:
@@ -245,9 +248,9 @@ def run_other_config(args, dev, rank, world, use_dist, t_start):
         ips = args.batch * world * args.steps / dt
         gflop = cfg["gmac"] * 6.0
         out = {
-            "metric": "training images/sec, %s, bf16" % args.config.upper(), "value": round(ips, 2), "unit": "images/sec",
+            "metric": "training images/sec, %s, %s" % (args.config.upper(), ACT_NAME), "value": round(ips, 2), "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
-            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": ACT_NAME, "data": "synthetic",
             "config": {"workload": cfg["workload"] % args.batch + (" + flat-gradient all-reduce after backward (RCCL, %s)" % args.grad_dtype
                                                                    if world > 1 else ""),
                        "global_batch": args.batch * world, "per_gpu_batch": args.batch, "parallelism": "dp%d" % world,
@@ -373,15 +376,19 @@ def main():
     ws, loss = ops.silog_ws(dev), torch.empty(1, device=dev)
     dy = torch.empty(args.batch, 1, H, W, device=dev)
     lr = 1e-4
+    # the fp16 storage build (MDE_ACT_DTYPE=fp16) trains with a static loss scale, as the reference's precision=16 run does with
+    # torch's GradScaler: the loss gradient goes into the backward pass multiplied by it, the optimiser step divides it out
+    S = LOSS_SCALE
+    gscale = torch.full((1,), S, device=dev) if S != 1.0 else None
 
     def step():
         y = eng.forward(x, True)
         ops.silog_fwd(y, tgt, 0.85, ws, loss)
-        ops.silog_bwd(y, tgt, 0.85, ws, None, dy)
+        ops.silog_bwd(y, tgt, 0.85, ws, gscale, dy)
         store.G.zero_()
         eng.backward(dy, reducer.ready, consumer_waits_side=True)
         reducer.finish()
-        store.adam_step(lr, 10 * lr, grad_scale=1.0 / world)
+        store.adam_step(lr, 10 * lr, grad_scale=1.0 / (world * S))
 
     def fence():
         if use_dist:
@@ -434,9 +441,9 @@ def main():
     if rank == 0:
         ips = args.batch * world * args.steps / dt
         out = {
-            "metric": "training images/sec, FCRN 640x480 bf16", "value": round(ips, 2), "unit": "images/sec",
+            "metric": "training images/sec, FCRN 640x480 %s" % ACT_NAME, "value": round(ips, 2), "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
-            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": ACT_NAME, "data": "synthetic",
             "config": {"workload": "FCRN ResNet-50 + UpProj (reference network/FCRN.py), %dx3x480x640 per GPU -> 1x480x640 "
                                    "depth, train step = fwd + SILog(0.85) + bwd + Adam(lr, 10*lr)%s" % (
                                        args.batch, " + flat-gradient all-reduce (RCCL, %s buckets)" % args.grad_dtype if world > 1 else ""),

@@ -34,6 +34,10 @@ extern "C" {
 const char* mde_last_error(void);
 /* ABI version of this header (checked by the Python loader). */
 int mde_abi_version(void);
+/* The 16-bit storage type this build of the library uses for activations, their gradients and the GEMM weight shadows
+ * (every `void*` tensor argument documented as bf16 below): 0 = bf16 (libmde_hip.so), 1 = IEEE fp16 (libmde_hip_f16.so, the same
+ * sources compiled with -DMDE_ACT_F16: BASELINE configuration 5 / reference train.py:139-140 precision=16). */
+int mde_act_dtype(void);
 /* Number of CUs of the current device (used by hosts to size split-K). */
 int mde_device_cu_count(int* out);
 

@@ -7,13 +7,23 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("MDE_LIB_PATH") or os.path.join(_HERE, "libmde_hip.so")   # override: diagnostic builds only
-ABI_VERSION = 9
-MAX_TAPS = 32
 
 
 class MdeError(RuntimeError):
     pass
+
+
+# MDE_ACT_DTYPE=fp16 selects the build whose 16-bit storage type is IEEE half (libmde_hip_f16.so: the same sources with
+# -DMDE_ACT_F16; BASELINE configuration 5's precision) for the whole process; default bf16.  ops.ACT_DTYPE is the matching torch dtype.
+ACT_NAME = os.environ.get("MDE_ACT_DTYPE", "bf16").lower()
+if ACT_NAME in ("float16", "half", "f16"):
+    ACT_NAME = "fp16"
+if ACT_NAME not in ("bf16", "fp16"):
+    raise MdeError("MDE_ACT_DTYPE=%s: bf16 (default) or fp16" % ACT_NAME)
+LIB_NAME = "libmde_hip_f16.so" if ACT_NAME == "fp16" else "libmde_hip.so"
+LIB_PATH = os.environ.get("MDE_LIB_PATH") or os.path.join(_HERE, LIB_NAME)   # override: diagnostic builds only
+ABI_VERSION = 10
+MAX_TAPS = 32
 
 
 class BnRed(C.Structure):
@@ -56,6 +66,7 @@ _P, _I, _L, _F, _Z, _U = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t, 
 # name -> (restype, argtypes); every symbol include/mde_hip.h declares
 SIGNATURES = {
     "mde_last_error": (C.c_char_p, []),
+    "mde_act_dtype": (_I, []),
     "mde_abi_version": (_I, []),
     "mde_device_cu_count": (_I, [C.POINTER(_I)]),
     "mde_det_scratch_bytes": (_Z, [_L]),
@@ -188,8 +199,8 @@ def load():
         return _lib
     if not os.path.exists(LIB_PATH):
         raise MdeError(
-            "libmde_hip.so not found at %s — build it with `python -c 'import __graft_entry__ as g; "
-            "g.build()'` (or mono_depth_estimation_amd/csrc/build.sh). There is no CPU fallback." % LIB_PATH)
+            "%s not found at %s — build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` (or mono_depth_estimation_amd/csrc/build.sh). There is no CPU fallback." % (LIB_NAME, LIB_PATH))
     lib = C.CDLL(LIB_PATH)
     missing = []
     for name, (res, args) in SIGNATURES.items():
@@ -203,7 +214,9 @@ def load():
     if missing:
         raise MdeError("libmde_hip.so lacks symbols declared in include/mde_hip.h: %s" % ", ".join(missing))
     if lib.mde_abi_version() != ABI_VERSION:
-        raise MdeError("libmde_hip.so ABI %d != binding ABI %d" % (lib.mde_abi_version(), ABI_VERSION))
+        raise MdeError("%s ABI %d != binding ABI %d" % (LIB_NAME, lib.mde_abi_version(), ABI_VERSION))
+    if lib.mde_act_dtype() != (1 if ACT_NAME == "fp16" else 0):
+        raise MdeError("%s stores %s, the process asked for %s" % (LIB_NAME, ("bf16", "fp16")[lib.mde_act_dtype()], ACT_NAME))
     _lib = lib
     return lib
 

@@ -367,7 +367,7 @@ __global__ __launch_bounds__(NT, HALO ? (NT == 512 ? 4 : BC <= 64 ? 5 : 4)
         for (int i = 0; i < CF; ++i)
 #pragma unroll
             for (int j = 0; j < PF; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = MDE_MFMA_16x16x32(fa[i], fb[j], acc[i][j]);
         if constexpr (MDE_SETPRIO) __builtin_amdgcn_s_setprio(0);
 #endif
     };
@@ -559,7 +559,7 @@ __global__ __launch_bounds__(NT, HALO ? (NT == 512 ? 4 : BC <= 64 ? 5 : 4)
                     for (int i = 0; i < 4; ++i)
 #pragma unroll
                         for (int j = 0; j < PF; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][kb], fb[j][kb], acc[i][j], 0, 0, 0);
+                            acc[i][j] = MDE_MFMA_16x16x32(fa[i][kb], fb[j][kb], acc[i][j]);
                 __builtin_amdgcn_s_setprio(0);
                 PP_ADD(2, t0); t0 = PP_T();
                 PP_BARRIER();
@@ -588,7 +588,7 @@ __global__ __launch_bounds__(NT, HALO ? (NT == 512 ? 4 : BC <= 64 ? 5 : 4)
                     for (int i = 0; i < 4; ++i)
 #pragma unroll
                         for (int j = 0; j < PF; ++j)
-                            acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][kb], fb[j][kb], acc[4 + i][j], 0, 0, 0);
+                            acc[4 + i][j] = MDE_MFMA_16x16x32(fa[i][kb], fb[j][kb], acc[4 + i][j]);
                 __builtin_amdgcn_s_setprio(0);
                 PP_ADD(2, t0); t0 = PP_T();
                 if (!grpB) {
@@ -676,7 +676,7 @@ __global__ __launch_bounds__(NT, HALO ? (NT == 512 ? 4 : BC <= 64 ? 5 : 4)
                     for (int i = 0; i < CF; ++i)
 #pragma unroll
                         for (int j = 0; j < PF; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = MDE_MFMA_16x16x32(fa[i], fb[j], acc[i][j]);
                 }
             };
             int cc = 0, t = 0;
@@ -835,7 +835,7 @@ __global__ __launch_bounds__(NT, HALO ? (NT == 512 ? 4 : BC <= 64 ? 5 : 4)
                     }
 #pragma unroll
                     for (int i = 0; i < CF; ++i)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa0[i], fb[j & 1], acc[i][j], 0, 0, 0);
+                        acc[i][j] = MDE_MFMA_16x16x32(fa0[i], fb[j & 1], acc[i][j]);
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -856,7 +856,7 @@ __global__ __launch_bounds__(NT, HALO ? (NT == 512 ? 4 : BC <= 64 ? 5 : 4)
                     fb[(j + 1) & 1] = RB(1, j + 1);
 #pragma unroll
                     for (int i = 0; i < CF; ++i)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa1[i], fb[(PF + j) & 1], acc[i][j], 0, 0, 0);
+                        acc[i][j] = MDE_MFMA_16x16x32(fa1[i], fb[(PF + j) & 1], acc[i][j]);
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                     __builtin_amdgcn_sched_group_barrier(0x008, 7, 0);
@@ -878,7 +878,7 @@ __global__ __launch_bounds__(NT, HALO ? (NT == 512 ? 4 : BC <= 64 ? 5 : 4)
                     fb[0] = *reinterpret_cast<const bf16x8_t*>(nxb + rd_off[0]);
 #pragma unroll
                     for (int i = 0; i < CF; ++i)
-                        acc[i][PF - 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa1[i], fb[(PF + PF - 1) & 1], acc[i][PF - 1], 0, 0, 0);
+                        acc[i][PF - 1] = MDE_MFMA_16x16x32(fa1[i], fb[(PF + PF - 1) & 1], acc[i][PF - 1]);
 #pragma unroll
                     for (int i = 0; i < CF; ++i) {
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);

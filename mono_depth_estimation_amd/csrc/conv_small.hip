@@ -226,9 +226,9 @@ __global__ __launch_bounds__(NTF, 1) void stem_fwd_k(const float* __restrict__ x
                 acc[1][1] += (float)bh[2] + (float)bl[3] + (float)bh[4] + (float)bl[5] + (float)bh[6] + (float)bl[7];
 #else
 #pragma unroll
-                for (int cb = 0; cb < 4; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[cb][ks], bh, acc[cb], 0, 0, 0);
+                for (int cb = 0; cb < 4; ++cb) acc[cb] = MDE_MFMA_16x16x32(wa[cb][ks], bh, acc[cb]);
 #pragma unroll
-                for (int cb = 0; cb < 4; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[cb][ks], bl, acc[cb], 0, 0, 0);
+                for (int cb = 0; cb < 4; ++cb) acc[cb] = MDE_MFMA_16x16x32(wa[cb][ks], bl, acc[cb]);
 #endif
             }
             // D: col = pixel (lane&15), rows = channels cb*16 + lg*4 + r
@@ -387,8 +387,8 @@ __global__ __launch_bounds__(NT, 2) void stem_wgrad_k(const float* __restrict__ 
                 stem_unpack8(wv, bh, bl);
 #pragma unroll
                 for (int cb = 0; cb < 4; ++cb) {
-                    acc[cb][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[cb], bh, acc[cb][f], 0, 0, 0);
-                    acc[cb][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[cb], bl, acc[cb][f], 0, 0, 0);
+                    acc[cb][f] = MDE_MFMA_16x16x32(fa[cb], bh, acc[cb][f]);
+                    acc[cb][f] = MDE_MFMA_16x16x32(fa[cb], bl, acc[cb][f]);
                 }
             }
         }
@@ -551,7 +551,7 @@ __global__ __launch_bounds__(NT) void head_wgrad_k(const bf16_t* __restrict__ x,
 // (18 instead of 36 per run).  All weights sit in registers; out-of-image taps are buffer loads
 // with an out-of-range offset (read as 0).
 constexpr int HR = 4;
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16pair_t;
+typedef bf16x2_t bf16pair_t;
 
 __device__ __forceinline__ float head_sum8(float v) {     // sum over the 8 lanes of a pixel, result in all of them
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
@@ -607,8 +607,8 @@ __global__ __launch_bounds__(NT) void head1_fwd_k(const bf16_t* __restrict__ x, 
                     for (int i = 0; i < 4; ++i) {
                         const int xi = v[p + kx][i];      // (scalar copy on purpose: __builtin_bit_cast applied to a
                         const bf16pair_t xv = __builtin_bit_cast(bf16pair_t, xi);   //  vector-element expression reads element 0)
-                        acc[p] = __builtin_amdgcn_fdot2_f32_bf16(xv, wh[ky * 3 + kx][i], acc[p], false);
-                        acc[p] = __builtin_amdgcn_fdot2_f32_bf16(xv, wl[ky * 3 + kx][i], acc[p], false);
+                        acc[p] = MDE_FDOT2(xv, wh[ky * 3 + kx][i], acc[p]);
+                        acc[p] = MDE_FDOT2(xv, wl[ky * 3 + kx][i], acc[p]);
                     }
         }
         float mine = 0.f;
@@ -719,7 +719,12 @@ __global__ __launch_bounds__(NT) void head1_wgrad_k(const bf16_t* __restrict__ x
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const uint32_t u = (uint32_t)xv[p][i];
-                xf[i] = f32x2_t{__builtin_bit_cast(float, u << 16), __builtin_bit_cast(float, u & 0xFFFF0000u)};
+#ifdef MDE_ACT_F16
+                const bf16x2_t h2 = __builtin_bit_cast(bf16x2_t, u);
+                xf[i] = f32x2_t{(float)h2[0], (float)h2[1]};
+#else
+                xf[i] = f32x2_t{__builtin_bit_cast(float, u << 16), __builtin_bit_cast(float, u & 0xFFFF0000u)};   // bf16 -> fp32 is a shift
+#endif
             }
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky)

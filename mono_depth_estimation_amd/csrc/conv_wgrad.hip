@@ -184,7 +184,7 @@ __global__ __launch_bounds__(NT, NBUF == 1 ? 4 : 2) void conv_wgrad_tn(const KAr
             for (int i = 0; i < FA; ++i)
 #pragma unroll
                 for (int j = 0; j < FB; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = MDE_MFMA_16x16x32(fa[i], fb[j], acc[i][j]);
         }
     };
 

@@ -190,8 +190,8 @@ __global__ __launch_bounds__(NT, 4) void conv_wgrad_win(const WArgs a) {
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
-                        acc[t][i][j] = GA ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fd[i], acc[t][i][j], 0, 0, 0)
-                                          : __builtin_amdgcn_mfma_f32_16x16x32_bf16(fd[i], fw[j], acc[t][i][j], 0, 0, 0);
+                        acc[t][i][j] = GA ? MDE_MFMA_16x16x32(fw[j], fd[i], acc[t][i][j])
+                                          : MDE_MFMA_16x16x32(fd[i], fw[j], acc[t][i][j]);
             }
             if constexpr (T > 2) __builtin_amdgcn_sched_barrier(0);   // (keeps the second half's fragments out of the first's registers: no spills at 128)
         }

@@ -7,10 +7,29 @@
 
 #include "../../include/mde_hip.h"
 
+// The 16-bit storage type of activations, their gradients and the GEMM weight shadows.  Default build (libmde_hip.so): bf16 --
+// hence the names.  -DMDE_ACT_F16 (libmde_hip_f16.so, build.sh): IEEE half, the storage type BASELINE configuration 5 names
+// (reference train.py:139-140, precision=16): 11 significand bits instead of 8, range 6e-5 ... 65504 -- the caller scales the
+// loss as the reference's GradScaler does.  Same kernels: every conversion goes through (float) / (bf16_t), the MFMA and dot
+// instructions of the two types have the same shapes and rates (MDE_MFMA_16x16x32, MDE_FDOT2), the LDS-DMA and transposed LDS
+// reads move 16-bit words of either.  fp32 everywhere a sum crosses pixels (BatchNorm statistics, weight gradients, losses).
+#ifdef MDE_ACT_F16
+typedef _Float16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) _Float16 bf16x4_t;
+typedef __attribute__((ext_vector_type(2))) _Float16 bf16x2_t;
+#define MDE_MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)
+#define MDE_FDOT2(a, b, c) __builtin_amdgcn_fdot2(a, b, c, false)
+#define MDE_ACT_DTYPE_CODE 1
+#else
 typedef __bf16 bf16_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+#define MDE_MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
+#define MDE_FDOT2(a, b, c) __builtin_amdgcn_fdot2_f32_bf16(a, b, c, false)
+#define MDE_ACT_DTYPE_CODE 0
+#endif
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 typedef __attribute__((ext_vector_type(2))) float f32x2_t;

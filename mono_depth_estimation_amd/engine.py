@@ -42,7 +42,7 @@ class Act:
         self.parent, self.c0 = parent, c0
         if parent is None:
             self.ld = C
-            self.t = torch.empty(N, H, W, C, dtype=torch.bfloat16, device=dev)
+            self.t = torch.empty(N, H, W, C, dtype=ops.ACT_DTYPE, device=dev)
         else:                                             # (c0 is absolute: the channel offset inside the ROOT tensor)
             self.ld = parent.ld
             self.t = parent.t[..., c0 - parent.c0:c0 - parent.c0 + C]
@@ -236,8 +236,8 @@ class GroupedConv:
         self.O, self.T, self.I, self.G = O, T, 64, G
         self.store, self.off, self.n = store, off, O * T * G
         self.w32 = store.P[off:off + self.n]
-        self.wf = torch.zeros(O * T * 64, dtype=torch.bfloat16, device=store.dev)
-        self.wd = torch.zeros(O * T * 64, dtype=torch.bfloat16, device=store.dev)
+        self.wf = torch.zeros(O * T * 64, dtype=ops.ACT_DTYPE, device=store.dev)
+        self.wd = torch.zeros(O * T * 64, dtype=ops.ACT_DTYPE, device=store.dev)
 
     @property
     def dw(self):
@@ -333,8 +333,8 @@ class FlatStore:
         self.G = torch.zeros(size, dtype=torch.float32, device=dev)
         self.G2 = None                    # second gradient buffer, only for the autograd path (see begin_autograd_backward)
         self.Gcur = self.G                # where the engine's backward accumulates parameter gradients
-        self.Pb = torch.zeros(size, dtype=torch.bfloat16, device=dev)
-        self.WD = torch.zeros(size, dtype=torch.bfloat16, device=dev)     # transposed conv weights, same offsets as P
+        self.Pb = torch.zeros(size, dtype=ops.ACT_DTYPE, device=dev)
+        self.WD = torch.zeros(size, dtype=ops.ACT_DTYPE, device=dev)     # transposed conv weights, same offsets as P
         self._pack_jobs = None
         self.p_off = {}
         for (kind, ts), off in zip(plist, offs):

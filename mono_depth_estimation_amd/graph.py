@@ -189,7 +189,7 @@ class Conv(Op):
         self.f_part = ops.new_stat_buffer(out.C, self.eng.dev) if bias is not None else None
         assert old_ld == o.C, "only a conv that owns a dense output is fused (its gradient descriptors address pre_g, stride C)"
         self.fdesc.ld_out = out.ld                   # the forward descriptor carries the NEW output's pixel stride
-        self.pre_g = torch.empty(out.N, out.H, out.W, out.C, dtype=torch.bfloat16, device=self.eng.dev)
+        self.pre_g = torch.empty(out.N, out.H, out.W, out.C, dtype=ops.ACT_DTYPE, device=self.eng.dev)
         return self
 
     def acts(self):
@@ -970,7 +970,7 @@ class PixelShuffle2(Op):
             ops.pixel_shuffle2(x.g, _ldg(x), o.g, _ldg(o), x.N, x.H, x.W, o.C, inverse=True)
             return
         if self.tmp is None:                               # the input has another consumer: permute into scratch, then add
-            self.tmp = torch.empty(x.N, x.H, x.W, x.C, dtype=torch.bfloat16, device=x.t.device)
+            self.tmp = torch.empty(x.N, x.H, x.W, x.C, dtype=ops.ACT_DTYPE, device=x.t.device)
         ops.pixel_shuffle2(self.tmp, x.C, o.g, _ldg(o), x.N, x.H, x.W, o.C, inverse=True)
         ops.pw_fwd(self.tmp, x.C, None, x.g, _ldg(x), x.g, _ldg(x), x.M, x.C, None)
 

@@ -11,6 +11,10 @@ from . import _lib
 from ._lib import ConvDesc, WgradDesc, check
 
 
+# the torch dtype of the library's 16-bit storage type: every activation, activation gradient and GEMM weight shadow
+ACT_DTYPE = torch.float16 if _lib.ACT_NAME == "fp16" else torch.bfloat16
+
+
 def _p(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 

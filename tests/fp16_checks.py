@@ -1,0 +1,89 @@
+"""Run under MDE_ACT_DTYPE=fp16 (tests/test_fp16_build_gpu.py starts it as a subprocess): end-to-end checks of the fp16 storage
+build (libmde_hip_f16.so) that need a loss scale -- the reference's precision=16 run scales its loss with torch's GradScaler
+(train.py:139-140), and so must whoever trains through this build: fp16 gradients below 6e-8 are zero.  Prints one JSON line."""
+import json
+import sys
+
+import numpy as np
+import torch
+
+from oracle import fcrn as ofcrn
+from oracle import losses as L
+from oracle import metrics as OM
+from oracle import nets
+from oracle import weights as W
+
+
+def norm_ratios(named_hip, grads_oracle, scale):
+    r = []
+    for k, p in named_hip:
+        go = grads_oracle.get(k)
+        if go is None or p.grad is None or float(go.norm()) < 1e-9:
+            continue
+        r.append(float((p.grad.detach().cpu() / scale).norm() / go.norm()))
+    return np.array(r)
+
+
+def fcrn(out):
+    from mono_depth_estimation_amd import criteria, metrics
+    from mono_depth_estimation_amd.network import FCRN
+    size = (96, 128)
+    ora = ofcrn.FCRNOracle(50, size, out_channels=1)
+    W.fcrn_conditioned_state(ora, 11)
+    rgb, tgt = W.synthetic_batch(11, 2, *size)
+    W.calibrate_running_stats(ora, rgb)
+    hip = FCRN.ResNet(layers=50, output_size=size, out_channels=1, pretrained=False)
+    hip.load_state_dict(ora.state_dict())
+    hip = hip.cuda().eval()
+    ora.eval()
+    with torch.no_grad():
+        y, yo = hip(rgb.cuda()), ora(rgb)
+    a_h = float(metrics.MetricComputation(["absrel"]).compute(y, tgt.cuda())[0])
+    a_o = float(OM.compute(yo, tgt)["absrel"])
+    out["fcrn_eval_absrel_delta"] = abs(a_h - a_o)
+    out["fcrn_eval_rel_l2"] = float((y.cpu() - yo).norm() / yo.norm())
+    hip.train()
+    ora.train()
+    for scale, tag in ((1.0, "unscaled"), (4096.0, "scaled")):
+        hip.zero_grad(set_to_none=True)
+        ora.zero_grad(set_to_none=True)
+        loss = criteria.silog_loss(0.85)(hip(rgb.cuda()), tgt.cuda())
+        (loss * scale).backward()
+        lo = L.silog(ora(rgb), tgt, 0.85)
+        lo.backward()
+        go = {k: p.grad.clone() for k, p in ora.named_parameters() if p.grad is not None}
+        r = norm_ratios(hip.named_parameters(), go, scale)
+        out["fcrn_train_loss_rel_%s" % tag] = abs(float(loss.detach()) - float(lo.detach())) / float(lo.detach())
+        out["fcrn_grad_norm_within_10pct_%s" % tag] = float(np.mean(np.abs(r - 1) < 0.10))
+
+
+def midas(out):
+    from mono_depth_estimation_amd import criteria
+    from mono_depth_estimation_amd.network import MiDaS
+    torch.manual_seed(0)
+    net = MiDaS.MidasNet(features=256)
+    sd = W.midas_fixture_state(net, 43)
+    rgb, tgt = W.synthetic_batch(43, 2, 64, 96)
+    P0 = nets.leaf_state(sd)
+    with torch.no_grad():
+        nets.midas_forward(P0, rgb, True, momentum=1.0)
+    net.load_state_dict({k: v.clone() for k, v in P0.items()})
+    net = net.cuda().train()
+    P = nets.leaf_state(P0, requires_grad=True)
+    L.midas_loss(nets.midas_forward(P, rgb, True)[:, :1], tgt, alpha=0.5, loss="ssimse").backward()
+    go = {k: v.grad for k, v in P.items() if v.grad is not None}
+    for scale, tag in ((1.0, "unscaled"), (1024.0, "scaled")):
+        net.zero_grad(set_to_none=True)
+        loss = criteria.MidasLoss(alpha=0.5, loss="ssimse")(net(rgb.cuda())[:, :1], tgt.cuda())
+        (loss * scale).backward()
+        r = norm_ratios(net.named_parameters(), go, scale)
+        out["midas_grad_norm_within_15pct_%s" % tag] = float(np.mean(np.abs(r - 1) < 0.15))
+
+
+if __name__ == "__main__":
+    from mono_depth_estimation_amd import _lib, ops
+    assert _lib.ACT_NAME == "fp16" and ops.ACT_DTYPE == torch.float16 and _lib.load().mde_act_dtype() == 1
+    res = {"lib": _lib.LIB_NAME}
+    fcrn(res)
+    midas(res)
+    sys.stdout.write(json.dumps(res) + "\n")

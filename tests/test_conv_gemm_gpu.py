@@ -3,6 +3,8 @@ ops on the same bf16-rounded operands.  Tolerance: the kernel accumulates in fp3
 rounds once to bf16, so |hip - ref| <= 2^-8 * |ref| + 2^-8 * rms(ref) (stated here)."""
 import pytest
 import torch
+
+from mono_depth_estimation_amd.ops import ACT_DTYPE as ACT        # the library's 16-bit storage type (bf16; fp16 under MDE_ACT_DTYPE=fp16)
 import torch.nn.functional as F
 
 from oracle import weights as W
@@ -46,11 +48,11 @@ def conv_form(request):
 
 
 def _bf(t):
-    return t.to(torch.bfloat16).to(torch.float32)
+    return t.to(ACT).to(torch.float32)
 
 
 def _nhwc(t):  # NCHW fp32 cpu -> NHWC bf16 cuda
-    return t.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).cuda()
+    return t.permute(0, 2, 3, 1).contiguous().to(ACT).cuda()
 
 
 def _nchw(t):  # NHWC bf16 cuda -> NCHW fp32 cpu
@@ -59,12 +61,12 @@ def _nchw(t):  # NHWC bf16 cuda -> NCHW fp32 cpu
 
 def _pack_fwd(w):  # OIHW fp32 -> [O][kh*kw][I] bf16 cuda
     o, i, kh, kw = w.shape
-    return w.permute(0, 2, 3, 1).reshape(o, kh * kw, i).contiguous().to(torch.bfloat16).cuda()
+    return w.permute(0, 2, 3, 1).reshape(o, kh * kw, i).contiguous().to(ACT).cuda()
 
 
 def _pack_dgrad(w):  # OIHW -> [I][kh*kw][O]
     o, i, kh, kw = w.shape
-    return w.permute(1, 2, 3, 0).reshape(i, kh * kw, o).contiguous().to(torch.bfloat16).cuda()
+    return w.permute(1, 2, 3, 0).reshape(i, kh * kw, o).contiguous().to(ACT).cuda()
 
 
 def _assert_close(got, ref, what, tol=2.0 ** -8):
@@ -94,7 +96,7 @@ def test_conv_forward(N, H, Wd, Cin, Cout, k, s, p):
     xd, wd = _nhwc(x), _pack_fwd(w)
     OH, OW = ref.shape[2:]
     ld_out = Cout + 8                                    # channel-sliced output view
-    out = torch.full((N, OH, OW, ld_out), 7.0, dtype=torch.bfloat16, device="cuda")
+    out = torch.full((N, OH, OW, ld_out), 7.0, dtype=ACT, device="cuda")
     d = ops.fwd_desc(N, H, Wd, Cin, Cin, xd.numel() * 2, k, s, p, Cout, ld_out)
     stats = ops.new_stat_buffer(Cout)
     ops.conv_gemm(d, xd, wd, out, stats)
@@ -125,7 +127,7 @@ def test_conv_dgrad(N, H, Wd, Cin, Cout, k, s, p):
     F.conv2d(x, w, stride=s, padding=p).backward(dy)
     ref = x.grad
     dyd, wd = _nhwc(dy), _pack_dgrad(w)
-    dx = torch.full((N, H, Wd, Cin), 3.0, dtype=torch.bfloat16, device="cuda")
+    dx = torch.full((N, H, Wd, Cin), 3.0, dtype=ACT, device="cuda")
     descs, zero = ops.dgrad_descs(N, H, Wd, Cin, Cin, OH, OW, Cout, Cout, dyd.numel() * 2, k, s, p)
     if zero:
         dx.zero_()
@@ -161,7 +163,7 @@ def test_upproj_phases_fwd_and_dgrad(N, h, w, Cin):
     xi = x.clone().requires_grad_(True)
     ref = F.conv2d(_unpool(xi), wcat, padding=2)
     xd = _nhwc(x)
-    out = torch.empty(N, 2 * h, 2 * w, 2 * Cout, dtype=torch.bfloat16, device="cuda")
+    out = torch.empty(N, 2 * h, 2 * w, 2 * Cout, dtype=ACT, device="cuda")
     for d in ops.upproj_fwd_descs(N, h, w, Cin, Cin, xd.numel() * 2, 2 * Cout, 2 * Cout):
         ops.conv_gemm(d, xd, _pack_fwd(wcat), out)
     torch.cuda.synchronize()
@@ -169,7 +171,7 @@ def test_upproj_phases_fwd_and_dgrad(N, h, w, Cin):
     dy = _bf(W.normal(3, "dy", tuple(ref.shape)))
     ref.backward(dy)
     dyd = _nhwc(dy)
-    dx = torch.empty(N, h, w, Cin, dtype=torch.bfloat16, device="cuda")
+    dx = torch.empty(N, h, w, Cin, dtype=ACT, device="cuda")
     d = ops.upproj_dgrad_desc(N, h, w, Cin, Cin, 2 * Cout, 2 * Cout, dyd.numel() * 2)
     ops.conv_gemm(d, dyd, _pack_dgrad(wcat), dx)
     torch.cuda.synchronize()
@@ -178,9 +180,9 @@ def test_upproj_phases_fwd_and_dgrad(N, h, w, Cin):
 
 def test_conv_rejects_bad_args():
     from mono_depth_estimation_amd import _lib, ops
-    x = torch.zeros(1, 4, 4, 48, dtype=torch.bfloat16, device="cuda")
-    w = torch.zeros(64, 1, 48, dtype=torch.bfloat16, device="cuda")
-    out = torch.zeros(1, 4, 4, 64, dtype=torch.bfloat16, device="cuda")
+    x = torch.zeros(1, 4, 4, 48, dtype=ACT, device="cuda")
+    w = torch.zeros(64, 1, 48, dtype=ACT, device="cuda")
+    out = torch.zeros(1, 4, 4, 64, dtype=ACT, device="cuda")
     d = ops.fwd_desc(1, 4, 4, 48, 44, x.numel() * 2, 1, 1, 0, 64, 64)
     with pytest.raises(_lib.MdeError, match="multiple of 8"):
         ops.conv_gemm(d, x, w, out)
@@ -202,9 +204,9 @@ def test_atrous_conv_fwd_dgrad_wgrad(N, H, Wd, Cin, Cout, dil):
     dy = _bf(W.normal(6, "dy", tuple(ref.shape)))
     ref.backward(dy)
     xd, dyd = _nhwc(x), _nhwc(dy)
-    out = torch.empty(N, H, Wd, Cout, dtype=torch.bfloat16, device="cuda")
+    out = torch.empty(N, H, Wd, Cout, dtype=ACT, device="cuda")
     ops.conv_gemm(ops.fwd_desc(N, H, Wd, Cin, Cin, xd.numel() * 2, 3, 1, dil, Cout, Cout, dil=dil), xd, _pack_fwd(w), out)
-    dx = torch.empty(N, H, Wd, Cin, dtype=torch.bfloat16, device="cuda")
+    dx = torch.empty(N, H, Wd, Cin, dtype=ACT, device="cuda")
     descs, zero = ops.dgrad_descs(N, H, Wd, Cin, Cin, H, Wd, Cout, Cout, dyd.numel() * 2, 3, 1, dil, dil=dil)
     assert len(descs) == 1 and not zero
     ops.conv_gemm(descs[0], dyd, _pack_dgrad(w), dx)
@@ -245,7 +247,7 @@ def test_random_shapes_fwd_dgrad_wgrad():
         ref.backward(dy)
         xd, dyd = _nhwc(x), _nhwc(dy)
         tag = "trial %d: N%d %dx%d C%d->%d k%d s%d d%d" % (trial, N, H, Wd, Cin, Cout, k, s, dil)
-        out = torch.empty(N, OH, OW, Cout, dtype=torch.bfloat16, device="cuda")
+        out = torch.empty(N, OH, OW, Cout, dtype=ACT, device="cuda")
         stats = ops.new_stat_buffer(Cout)
         ops.conv_gemm(ops.fwd_desc(N, H, Wd, Cin, Cin, xd.numel() * 2, k, s, p, Cout, Cout, dil=dil), xd, _pack_fwd(w), out, stats)
         _assert_close(_nchw(out), ref.detach(), tag + " fwd")
@@ -253,7 +255,7 @@ def test_random_shapes_fwd_dgrad_wgrad():
         r1, r2 = ref.detach().sum((0, 2, 3)), (ref.detach() ** 2).sum((0, 2, 3))
         assert torch.allclose(st[0], r1, rtol=2e-3, atol=2e-2 * r2.max().sqrt().item()), tag + " stats"
         assert torch.allclose(st[1], r2, rtol=2e-3, atol=2e-3 * r2.max().item()), tag + " stats"
-        dx = torch.full((N, H, Wd, Cin), 3.0, dtype=torch.bfloat16, device="cuda")
+        dx = torch.full((N, H, Wd, Cin), 3.0, dtype=ACT, device="cuda")
         descs, zero = ops.dgrad_descs(N, H, Wd, Cin, Cin, OH, OW, Cout, Cout, dyd.numel() * 2, k, s, p, dil=dil)
         if zero:
             dx.zero_()
@@ -287,7 +289,7 @@ def test_fused_epilogue_equals_conv_plus_pointwise_pass(N, H, Wd, Cin, Cout, k, 
     bias = W.normal(7, "b", (Cout,), 0.5).cuda() if with_bias else None
     res = _nhwc(_bf(W.normal(7, "r", (N, Cout, H, Wd)))) if with_res else None
     d = ops.fwd_desc(N, H, Wd, Cin, Cin, xd.numel() * 2, k, 1, p, Cout, Cout)
-    plain = torch.empty(N, H, Wd, Cout, dtype=torch.bfloat16, device="cuda")
+    plain = torch.empty(N, H, Wd, Cout, dtype=ACT, device="cuda")
     ops.conv_gemm(d, xd, wd, plain)
     want = torch.empty_like(plain)
     ops.pw_fwd(plain, Cout, bias, res, Cout if with_res else 0, want, Cout, N * H * Wd, Cout, act)
@@ -302,7 +304,7 @@ def test_fused_epilogue_equals_conv_plus_pointwise_pass(N, H, Wd, Cin, Cout, k, 
     # same four in every form of the loop).  The bound is therefore taken against |conv|, the quantity that was rounded;
     # all three activations are 1-Lipschitz, so the error cannot grow behind them.
     conv = F.conv2d(x, w, padding=p)
-    ref = conv.to(torch.bfloat16).float()
+    ref = conv.to(ACT).float()
     if with_bias:
         ref = ref + bias.cpu().view(1, -1, 1, 1)
     if with_res:
@@ -316,9 +318,9 @@ def test_fused_epilogue_equals_conv_plus_pointwise_pass(N, H, Wd, Cin, Cout, k, 
 
 def test_fused_epilogue_rejects_an_accumulating_launch():
     from mono_depth_estimation_amd import _lib, ops
-    x = torch.zeros(1, 4, 4, 64, dtype=torch.bfloat16, device="cuda")
-    w = torch.zeros(64, 1, 64, dtype=torch.bfloat16, device="cuda")
-    out = torch.zeros(1, 4, 4, 64, dtype=torch.bfloat16, device="cuda")
+    x = torch.zeros(1, 4, 4, 64, dtype=ACT, device="cuda")
+    w = torch.zeros(64, 1, 64, dtype=ACT, device="cuda")
+    out = torch.zeros(1, 4, 4, 64, dtype=ACT, device="cuda")
     d = ops.fwd_desc(1, 4, 4, 64, 64, x.numel() * 2, 1, 1, 0, 64, 64)
     d.accumulate = 1
     with pytest.raises(_lib.MdeError, match="accumulating"):
@@ -348,7 +350,7 @@ def test_dgrad_with_fused_batchnorm_backward_sums(N, H, Wd, Cin, Cout, k, s, mod
     OH, OW = ops.out_size(H, k, s, p), ops.out_size(Wd, k, s, p)
     dyd, wd = _nhwc(_bf(W.normal(5, "dy", (N, Cout, OH, OW)))), _pack_dgrad(w)
     M = N * H * Wd
-    xfull = W.normal(5, "x", (N, H, Wd, Cin * xmul), std=1.5).add_(0.3).to(torch.bfloat16).cuda()     # the site's input (pre-BN)
+    xfull = W.normal(5, "x", (N, H, Wd, Cin * xmul), std=1.5).add_(0.3).to(ACT).cuda()     # the site's input (pre-BN)
     xs = xfull[..., :Cin]
     mean, rstd = W.normal(5, "mu", (Cin,), std=0.5).cuda(), W.uniform(5, "rs", (Cin,), 0.5, 2.0).cuda()
     gamma, beta = W.normal(5, "g", (Cin,)).cuda(), W.normal(5, "b", (Cin,), std=0.3).cuda()
@@ -357,7 +359,7 @@ def test_dgrad_with_fused_batchnorm_backward_sums(N, H, Wd, Cin, Cout, k, s, mod
     bits = None
     second = None
     if mode == "join":
-        x2full = W.normal(5, "x2", (N, H, Wd, Cin * xmul), std=0.7).add_(-0.2).to(torch.bfloat16).cuda()
+        x2full = W.normal(5, "x2", (N, H, Wd, Cin * xmul), std=0.7).add_(-0.2).to(ACT).cuda()
         x2 = x2full[..., Cin * (xmul - 1):]
         mean2, rstd2 = W.normal(5, "mu2", (Cin,), std=0.5).cuda(), W.uniform(5, "rs2", (Cin,), 0.5, 2.0).cuda()
         part_b = ops.new_stat_buffer(Cin)
@@ -374,7 +376,7 @@ def test_dgrad_with_fused_batchnorm_backward_sums(N, H, Wd, Cin, Cout, k, s, mod
     descs, zero = ops.dgrad_descs(N, H, Wd, Cin, Cin, OH, OW, Cout, Cout, dyd.numel() * 2, k, s, p)
 
     def run(red):
-        dx = base.clone() if acc else torch.full((N, H, Wd, Cin), 3.0, dtype=torch.bfloat16, device="cuda")
+        dx = base.clone() if acc else torch.full((N, H, Wd, Cin), 3.0, dtype=ACT, device="cuda")
         if zero and not acc:
             dx.zero_()
         for d in descs:
@@ -416,14 +418,14 @@ def test_dgrad_with_fused_batchnorm_backward_sums(N, H, Wd, Cin, Cout, k, s, mod
         src = _nhwc(_bf(W.normal(5, "dout", (N, Cin, H, Wd))))
         m2 = torch.from_numpy((W.uniform(5, "m2", (N, H, Wd, Cin)) > 0.3).numpy()).cuda()
         bits2 = (m2.view(N, H, Wd, Cin // 8, 8).long() * (2 ** torch.arange(8, device="cuda")).view(1, 1, 1, 1, 8)).sum(-1).to(torch.uint8).contiguous()
-        masked = torch.where(m2, src, torch.zeros((), dtype=torch.bfloat16, device="cuda"))
+        masked = torch.where(m2, src, torch.zeros((), dtype=ACT, device="cuda"))
         ref_out = masked.clone()
         descs[0].accumulate = 1
         ops.conv_gemm(descs[0], dyd, wd, ref_out)
         part.zero_()
         if second is not None:
             second[3].zero_()
-        out = torch.full((N, H, Wd, Cin), 3.0, dtype=torch.bfloat16, device="cuda")
+        out = torch.full((N, H, Wd, Cin), 3.0, dtype=ACT, device="cuda")
         descs[0].accumulate = 0
         ops.conv_gemm(descs[0], dyd, wd, out, red=ops.bn_red_with_add(red, src, bits2))
         torch.cuda.synchronize()

@@ -3,6 +3,8 @@ the same bf16-rounded operands.  fp32 accumulation (MFMA + fp32 atomics): tolera
 |hip - ref| <= 1e-3*|ref| + 1e-3*rms(ref)."""
 import pytest
 import torch
+
+from mono_depth_estimation_amd.ops import ACT_DTYPE as ACT        # the library's 16-bit storage type (bf16; fp16 under MDE_ACT_DTYPE=fp16)
 import torch.nn.functional as F
 
 from oracle import weights as W
@@ -33,11 +35,11 @@ def wgrad_form(request):
 
 
 def _bf(t):
-    return t.to(torch.bfloat16).to(torch.float32)
+    return t.to(ACT).to(torch.float32)
 
 
 def _nhwc(t):
-    return t.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).cuda()
+    return t.permute(0, 2, 3, 1).contiguous().to(ACT).cuda()
 
 
 def _run(ops, form, d, direct, gathered, shape):

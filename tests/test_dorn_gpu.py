@@ -16,6 +16,8 @@ import types
 import numpy as np
 import pytest
 import torch
+
+from mono_depth_estimation_amd.ops import ACT_DTYPE as ACT        # the library's 16-bit storage type (bf16; fp16 under MDE_ACT_DTYPE=fp16)
 import torch.nn.functional as F
 
 from oracle import losses as L
@@ -34,7 +36,7 @@ def _rel(a, b):
 
 
 def _bf(t):
-    return t.to(torch.bfloat16).to(torch.float32)
+    return t.to(ACT).to(torch.float32)
 
 
 # ---------------------------------------------------------------------------------------------- kernels
@@ -44,7 +46,7 @@ def test_chan_scale_and_flat_avgpool_against_torch():
     N, H, W_, C, k = 3, 9, 11, 64, 4
     x = _bf(torch.randn(N, C, H, W_))
     m = (torch.rand(N, C) > 0.5).float() * 2.0
-    xh = x.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).cuda()
+    xh = x.permute(0, 2, 3, 1).contiguous().to(ACT).cuda()
     out = torch.empty_like(xh)
     ops.chan_scale(xh, C, m.cuda(), out, C, N, H * W_, C)
     want = x * m.view(N, C, 1, 1)
@@ -56,27 +58,27 @@ def test_chan_scale_and_flat_avgpool_against_torch():
     xr = x.clone().requires_grad_(True)
     pooled = F.avg_pool2d(xr, k, k, k // 2) * m.view(N, C, 1, 1)
     oh, ow = pooled.shape[2:]
-    flat = torch.empty(N, C * oh * ow, dtype=torch.bfloat16, device="cuda")
+    flat = torch.empty(N, C * oh * ow, dtype=ACT, device="cuda")
     ops.avgpool_flat_fwd(xh, C, m.cuda(), flat, N, H, W_, C, k, k, k // 2)
     assert (flat.float().cpu() - pooled.detach().reshape(N, -1)).abs().max() < 2e-2 * pooled.abs().max()
     g = _bf(torch.randn(N, C * oh * ow))
     pooled.reshape(N, -1).backward(g)
     dx = torch.empty_like(xh)
-    ops.avgpool_flat_bwd(g.to(torch.bfloat16).cuda(), m.cuda(), dx, C, N, H, W_, C, k, k, k // 2)
+    ops.avgpool_flat_bwd(g.to(ACT).cuda(), m.cuda(), dx, C, N, H, W_, C, k, k, k // 2)
     assert (dx.float().cpu().permute(0, 3, 1, 2) - xr.grad).abs().max() < 1e-2 * xr.grad.abs().max()
     dx2 = xh.clone()
-    ops.avgpool_flat_bwd(g.to(torch.bfloat16).cuda(), m.cuda(), dx2, C, N, H, W_, C, k, k, k // 2, accumulate=True)
+    ops.avgpool_flat_bwd(g.to(ACT).cuda(), m.cuda(), dx2, C, N, H, W_, C, k, k, k // 2, accumulate=True)
     assert (dx2.float().cpu().permute(0, 3, 1, 2) - (xr.grad + x)).abs().max() < 2e-2 * (xr.grad + x).abs().max()
     # overlapping windows (stride < kernel) exercise the general gather bounds of the backward kernel
     xr = x.clone().requires_grad_(True)
     pooled = F.avg_pool2d(xr, 4, 2, 1)
     oh, ow = pooled.shape[2:]
-    flat = torch.empty(N, C * oh * ow, dtype=torch.bfloat16, device="cuda")
+    flat = torch.empty(N, C * oh * ow, dtype=ACT, device="cuda")
     ops.avgpool_flat_fwd(xh, C, None, flat, N, H, W_, C, 4, 2, 1)
     assert (flat.float().cpu() - pooled.detach().reshape(N, -1)).abs().max() < 2e-2 * pooled.abs().max()
     g = _bf(torch.randn(N, C * oh * ow))
     pooled.reshape(N, -1).backward(g)
-    ops.avgpool_flat_bwd(g.to(torch.bfloat16).cuda(), None, dx, C, N, H, W_, C, 4, 2, 1)
+    ops.avgpool_flat_bwd(g.to(ACT).cuda(), None, dx, C, N, H, W_, C, 4, 2, 1)
     assert (dx.float().cpu().permute(0, 3, 1, 2) - xr.grad).abs().max() < 1e-2 * xr.grad.abs().max()
 
 
@@ -90,15 +92,15 @@ def test_maxpool_ceil_mode_against_torch(hw):
     y = F.max_pool2d(x, 3, 2, 1, ceil_mode=True)
     OH, OW = ops.maxpool_out_size(H, True), ops.maxpool_out_size(W_, True)
     assert (OH, OW) == tuple(y.shape[2:])
-    xh = x.detach().permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).cuda()
-    out = torch.empty(N, OH, OW, C, dtype=torch.bfloat16, device="cuda")
+    xh = x.detach().permute(0, 2, 3, 1).contiguous().to(ACT).cuda()
+    out = torch.empty(N, OH, OW, C, dtype=ACT, device="cuda")
     idx = torch.empty(N, OH, OW, C, dtype=torch.uint8, device="cuda")
     ops.maxpool_fwd(xh, out, idx, N, H, W_, C, True)
     assert torch.equal(out.float().cpu().permute(0, 3, 1, 2), y.detach())
     g = _bf(torch.randn_like(y))
     y.backward(g)
     dx = torch.empty_like(xh)
-    ops.maxpool_bwd(g.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).cuda(), idx, dx, N, H, W_, C, True)
+    ops.maxpool_bwd(g.permute(0, 2, 3, 1).contiguous().to(ACT).cuda(), idx, dx, N, H, W_, C, True)
     assert (dx.float().cpu().permute(0, 3, 1, 2) - x.grad).abs().max() <= 2 ** -7 * x.grad.abs().max()
 
 
@@ -112,8 +114,8 @@ def test_ordinal_head_against_torch(K, HW, ld):
     x[0, 1, :7, 0] = 3e4
     xr = x.clone().requires_grad_(True)
     label, prob = nets.ordinal_layer(xr)
-    xh = torch.zeros(N, HW, ld, dtype=torch.bfloat16, device="cuda")
-    xh[..., :2 * K] = x[..., 0].permute(0, 2, 1).to(torch.bfloat16).cuda()
+    xh = torch.zeros(N, HW, ld, dtype=ACT, device="cuda")
+    xh[..., :2 * K] = x[..., 0].permute(0, 2, 1).to(ACT).cuda()
     ph = torch.empty(N, K, HW, device="cuda")
     lh = torch.empty(N, HW, dtype=torch.int64, device="cuda")
     ops.ordinal_fwd(xh, ld, ph, lh, N, HW, K)
@@ -121,7 +123,7 @@ def test_ordinal_head_against_torch(K, HW, ld):
     assert (lh.cpu() != label.reshape(N, HW)).float().mean() < 1e-3
     g = torch.randn(N, K, HW)
     prob.reshape(N, K, HW).backward(g)
-    dx = torch.full((N, HW, ld), 7.0, dtype=torch.bfloat16, device="cuda")
+    dx = torch.full((N, HW, ld), 7.0, dtype=ACT, device="cuda")
     ops.ordinal_bwd(g.cuda(), xh, ld, dx, ld, N, HW, K)
     want = xr.grad[..., 0].permute(0, 2, 1)
     got = dx.float().cpu()

@@ -4,6 +4,8 @@ bf16-output kernels: |hip - ref| <= 2^-8|ref| + 2^-8 rms(ref); fp32 kernels: rto
 import numpy as np
 import pytest
 import torch
+
+from mono_depth_estimation_amd.ops import ACT_DTYPE as ACT        # the library's 16-bit storage type (bf16; fp16 under MDE_ACT_DTYPE=fp16)
 import torch.nn.functional as F
 
 from oracle import losses as OL
@@ -14,11 +16,11 @@ pytestmark = pytest.mark.gpu
 
 
 def _bf(t):
-    return t.to(torch.bfloat16).to(torch.float32)
+    return t.to(ACT).to(torch.float32)
 
 
 def _nhwc(t):
-    return t.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).cuda()
+    return t.permute(0, 2, 3, 1).contiguous().to(ACT).cuda()
 
 
 def _nchw(t):
@@ -134,7 +136,7 @@ def test_bn_eval_and_channel_slices():
     scale, shift = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
     ops.bn_eval_scale_shift(bn.weight.cuda(), bn.bias.cuda(), bn.running_mean.cuda(), bn.running_var.cuda(), 1e-5, C,
                             scale, shift)
-    out = torch.zeros(N, H, Wd, C, dtype=torch.bfloat16, device="cuda")
+    out = torch.zeros(N, H, Wd, C, dtype=ACT, device="cuda")
     ops.bn_apply(xd[..., C:], LD, scale, shift, out, C, M, C, True)
     torch.cuda.synchronize()
     _close_bf16(_nchw(out), ref, "bn eval slice")
@@ -150,7 +152,7 @@ def test_maxpool(N, H, Wd, C):
     y.backward(dy)
     OH, OW = y.shape[2:]
     xd, dyd = _nhwc(x.detach()), _nhwc(dy)
-    out = torch.empty(N, OH, OW, C, dtype=torch.bfloat16, device="cuda")
+    out = torch.empty(N, OH, OW, C, dtype=ACT, device="cuda")
     idx = torch.empty(N, OH, OW, C, dtype=torch.uint8, device="cuda")
     dx = torch.empty_like(xd)
     ops.maxpool_fwd(xd, out, idx, N, H, Wd, C)
@@ -417,14 +419,14 @@ def test_adam_matches_torch():
     p = torch.nn.Parameter(p0.clone())
     opt = torch.optim.Adam([p], lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
     pd, m, v = p0.clone().cuda(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
-    pb = torch.empty(n, dtype=torch.bfloat16, device="cuda")
+    pb = torch.empty(n, dtype=ACT, device="cuda")
     for step, g in enumerate((g1, g2), 1):
         p.grad = g.clone()
         opt.step()
         ops.adam_step(pd, (2.0 * g).cuda(), m, v, pb, n, 1e-3, 0.9, 0.999, 1e-8, 0.01, 0.5, step)
     torch.cuda.synchronize()
     assert torch.allclose(pd.cpu(), p.detach(), rtol=1e-5, atol=1e-7)
-    assert torch.equal(pb.cpu(), pd.cpu().to(torch.bfloat16))
+    assert torch.equal(pb.cpu(), pd.cpu().to(ACT))
 
 
 def test_adamw_and_sgd_match_torch():
@@ -439,7 +441,7 @@ def test_adamw_and_sgd_match_torch():
     sgd = torch.optim.SGD([ps], lr=1e-2, momentum=0.9, weight_decay=5e-4)
     da, m, v = p0.clone().cuda(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
     ds, buf = p0.clone().cuda(), torch.zeros(n, device="cuda")
-    ba, bs = torch.empty(n, dtype=torch.bfloat16, device="cuda"), torch.empty(n, dtype=torch.bfloat16, device="cuda")
+    ba, bs = torch.empty(n, dtype=ACT, device="cuda"), torch.empty(n, dtype=ACT, device="cuda")
     for step, g in enumerate(gs, 1):
         pa.grad, ps.grad = g.clone(), g.clone()
         adamw.step()
@@ -449,7 +451,7 @@ def test_adamw_and_sgd_match_torch():
     torch.cuda.synchronize()
     assert torch.allclose(da.cpu(), pa.detach(), rtol=1e-5, atol=1e-7)
     assert torch.allclose(ds.cpu(), ps.detach(), rtol=1e-5, atol=1e-7)
-    assert torch.equal(ba.cpu(), da.cpu().to(torch.bfloat16)) and torch.equal(bs.cpu(), ds.cpu().to(torch.bfloat16))
+    assert torch.equal(ba.cpu(), da.cpu().to(ACT)) and torch.equal(bs.cpu(), ds.cpu().to(ACT))
 
 
 def test_cast_and_pack():
@@ -457,13 +459,13 @@ def test_cast_and_pack():
     O, T, I = 70, 9, 130
     w = W.normal(13, "w", (O, T, I))
     wd = w.cuda()
-    c = torch.empty(O, T, I, dtype=torch.bfloat16, device="cuda")
-    t = torch.empty(I, T, O, dtype=torch.bfloat16, device="cuda")
+    c = torch.empty(O, T, I, dtype=ACT, device="cuda")
+    t = torch.empty(I, T, O, dtype=ACT, device="cuda")
     ops.cast_bf16(wd, c)
     ops.pack_wt(wd, t, O, T, I)
     torch.cuda.synchronize()
-    assert torch.equal(c.cpu(), w.to(torch.bfloat16))
-    assert torch.equal(t.cpu(), w.permute(2, 1, 0).contiguous().to(torch.bfloat16))
+    assert torch.equal(c.cpu(), w.to(ACT))
+    assert torch.equal(t.cpu(), w.permute(2, 1, 0).contiguous().to(ACT))
     # batched form: several weights of one flat buffer (with gaps between them) in one launch
     shapes = [(70, 9, 130), (64, 1, 64), (33, 25, 40), (256, 1, 1024)]
     offs, total = [], 8
@@ -471,19 +473,19 @@ def test_cast_and_pack():
         offs.append(total)
         total += o * t_ * i + 24
     flat = W.normal(13, "flat", (total,)).cuda()
-    dst = torch.full((total,), 7.0, dtype=torch.bfloat16, device="cuda")
+    dst = torch.full((total,), 7.0, dtype=ACT, device="cuda")
     jobs, nblocks = ops.pack_jobs([(off, o, t_, i) for off, (o, t_, i) in zip(offs, shapes)], "cuda")
     ops.pack_wt_batch(flat, dst, jobs, nblocks)
     torch.cuda.synchronize()
     covered = torch.zeros(total, dtype=torch.bool)
     for off, (o, t_, i) in zip(offs, shapes):
         n = o * t_ * i
-        ref = flat[off:off + n].cpu().view(o, t_, i).permute(2, 1, 0).contiguous().to(torch.bfloat16)
+        ref = flat[off:off + n].cpu().view(o, t_, i).permute(2, 1, 0).contiguous().to(ACT)
         assert torch.equal(dst[off:off + n].cpu().view(i, t_, o), ref)
         covered[off:off + n] = True
     assert (dst.cpu()[~covered].float() == 7.0).all(), "wrote outside the weights"
     x = W.normal(13, "x", (2, 5, 6, 7))
-    xd = torch.empty(2, 6, 7, 5, dtype=torch.bfloat16, device="cuda")
+    xd = torch.empty(2, 6, 7, 5, dtype=ACT, device="cuda")
     ops.nchw_to_nhwc_bf16(x.cuda(), xd)
     back = torch.empty(2, 5, 6, 7, device="cuda")
     ops.nhwc_bf16_to_nchw(xd, back)
@@ -498,9 +500,9 @@ def test_bn_join_backward_two_sites(N, H, Wd, C):
     from mono_depth_estimation_amd import ops
     M = N * H * Wd
     ld_b = C + 24                                             # second site is a channel slice of a wider tensor
-    dout = _bf(W.normal(21, "dout", (M, C))).to(torch.bfloat16).cuda()
-    xa = _bf(W.normal(21, "xa", (M, C)) * 1.5 + 0.2).to(torch.bfloat16).cuda()
-    xb_full = _bf(W.normal(21, "xb", (M, ld_b)) * 0.7 - 0.1).to(torch.bfloat16).cuda()
+    dout = _bf(W.normal(21, "dout", (M, C))).to(ACT).cuda()
+    xa = _bf(W.normal(21, "xa", (M, C)) * 1.5 + 0.2).to(ACT).cuda()
+    xb_full = _bf(W.normal(21, "xb", (M, ld_b)) * 0.7 - 0.1).to(ACT).cuda()
     xb = xb_full[:, 8:8 + C]
     bits = (W.uniform(21, "bits", (M, C // 8)) * 256).to(torch.uint8).cuda()
     stats = [[(W.normal(21, "m%d" % i, (C,)) * 0.3).cuda(), (W.uniform(21, "r%d" % i, (C,)) + 0.5).cuda(),
@@ -511,14 +513,14 @@ def test_bn_join_backward_two_sites(N, H, Wd, C):
     for i in range(2):
         part = ops.new_stat_buffer(C)
         coef, dg, db = torch.empty(3, C, device="cuda"), torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
-        dx = torch.empty(M, C, dtype=torch.bfloat16, device="cuda")
+        dx = torch.empty(M, C, dtype=ACT, device="cuda")
         ops.bn_bwd_reduce(dout, C, None, 0, xs[i], lds[i], stats[i][0], stats[i][1], M, C, True, part, relu_bits=bits)
         ops.bn_bwd_finalize(part, M, C, stats[i][2], stats[i][1], dg, db, coef)
         ops.bn_bwd_apply(dout, C, None, 0, xs[i], lds[i], stats[i][0], stats[i][1], coef, M, C, True, dx, C, relu_bits=bits)
         ref_dx.append(dx); ref_coef.append(coef); ref_dg.append(dg); ref_db.append(db)
     pa, pb = ops.new_stat_buffer(C), ops.new_stat_buffer(C)
     ops.bn_bwd_reduce2(dout, C, xa, C, xb, ld_b, stats[0][0], stats[0][1], stats[1][0], stats[1][1], bits, M, C, pa, pb)
-    got_dx = [torch.empty(M, C, dtype=torch.bfloat16, device="cuda"), torch.full((M, C + 8), 5.0, dtype=torch.bfloat16, device="cuda")]
+    got_dx = [torch.empty(M, C, dtype=ACT, device="cuda"), torch.full((M, C + 8), 5.0, dtype=ACT, device="cuda")]
     coefs = []
     for i, part in enumerate((pa, pb)):
         coef, dg, db = torch.empty(3, C, device="cuda"), torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
@@ -548,7 +550,7 @@ def test_stem_conv(N, H, Wd):
     y.backward(dy)
     w_ohwi = w.detach().permute(0, 2, 3, 1).contiguous().cuda()
     OH, OW = y.shape[2:]
-    out = torch.empty(N, OH, OW, 64, dtype=torch.bfloat16, device="cuda")
+    out = torch.empty(N, OH, OW, 64, dtype=ACT, device="cuda")
     dw = torch.zeros(64, 7, 7, 3, device="cuda")
     part = ops.new_stat_buffer(64)
     ops.stem_conv_fwd(x.cuda(), w_ohwi, out, part)
@@ -595,7 +597,7 @@ def test_pixel_shuffle2_matches_torch():
     src = W.normal(44, "ps", (N, 4 * C + 16, h, w))                       # NCHW reference; 16 extra channels = a wider parent
     ref = F.pixel_shuffle(_bf(src[:, 8:8 + 4 * C]), 2)                    # [N, C, 2h, 2w]
     s_nhwc = _nhwc(src)                                                   # [N, h, w, 4C+16]
-    dst = torch.zeros(N, 2 * h, 2 * w, C + 8, dtype=torch.bfloat16, device="cuda")
+    dst = torch.zeros(N, 2 * h, 2 * w, C + 8, dtype=ACT, device="cuda")
     ops.pixel_shuffle2(s_nhwc[..., 8:8 + 4 * C], s_nhwc.shape[-1], dst[..., :C], dst.shape[-1], N, h, w, C)
     torch.cuda.synchronize()
     assert torch.equal(_nchw(dst[..., :C]), ref) and float(dst[..., C:].float().abs().max()) == 0.0
@@ -618,19 +620,19 @@ def test_maxpool_view(N, H, Wd, C, k, s, y0, x0, Hv, Wv):
     """mde_maxpool_view_fwd / _bwd against torch's MaxPool2d on the cropped tensor, values exact (bf16 in, bf16 out) and the
     gradient routed to the same argmax; pixels outside the view get exactly zero."""
     from mono_depth_estimation_amd import ops
-    x = W.normal(11, "x", (N, C, H, Wd)).to(torch.bfloat16).float()
+    x = W.normal(11, "x", (N, C, H, Wd)).to(ACT).float()
     xi = x.clone().requires_grad_(True)
     ref = F.max_pool2d(xi[:, :, y0:y0 + Hv, x0:x0 + Wv], k, s)
     OH, OW = ref.shape[2:]
-    dy = W.normal(11, "dy", tuple(ref.shape)).to(torch.bfloat16).float()
+    dy = W.normal(11, "dy", tuple(ref.shape)).to(ACT).float()
     ref.backward(dy)
-    xd = x.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).cuda()
-    out = torch.empty(N, OH, OW, C, dtype=torch.bfloat16, device="cuda")
+    xd = x.permute(0, 2, 3, 1).contiguous().to(ACT).cuda()
+    out = torch.empty(N, OH, OW, C, dtype=ACT, device="cuda")
     idx = torch.empty(N, OH, OW, C, dtype=torch.uint8, device="cuda")
     ops.maxpool_view_fwd(xd[:, y0:, x0:], C, Wd, H * Wd, Hv, Wv, out, C, idx, N, C, k, s)
     assert torch.equal(out.float().cpu().permute(0, 3, 1, 2), ref.detach())
-    dyd = dy.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).cuda()
-    dx = torch.zeros(N, H, Wd, C, dtype=torch.bfloat16, device="cuda")
+    dyd = dy.permute(0, 2, 3, 1).contiguous().to(ACT).cuda()
+    dx = torch.zeros(N, H, Wd, C, dtype=ACT, device="cuda")
     ops.maxpool_view_bwd(dyd, C, idx, dx[:, y0:, x0:], C, Wd, H * Wd, Hv, Wv, N, C, k, s, accumulate=True)
     got = dx.float().cpu().permute(0, 3, 1, 2)
-    assert torch.allclose(got, xi.grad.to(torch.bfloat16).float(), rtol=2.0 ** -7, atol=1e-6), float((got - xi.grad).abs().max())
+    assert torch.allclose(got, xi.grad.to(ACT).float(), rtol=2.0 ** -7, atol=1e-6), float((got - xi.grad).abs().max())

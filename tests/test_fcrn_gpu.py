@@ -20,6 +20,8 @@ import numpy as np
 import pytest
 import torch
 
+from mono_depth_estimation_amd.ops import ACT_DTYPE as ACT        # the library's 16-bit storage type (bf16; fp16 under MDE_ACT_DTYPE=fp16)
+
 from oracle import fcrn as ofcrn
 from oracle import losses as OL
 from oracle import metrics as OM
@@ -157,11 +159,11 @@ def test_train_loss_and_running_stats(setup, golden):
 
 
 def _emulate_bf16(ora):
-    rnd = lambda mod, inp, out: out.to(torch.bfloat16).float()
+    rnd = lambda mod, inp, out: out.to(ACT).float()
     for name, mod in ora.named_modules():
         if isinstance(mod, torch.nn.Conv2d):
             if name not in ("conv1", "conv3"):
-                mod.weight.data = mod.weight.data.to(torch.bfloat16).float()
+                mod.weight.data = mod.weight.data.to(ACT).float()
             if name != "conv3":
                 mod.register_forward_hook(rnd)
         elif isinstance(mod, (torch.nn.ReLU, ofcrn.UpProjModule)) or name == "bn2":
@@ -208,7 +210,7 @@ def test_layers_teacher_forced(setup):
         hip(rgb.cuda())
     eng = next(iter(hip._engines.values()))
     hp = dict(hip.named_parameters())
-    dev = lambda t: t.detach().permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).cuda()
+    dev = lambda t: t.detach().permute(0, 2, 3, 1).contiguous().to(ACT).cuda()
     report = []
     for n, L in zip(names, eng.layers):
         L.x.t.copy_(dev(ins[n]))
@@ -658,11 +660,11 @@ def test_decoder_layers_teacher_forced(dec, layers):
     hip = FCRN.ResNet(layers=layers, decoder=dec, output_size=size, out_channels=1, pretrained=False)
     hip.load_state_dict(sd)
     hip = hip.cuda().train()
-    rnd = lambda mod, inp, out: out.to(torch.bfloat16).float()
+    rnd = lambda mod, inp, out: out.to(ACT).float()
     for name, mod in ora.named_modules():
         if isinstance(mod, (torch.nn.Conv2d, torch.nn.ConvTranspose2d)):
             if name not in ("conv1", "conv3"):
-                mod.weight.data = mod.weight.data.to(torch.bfloat16).float()
+                mod.weight.data = mod.weight.data.to(ACT).float()
             if name != "conv3":
                 mod.register_forward_hook(rnd)
         elif isinstance(mod, torch.nn.ReLU) or name == "bn2" or (name.startswith("upSample.") and name.endswith("bn1")):
@@ -676,7 +678,7 @@ def test_decoder_layers_teacher_forced(dec, layers):
         m.register_forward_pre_hook(lambda mod, inp, i=i: ins.__setitem__(i, inp[0]))
 
         def post(mod, inp, out, i=i):
-            out = out.to(torch.bfloat16).float()
+            out = out.to(ACT).float()
             out.retain_grad()
             outs[i] = out
             return out
@@ -689,7 +691,7 @@ def test_decoder_layers_teacher_forced(dec, layers):
         hip(rgb.cuda())
     eng = next(iter(hip._engines.values()))
     hp = dict(hip.named_parameters())
-    dev = lambda t: t.detach().permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).cuda()
+    dev = lambda t: t.detach().permute(0, 2, 3, 1).contiguous().to(ACT).cuda()
     report = []
     for i, L in zip((1, 2, 3, 4), eng.layers[-4:]):
         ci, co = ins[i].shape[1], outs[i].shape[1]            # real channels; the engine's tensors may be padded to 64

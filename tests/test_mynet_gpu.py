@@ -11,6 +11,8 @@ DenseNet trunk at random weights decorrelates under rounding on both sides, see 
 import numpy as np
 import pytest
 import torch
+
+from mono_depth_estimation_amd.ops import ACT_DTYPE as ACT        # the library's 16-bit storage type (bf16; fp16 under MDE_ACT_DTYPE=fp16)
 import torch.nn.functional as F
 
 from oracle import losses as L
@@ -26,11 +28,11 @@ def _rel(a, b):
 
 
 def _bf(t):
-    return t.to(torch.bfloat16).to(torch.float32)
+    return t.to(ACT).to(torch.float32)
 
 
 def _nhwc(t):
-    return t.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).cuda()
+    return t.permute(0, 2, 3, 1).contiguous().to(ACT).cuda()
 
 
 # ---------------------------------------------------------------------------------------------- kernels

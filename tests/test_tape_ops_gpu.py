@@ -6,6 +6,8 @@ bf16-rounded operands, all through the C ABI:
 Tolerance for bf16 outputs: |hip - ref| <= 2^-8 |ref| + 2^-8 rms(ref) (one rounding of an fp32 result); fp32 outputs 1e-5."""
 import pytest
 import torch
+
+from mono_depth_estimation_amd.ops import ACT_DTYPE as ACT        # the library's 16-bit storage type (bf16; fp16 under MDE_ACT_DTYPE=fp16)
 import torch.nn.functional as F
 
 from oracle import weights as W
@@ -14,11 +16,11 @@ pytestmark = pytest.mark.gpu
 
 
 def _bf(t):
-    return t.to(torch.bfloat16).to(torch.float32)
+    return t.to(ACT).to(torch.float32)
 
 
 def _nhwc(t, pad=0):
-    t = t.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16)
+    t = t.permute(0, 2, 3, 1).contiguous().to(ACT)
     if pad:
         t = F.pad(t, (0, pad))
     return t.cuda()
@@ -38,12 +40,12 @@ def _close(got, ref, what, tol=2.0 ** -8):
 
 def _pack_fwd(w):
     o, i, kh, kw = w.shape
-    return w.permute(0, 2, 3, 1).reshape(o, kh * kw, i).contiguous().to(torch.bfloat16).cuda()
+    return w.permute(0, 2, 3, 1).reshape(o, kh * kw, i).contiguous().to(ACT).cuda()
 
 
 def _pack_dgrad(w):
     o, i, kh, kw = w.shape
-    return w.permute(1, 2, 3, 0).reshape(i, kh * kw, o).contiguous().to(torch.bfloat16).cuda()
+    return w.permute(1, 2, 3, 0).reshape(i, kh * kw, o).contiguous().to(ACT).cuda()
 
 
 # ---------------------------------------------------------------------------------------------- conv K tail
@@ -61,9 +63,9 @@ def test_conv_channel_counts_that_are_not_multiples_of_64(Cin, Cout, k, dil):
     ref = F.conv2d(xr, wr, padding=p, dilation=dil)
     ref.backward(dy)
     ld_x = Cin + 16                                             # the neighbouring channels hold junk the kernel must not use
-    xd = torch.full((N, H, Wd, ld_x), 100.0, dtype=torch.bfloat16, device="cuda")
+    xd = torch.full((N, H, Wd, ld_x), 100.0, dtype=ACT, device="cuda")
     xd[..., :Cin] = _nhwc(x)
-    out = torch.zeros(N, H, Wd, Cout, dtype=torch.bfloat16, device="cuda")
+    out = torch.zeros(N, H, Wd, Cout, dtype=ACT, device="cuda")
     d = ops.fwd_desc(N, H, Wd, ld_x, Cin, xd.numel() * 2, k, 1, p, Cout, Cout, dil=dil)
     stats = ops.new_stat_buffer(Cout)
     ops.conv_gemm(d, xd, _pack_fwd(w), out, stats)
@@ -72,9 +74,9 @@ def test_conv_channel_counts_that_are_not_multiples_of_64(Cin, Cout, k, dil):
     assert torch.allclose(stats.sum(0)[0].cpu(), ref.detach().sum((0, 2, 3)), rtol=1e-3, atol=1e-2 * ref.detach().abs().sum((0, 2, 3)).max().item() * 1e-1 + 1e-2)
     # input gradient: contraction over Cout (also not a multiple of 64)
     ld_dy = Cout + 8
-    dyd = torch.full((N, H, Wd, ld_dy), -50.0, dtype=torch.bfloat16, device="cuda")
+    dyd = torch.full((N, H, Wd, ld_dy), -50.0, dtype=ACT, device="cuda")
     dyd[..., :Cout] = _nhwc(dy)
-    dx = torch.zeros(N, H, Wd, Cin, dtype=torch.bfloat16, device="cuda")
+    dx = torch.zeros(N, H, Wd, Cin, dtype=ACT, device="cuda")
     descs, zero = ops.dgrad_descs(N, H, Wd, Cin, Cin, H, Wd, ld_dy, Cout, dyd.numel() * 2, k, 1, p, dil=dil)
     assert not zero
     for dd in descs:
@@ -107,11 +109,11 @@ def test_grouped_conv_fwd_dgrad_wgrad(D, G, stride, dil, H, Wd):
     dy = _bf(W.normal(5, "dy", (N, D, OH, OW)))
     ref.backward(dy)
     src = w.permute(0, 2, 3, 1).reshape(D, 9, G).contiguous().cuda()                  # master layout [O][T][G] fp32
-    wf = torch.empty(D * 9 * 64, dtype=torch.bfloat16, device="cuda")
-    wdg = torch.empty(D * 9 * 64, dtype=torch.bfloat16, device="cuda")
+    wf = torch.empty(D * 9 * 64, dtype=ACT, device="cuda")
+    wdg = torch.empty(D * 9 * 64, dtype=ACT, device="cuda")
     ops.pack_grouped(src, wf, wdg, D, 9, G)
     xd = _nhwc(x)
-    out = torch.zeros(N, OH, OW, D, dtype=torch.bfloat16, device="cuda")
+    out = torch.zeros(N, OH, OW, D, dtype=ACT, device="cuda")
     d = ops.fwd_desc(N, H, Wd, D, 64, xd.numel() * 2, 3, stride, dil, D, D, dil=dil)
     d.grouped = 1
     stats = ops.new_stat_buffer(D)
@@ -121,7 +123,7 @@ def test_grouped_conv_fwd_dgrad_wgrad(D, G, stride, dil, H, Wd):
     s2 = (ref.detach() ** 2).sum((0, 2, 3))
     assert torch.allclose(stats.sum(0)[1].cpu(), s2, rtol=2e-3, atol=1e-3 * s2.max().item())
     dyd = _nhwc(dy)
-    dx = torch.full((N, H, Wd, D), 9.0, dtype=torch.bfloat16, device="cuda")
+    dx = torch.full((N, H, Wd, D), 9.0, dtype=ACT, device="cuda")
     descs, zero = ops.dgrad_descs(N, H, Wd, D, D, OH, OW, D, 64, dyd.numel() * 2, 3, stride, dil, dil=dil)
     if zero:
         dx.zero_()
@@ -155,7 +157,7 @@ def test_pw_fwd_bwd(act, C, with_r, with_b):
     pre = xr + (br.view(1, C, 1, 1) if with_b else 0) + (rr if with_r else 0)
     ref = fn(pre)
     xd, rd = _nhwc(x, 8), (_nhwc(r) if with_r else None)
-    out = torch.zeros(N, H, Wd, C + 16, dtype=torch.bfloat16, device="cuda")
+    out = torch.zeros(N, H, Wd, C + 16, dtype=ACT, device="cuda")
     M = N * H * Wd
     ops.pw_fwd(xd, C + 8, b.cuda() if with_b else None, rd, C, out, C + 16, M, C, act)
     torch.cuda.synchronize()
@@ -166,8 +168,8 @@ def test_pw_fwd_bwd(act, C, with_r, with_b):
     y = _nchw(out[..., :C])
     gy = {"none": torch.ones_like(y), "relu": (y > 0).float(), "elu": torch.where(y > 0, torch.ones_like(y), y + 1), "sigmoid": y * (1 - y)}[act]
     g = dy * gy
-    dx = torch.full((N, H, Wd, C), 1.0, dtype=torch.bfloat16, device="cuda")
-    dr = torch.zeros(N, H, Wd, C, dtype=torch.bfloat16, device="cuda") if with_r else None
+    dx = torch.full((N, H, Wd, C), 1.0, dtype=ACT, device="cuda")
+    dr = torch.zeros(N, H, Wd, C, dtype=ACT, device="cuda") if with_r else None
     db = torch.zeros(C, device="cuda") if with_b else None
     ops.pw_bwd(_nhwc(dy), C, out, C + 16, dx, C, True, dr, C, False, db, M, C, act)
     torch.cuda.synchronize()
@@ -183,26 +185,26 @@ def test_spatial_mean_broadcast_and_gate():
     N, C, H, Wd = 3, 264, 9, 11
     x = _bf(W.normal(9, "x", (N, C, H, Wd)))
     xd = _nhwc(x, 8)
-    pooled = torch.zeros(N, 2 * C, dtype=torch.bfloat16, device="cuda")
+    pooled = torch.zeros(N, 2 * C, dtype=ACT, device="cuda")
     ops.spatial_sum(xd, C + 8, N, H * Wd, C, 1.0 / (H * Wd), pooled[:, C:], 2 * C)
     torch.cuda.synchronize()
     _close(pooled[:, C:].float().cpu(), x.mean((2, 3)), "spatial mean")
     assert float(pooled[:, :C].float().abs().max()) == 0.0
-    out = torch.full((N, H, Wd, C), 2.0, dtype=torch.bfloat16, device="cuda")
+    out = torch.full((N, H, Wd, C), 2.0, dtype=ACT, device="cuda")
     ops.spatial_bcast(pooled[:, C:], 2 * C, 0.5, out, C, N, H * Wd, C, accumulate=True)
     torch.cuda.synchronize()
     _close(_nchw(out), 2.0 + 0.5 * _bf(x.mean((2, 3))).view(N, C, 1, 1).expand(-1, -1, H, Wd), "broadcast")
     # gate
     w = _bf(torch.sigmoid(W.normal(9, "w", (N, C))))
     lat, top, dy = (_bf(W.normal(9, k, (N, C, H, Wd))) for k in ("lat", "top", "dy"))
-    wd_ = w.to(torch.bfloat16).cuda()
-    o = torch.zeros(N, H, Wd, C, dtype=torch.bfloat16, device="cuda")
+    wd_ = w.to(ACT).cuda()
+    o = torch.zeros(N, H, Wd, C, dtype=ACT, device="cuda")
     ops.gate_fwd(wd_, C, _nhwc(lat), C, _nhwc(top), C, o, C, N, H * Wd, C)
     torch.cuda.synchronize()
     _close(_nchw(o), w.view(N, C, 1, 1) * lat + top, "gate fwd")
-    dlat = torch.zeros(N, H, Wd, C, dtype=torch.bfloat16, device="cuda")
-    dtop = torch.full((N, H, Wd, C), 1.0, dtype=torch.bfloat16, device="cuda")
-    dw = torch.zeros(N, C, dtype=torch.bfloat16, device="cuda")
+    dlat = torch.zeros(N, H, Wd, C, dtype=ACT, device="cuda")
+    dtop = torch.full((N, H, Wd, C), 1.0, dtype=ACT, device="cuda")
+    dw = torch.zeros(N, C, dtype=ACT, device="cuda")
     ops.gate_bwd(_nhwc(dy), C, wd_, C, _nhwc(lat), C, dlat, C, False, dtop, C, True, dw, C, N, H * Wd, C)
     torch.cuda.synchronize()
     _close(_nchw(dlat), w.view(N, C, 1, 1) * dy, "gate dlat")
@@ -220,11 +222,11 @@ def test_bilinear_resize_fwd_bwd(align, H, Wd, OH, OW):
     ref = F.interpolate(xr, size=(OH, OW), mode="bilinear", align_corners=align)
     dy = _bf(W.normal(11, "dy", (N, C, OH, OW)))
     ref.backward(dy)
-    out = torch.zeros(N, OH, OW, C + 8, dtype=torch.bfloat16, device="cuda")
+    out = torch.zeros(N, OH, OW, C + 8, dtype=ACT, device="cuda")
     ops.resize_bilinear_fwd(_nhwc(x), C, out, C + 8, N, H, Wd, C, OH, OW, align)
     torch.cuda.synchronize()
     _close(_nchw(out[..., :C]), ref.detach(), "resize fwd")
-    dx = torch.full((N, H, Wd, C), 0.5, dtype=torch.bfloat16, device="cuda")
+    dx = torch.full((N, H, Wd, C), 0.5, dtype=ACT, device="cuda")
     ops.resize_bilinear_bwd(_nhwc(dy), C, dx, C, N, H, Wd, C, OH, OW, align, accumulate=True)
     torch.cuda.synchronize()
     _close(_nchw(dx), xr.grad + 0.5, "resize bwd")
@@ -234,19 +236,19 @@ def test_nearest2_and_avgpool2():
     from mono_depth_estimation_amd import ops
     N, C, H, Wd = 2, 40, 5, 7
     x = _bf(W.normal(13, "x", (N, C, H, Wd)))
-    up = torch.zeros(N, 2 * H, 2 * Wd, C, dtype=torch.bfloat16, device="cuda")
+    up = torch.zeros(N, 2 * H, 2 * Wd, C, dtype=ACT, device="cuda")
     ops.nearest2_fwd(_nhwc(x), C, up, C, N, H, Wd, C)
     torch.cuda.synchronize()
     assert torch.equal(_nchw(up), F.interpolate(x, scale_factor=2, mode="nearest"))
     big = _bf(W.normal(13, "big", (N, C, 2 * H, 2 * Wd)))
-    dst = torch.zeros(N, H, Wd, C, dtype=torch.bfloat16, device="cuda")
+    dst = torch.zeros(N, H, Wd, C, dtype=ACT, device="cuda")
     ops.sum2x2(_nhwc(big), C, dst, C, N, H, Wd, C, 0.25)
     torch.cuda.synchronize()
     _close(_nchw(dst), F.avg_pool2d(big, 2, 2), "avgpool2 fwd")
     ops.sum2x2(_nhwc(big), C, dst, C, N, H, Wd, C, 1.0)             # nearest-x2 backward
     torch.cuda.synchronize()
     _close(_nchw(dst), 4 * F.avg_pool2d(big, 2, 2), "nearest2 bwd")
-    spread = torch.full((N, 2 * H, 2 * Wd, C), 1.0, dtype=torch.bfloat16, device="cuda")
+    spread = torch.full((N, 2 * H, 2 * Wd, C), 1.0, dtype=ACT, device="cuda")
     ops.spread2x2(_nhwc(x), C, spread, C, N, H, Wd, C, 0.25, accumulate=True)
     torch.cuda.synchronize()
     _close(_nchw(spread), 1.0 + 0.25 * F.interpolate(x, scale_factor=2, mode="nearest"), "avgpool2 bwd")
@@ -259,8 +261,8 @@ def test_softmax_head(C, HW):
     ld = (C + 7) // 8 * 8
     x = _bf(W.normal(15, "x", (N, C, HW), 2.0))
     b = W.normal(15, "b", (C,), 0.3)
-    xd = torch.full((N, HW, ld), 40.0, dtype=torch.bfloat16, device="cuda")
-    xd[..., :C] = x.permute(0, 2, 1).to(torch.bfloat16).cuda()
+    xd = torch.full((N, HW, ld), 40.0, dtype=ACT, device="cuda")
+    xd[..., :C] = x.permute(0, 2, 1).to(ACT).cuda()
     logit, prob = torch.empty(N, C, HW, device="cuda"), torch.empty(N, C, HW, device="cuda")
     ops.softmax_head_fwd(xd, ld, b.cuda(), logit, prob, N, HW, C)
     torch.cuda.synchronize()
@@ -275,7 +277,7 @@ def test_softmax_head(C, HW):
     ((pr * dp).sum() + (lr * dl).sum()).backward()
     g2 = lr.grad.clone()
     for dlog, dprob, ref in ((dl, None, g1), (dl, dp, g2)):
-        dx = torch.full((N, HW, ld), 3.0, dtype=torch.bfloat16, device="cuda")
+        dx = torch.full((N, HW, ld), 3.0, dtype=ACT, device="cuda")
         db = torch.zeros(ld, device="cuda")
         ops.softmax_head_bwd(dlog.cuda(), dprob.cuda() if dprob is not None else None, prob, dx, ld, db, N, HW, C)
         torch.cuda.synchronize()
@@ -291,8 +293,8 @@ def test_to_nchw_act(C, act, scale):
     ld = (C + 7) // 8 * 8
     x = _bf(W.normal(17, "x", (N, C, HW)))
     b = W.normal(17, "b", (C,), 0.3)
-    xd = torch.full((N, HW, ld), 9.0, dtype=torch.bfloat16, device="cuda")
-    xd[..., :C] = x.permute(0, 2, 1).to(torch.bfloat16).cuda()
+    xd = torch.full((N, HW, ld), 9.0, dtype=ACT, device="cuda")
+    xd[..., :C] = x.permute(0, 2, 1).to(ACT).cuda()
     y = torch.empty(N, C, HW, device="cuda")
     ops.to_nchw_act_fwd(xd, ld, b.cuda(), y, N, HW, C, act, scale)
     torch.cuda.synchronize()
@@ -301,7 +303,7 @@ def test_to_nchw_act(C, act, scale):
     assert torch.allclose(y.cpu(), ref.detach(), rtol=1e-5, atol=1e-6)
     dy = W.normal(17, "dy", (N, C, HW))
     ref.backward(dy)
-    dx = torch.full((N, HW, ld), 3.0, dtype=torch.bfloat16, device="cuda")
+    dx = torch.full((N, HW, ld), 3.0, dtype=ACT, device="cuda")
     db = torch.zeros(ld, device="cuda")
     ops.to_nchw_act_bwd(dy.cuda(), y, dx, ld, db, N, HW, C, act, scale)
     torch.cuda.synchronize()

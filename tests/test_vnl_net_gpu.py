@@ -241,11 +241,17 @@ def test_vnl_loss_curves_agree_with_the_oracle():
     absrel = lambda d: float(((d - t).abs() / t.clamp(min=1e-9))[m].mean())
     s16, sbf, sact, ship = (abs(absrel(d) - absrel(do)) for d in (d16, dbf, dact, dh))
     print("trained-like state, eval AbsRel: HIP %.6f oracle %.6f" % (absrel(dh), absrel(do)))
+    from mono_depth_estimation_amd import _lib
     print("AbsRel shift of the ORACLE under 16-bit storage: fp16 weights + activations %.2e, bf16 weights + activations %.2e "
-          "(bf16 activations alone %.2e); the HIP path (bf16): %.2e" % (s16, sbf, sact, ship))
-    # BASELINE configuration 5 names fp16 (the reference's precision=16 AMP run) and this path stores bf16: both shifts are on
-    # record above; the HIP path is held to 1.5 x the bf16 oracle's shift, and that shift itself to 2e-3
-    assert ship <= 1.5 * sbf + 2e-4 and sbf <= 2e-3 and s16 <= sbf + 1e-4
+          "(bf16 activations alone %.2e); the HIP path (%s): %.2e" % (s16, sbf, sact, _lib.ACT_NAME, ship))
+    # BASELINE configuration 5 names fp16 (the reference's precision=16 AMP run).  Both oracles' shifts are on record above.
+    # The default build stores bf16: held to 1.5 x the bf16 oracle's shift, and that shift itself to 2e-3.  The fp16 build
+    # (MDE_ACT_DTYPE=fp16, tests/test_fp16_build_gpu.py runs this test under it) is held to the fp16 oracle's: measured 1.07e-4
+    # against 1.05e-4.
+    if _lib.ACT_NAME == "fp16":
+        assert ship <= 1.5 * s16 + 5e-5 and ship <= 2.5e-4, (ship, s16)
+    else:
+        assert ship <= 1.5 * sbf + 2e-4 and sbf <= 2e-3 and s16 <= sbf + 1e-4
     # (b)
     _, _, _, _, _, _, lh, lo, lq = _vnl_trajectories(6, 12, True)
     print("WCEL + 6 VNL, HIP            :", np.round(lh[[0, 1, 2, 4, 7, 11]], 4))
