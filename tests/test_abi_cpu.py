@@ -30,6 +30,22 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
     assert lib.mde_stat_slots() == 32
 
 
+def test_the_fp16_storage_build_exports_the_same_interface(lib):
+    """libmde_hip_f16.so (the sources compiled with -DMDE_ACT_F16; MDE_ACT_DTYPE=fp16 selects it for a process): every declared
+    symbol, the same ABI version, and it says which storage type it was built for -- as does the default library; a process
+    that asks for one and finds the other refuses to bind (_lib.load)."""
+    from mono_depth_estimation_amd import _lib
+    path = os.path.join(os.path.dirname(_lib.LIB_PATH), "libmde_hip_f16.so")
+    assert os.path.exists(path), "build.sh builds both libraries"
+    f16 = C.CDLL(path)
+    for name in _lib.SIGNATURES:
+        assert hasattr(f16, name), name
+    assert f16.mde_abi_version() == _lib.ABI_VERSION and f16.mde_act_dtype() == 1
+    assert lib.mde_act_dtype() == (1 if _lib.ACT_NAME == "fp16" else 0)
+    st = C.sizeof(_lib.BnRed)
+    assert st == 15 * 8, st            # mde_bn_red: 13 pointers + 2 int32 (each padded to 8 in front of a pointer)
+
+
 def test_struct_layouts_match_header():
     """sizeof / field offsets as a C compiler lays the header's structs out."""
     from mono_depth_estimation_amd._lib import ConvDesc, WgradDesc, MAX_TAPS
