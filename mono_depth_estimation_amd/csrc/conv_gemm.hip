@@ -1204,11 +1204,12 @@ __global__ __launch_bounds__(NT, HALO ? (NT == 512 ? 4 : BC <= 64 ? 5 : 4)
         __syncthreads();                 // the last slab has been read out of the staging area
         float* red = reinterpret_cast<float*>(smem);     // [RPP][2][BC]
         const int chunk = tid % CPR, rl = tid / CPR;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            red[(rl * 2 + 0) * BC + chunk * 8 + e] = red1[e];
-            red[(rl * 2 + 1) * BC + chunk * 8 + e] = red2[e];
-        }
+        // (as 16-byte stores: eight scalar stores 32 bytes apart put 16 lanes on 4 banks -- 31 % of this form's LDS cycles
+        //  were bank conflicts, profiles/r03_pmc_gemm_in_network.txt)
+        *reinterpret_cast<f32x4_t*>(red + (rl * 2 + 0) * BC + chunk * 8) = f32x4_t{red1[0], red1[1], red1[2], red1[3]};
+        *reinterpret_cast<f32x4_t*>(red + (rl * 2 + 0) * BC + chunk * 8 + 4) = f32x4_t{red1[4], red1[5], red1[6], red1[7]};
+        *reinterpret_cast<f32x4_t*>(red + (rl * 2 + 1) * BC + chunk * 8) = f32x4_t{red2[0], red2[1], red2[2], red2[3]};
+        *reinterpret_cast<f32x4_t*>(red + (rl * 2 + 1) * BC + chunk * 8 + 4) = f32x4_t{red2[4], red2[5], red2[6], red2[7]};
         __syncthreads();
         for (int e = tid; e < 2 * BC; e += NT) {
             const int which = e / BC, ch = e - which * BC;
@@ -1221,8 +1222,8 @@ __global__ __launch_bounds__(NT, HALO ? (NT == 512 ? 4 : BC <= 64 ? 5 : 4)
         }
         if constexpr (RED == 2) {        // the second site's sum(g' * xhat), through the same area
             __syncthreads();
-#pragma unroll
-            for (int e = 0; e < 8; ++e) red[rl * BC + chunk * 8 + e] = red3[e];
+            *reinterpret_cast<f32x4_t*>(red + rl * BC + chunk * 8) = f32x4_t{red3[0], red3[1], red3[2], red3[3]};
+            *reinterpret_cast<f32x4_t*>(red + rl * BC + chunk * 8 + 4) = f32x4_t{red3[4], red3[5], red3[6], red3[7]};
             __syncthreads();
             for (int ch = tid; ch < BC; ch += NT) {
                 if (n0 + ch < d.ncols) {
