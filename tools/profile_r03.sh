@@ -17,22 +17,7 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $O/pmc_sq1 -o p -- python3 $B > $O/sq1.log 2>&1
 rocprofv3 --pmc SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_sq2 -o p -- python3 $B > $O/sq2.log 2>&1
 python tools/hbm_traffic.py $O/pmc_fetch $O/pmc_write 4 143 61 > $O/hbm_traffic.json
-python - <<'PY'
-import csv, glob, collections
-O="gpurun_out/prof_r03"
-for d in ("pmc_sq1","pmc_sq2"):
-    f=glob.glob(O+"/"+d+"/**/*counter_collection.csv", recursive=True)[0]
-    tot=collections.defaultdict(lambda: collections.Counter()); n=collections.Counter()
-    for r in csv.DictReader(open(f)):
-        k=r["Kernel_Name"]
-        key = "conv_gemm_nt halo<256,128>" if ("conv_gemm_nt<256, 128" in k and k.rstrip(">() ").split("(")[0].rstrip(" >").endswith("true")) else "conv_gemm_nt halo<256,64>" if ("conv_gemm_nt<256, 64" in k) else "conv_wgrad_win" if "conv_wgrad_win" in k else "conv_gemm_nt<256,256>" if "conv_gemm_nt<256, 256" in k else "conv_gemm_nt<192,256>" if "conv_gemm_nt<192" in k else "conv_gemm_nt<128,128>" if "conv_gemm_nt<128, 128" in k else "conv_gemm_nt<128,64>" if "conv_gemm_nt<128, 64" in k else "conv_wgrad_tn" if "conv_wgrad_tn" in k else None
-        if key is None: continue
-        tot[key][r["Counter_Name"]] += float(r["Counter_Value"])
-    with open(O+"/"+d+"_summary.txt","w") as w:
-        for key in sorted(tot):
-            w.write(key+": "+"  ".join("%s %.4g"%(c,v) for c,v in sorted(tot[key].items()))+"\n")
-    print(open(O+"/"+d+"_summary.txt").read())
-PY
+python tools/sq_summary.py $O > $O/pmc_gemm_in_network.txt; head -24 $O/pmc_gemm_in_network.txt
 f=$(find $O/stats -name "*kernel_stats.csv" | head -1); cp "$f" $O/kernel_stats.csv; head -12 $O/kernel_stats.csv
 f=$(find $O/stats2 -name "*kernel_stats.csv" | head -1); cp "$f" $O/kernel_stats_two_streams.csv
 cat $O/hbm_traffic.json
