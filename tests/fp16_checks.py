@@ -80,10 +80,45 @@ def midas(out):
         out["midas_grad_norm_within_15pct_%s" % tag] = float(np.mean(np.abs(r - 1) < 0.15))
 
 
+def vnl(out):
+    """What 16-bit storage costs where the weights are NOT on a 16-bit grid (a trained state; the fixtures' weights are
+    bf16-exact and hide it): the VNL fixture with every conv / linear weight moved off the grid by a relative 1e-3 N(0, 1).  The
+    fp32 oracle's AbsRel against the oracle with weights and activations rounded to fp16 and to bf16, and the HIP path of this
+    build.  (The free-running version of this measurement -- 20 SGD steps of the oracle -- is
+    tests/test_vnl_net_gpu.py::test_vnl_loss_curves_agree_with_the_oracle: 1.07e-4 here against 7.8e-4 for the bf16 build.)"""
+    from mono_depth_estimation_amd.network import VNL
+    params = nets.vnl_params()
+    torch.manual_seed(0)
+    net = VNL.MetricDepthModel(params)
+    sd = W.vnl_fixture_state(net, 41)
+    rgb, tgt = W.synthetic_batch(41, 2, 64, 96)
+    g = torch.Generator().manual_seed(5)
+    sd = {k: (v * (1.0 + 1e-3 * torch.randn(v.shape, generator=g)) if v.dtype.is_floating_point and v.dim() >= 2 else v) for k, v in sd.items()}
+    P = nets.leaf_state(sd)
+    with torch.no_grad():
+        nets.vnl_forward(P, rgb, True, momentum=1.0)
+    net.load_state_dict({k: v.clone() for k, v in P.items()})
+    net = net.cuda().eval()
+    border = torch.tensor(params.depth_bin_border, dtype=torch.float32)
+    rw = lambda f: {k: (f(v) if v.dtype.is_floating_point and v.dim() >= 2 else v) for k, v in P.items()}
+    with torch.no_grad():
+        dh = L.bins_to_depth(net(rgb.cuda())[1].cpu(), border)
+        do = L.bins_to_depth(nets.vnl_forward(P, rgb, False)[1], border)
+        d16 = L.bins_to_depth(nets.vnl_forward(rw(nets.fp16_round), rgb, False, q=nets.fp16_round)[1], border)
+        dbf = L.bins_to_depth(nets.vnl_forward(rw(nets.bf16_round), rgb, False, q=nets.bf16_round)[1], border)
+    t = tgt.clamp(min=0)
+    m = t > 0
+    absrel = lambda d: float(((d - t).abs() / t.clamp(min=1e-9))[m].mean())
+    out["vnl_absrel_shift_hip_fp16"] = abs(absrel(dh) - absrel(do))
+    out["vnl_absrel_shift_oracle_fp16"] = abs(absrel(d16) - absrel(do))
+    out["vnl_absrel_shift_oracle_bf16"] = abs(absrel(dbf) - absrel(do))
+
+
 if __name__ == "__main__":
     from mono_depth_estimation_amd import _lib, ops
     assert _lib.ACT_NAME == "fp16" and ops.ACT_DTYPE == torch.float16 and _lib.load().mde_act_dtype() == 1
     res = {"lib": _lib.LIB_NAME}
     fcrn(res)
     midas(res)
+    vnl(res)
     sys.stdout.write(json.dumps(res) + "\n")

@@ -3,12 +3,13 @@ their gradients and the GEMM weight shadows; BASELINE configuration 5's precisio
 chosen per PROCESS (MDE_ACT_DTYPE=fp16), so everything here runs in subprocesses:
   * the kernel parity tests of the default build, unchanged, on fp16 operands (their helpers take the storage type from
     ops.ACT_DTYPE): convolution forward / input gradient / fused epilogues / weight gradient, the tape networks' kernels;
-  * the VNL convergence test, whose last part measures what 16-bit storage costs on a TRAINED state: the bf16 build differs from
-    the fp32 oracle by 7.8e-4 in AbsRel there (weights that are not bf16-representable), this build by 1.07e-4 -- what an fp16
-    rounding of the oracle predicts (1.05e-4);
   * tests/fp16_checks.py: FCRN eval AbsRel within 1e-4; FCRN and MiDaS training steps WITH a loss scale agree with the
     oracle's gradients as the bf16 build's do, and WITHOUT one they do not (fp16 gradients underflow: the caller scales the loss,
-    as the reference's GradScaler does)."""
+    as the reference's GradScaler does); and what 16-bit storage costs where the weights are not on a 16-bit grid -- VNL with
+    perturbed weights: this build moves AbsRel as an fp16 rounding of the oracle does, bf16 several times more.  (The
+    free-running form of that measurement is the last part of test_vnl_loss_curves_agree_with_the_oracle: run under
+    MDE_ACT_DTYPE=fp16 it gave 1.07e-4 for this build against the fp16-rounding oracle's 1.05e-4, where the bf16 build has
+    7.8e-4; it trains the CPU oracle for 32 steps, too long to repeat in a subprocess of every test run.)"""
 import json
 import os
 import subprocess
@@ -37,16 +38,6 @@ def test_kernel_parity_tests_pass_on_the_fp16_build():
     print(tail.strip().splitlines()[-1])
 
 
-def test_vnl_trained_state_absrel_on_the_fp16_build():
-    cmd = [sys.executable, "-m", "pytest", "-x", "-q", "-s", "-p", "no:cacheprovider", os.path.join(ROOT, "tests", "test_vnl_net_gpu.py"),
-           "-k", "test_vnl_eval_against_oracle_and_reference or test_vnl_loss_curves_agree_with_the_oracle"]
-    r = subprocess.run(cmd, cwd=ROOT, env=_env(), capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1500:]
-    line = [l for l in r.stdout.splitlines() if "the HIP path (fp16)" in l]
-    assert line, r.stdout[-2000:]
-    print(line[0])
-
-
 def test_training_steps_on_the_fp16_build_need_and_take_a_loss_scale():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fp16_checks.py")], cwd=ROOT, env=_env(), capture_output=True,
                        text=True, timeout=900)
@@ -60,3 +51,7 @@ def test_training_steps_on_the_fp16_build_need_and_take_a_loss_scale():
     # the same steps without a loss scale: MiDaS' gradients (a mean over pixels of a scale-invariant loss) are mostly below fp16's
     # smallest number
     assert d["midas_grad_norm_within_15pct_unscaled"] < 0.5
+    # weights off the 16-bit grid (what training leaves): this build moves AbsRel like an fp16 rounding of the oracle does,
+    # several times less than bf16 storage would
+    assert d["vnl_absrel_shift_hip_fp16"] <= 1.5 * d["vnl_absrel_shift_oracle_fp16"] + 5e-5, d
+    assert d["vnl_absrel_shift_hip_fp16"] <= 2.5e-4 and d["vnl_absrel_shift_oracle_bf16"] >= 2.0 * d["vnl_absrel_shift_oracle_fp16"], d
