@@ -365,6 +365,8 @@ int mde_slot_to_map_add(const void* dslot, int ld, float* dsrc, int N, int H, in
  * group, O == I, O % 64 == 0, G divides 64) -> fwd bf16 [O][T][64] for mde_conv_gemm(grouped) and dgrad bf16 [O][T][64]
  * (the transposed blocks, for the input gradient); either may be NULL. */
 int mde_pack_grouped(const float* src, void* fwd, void* dgrad, int O, int T, int G, void* stream);
+/* The two-term eval shadow (mde_pack_split_batch) of a grouped weight: fwd2 bf16 [O][2T][64]. */
+int mde_pack_grouped_split(const float* src, void* fwd2, int O, int T, int G, void* stream);
 
 /* ---- DORN pieces (network/Dorn.py) ---- */
 /* nn.MaxPool2d(3, 2, 1, ceil_mode=True) (Dorn.py:235): as mde_maxpool_fwd / _bwd with the output size of ATen's ceil rule
@@ -608,6 +610,15 @@ typedef struct mde_pack_job {
 } mde_pack_job;
 int mde_pack_wt_batch(const float* src, void* dst, const mde_pack_job* jobs, int njobs, int64_t nblocks,
                       void* stream);
+/* The eval-mode TWO-TERM weight shadow (north_star: "AbsRel within 1e-4 of CPU reference on identical weights"; the
+ * reference's eval forward, e.g. network/FCRN.py:351-371, multiplies with fp32 weights): w = hi + lo + O(2^-17 |w|) with
+ * hi = (bf16)w and lo = (bf16)(w - hi).  Job j (as above) writes the TAP-DOUBLED GEMM operand of its weight at dst + 2*off:
+ * transposed == 0: [O][2T][I], hi in taps [0, T), lo in taps [T, 2T); transposed != 0: [I][2T][O] likewise.  A convolution
+ * whose descriptor lists every tap twice -- (dy, dx, wtap) and (dy, dx, wtap + T), wtaps_total = 2T -- then contracts the
+ * activation with both terms in ONE fp32 accumulation: the weight-rounding error of an eval-mode output drops from 2^-9 to
+ * 2^-17 relative at twice the MFMA work.  Training keeps the one-term shadow (mde_cast_bf16 / the optimiser steps). */
+int mde_pack_split_batch(const float* src, void* dst, const mde_pack_job* jobs, int njobs, int64_t nblocks,
+                         int transposed, void* stream);
 /* Detecting parameter writes torch's version counters do not see (`.data` writes, collectives into detached views):
  * mde_param_fingerprint folds the raw words of the flat fp32 range into a 64-bit position-weighted sum and records in
  * `state` (DEVICE, >= mde_param_fingerprint_state_bytes(), zero-initialised once) whether it differs from the previous

@@ -22,7 +22,7 @@ if ACT_NAME not in ("bf16", "fp16"):
     raise MdeError("MDE_ACT_DTYPE=%s: bf16 (default) or fp16" % ACT_NAME)
 LIB_NAME = "libmde_hip_f16.so" if ACT_NAME == "fp16" else "libmde_hip.so"
 LIB_PATH = os.environ.get("MDE_LIB_PATH") or os.path.join(_HERE, LIB_NAME)   # override: diagnostic builds only
-ABI_VERSION = 10
+ABI_VERSION = 11
 MAX_TAPS = 32
 
 
@@ -184,6 +184,8 @@ SIGNATURES = {
     "mde_refresh_if_changed": (_I, [_P, _P, _P, _P, _I, _L, _L, _P, _P]),
     "mde_pack_wt": (_I, [_P, _P, _I, _I, _I, _P]),
     "mde_pack_wt_batch": (_I, [_P, _P, _P, _I, _L, _P]),
+    "mde_pack_split_batch": (_I, [_P, _P, _P, _I, _L, _I, _P]),
+    "mde_pack_grouped_split": (_I, [_P, _P, _I, _I, _I, _P]),
     "mde_nchw_to_nhwc_bf16": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "mde_nchw_to_nhwc_bf16_pad": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "mde_nhwc_bf16_to_nchw": (_I, [_P, _P, _I, _I, _I, _I, _P]),

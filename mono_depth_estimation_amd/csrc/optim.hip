@@ -146,6 +146,51 @@ __global__ void pack_wt_batch_k(const float* __restrict__ src, bf16_t* __restric
     }
 }
 
+// The eval-mode two-term weight shadow of many weights in one launch (blocks as pack_wt_batch_k): hi = (bf16)w,
+// lo = (bf16)(w - hi), written as the tap-doubled GEMM operand of job j at dst + 2 * off:
+//   TR = false: dst[o][h * T + t][i]   (forward operand [O][2T][I]);   TR = true: dst[i][h * T + t][o]   (transposed, [I][2T][O])
+template <bool TR>
+__global__ void pack_split_batch_k(const float* __restrict__ src, bf16_t* __restrict__ dst,
+                                   const mde_pack_job* __restrict__ jobs, int njobs) {
+    __shared__ float tile[32][33];
+    int lo = 0, hi = njobs - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].first_block <= (int64_t)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const mde_pack_job j = jobs[lo];
+    const int O = (int)j.O, T = (int)j.T, I = (int)j.I;
+    const int nib = (I + 31) / 32, nob = (O + 31) / 32;
+    const int local = (int)((int64_t)blockIdx.x - j.first_block);
+    const int ib = local % nib, ob = (local / nib) % nob, t = local / (nib * nob);
+    if (t >= T) return;
+    const float* s = src + j.off;
+    bf16_t* d = dst + 2 * j.off;
+    const int i0 = ib * 32, o0 = ob * 32;
+    for (int r = threadIdx.y; r < 32; r += 8) {
+        const int o = o0 + r, i = i0 + threadIdx.x;
+        const float v = (o < O && i < I) ? s[((size_t)o * T + t) * I + i] : 0.f;
+        if (TR) {
+            tile[r][threadIdx.x] = v;
+        } else if (o < O && i < I) {
+            const bf16_t h = (bf16_t)v;
+            d[((size_t)o * 2 * T + t) * I + i] = h;
+            d[((size_t)o * 2 * T + T + t) * I + i] = (bf16_t)(v - (float)h);
+        }
+    }
+    if (!TR) return;
+    __syncthreads();
+    for (int r = threadIdx.y; r < 32; r += 8) {
+        const int i = i0 + r, o = o0 + threadIdx.x;
+        if (i < I && o < O) {
+            const float v = tile[threadIdx.x][r];
+            const bf16_t h = (bf16_t)v;
+            d[((size_t)i * 2 * T + t) * O + o] = h;
+            d[((size_t)i * 2 * T + T + t) * O + o] = (bf16_t)(v - (float)h);
+        }
+    }
+}
+
 // Position-weighted 64-bit sum of the raw words of a flat fp32 range: any in-place change of a parameter that torch's
 // version counters do not see (writes through `.data`, collectives into detached views) changes it.
 struct FpState { unsigned long long acc, last; uint32_t changed, pad; };
@@ -269,5 +314,16 @@ extern "C" int mde_pack_wt(const float* src, void* dst, int O, int T, int I, voi
     MDE_REQUIRE(src && dst && O > 0 && T > 0 && I > 0 && T <= 65535, "mde_pack_wt: bad argument");
     pack_wt_k<<<dim3(mde_cdiv(I, 32), mde_cdiv(O, 32), T), dim3(32, 8), 0, (hipStream_t)stream>>>(src, (bf16_t*)dst, O, T, I);
     MDE_LAUNCH_CHECK("pack_wt_k");
+    return MDE_OK;
+}
+
+extern "C" int mde_pack_split_batch(const float* src, void* dst, const mde_pack_job* jobs, int njobs, int64_t nblocks,
+                                    int transposed, void* stream) {
+    MDE_REQUIRE(src && dst && jobs && njobs > 0 && nblocks > 0 && nblocks < (1ll << 31), "mde_pack_split_batch: bad argument");
+    if (transposed)
+        pack_split_batch_k<true><<<dim3((unsigned)nblocks), dim3(32, 8), 0, (hipStream_t)stream>>>(src, (bf16_t*)dst, jobs, njobs);
+    else
+        pack_split_batch_k<false><<<dim3((unsigned)nblocks), dim3(32, 8), 0, (hipStream_t)stream>>>(src, (bf16_t*)dst, jobs, njobs);
+    MDE_LAUNCH_CHECK("pack_split_batch_k");
     return MDE_OK;
 }

@@ -653,6 +653,25 @@ __global__ __launch_bounds__(NT) void pack_grouped_k(const float* __restrict__ s
     }
 }
 
+// The eval-mode two-term shadow of a grouped weight (mde_pack_split_batch's counterpart): fwd2 [O][2T][64], the block-diagonal
+// packing of hi = (bf16)w in taps [0, T) and of lo = (bf16)(w - hi) in taps [T, 2T).
+__global__ __launch_bounds__(NT) void pack_grouped_split_k(const float* __restrict__ src, bf16_t* __restrict__ fwd2, int O, int T, int G) {
+    const int64_t total = (int64_t)O * T * 64;
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
+        const int j = (int)(i & 63);
+        const int64_t ot = i >> 6;
+        const int t = (int)(ot % T);
+        const int o = (int)(ot / T);
+        const int other = (o & ~63) + j;
+        const bool same = (other / G) == (o / G);
+        const int g0 = (o / G) * G;
+        const float v = same ? src[((int64_t)o * T + t) * G + (other - g0)] : 0.f;
+        const bf16_t h = (bf16_t)v;
+        fwd2[((int64_t)o * 2 * T + t) * 64 + j] = h;
+        fwd2[((int64_t)o * 2 * T + T + t) * 64 + j] = (bf16_t)(v - (float)h);
+    }
+}
+
 }  // namespace
 
 #define PW_ALIGNED(p) (((uintptr_t)(p) % 16) == 0)
@@ -913,6 +932,14 @@ extern "C" int mde_pack_grouped(const float* src, void* fwd, void* dgrad, int O,
                 "mde_pack_grouped: O=%d must be a multiple of 64 and the group size %d must divide 64", O, G);
     pack_grouped_k<<<grid_flat((int64_t)O * T * 64), NT, 0, (hipStream_t)stream>>>(src, (bf16_t*)fwd, (bf16_t*)dgrad, O, T, G);
     MDE_LAUNCH_CHECK("pack_grouped_k");
+    return MDE_OK;
+}
+
+extern "C" int mde_pack_grouped_split(const float* src, void* fwd2, int O, int T, int G, void* stream) {
+    MDE_REQUIRE(src && fwd2 && O > 0 && O % 64 == 0 && T > 0 && G > 0 && 64 % G == 0,
+                "mde_pack_grouped_split: O=%d must be a multiple of 64 and the group size %d must divide 64", O, G);
+    pack_grouped_split_k<<<grid_flat((int64_t)O * T * 64), NT, 0, (hipStream_t)stream>>>(src, (bf16_t*)fwd2, O, T, G);
+    MDE_LAUNCH_CHECK("pack_grouped_split_k");
     return MDE_OK;
 }
 

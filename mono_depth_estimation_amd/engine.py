@@ -221,10 +221,26 @@ class Conv:
         self.w32 = store.P[off:off + n]
         self.wf = store.Pb[off:off + n]
         self.wd = store.WD[off:off + n] if need_dgrad else None    # slice of the flat transposed-weight buffer
+        self.fwd_transposed = False
 
     @property
     def dw(self):                         # gradient slice of the buffer the current backward accumulates into
         return self.store.Gcur[self.off:self.off + self.n]
+
+    # the eval-mode two-term operands (FlatStore.ensure_split): [O][2T][I] and, for the layers whose FORWARD contracts with the
+    # transposed packing (ConvTranspose2d: DeConvLayer, graph.ConvT), [I][2T][O]
+    @property
+    def w2(self):
+        return self.store.W2[2 * self.off:2 * (self.off + self.n)]
+
+    @property
+    def w2d(self):
+        return self.store.W2D[2 * self.off:2 * (self.off + self.n)]
+
+    def want_w2d(self):
+        if not self.fwd_transposed:
+            self.fwd_transposed = True
+            self.store._split_jobs = None
 
 
 class GroupedConv:
@@ -238,6 +254,7 @@ class GroupedConv:
         self.w32 = store.P[off:off + self.n]
         self.wf = torch.zeros(O * T * 64, dtype=ops.ACT_DTYPE, device=store.dev)
         self.wd = torch.zeros(O * T * 64, dtype=ops.ACT_DTYPE, device=store.dev)
+        self.w2 = None                  # eval-mode two-term operand [O][2T][64], built on first use (pack_split)
 
     @property
     def dw(self):
@@ -245,6 +262,11 @@ class GroupedConv:
 
     def pack(self):
         ops.pack_grouped(self.w32, self.wf, self.wd, self.O, self.T, self.G)
+
+    def pack_split(self):
+        if self.w2 is None:
+            self.w2 = torch.zeros(2 * self.O * self.T * 64, dtype=ops.ACT_DTYPE, device=self.store.dev)
+        ops.pack_grouped_split(self.w32, self.w2, self.O, self.T, self.G)
 
 
 class FlatStore:
@@ -264,6 +286,12 @@ class FlatStore:
         self.sgd_state = None
         self._fp_state, self._fp_valid = None, False     # device fingerprint of P (refresh_weights(check_data=True))
         self.step_count = 0
+        # eval-mode forward passes contract with a TWO-TERM weight shadow, bf16(w) + bf16(w - bf16(w)) (ensure_split; north_star:
+        # "AbsRel within 1e-4 of CPU reference on identical weights" for weights that are not on the 16-bit grid); MDE_EVAL_SPLIT=0:
+        # the one-term shadow the training step uses (A/B, tests)
+        self.split_eval = os.environ.get("MDE_EVAL_SPLIT", "1") != "0"
+        self.W2 = self.W2D = None
+        self._split_jobs, self._split_epoch, self.shadow_epoch = None, -1, 0
         self._flatten_parameters()
         self.deterministic, self._det_scratch = False, None
         if os.environ.get("MDE_DETERMINISTIC", "0") == "1":
@@ -463,7 +491,7 @@ class FlatStore:
             _, kh, kw, I = self.sdims[id(t0)]
             c = Conv(self, self.p_off[id(t0)], O, kh * kw, I, need_dgrad)
             self.convs[id(t0)] = c
-            self._pack_jobs = None
+            self._pack_jobs = self._split_jobs = None
         return c
 
     def linear(self, w, need_dgrad=True):
@@ -475,7 +503,7 @@ class FlatStore:
             assert w.dim() == 2 and O % 8 == 0 and I % 8 == 0 and self.sdims[id(w)] == (O * I,), (tuple(w.shape), self.sdims[id(w)])
             c = Conv(self, self.p_off[id(w)], O, 1, I, need_dgrad)
             self.convs[id(w)] = c
-            self._pack_jobs = None
+            self._pack_jobs = self._split_jobs = None
         return c
 
     def layer_boundaries(self):
@@ -491,6 +519,7 @@ class FlatStore:
             self.convs[id(w)] = c
             self.grouped.append(c)
             self.packed_version = -1           # its packings do not exist yet
+            self._split_jobs = None
         return c
 
     def params_version(self):
@@ -510,6 +539,7 @@ class FlatStore:
             ops.cast_bf16(self.P, self.Pb)
             self.repack()
             self.packed_version = v
+            self.shadow_epoch += 1
             self._fp_valid = False
             if check_data:
                 self._record_fingerprint()     # the shadows are fresh NOW: a .data write before the next forward must show
@@ -600,7 +630,34 @@ class FlatStore:
                  betas[0], betas[1], eps, wd[1] if dec else wd[0], grad_scale, self.step_count)
         self._after_fused_step()
 
+    def ensure_split(self, always=False):
+        """The eval-mode two-term operands of every conv weight follow the fp32 masters (mde_pack_split_batch: one launch per
+        layout over a device job table; grouped weights one small launch each).  Re-derived when the one-term shadows were
+        (`shadow_epoch`), or on every call (`always`: the nn.Module path, where a `.data` write is only known to the device)."""
+        if not self.split_eval:
+            return False
+        if self._split_jobs is None:
+            fw = sorted((c.off, c.O, c.T, c.I) for c in self.convs.values() if isinstance(c, Conv))
+            tr = sorted((c.off, c.O, c.T, c.I) for c in self.convs.values() if isinstance(c, Conv) and c.fwd_transposed)
+            self._split_jobs = (ops.pack_jobs(fw, self.dev) if fw else (None, 0), ops.pack_jobs(tr, self.dev) if tr else (None, 0))
+            self._split_epoch = -1
+        if always or self._split_epoch != self.shadow_epoch:
+            (jf, nf), (jt, nt) = self._split_jobs
+            if jf is not None:
+                if self.W2 is None:
+                    self.W2 = torch.zeros(2 * self.P.numel(), dtype=ops.ACT_DTYPE, device=self.dev)
+                ops.pack_split_batch(self.P, self.W2, jf, nf)
+            if jt is not None:
+                if self.W2D is None:
+                    self.W2D = torch.zeros(2 * self.P.numel(), dtype=ops.ACT_DTYPE, device=self.dev)
+                ops.pack_split_batch(self.P, self.W2D, jt, nt, transposed=True)
+            for g in self.grouped:
+                g.pack_split()
+            self._split_epoch = self.shadow_epoch
+        return True
+
     def _after_fused_step(self):
+        self.shadow_epoch += 1
         self.repack()
         self.packed_version = self.params_version()   # shadow + packings are current (the kernels bump no version counter)
         self._fp_valid = False
@@ -705,9 +762,28 @@ class EngineCore:
         # while ops.TIMER is recording (bench.py's roofline leg: one instrumented step) everything runs on ONE stream.
         self.side = torch.cuda.Stream(self.dev) if os.environ.get("MDE_WGRAD_STREAM", "1") == "1" else None
         self.side_busy = False
+        self.split = False            # this forward runs over the two-term eval operands (begin_forward)
 
     def attach_grads(self):
         return self.store.attach_grads()
+
+    def begin_forward(self, train, check_data):
+        """Weight shadows current for this forward: the one-term shadow always, the two-term eval operands in eval mode."""
+        self.store.det_begin()
+        self.store.refresh_weights(check_data=check_data)
+        self.split = (not train) and self.store.ensure_split(always=check_data)
+
+    def fwd_conv(self, desc, x, conv, out, stats=None, transposed=False, bias=None, res=None, act=None):
+        """A FORWARD convolution launch.  Training (and MDE_EVAL_SPLIT=0): the one-term bf16 shadow (`conv.wf`, or `conv.wd`
+        where the forward contracts with the transposed packing), BatchNorm statistics from the epilogue.  Eval mode: the
+        tap-doubled launch over the two-term operand (ops.conv_gemm_eval) -- except a fused-epilogue conv whose doubled tap
+        list does not fit one launch (a dense 5x5 with bias / activation: Eigen's stacks), which keeps the one-term shadow."""
+        fused = bias is not None or res is not None or bool(ops.ACT_CODE[act])
+        if self.split and (not fused or ops.split_fits(desc)):
+            w2 = conv.w2d if transposed else conv.w2
+            ops.conv_gemm_eval(desc, x, w2, out, bias=bias, res=res, act=act)
+            return
+        ops.conv_gemm(desc, x, conv.wd if transposed else conv.wf, out, stats, bias=bias, res=res, act=act)
 
     # ------------------------------------------------------------------ plan helpers
     def _conv(self, weights, need_dgrad=True):
@@ -847,8 +923,7 @@ class FCRNEngine(EngineCore):
     # ------------------------------------------------------------------ execution
     def forward(self, x, train, check_data=False):
         assert x.shape == (self.N, self.cin, self.H, self.W) and x.dtype == torch.float32 and x.is_contiguous()
-        self.store.det_begin()
-        self.store.refresh_weights(check_data=check_data)
+        self.begin_forward(train, check_data)
         self.x = x
         s = self.stem_site
         if self.cin == 3:
@@ -856,7 +931,7 @@ class FCRNEngine(EngineCore):
         else:
             ops.nchw_to_nhwc_bf16_pad(x, self.xin.t, self.xin.C)
             for d in self.stem_fd:
-                ops.conv_gemm(d, self.xin.t, self.stem_w.wf, self.stem_c.t)
+                self.fwd_conv(d, self.xin.t, self.stem_w, self.stem_c.t)
             if train:
                 ops.bn_stats(self.stem_c.t, self.stem_c.M, 64, 64, s.part)
         s.finalize(self.stem_c.M, train)
@@ -954,7 +1029,7 @@ class ConvBN:
             self.out.gw = False
 
     def conv_fwd(self, train):
-        ops.conv_gemm(self.fdesc, self.x.t, self.conv.wf, self.c.t, self.site.part if train else None)
+        self.eng.fwd_conv(self.fdesc, self.x.t, self.conv, self.c.t, self.site.part if train else None)
         self.site.finalize(self.c.M, train)
 
     def fwd(self, train):
@@ -1159,7 +1234,7 @@ class UpProjLayer:
     def fwd(self, train):
         x, y = self.x, self.y55
         for d in self.fdescs:
-            ops.conv_gemm(d, x.t, self.w55.wf, y.t, self.site55.part if train else None)
+            self.eng.fwd_conv(d, x.t, self.w55, y.t, self.site55.part if train else None)
         self.site55.finalize(y.M, train)
         su = self.site_u
         ops.bn_apply(self.y_u.t, y.ld, su.scale, su.shift, self.a1.t, self.a1.ld, y.M, su.C, True)
@@ -1210,7 +1285,7 @@ class UpConvLayer:
     def fwd(self, train):
         x, y, s = self.x, self.y, self.site
         for d in self.fdescs:
-            ops.conv_gemm(d, x.t, self.w.wf, y.t, s.part if train else None)
+            self.eng.fwd_conv(d, x.t, self.w, y.t, s.part if train else None)
         s.finalize(y.M, train)
         ops.bn_apply(y.t, y.ld, s.scale, s.shift, self.out.t, self.out.ld, y.M, y.C, True)
 
@@ -1239,6 +1314,7 @@ class DeConvLayer:
         assert ops.out_size(2 * h, k, 2, pad) == h and ops.out_size(2 * w, k, 2, pad) == w
         self.convt = getattr(mod, "deconv%d" % k)
         self.w = eng._conv([self.convt.weight])          # O = Cin (of the ConvTranspose), I = C
+        self.w.want_w2d()
         self.site = eng._site([mod.batchnorm])
         self.y = Act(dev, N, 2 * h, 2 * w, C)          # pre-BN
         self.out = Act(dev, N, 2 * h, 2 * w, C)
@@ -1261,7 +1337,7 @@ class DeConvLayer:
             y.t.zero_()
         for d in self.fdescs:
             d.accumulate = 0
-            ops.conv_gemm(d, x.t, self.w.wd, y.t, s.part if train else None)
+            self.eng.fwd_conv(d, x.t, self.w, y.t, s.part if train else None, transposed=True)
         s.finalize(y.M, train)
         ops.bn_apply(y.t, y.ld, s.scale, s.shift, self.out.t, self.out.ld, y.M, y.C, True)
 
@@ -1298,7 +1374,7 @@ class _BiasedConvBN:
 
     def fwd(self, train, relu):
         s, y = self.site, self.y
-        ops.conv_gemm(self.fdesc, self.x.t, self.conv.wf, y.t, s.part if train else None)
+        self.eng.fwd_conv(self.fdesc, self.x.t, self.conv, y.t, s.part if train else None)
         s.finalize(y.M, train)
         with torch.no_grad():
             if train:

@@ -204,11 +204,11 @@ class Conv(Op):
         if self.fused:
             r = self.f_res
             for i in self._chunks():
-                ops.conv_gemm(self.fdesc, self.x.t[i:i + n], self.conv.wf, self.out.t[i:i + n], bias=self.f_bias,
-                              res=r.t[i:i + n] if r is not None else None, act=self.f_act)
+                self.eng.fwd_conv(self.fdesc, self.x.t[i:i + n], self.conv, self.out.t[i:i + n], bias=self.f_bias,
+                                  res=r.t[i:i + n] if r is not None else None, act=self.f_act)
             return
         for i in self._chunks():
-            ops.conv_gemm(self.fdesc, self.x.t[i:i + n], self.conv.wf, self.out.t[i:i + n], stats)
+            self.eng.fwd_conv(self.fdesc, self.x.t[i:i + n], self.conv, self.out.t[i:i + n], stats)
 
     def bwd(self):
         x, o, eng, n = self.x, self.out, self.eng, self.chunk
@@ -534,7 +534,7 @@ class ImageStem(Op):
         if self.owns_xin:
             ops.nchw_to_nhwc_bf16_pad(self.x, self.xin.t, self.xin.C)
         for d in self.fd:
-            ops.conv_gemm(d, self.xin.t, self.w.wf, self.out.t)
+            self.eng.fwd_conv(d, self.xin.t, self.w, self.out.t)
         if train and self.site is not None:               # (Eigen's 9 x 9 / 2 image convs have no BatchNorm: Eigen.py:22,51)
             ops.bn_stats(self.out.t, self.out.M, self.out.C, self.out.ld, self.site.part)
 
@@ -920,6 +920,7 @@ class ConvT(Op):
         pad 2 (h -> 2 h - 1).  Output size (h - 1) stride - 2 pad + k, as nn.ConvTranspose2d without output_padding."""
         self.eng, self.x = eng, x
         self.w = eng.store.conv([w])                       # O = Cin, I = Cout (storage, possibly padded to 8)
+        self.w.want_w2d()
         Cin, C = self.w.O, self.w.I
         N, h, wd, st = x.N, x.H, x.W, stride
         H2, W2 = (h - 1) * st - 2 * pad + k, (wd - 1) * st - 2 * pad + k
@@ -938,7 +939,7 @@ class ConvT(Op):
         if self.fzero:
             self.out.t.zero_()
         for d in self.fdescs:
-            ops.conv_gemm(d, self.x.t, self.w.wd, self.out.t)
+            self.eng.fwd_conv(d, self.x.t, self.w, self.out.t, transposed=True)
 
     def bwd(self):
         x, o = self.x, self.out
@@ -1093,8 +1094,7 @@ class TapeEngine(EngineCore):
 
     def forward(self, x, train, check_data=False):
         assert x.dtype == torch.float32 and x.is_contiguous() and tuple(x.shape) == (self.N, 3, self.H, self.W), tuple(x.shape)
-        self.store.det_begin()
-        self.store.refresh_weights(check_data=check_data)
+        self.begin_forward(train, check_data)
         self.stem.x = x
         for op in self.tape:
             op.fwd(train)

@@ -230,6 +230,45 @@ def conv_gemm(desc, x, w, out, stats=None, bias=None, res=None, act=None, red=No
            "M=%d N=%d taps=%d C=%d s=%d%s" % (M, desc.ncols, desc.ntaps, desc.C, desc.sy, " acc" if desc.accumulate else ""), nbytes)
 
 
+def split_descs(d):
+    """The eval-mode form of a conv descriptor over the TWO-TERM weight operand (mde_pack_split_batch: [rows][2T][C], hi = bf16(w)
+    in taps [0, T), lo = bf16(w - hi) in [T, 2T)): every tap listed twice, (dy, dx, wtap) and (dy, dx, wtap + T), so ONE fp32
+    accumulation contracts the activation with both terms.  More than MDE_MAX_TAPS taps run as several launches, the later ones
+    accumulating.  Cached on the descriptor (a forward descriptor's fields are fixed at plan time)."""
+    sp = getattr(d, "_split", None)
+    if sp is None:
+        T = d.wtaps_total
+        taps = [(d.dy[i], d.dx[i], d.wtap[i]) for i in range(d.ntaps)]
+        both = [(dy, dx, wt + h * T) for (dy, dx, wt) in taps for h in (0, 1)]
+        sp = []
+        for t0 in range(0, len(both), _lib.MAX_TAPS):
+            e = ConvDesc.from_buffer_copy(d)
+            _fill_taps(e, both[t0:t0 + _lib.MAX_TAPS], "wtap")
+            e.wtaps_total = 2 * T
+            if t0:
+                e.accumulate = 1
+            if hasattr(d, "_useful"):
+                e._useful = d._useful
+            sp.append(e)
+        d._split = sp
+    return sp
+
+
+def conv_gemm_eval(desc, x, w2, out, bias=None, res=None, act=None):
+    """An eval-mode forward conv with the two-term weight operand `w2` (split_descs).  A fused epilogue needs the whole
+    contraction in one launch (an accumulating launch has none): the caller checks split_fits first."""
+    ds = split_descs(desc)
+    fused = bias is not None or res is not None or ACT_CODE[act]
+    assert len(ds) == 1 or not fused
+    for d in ds:
+        conv_gemm(d, x, w2, out, bias=bias, res=res, act=act)
+
+
+def split_fits(desc):
+    """True if the doubled tap list of split_descs(desc) is ONE launch (what a fused epilogue needs)."""
+    return 2 * desc.ntaps <= _lib.MAX_TAPS
+
+
 def stat_slots():
     return _lib.load().mde_stat_slots()
 
@@ -817,6 +856,15 @@ def pack_jobs(convs, device):
 
 def pack_wt_batch(src, dst, jobs, nblocks):
     check(_lib.load().mde_pack_wt_batch(_p(src), _p(dst), _p(jobs), jobs.shape[0], nblocks, _stream()), "mde_pack_wt_batch")
+
+
+def pack_split_batch(src, dst, jobs, nblocks, transposed=False):
+    check(_lib.load().mde_pack_split_batch(_p(src), _p(dst), _p(jobs), jobs.shape[0], nblocks, int(transposed), _stream()),
+          "mde_pack_split_batch")
+
+
+def pack_grouped_split(src, fwd2, O, T, G):
+    check(_lib.load().mde_pack_grouped_split(_p(src), _p(fwd2), O, T, G, _stream()), "mde_pack_grouped_split")
 
 
 def pack_wt(src, dst, O, T, I):

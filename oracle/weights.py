@@ -151,6 +151,36 @@ def midas_fixture_state(model, seed):
     return sd
 
 
+def midas_conditioned_state(model, seed):
+    """A WELL-CONDITIONED MiDaS state (the counterpart of fcrn_conditioned_state / bts_conditioned_state): midas_fixture_state
+    with (i) the second conv of every ResidualConvUnit x 0.1 -- the BN-free decoder's residual branches, the "zero-init
+    residual" regime -- and (ii) layer3_rn / layer4_rn x 0.1: the two coarsest pyramid levels are 4 x 6 and 2 x 3 maps on a
+    64 x 96 fixture, so ONE rounded value there moves a sixth of the image coherently and does not average out of a mean over
+    pixels (midas_fixture_state: the fp32 oracle's own AbsRel moves by 4e-4 when its activations are rounded to bf16, with
+    per-image mean shifts of 1e-3).  Here that shift is 4.5e-5 (output noise 6e-4); every layer still feeds the output."""
+    sd = midas_fixture_state(model, seed)
+    for k in sd:
+        if ("resConfUnit" in k and k.endswith("conv2.weight")) or k in ("scratch.layer3_rn.weight", "scratch.layer4_rn.weight"):
+            sd[k] = (sd[k] * 0.1).to(torch.bfloat16).to(torch.float32)
+    model.load_state_dict(sd)
+    return sd
+
+
+def off_grid(model, sd, seed, rel=2.0 ** -8):
+    """Move every conv / linear weight of a state OFF the 16-bit grids (the conditioned fixtures' weights are exactly
+    bf16-representable, which hides what a 16-bit weight shadow costs: DESIGN.md section 4): w (1 + rel u), u ~ U(-1, 1) per
+    element from the Philox stream of (seed, tensor name) -- generic fp32 values, as a trained state's are."""
+    out = {}
+    for k, v in sd.items():
+        if v.dtype.is_floating_point and v.ndim >= 2:
+            out[k] = v * (1.0 + rel * uniform(seed, "offgrid:" + k, v.shape, -1.0, 1.0))
+        else:
+            out[k] = v
+    if model is not None:
+        model.load_state_dict(out)
+    return out
+
+
 def bts_fixture_state(model, seed):
     """BTS parity fixture: net_conditioned_state (DenseNet has no residual sums to damp) with the three kinds of head conv
     scaled down so their sigmoids are not saturated (He-scale weights on the BN-free ELU chains give pre-activations of

@@ -697,6 +697,77 @@ def gen_bts_conditioned(criteria, metrics):
         out["eval_final"].min(), out["eval_final"].max(), float(out["eval_absrel"]), float(out["train_loss"])))
 
 
+OFFGRID_FCRN_SEEDS = (7, 21, 22)
+
+
+def gen_offgrid(criteria, metrics, FCRN):
+    """The north-star bound "AbsRel within 1e-4 of the CPU reference on identical weights" for weights that are NOT on the
+    16-bit grid (every other conditioned fixture rounds its conv weights to bf16 first): the four networks of BASELINE
+    configurations 2-5 -- the reference's own network/FCRN.py (three seeds), Bts.py, VNL.py, MiDaS.py -- on their conditioned
+    states with every conv / linear weight moved off the grid (oracle/weights.off_grid), eval-mode outputs and the
+    reference's metrics.py on them.  Also the ON-grid golden of the conditioned MiDaS state (weights.midas_conditioned_state)."""
+    from network import Bts, MiDaS, VNL
+    from oracle import nets, trunks
+    names = ["absrel", "rmse", "delta1", "log10"]
+    out = {}
+
+    def record(tag, y, tgt, keep_output):
+        mc = metrics.MetricComputation(names)
+        for n, v in zip(mc.names, mc.compute(y, tgt)):
+            out["%s_%s" % (tag, n)] = _np(v)
+        if keep_output:
+            out[tag + "_out"] = _np(y)
+        print("offgrid.npz %-12s range %.4f..%.4f AbsRel %.6f" % (tag, float(y.min()), float(y.max()), float(out[tag + "_absrel"])))
+
+    size = (96, 128)
+    for seed in OFFGRID_FCRN_SEEDS:
+        ref = FCRN.ResNet(layers=50, decoder="upproj", output_size=size, in_channels=3, out_channels=1, pretrained=False)
+        W.off_grid(ref, W.fcrn_conditioned_state(ref, seed), seed)
+        rgb, tgt = W.synthetic_batch(seed, 2, *size)
+        W.calibrate_running_stats(ref, rgb)
+        ref.eval()
+        with torch.no_grad():
+            record("fcrn_s%d" % seed, ref(rgb), tgt, seed == OFFGRID_FCRN_SEEDS[0])
+
+    torch.manual_seed(0)
+    ref = Bts.BtsModel(bts_size=512, max_depth=10, out_channels=1, encoder_version="densenet161_bts")
+    W.off_grid(ref, W.bts_conditioned_state(ref, 53), 53)
+    rgb, tgt = W.synthetic_batch(53, 2, *BTS_SIZE)
+    W.calibrate_running_stats(ref, rgb)
+    ref.eval()
+    with torch.no_grad():
+        record("bts", ref(rgb)[4], tgt * 10.0, True)
+
+    if not hasattr(np, "int"):
+        np.int = int
+    params = nets.vnl_params()
+    torch.manual_seed(0)
+    ref = VNL.MetricDepthModel(params)
+    W.off_grid(ref, W.vnl_fixture_state(ref, 41), 41)
+    rgb, tgt = W.synthetic_batch(41, 2, *VNL_SIZE)
+    W.calibrate_running_stats(ref, rgb)
+    border = torch.tensor(params.depth_bin_border, dtype=torch.float32)
+    ref.eval()
+    with torch.no_grad():
+        prob = ref(rgb)[1]
+        depth = 10 ** (prob.permute(0, 2, 3, 1) * border).sum(3, dtype=torch.float32, keepdim=True).permute(0, 3, 1, 2)
+        record("vnl", depth, tgt, True)
+
+    MiDaS._make_pretrained_resnext101_wsl = lambda use_pretrained: MiDaS._make_resnet_backbone(trunks.resnext101_32x8d())
+    for tag, off in (("midas_ongrid", False), ("midas", True)):
+        torch.manual_seed(0)
+        ref = MiDaS.MidasNet(features=256)
+        sd = W.midas_conditioned_state(ref, 43)
+        if off:
+            W.off_grid(ref, sd, 43)
+        rgb, tgt = W.synthetic_batch(43, 2, *MIDAS_SIZE)
+        W.calibrate_running_stats(ref, rgb)
+        ref.eval()
+        with torch.no_grad():
+            record(tag, ref(rgb)[:, :1], tgt, True)
+    np.savez_compressed(os.path.join(HERE, "offgrid.npz"), **out)
+
+
 def gen_eigen(criteria):
     """C1 / BASELINE configuration 1 (CPU plumbing): the reference's own network/Eigen.py (Eigen, Scale2, Scale3, VGG) over
     the vgg19_bn stand-in, 4 x 3 x 240 x 320 (the two Linear layers fix that input size; 64 x 64 is rejected by the
@@ -895,6 +966,8 @@ def main():
         gen_bts_resnet(criteria)
     if want("bts_imgres"):
         gen_bts_image_residuals(criteria)
+    if want("offgrid"):
+        gen_offgrid(criteria, metrics, FCRN)
     if want("eigen"):
         gen_eigen(criteria)
     if want("dorn_net"):

@@ -1,0 +1,81 @@
+"""The north-star bound -- "AbsRel within 1e-4 of the CPU reference on identical weights" -- for weights that are NOT on the
+16-bit grid, for the four networks of BASELINE configurations 2-5, against vectors minted from the REFERENCE's own network
+classes and metrics.py (tests/golden/offgrid.npz; tests/test_offgrid_cpu.py pins the oracle to the same vectors).
+
+Every other conditioned fixture rounds its conv weights to bf16 first, which hides what a 16-bit weight shadow costs: a
+weight's rounding error is the same for every pixel and does not average out of a mean over pixels (on these states the
+fp32 oracle's own AbsRel moves by 7e-5 (FCRN), 7e-4 (BTS), 4e-4 (MiDaS) when only its weights are rounded).  The HIP path's
+EVAL forward therefore contracts with a two-term shadow, bf16(w) + bf16(w - bf16(w)), through tap-doubled launches
+(include/mde_hip.h: mde_pack_split_batch; FlatStore.ensure_split): the tests assert |dAbsRel| <= 1e-4 (and 'rmse', log10)
+with it, and print the one-term figure (MDE_EVAL_SPLIT=0's path) beside it."""
+import pytest
+import torch
+
+import offgrid_states as S
+
+pytestmark = pytest.mark.gpu
+NAMES = ["absrel", "rmse", "log10"]
+
+
+def _metrics(y, tgt):
+    from mono_depth_estimation_amd import metrics
+    return [float(v) for v in metrics.MetricComputation(NAMES).compute(y.cuda().float().contiguous(), tgt.cuda())]
+
+
+def _eval_both(net, rgb, select):
+    """Eval-mode outputs with the two-term weight shadow (the default) and with the one-term shadow the training step uses."""
+    net = net.cuda().eval()
+    outs = []
+    for split in (True, False):
+        net._store.split_eval = split
+        with torch.no_grad():
+            ys = net(rgb.cuda())
+        outs.append(select(ys).detach().clone())
+    net._store.split_eval = True
+    return outs
+
+
+def _assert_within(tag, g, two, one, tgt, bound=1e-4, depth_scale=1.0):
+    """AbsRel and log10 are scale-free: 1e-4 as the north star states it.  The reference's 'rmse' = mean(sqrt((p - t)^2 / t))
+    (metrics.py:106-109) carries the square root of the depth unit: BTS predicts depth x 10 (max_depth), so its bound is
+    1e-4 sqrt(10) -- the same bound in the unit every other fixture uses."""
+    m2, m1 = _metrics(two, tgt), _metrics(one, tgt)
+    ref = [float(g["%s_%s" % (tag, n)]) for n in NAMES]
+    for n, r, a, b in zip(NAMES, ref, m2, m1):
+        print("%-12s %-6s reference %.6f | two-term shadow %.6f (delta %.2e) | one-term %.6f (delta %.2e)" % (tag, n, r, a, abs(a - r), b, abs(b - r)))
+    if tag + "_out" in g:
+        ref_out = torch.from_numpy(g[tag + "_out"])
+        print("%-12s output rel. L2 vs reference: two-term %.2e, one-term %.2e" % (
+            tag, float((two.cpu() - ref_out).norm() / ref_out.norm()), float((one.cpu() - ref_out).norm() / ref_out.norm())))
+    for n, r, a in zip(NAMES, ref, m2):
+        assert abs(a - r) <= bound * (depth_scale ** 0.5 if n == "rmse" else 1.0), (tag, n, a, r)
+    return abs(m2[0] - ref[0]), abs(m1[0] - ref[0])
+
+
+@pytest.mark.parametrize("seed", S.FCRN_SEEDS)
+def test_fcrn_off_grid_absrel_within_1e4_of_the_reference(seed, golden):
+    """Three seeds: the 1.7e-5 the trained FCRN state of tests/test_fcrn_convergence_gpu.py lands at is not luck."""
+    from mono_depth_estimation_amd.network import FCRN
+    sd, _, rgb, tgt, select = S.fcrn(seed)
+    hip = FCRN.ResNet(layers=50, output_size=S.FCRN_SIZE, out_channels=1, pretrained=False)
+    hip.load_state_dict(sd)
+    two, one = _eval_both(hip, rgb, select)
+    _assert_within("fcrn_s%d" % seed, golden("offgrid"), two, one, tgt)
+
+
+@pytest.mark.parametrize("name", ["bts", "vnl", "midas"])
+def test_tape_networks_off_grid_absrel_within_1e4_of_the_reference(name, golden):
+    (net, P), _, rgb, tgt, select = getattr(S, name)()
+    net.load_state_dict({k: v.clone() for k, v in P.items()})
+    two, one = _eval_both(net, rgb, select)
+    _assert_within(name, golden("offgrid"), two, one, tgt, depth_scale=10.0 if name == "bts" else 1.0)
+
+
+def test_midas_conditioned_on_grid_absrel_within_1e4_of_the_reference(golden):
+    """The conditioned MiDaS state with bf16-exact weights (the counterpart of fcrn50_cond.npz / bts_cond.npz): both shadows
+    hold the weights exactly (the second term is zero)."""
+    (net, P), _, rgb, tgt, select = S.midas(offgrid=False)
+    net.load_state_dict({k: v.clone() for k, v in P.items()})
+    two, one = _eval_both(net, rgb, select)
+    d2, d1 = _assert_within("midas_ongrid", golden("offgrid"), two, one, tgt)
+    assert d1 <= 1e-4
