@@ -188,8 +188,9 @@ def build_other(name, n, dev):
 
 def run_other_config(args, dev, rank, world, use_dist, t_start):
     """The same contract (warm-up, K timed steps between barriers, max over ranks, one JSON line with a roofline leg) for
-    BASELINE.json configurations 3 / 4 / 5.  The gradient exchange (N > 1) is one flat all-reduce per bucket after backward:
-    the tape engine's backward does not report its progress, so it is not overlapped here."""
+    BASELINE.json configurations 3 / 4 / 5.  The gradient exchange (N > 1) is overlapped with backward as in the FCRN path: the
+    module's backward feeds the reducer (TapeModule.set_grad_reducer -> TapeEngine.backward(on_progress)), a bucket's all-reduce
+    goes out on the exchange stream as soon as the tape has passed the bucket's first element."""
     import torch.distributed as dist
     from mono_depth_estimation_amd import dp, ops
     cfg = OTHER_CONFIGS[args.config]
@@ -204,17 +205,20 @@ def run_other_config(args, dev, rank, world, use_dist, t_start):
         net.zero_grad(set_to_none=True)
         loss = fwd_loss()
         (loss * LOSS_SCALE if LOSS_SCALE != 1.0 else loss).backward()      # (fp16 build: static loss scale, divided out by the optimiser step)
-        store = net._store
         if use_dist:
-            if "red" not in state:
-                dist.broadcast(store.P, 0)
-                state["red"] = dp.FlatGradReducer(store.grad_buffer(), store.layer_boundaries(), target_bytes=64 << 20,
-                                                  wire_dtype=torch.bfloat16 if args.grad_dtype == "bf16" else None)
-            state["red"].flat = store.grad_buffer()          # the flat buffer this backward's .grad views live in
-            state["red"].ready(0)
             state["red"].finish()
         opt()
         state["loss"] = loss
+
+    if use_dist:
+        store = net._store
+        dist.broadcast(store.P, 0)
+        dist.broadcast(store.B, 0)
+        # (no extra_streams: the plans -- and their weight-gradient streams -- do not exist before the first forward; the engine
+        #  joins that stream into the main one before each of the handful of bucket callbacks instead)
+        state["red"] = dp.FlatGradReducer(store.G, store.layer_boundaries(), target_bytes=int(os.environ.get("MDE_DP_BUCKET_MB", "64")) << 20,
+                                          wire_dtype=torch.bfloat16 if args.grad_dtype == "bf16" else None)
+        net.set_grad_reducer(state["red"])
 
     def log(msg):
         if rank == 0:
@@ -243,6 +247,14 @@ def run_other_config(args, dev, rank, world, use_dist, t_start):
     if use_dist:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt)
+    drift = None
+    if use_dist:       # replicas must hold bit-identical weights after the timed steps (see the FCRN path below)
+        P = net._store.P
+        cs = torch.stack([P.double().sum(), P.double().square().sum()])
+        hi, lo = cs.clone(), cs.clone()
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        drift = float((hi - lo).abs().max())
     log("timed region done: %.1f ms/step" % (1e3 * dt / args.steps))
     if rank == 0:
         ips = args.batch * world * args.steps / dt
@@ -251,10 +263,12 @@ def run_other_config(args, dev, rank, world, use_dist, t_start):
             "metric": "training images/sec, %s, %s" % (args.config.upper(), ACT_NAME), "value": round(ips, 2), "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": ACT_NAME, "data": "synthetic",
-            "config": {"workload": cfg["workload"] % args.batch + (" + flat-gradient all-reduce after backward (RCCL, %s)" % args.grad_dtype
-                                                                   if world > 1 else ""),
+            "config": {"workload": cfg["workload"] % args.batch + (" + flat-gradient all-reduce overlapped with backward (RCCL, %s buckets)" % args.grad_dtype
+                                                                   if use_dist else ""),
                        "global_batch": args.batch * world, "per_gpu_batch": args.batch, "parallelism": "dp%d" % world,
-                       "final_loss": round(float(state["loss"]), 5), "algorithmic_gflop_per_image": round(gflop, 1)},
+                       "final_loss": round(float(state["loss"]), 5), "algorithmic_gflop_per_image": round(gflop, 1),
+                       **({"replica_drift": drift, "exchange_buckets": len(state["red"].buckets),
+                           "buckets_issued_before_backward_ended": state["red"].early} if use_dist else {})},
             "step_mfma_frac": round(ips * gflop / 1e3 / (world * PEAK_BF16_TFLOPS), 4),
         }
         if timer is not None:

@@ -100,10 +100,12 @@ typedef struct mde_conv_desc {
  * into the conv epilogue; feed it to mde_bn_finalize as `part`. */
 int mde_conv_gemm(const mde_conv_desc* d, const void* in, const void* w, void* out,
                   float* stats, void* stream);
-/* The same launch with a fused epilogue: out = act(bf16(result) + bias + residual) -- a conv bias (Conv2d(bias=True):
- * MiDaS.py:163-229, VNL.py:331-350, Dorn.py:58-80), an activation (act: 0 none, 1 ReLU, 2 ELU (Bts.py:69-80), 3 sigmoid) and a
- * residual sum (ResidualConvUnit, FTB_block) without the extra pass over the conv's output.  The result is rounded to bf16
- * BEFORE bias / residual / activation, so the output equals conv + mde_pw_fwd bit for bit.  bias: fp32 [ncols] or NULL;
+/* The same launch with a fused epilogue -- a conv bias (Conv2d(bias=True): MiDaS.py:163-229, VNL.py:331-350, Dorn.py:58-80), an
+ * activation (act: 0 none, 1 ReLU, 2 ELU (Bts.py:69-80), 3 sigmoid) and a residual sum (ResidualConvUnit, FTB_block) without
+ * the extra pass over the conv's output.  The bias joins the fp32 accumulator, so the sum is rounded to bf16 ONCE:
+ * out = bf16(act(result + bias)) without a residual, out = bf16(act(bf16(result + bias) + residual)) with one.  (A rounding
+ * of the bare result before a per-channel constant is added and the sum rounded again has an error that depends on the
+ * constant only, the same for every pixel of the channel: a mean over pixels keeps it.)  bias: fp32 [ncols] or NULL;
  * residual: bf16, laid out and addressed exactly like `out` (same N, OH, OW, ld_out), or NULL; d->accumulate must be 0. */
 int mde_conv_gemm_act(const mde_conv_desc* d, const void* in, const void* w, void* out, const float* bias,
                       const void* residual, int act, void* stream);
@@ -635,6 +637,14 @@ int mde_nchw_to_nhwc_bf16(const float* src, void* dst, int N, int C, int H, int 
  * in_channels != 3), whose 7x7/2 conv runs on the GEMM kernel with the input channels padded to 64. */
 int mde_nchw_to_nhwc_bf16_pad(const float* src, void* dst, int N, int C, int H, int W, int Cpad, void* stream);
 int mde_nhwc_bf16_to_nchw(const void* src, float* dst, int N, int C, int H, int W, void* stream);
+/* Eval-mode operands of an image convolution on the GEMM kernel (densenet161's conv0, Bts.py:289; DORN's, Eigen's image convs):
+ * 16 channel slots per pixel / per (output channel, tap) -- image [xh | xl | xh | 0 ...], weight [wh | wh | wl | 0 ...] with
+ * h = (bf16)v, l = (bf16)(v - h) -- so ONE contraction over the slots is x w to 2^-16 relative: the fp32 image (as the
+ * reference's forward sees it) against the two-term weight shadow (mde_pack_split_batch), in as many launches as the training
+ * step's.  src image fp32 NCHW with C <= 5 channels -> dst bf16 [N][H][W][16]; src weight fp32 [rows = O * T][Cp] (C real
+ * channels) -> dst bf16 [rows][16]. */
+int mde_nchw_to_nhwc_split16(const float* src, void* dst, int N, int C, int H, int W, void* stream);
+int mde_stem_weight_split16(const float* src, void* dst, int64_t rows, int Cp, int C, void* stream);
 
 #ifdef __cplusplus
 }

@@ -189,6 +189,8 @@ SIGNATURES = {
     "mde_nchw_to_nhwc_bf16": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "mde_nchw_to_nhwc_bf16_pad": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "mde_nhwc_bf16_to_nchw": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "mde_nchw_to_nhwc_split16": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "mde_stem_weight_split16": (_I, [_P, _P, _L, _I, _I, _P]),
 }
 
 _lib = None

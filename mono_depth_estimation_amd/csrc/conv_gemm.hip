@@ -77,8 +77,14 @@ struct KArgs {
     int32_t vec_ok;   // 16-byte stores allowed
     int32_t col_fastest;  // tile order: 1 = all column tiles of a pixel tile are neighbours (activation tile reused from L2)
     int32_t det;          // deterministic mode: BatchNorm partial sums leave the workgroup as integer atomics (mde_common.h)
-    // fused epilogue (mde_conv_gemm_act): out = act(bf16(result) + bias + residual) -- the pass a biased / activated conv
-    // would otherwise make over its own output (pointwise.hip pw_fwd_k, whose arithmetic this repeats bit for bit)
+    // fused epilogue (mde_conv_gemm_act): the pass a biased / activated conv would otherwise make over its own output
+    // (pointwise.hip pw_fwd_k).  The bias joins the fp32 accumulator BEFORE the one rounding to the storage type; without a
+    // residual the activation does too: out = bf16(act(result + bias)).  With one: out = bf16(act(bf16(result + bias) + residual)).
+    // (Round 3 rounded the bare result first, as the separate pass sees it.  bf16(result) + bias, rounded again, is a
+    // DOUBLE rounding across a per-channel CONSTANT: where |result + bias| is a binade above |result| the second grid is
+    // coarser and the error of the pair depends on (bias mod ulp) only -- the same for every pixel of the channel, up to half
+    // an ulp, and it does not average out of a mean over pixels: MiDaS' biased decoder convs shifted the eval output's mean by
+    // 8e-5 relative on the CPU oracle's emulation of that order.)
     const float* bias;    // [ncols] or nullptr
     const void* resid;    // bf16, addressed exactly like `out` (same offsets), or nullptr
     int32_t act;          // 0 none, 1 ReLU, 2 ELU, 3 sigmoid
@@ -998,6 +1004,27 @@ __global__ __launch_bounds__(NT, HALO ? (NT == 512 ? 4 : BC <= 64 ? 5 : 4)
             }
         }
     }
+    if constexpr (RED == 0) {
+        if (a.bias || (a.act && !a.resid)) {
+            // fused epilogue, on the fp32 accumulators: + bias (the lane's 4 channels per column fragment), and the activation
+            // where nothing else joins before it
+            const int ch0 = n0 + wc * (CF * 16) + (lane >> 4) * 4;
+            const int actn = a.resid ? 0 : a.act;
+#pragma unroll
+            for (int i = 0; i < CF; ++i) {
+                float b4[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int c = ch0 + i * 16 + e;
+                    b4[e] = (a.bias && c < d.ncols) ? a.bias[c] : 0.f;
+                }
+#pragma unroll
+                for (int j = 0; j < PF; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[i][j][e] = epi_act(acc[i][j][e] + b4[e], actn);
+            }
+        }
+    }
     constexpr int CPR = BC / 8;          // 16-byte chunks per pixel row
     constexpr int RPP = NT / CPR;        // rows per store pass
     static_assert(RPP >= 1 && RPP * CPR == NT, "store tiling");
@@ -1075,11 +1102,6 @@ __global__ __launch_bounds__(NT, HALO ? (NT == 512 ? 4 : BC <= 64 ? 5 : 4)
                     const bf16_t* resp = reinterpret_cast<const bf16_t*>(a.resid);
                     const bf16_t* redx = reinterpret_cast<const bf16_t*>(a.red_x);
                     const bf16_t* redx2 = reinterpret_cast<const bf16_t*>(a.red_x2);
-                    float bv[8];
-                    if constexpr (ACC == 2) {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) bv[e] = a.bias ? a.bias[col + e] : 0.f;
-                    }
 #pragma unroll 1
                     for (int rb = 0; rb < ROWS_PT; rb += RBL) {
                         int oo[RBL];
@@ -1118,7 +1140,7 @@ __global__ __launch_bounds__(NT, HALO ? (NT == 512 ? 4 : BC <= 64 ? 5 : 4)
                             if constexpr (ACC == 2) {
                                 const bf16x8_t rv = __builtin_bit_cast(bf16x8_t, oldv[q]);
 #pragma unroll
-                                for (int e = 0; e < 8; ++e) v[e] = (bf16_t)epi_act((float)v[e] + bv[e] + (resp ? (float)rv[e] : 0.f), a.act);
+                                for (int e = 0; e < 8; ++e) v[e] = (bf16_t)epi_act((float)v[e] + (float)rv[e], a.act);     // (the bias is in already)
                             }
                             if (oo[q] >= 0) *reinterpret_cast<bf16x8_t*>(outp + (size_t)oo[q] + col) = v;
                             if constexpr (RM != 0) {
@@ -1170,8 +1192,8 @@ __global__ __launch_bounds__(NT, HALO ? (NT == 512 ? 4 : BC <= 64 ? 5 : 4)
                         if (d.accumulate) store_rows(T1{}, T3{}); else store_rows(T0{}, T3{});
                     }
                 } else {
-                    if (a.bias || a.resid || a.act)
-                        store_rows(T2{}, T0{});
+                    if (a.resid)
+                        store_rows(T2{}, T0{});                              // (without a residual the epilogue ran on the accumulators)
                     else if (d.accumulate)
                         store_rows(T1{}, T0{});
                     else
@@ -1184,12 +1206,11 @@ __global__ __launch_bounds__(NT, HALO ? (NT == 512 ? 4 : BC <= 64 ? 5 : 4)
                     const bf16x8_t v = *reinterpret_cast<const bf16x8_t*>(smem + r * ROWB + chunk * 16);
                     bf16_t* dst = outp + (size_t)oo + col;
                     const int nv = min(8, d.ncols - col);
-                    const bool fused = a.bias || a.resid || a.act;
+                    const bf16_t* resp = reinterpret_cast<const bf16_t*>(a.resid);
                     for (int e = 0; e < nv; ++e) {
                         float x = (float)v[e];
-                        if (fused) {
-                            const bf16_t* resp = reinterpret_cast<const bf16_t*>(a.resid);
-                            x = epi_act(x + (a.bias ? a.bias[col + e] : 0.f) + (resp ? (float)resp[(size_t)oo + col + e] : 0.f), a.act);
+                        if (resp) {
+                            x = epi_act(x + (float)resp[(size_t)oo + col + e], a.act);
                         } else if (d.accumulate) {
                             x += (float)dst[e];
                         }

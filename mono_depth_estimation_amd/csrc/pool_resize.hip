@@ -289,6 +289,55 @@ int grid_for(int64_t total) {
     return (int)(nb > 256 * 16 ? 256 * 16 : (nb < 1 ? 1 : nb));
 }
 
+// The eval-mode image / stem-weight operands of an image conv on the GEMM kernel (graph.ImageStem): 16 channel slots
+//   image  [xh | xl | xh | 0 ...]   xh = (bf16)x, xl = (bf16)(x - xh)          (C <= 5 image channels, 3 C <= 16)
+//   weight [wh | wh | wl | 0 ...]   wh = (bf16)w, wl = (bf16)(w - wh)
+// so one contraction over the 16 slots is xh wh + xl wh + xh wl = x w up to 2^-16 relative: the fp32 image against the
+// two-term weight shadow, in the launches the training step makes (a tap list doubled instead would split a 7x7 into four
+// accumulating launches whose partial sums each pass through a 16-bit rounding).
+__global__ __launch_bounds__(NT) void nchw2nhwc_split16_k(const float* __restrict__ src, bf16_t* __restrict__ dst, int N, int C, int H, int W) {
+    const int64_t HW = (int64_t)H * W, total = (int64_t)N * HW;
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
+        const int64_t n = i / HW, px = i - n * HW;
+        bf16_t o[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[e] = (bf16_t)0.f;
+        for (int c = 0; c < C; ++c) {
+            const float v = src[(n * C + c) * HW + px];
+            const bf16_t h = (bf16_t)v;
+            o[c] = h;
+            o[C + c] = (bf16_t)(v - (float)h);
+            o[2 * C + c] = h;
+        }
+        bf16x8_t a, b;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { a[e] = o[e]; b[e] = o[8 + e]; }
+        *reinterpret_cast<bf16x8_t*>(dst + i * 16) = a;
+        *reinterpret_cast<bf16x8_t*>(dst + i * 16 + 8) = b;
+    }
+}
+
+// src fp32 [rows][Cp] (rows = O * T of a stem weight stored with its C image channels padded to Cp) -> dst bf16 [rows][16]
+__global__ __launch_bounds__(NT) void stem_weight_split16_k(const float* __restrict__ src, bf16_t* __restrict__ dst, int64_t rows, int Cp, int C) {
+    for (int64_t r = (int64_t)blockIdx.x * NT + threadIdx.x; r < rows; r += (int64_t)gridDim.x * NT) {
+        bf16_t o[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[e] = (bf16_t)0.f;
+        for (int c = 0; c < C; ++c) {
+            const float v = src[r * Cp + c];
+            const bf16_t h = (bf16_t)v;
+            o[c] = h;
+            o[C + c] = h;
+            o[2 * C + c] = (bf16_t)(v - (float)h);
+        }
+        bf16x8_t a, b;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { a[e] = o[e]; b[e] = o[8 + e]; }
+        *reinterpret_cast<bf16x8_t*>(dst + r * 16) = a;
+        *reinterpret_cast<bf16x8_t*>(dst + r * 16 + 8) = b;
+    }
+}
+
 }  // namespace
 
 // nn.PixelShuffle(2) on NHWC bf16 (reference FCRN.py:236,245 — the FasterUpProj decoder):
@@ -449,6 +498,20 @@ extern "C" int mde_nchw_to_nhwc_bf16_pad(const float* src, void* dst, int N, int
     MDE_REQUIRE(src && dst && N > 0 && C > 0 && H > 0 && W > 0 && Cpad >= C, "mde_nchw_to_nhwc_bf16_pad: bad argument");
     nchw2nhwc_pad_k<<<grid_for((int64_t)N * Cpad * H * W), NT, 0, (hipStream_t)stream>>>(src, (bf16_t*)dst, N, C, H, W, Cpad);
     MDE_LAUNCH_CHECK("nchw2nhwc_pad_k");
+    return MDE_OK;
+}
+
+extern "C" int mde_nchw_to_nhwc_split16(const float* src, void* dst, int N, int C, int H, int W, void* stream) {
+    MDE_REQUIRE(src && dst && N > 0 && C > 0 && 3 * C <= 16 && H > 0 && W > 0 && ((uintptr_t)dst % 16) == 0, "mde_nchw_to_nhwc_split16: bad argument (C=%d)", C);
+    nchw2nhwc_split16_k<<<grid_for((int64_t)N * H * W), NT, 0, (hipStream_t)stream>>>(src, (bf16_t*)dst, N, C, H, W);
+    MDE_LAUNCH_CHECK("nchw2nhwc_split16_k");
+    return MDE_OK;
+}
+
+extern "C" int mde_stem_weight_split16(const float* src, void* dst, int64_t rows, int Cp, int C, void* stream) {
+    MDE_REQUIRE(src && dst && rows > 0 && C > 0 && 3 * C <= 16 && Cp >= C && ((uintptr_t)dst % 16) == 0, "mde_stem_weight_split16: bad argument (C=%d)", C);
+    stem_weight_split16_k<<<grid_for(rows), NT, 0, (hipStream_t)stream>>>(src, (bf16_t*)dst, rows, Cp, C);
+    MDE_LAUNCH_CHECK("stem_weight_split16_k");
     return MDE_OK;
 }
 

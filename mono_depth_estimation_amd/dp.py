@@ -88,6 +88,7 @@ class FlatGradReducer:
             self.active = False
         self.buckets = make_buckets(flat.numel(), boundaries, target_bytes, flat.element_size())
         self.stream = torch.cuda.Stream() if flat.is_cuda else None
+        self.early = 0
         self.wire = {}                     # bucket start -> (wire buffer, shard) when the wire format differs / rs_ag
         if self.active and (self.wire_dtype is not None or self.algo == "rs_ag"):
             dt = self.wire_dtype or flat.dtype
@@ -101,6 +102,14 @@ class FlatGradReducer:
 
     def reset(self):
         self.next, self.works = 0, []
+        self._early = 0
+
+    def begin(self, flat):
+        """A backward pass is about to accumulate into `flat` (same layout; the autograd path alternates between two flat
+        buffers: FlatStore.begin_autograd_backward)."""
+        assert flat.numel() == self.flat.numel() and flat.dtype == self.flat.dtype
+        self.flat = flat
+        self.reset()
 
     def _exchange(self, start, end):
         """Sum one bucket over the ranks (runs on the exchange stream when there is one)."""
@@ -140,10 +149,12 @@ class FlatGradReducer:
         while self.next < len(self.buckets) and self.buckets[self.next][0] >= offset:
             self._launch(*self.buckets[self.next])
             self.next += 1
+            self._early += int(offset > 0)         # issued while backward was still running (diagnostics: `early`)
 
     def finish(self):
         if self.active:
             self.ready(0)
+            self.early = self._early               # buckets of the pass just joined that went out before backward ended
             if self.stream is not None:
                 with torch.cuda.stream(self.stream):
                     for w in self.works:

@@ -292,6 +292,7 @@ class FlatStore:
         self.split_eval = os.environ.get("MDE_EVAL_SPLIT", "1") != "0"
         self.W2 = self.W2D = None
         self._split_jobs, self._split_epoch, self.shadow_epoch = None, -1, 0
+        self.grad_reducer = None          # module path: a dp.FlatGradReducer fed by backward (TapeModule.set_grad_reducer)
         self._flatten_parameters()
         self.deterministic, self._det_scratch = False, None
         if os.environ.get("MDE_DETERMINISTIC", "0") == "1":
@@ -754,13 +755,16 @@ class EngineCore:
         self.m, self.store, self.N, self.H, self.W, self.dev = module, store, N, H, W, store.dev
         self.P, self.G, self.B, self.Pb = store.P, store.G, store.B, store.Pb
         self.p_off, self.b_off, self.params = store.p_off, store.b_off, store.params
-        self.cus = torch.cuda.get_device_properties(self.dev).multi_processor_count
+        # (a plan can be BUILT over a CPU store -- the multi-process CPU tests walk real tapes with stub kernels -- but not run:
+        #  every launch needs the GPU)
+        on_gpu = torch.device(self.dev).type == "cuda"
+        self.cus = torch.cuda.get_device_properties(self.dev).multi_processor_count if on_gpu else 256
         # The weight-gradient GEMMs run on a second stream beside the input-gradient / BatchNorm chain (MDE_WGRAD_STREAM=0: one
         # stream).  With the round-1 kernels (64-128 KB of LDS per workgroup: nothing else fits beside them on a CU) this bought
         # 1 %; with the single-buffer tiles (36 KB) the two streams' workgroups share the CUs and the HBM-bound BatchNorm passes
         # overlap the MFMA-bound weight gradients: 999 -> 1 048 images/s.  Per-kernel durations then include the overlap, so
         # while ops.TIMER is recording (bench.py's roofline leg: one instrumented step) everything runs on ONE stream.
-        self.side = torch.cuda.Stream(self.dev) if os.environ.get("MDE_WGRAD_STREAM", "1") == "1" else None
+        self.side = torch.cuda.Stream(self.dev) if (on_gpu and os.environ.get("MDE_WGRAD_STREAM", "1") == "1") else None
         self.side_busy = False
         self.split = False            # this forward runs over the two-term eval operands (begin_forward)
 

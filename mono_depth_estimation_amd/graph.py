@@ -59,6 +59,15 @@ class Op:
         """Activations this op produces (their gradient flags are reset before a backward pass)."""
         return ()
 
+    def grad_ranges(self):
+        """[(begin, end)] element ranges of the flat gradient buffer this op's backward writes (TapeEngine.backward's
+        on_progress: a range is final once the last op that lists it has run)."""
+        return ()
+
+
+def _site_ranges(site):
+    return [(site.g_off, site.g_off + site.C), (site.b_off, site.b_off + site.C)]
+
 
 # The first backward of a plan records, per activation, the op that took its gradient LAST (every accumulating writer asks
 # _take for its flag; the few writers that do not are asserted first writers).  Where that op is a Conv reading the output of a
@@ -101,6 +110,9 @@ class Stem(Op):
 
     def acts(self):
         return (self.c, self.a, self.out)
+
+    def grad_ranges(self):
+        return [(self.w.off, self.w.off + self.w.n)] + _site_ranges(self.site)
 
     def fwd(self, train):
         s, c, a = self.site, self.c, self.a
@@ -195,6 +207,12 @@ class Conv(Op):
     def acts(self):
         return (self.out,) if self.own_out else ()
 
+    def grad_ranges(self):
+        r = [(self.conv.off, self.conv.off + self.conv.n)]
+        if self.f_bias is not None:
+            r.append((self.f_boff, self.f_boff + self.out.C))
+        return r
+
     def _chunks(self):
         return range(0, self.x.N, self.chunk)
 
@@ -268,6 +286,9 @@ class BN(Op):
     def acts(self):
         return (self.out,) if self.own_out else ()
 
+    def grad_ranges(self):
+        return _site_ranges(self.site) + (_site_ranges(self.res_site) if self.res_site is not None else [])
+
     def fwd(self, train):
         s, c, o = self.site, self.c, self.out
         s.finalize(c.M, train)
@@ -328,6 +349,9 @@ class Pw(Op):
 
     def acts(self):
         return (self.out,) if self.own_out else ()
+
+    def grad_ranges(self):
+        return [(self.b_off, self.b_off + self.x.C)] if self.bias is not None else []
 
     def fwd(self, train):
         x, r, o = self.x, self.r, self.out
@@ -439,6 +463,9 @@ class SoftmaxHead(Op):
         self.outputs = (self.logit, self.prob)
         self.douts = [None, None]
 
+    def grad_ranges(self):
+        return [(self.b_off, self.b_off + self.C)]
+
     def fwd(self, train):
         x = self.x
         ops.softmax_head_fwd(x.t, x.ld, self.bias, self.logit, self.prob, x.N, x.H * x.W, self.C)
@@ -461,6 +488,9 @@ class ToNCHW(Op):
         self.y = torch.empty(x.N, C, x.H, x.W, device=eng.dev)
         self.outputs = (self.y,)
         self.douts = [None]
+
+    def grad_ranges(self):
+        return [(self.b_off, self.b_off + self.C)] if self.bias is not None else []
 
     def fwd(self, train):
         x = self.x
@@ -521,16 +551,36 @@ class ImageStem(Op):
         taps = [(i - pd, j - pd, i * k + j) for i in range(k) for j in range(k)]
         ks = eng._ksplit(N * H2 * W2, O, Cp, min(32, k * k))
         self.fd, self.wd = [], []
+        self.fd16 = []          # eval mode: the same launches over the 16-slot hi / lo operands (mde_nchw_to_nhwc_split16)
         for t0 in range(0, k * k, 32):
             part = taps[t0:t0 + 32]
             self.fd.append(ops.conv_desc(N, H, W, Cp, Cp, self.xin.nbytes, H2, W2, st, st, part, k * k, H2, W2, O, ncols=O, accumulate=t0 > 0))
+            self.fd16.append(ops.conv_desc(N, H, W, 16, 16, N * H * W * 16 * 2, H2, W2, st, st, part, k * k, H2, W2, O, ncols=O, accumulate=t0 > 0))
             self.wd.append(ops.wgrad_desc(N, H2, W2, O, O, self.out.nbytes, H, W, Cp, Cp, self.xin.nbytes, st, st, part, k * k, False, ks))
+        self.cin, self.ntaps = conv.in_channels, k * k
+        self.w16 = None
         self.x = None
 
     def acts(self):
         return (self.out,)
 
+    def grad_ranges(self):
+        return [(self.w.off, self.w.off + self.w.n)]
+
     def fwd(self, train):
+        if self.eng.split and 3 * self.cin <= 16:
+            # eval: the fp32 image (hi + lo) against the two-term weight shadow, one contraction over 16 channel slots
+            xin = self.xin
+            if getattr(xin, "split16", None) is None:
+                xin.split16 = torch.empty(xin.N, xin.H, xin.W, 16, dtype=ops.ACT_DTYPE, device=self.eng.dev)
+            if self.owns_xin:
+                ops.nchw_to_nhwc_split16(self.x, xin.split16)
+            if self.w16 is None:
+                self.w16 = torch.empty(self.w.O * self.ntaps * 16, dtype=ops.ACT_DTYPE, device=self.eng.dev)
+            ops.stem_weight_split16(self.w.w32, self.w16, self.w.O * self.ntaps, self.w.I, self.cin)
+            for d in self.fd16:
+                ops.conv_gemm(d, xin.split16, self.w16, self.out.t)
+            return
         if self.owns_xin:
             ops.nchw_to_nhwc_bf16_pad(self.x, self.xin.t, self.xin.C)
         for d in self.fd:
@@ -741,6 +791,9 @@ class PrefixBN(Op):
     def acts(self):
         return (self.out,) if self.own_out else ()
 
+    def grad_ranges(self):
+        return [r for c in self.chunks for r in _site_ranges(c[0])]
+
     def fwd(self, train):
         for s, xs, os_, mean, var in self.chunks:
             s.finalize_moments(mean, var, xs.M, train)
@@ -935,6 +988,9 @@ class ConvT(Op):
     def acts(self):
         return (self.out,)
 
+    def grad_ranges(self):
+        return [(self.w.off, self.w.off + self.w.n)]
+
     def fwd(self, train):
         if self.fzero:
             self.out.t.zero_()
@@ -989,6 +1045,9 @@ class WeightedPool(Op):
         self.scale = torch.empty(x.N, device=eng.dev)
         self.dscale = dscale
 
+    def grad_ranges(self):
+        return [(self.w_off, self.w_off + self.x.H * self.x.W), (self.b_off, self.b_off + 1)]
+
     def fwd(self, train):
         x = self.x
         ops.weighted_pool_fwd(x.t, x.ld, self.w, self.b, self.pre, self.scale, x.N, x.H * x.W, x.C)
@@ -1032,6 +1091,7 @@ class TapeEngine(EngineCore):
         super().__init__(module, store, N, H, W)
         self.tape, self.heads, self.stem, self._bufs = [], [], None, []
         self._sums_planned = False
+        self._thr = None
         self._plan()
         self._acts = [a for op in self.tape for a in op.acts()] + self._bufs
 
@@ -1102,10 +1162,44 @@ class TapeEngine(EngineCore):
             self.store.nbt += 1
         return tuple(t for h in self.heads for t in h.outputs)
 
-    def backward(self, douts):
+    def progress_thresholds(self):
+        """thr[i]: once the i-th op of the REVERSED tape has run, every element >= thr[i] of the flat gradient buffer is
+        final -- no op that has not run yet writes at or above it (Op.grad_ranges; parameters no op writes, unused or frozen
+        ones, are final from the start).  The flat order is the module's parameter order, encoder first, so a backward pass
+        completes the buffer from its tail and the thresholds fall towards 0."""
+        if self._thr is None:
+            rev = list(reversed(self.tape))
+            last = {}
+            for i, op in enumerate(rev):
+                for r in op.grad_ranges():
+                    last[r] = i                                    # the last position that writes r
+            ends_at = {}
+            for (b, e), i in last.items():
+                ends_at[i] = max(ends_at.get(i, 0), e)
+            thr, pending = [0] * len(rev), 0
+            for i in range(len(rev) - 1, -1, -1):                    # pending(i) = ranges whose last writer comes after i
+                thr[i] = pending
+                pending = max(pending, ends_at.get(i, 0))
+            self._thr = thr
+        return self._thr
+
+    def backward(self, douts, on_progress=None, marks=None, consumer_waits_side=False):
         """douts: one fp32 gradient (or None) per output tensor, in the order forward returned them.  Adds the parameter
-        gradients into store.Gcur."""
+        gradients into store.Gcur.
+        on_progress(offset), if given, is called as backward walks the tape whenever every gradient element >= offset of the
+        flat buffer has become final (progress_thresholds) -- dp.FlatGradReducer.ready: the bucket's all-reduce goes out on its
+        own stream while the rest of backward runs, as engine.FCRNEngine.backward does.  marks: descending offsets the consumer
+        cares about (its bucket starts): the callback then fires only when a mark is passed.  consumer_waits_side: the
+        consumer orders itself behind the weight-gradient stream (FlatGradReducer(extra_streams=[eng.side])); otherwise that
+        stream is joined into the current one before every call."""
         self.store.det_begin()
+        if self.store.deterministic and on_progress is not None:
+            final_cb, on_progress = on_progress, None            # the gradients reach the buffer only with the final flush
+        else:
+            final_cb = on_progress
+        thr = self.progress_thresholds() if on_progress is not None else None
+        marks = sorted(set(marks), reverse=True) if marks is not None else None
+        mi, reported = 0, None
         for a in self._acts:
             a.gw = False
         for a in self._bufs:           # concatenation targets: consumers may cover only part of the channels, so every
@@ -1122,15 +1216,27 @@ class TapeEngine(EngineCore):
         if tracing:
             _TRACE = {}
         try:
-            for op in reversed(self.tape):
+            for i, op in enumerate(reversed(self.tape)):
                 _CUR_OP = op
                 op.bwd()
+                if thr is not None and thr[i] != reported and thr[i] > 0:
+                    if marks is not None:
+                        if mi >= len(marks) or thr[i] > marks[mi]:
+                            continue
+                        while mi < len(marks) and marks[mi] >= thr[i]:
+                            mi += 1
+                    if not consumer_waits_side:
+                        self.join_side()
+                    on_progress(thr[i])
+                    reported = thr[i]
         finally:
             trace, _TRACE, _CUR_OP = _TRACE, None, None
         if tracing:
             self._plan_fused_sums(trace)
         self.join_side()
         self.store.det_end()
+        if final_cb is not None:
+            final_cb(0)
 
     def _plan_fused_sums(self, last_taker):
         """After the first backward: every BatchNorm op whose output gradient is completed by a convolution's input-gradient
@@ -1179,7 +1285,8 @@ class TapeEngine(EngineCore):
             conv.first_writer = op.skip_dres = on
 
     def grad_boundaries(self):
-        return [0, self.store.encoder_numel]
+        """Flat-gradient offsets at which conv weights start: where dp.FlatGradReducer may cut its buckets."""
+        return self.store.layer_boundaries()
 
 
 class _TapeFunction(torch.autograd.Function):
@@ -1206,8 +1313,15 @@ class _TapeFunction(torch.autograd.Function):
                                "forward of the same input shape (forward #%d, latest #%d)." % (ctx.serial, eng.forward_serial))
         st = eng.store
         buf = st.begin_autograd_backward()
+        red = st.grad_reducer
         try:
-            eng.backward(douts)
+            if red is not None:
+                # the gradient exchange overlapped with this backward (TapeModule.set_grad_reducer): buckets go out on the
+                # reducer's stream as the tape passes their first element; the caller joins with reducer.finish()
+                red.begin(buf)
+                eng.backward(douts, on_progress=red.ready, marks=[b for b, _ in red.buckets], consumer_waits_side=eng.side in red.extra_streams)
+            else:
+                eng.backward(douts)
         finally:
             st.Gcur = st.G
         grads = tuple(st.grad_view(p, buf) if need else None for p, need in zip(eng.params, ctx.needs_input_grad[3:]))
@@ -1262,6 +1376,16 @@ class TapeModule(torch.nn.Module):
             state["_engines"] = {}
             return state
         return copy.deepcopy(self).__dict__
+
+    def set_grad_reducer(self, reducer):
+        """Overlap the data-parallel gradient exchange with backward on the nn.Module path (what Lightning's DDP cannot do
+        for a network that is ONE autograd node: its bucket hooks all fire when the node returns).  `reducer`: a
+        dp.FlatGradReducer over this module's flat gradient buffer (`module._store.G`, boundaries `_store.layer_boundaries()`);
+        `loss.backward()` then issues each bucket's all-reduce as soon as the tape has passed the bucket's first element, and
+        the caller joins with `reducer.finish()` before the optimiser step.  None switches it off."""
+        if self._store is None:
+            raise RuntimeError("set_grad_reducer: move the module to its GPU first (the flat gradient buffer lives there)")
+        self._store.grad_reducer = reducer
 
     def _engine(self, x):
         if x.dim() != 4 or x.shape[1] != 3:

@@ -308,8 +308,13 @@ class _FCRNFunction(torch.autograd.Function):
                 "pass." % (ctx.serial, eng.forward_serial))
         st = eng.store
         buf = st.begin_autograd_backward()
+        red = st.grad_reducer
         try:
-            eng.backward(dy.contiguous())
+            if red is not None:                  # the gradient exchange overlapped with this backward (ResNet.set_grad_reducer)
+                red.begin(buf)
+                eng.backward(dy.contiguous(), red.ready, consumer_waits_side=eng.side in red.extra_streams)
+            else:
+                eng.backward(dy.contiguous())
         finally:
             st.Gcur = st.G                       # the direct (non-autograd) path always accumulates into G
         grads = tuple(st.grad_view(p, buf) if need else None for p, need in zip(eng.params, ctx.needs_input_grad[3:]))
@@ -413,6 +418,13 @@ class ResNet(nn.Module):
             if dev.type == "cuda":
                 self._store = ParamStore(self, dev)
         return out
+
+    def set_grad_reducer(self, reducer):
+        """Overlap the data-parallel gradient exchange with backward on the nn.Module path: see graph.TapeModule.set_grad_reducer
+        (a dp.FlatGradReducer over `self._store.G` with `engine.grad_boundaries()`; join with `reducer.finish()`)."""
+        if self._store is None:
+            raise RuntimeError("set_grad_reducer: move the module to its GPU first (the flat gradient buffer lives there)")
+        self._store.grad_reducer = reducer
 
     def _engine(self, x):
         if x.dim() != 4 or x.shape[1] != self.conv1.in_channels:

@@ -546,6 +546,15 @@ def nchw_to_nhwc_bf16_pad(src, dst, Cpad):
     check(_lib.load().mde_nchw_to_nhwc_bf16_pad(_p(src), _p(dst), N, C_, H, W, Cpad, _stream()), "mde_nchw_to_nhwc_bf16_pad")
 
 
+def nchw_to_nhwc_split16(src, dst):
+    N, C_, H, W = src.shape
+    check(_lib.load().mde_nchw_to_nhwc_split16(_p(src), _p(dst), N, C_, H, W, _stream()), "mde_nchw_to_nhwc_split16")
+
+
+def stem_weight_split16(src, dst, rows, Cp, C_):
+    check(_lib.load().mde_stem_weight_split16(_p(src), _p(dst), rows, Cp, C_, _stream()), "mde_stem_weight_split16")
+
+
 def nhwc_bf16_to_nchw(src, dst):
     N, C_, H, W = dst.shape
     check(_lib.load().mde_nhwc_bf16_to_nchw(_p(src), _p(dst), N, C_, H, W, _stream()), "mde_nhwc_bf16_to_nchw")

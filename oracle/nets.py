@@ -23,10 +23,12 @@ class Net:
         self.P, self.train, self.q, self.momentum = P, train, (q or (lambda t: t)), momentum
 
     def conv(self, x, key, stride=1, pad=0, dil=1, groups=1, bias=True):
-        """(bf16 emulation: the conv result is stored once WITHOUT its bias; the bias joins the following pass.)"""
-        y = self.q(F.conv2d(x, self.P[key + ".weight"], None, stride, pad, dil, groups))
+        """(16-bit emulation: the conv result is stored once, WITH its bias -- the HIP path adds it to the fp32 accumulator in
+        the conv launch's epilogue, include/mde_hip.h: mde_conv_gemm_act; a conv bias in front of a BatchNorm is dropped by
+        the caller's plan and cancels here.)"""
         b = self.P.get(key + ".bias") if bias else None
-        return y if b is None else y + b.view(1, -1, 1, 1)
+        y = F.conv2d(x, self.P[key + ".weight"], None, stride, pad, dil, groups)
+        return self.q(y if b is None else y + b.view(1, -1, 1, 1))
 
     def bn(self, x, key, momentum=0.1, eps=1e-5):
         P = self.P
@@ -61,6 +63,14 @@ def _vnl_bottleneck(n, x, k, stride, dil):
 
 def bf16_round(t):
     return t.to(torch.bfloat16).to(torch.float32)
+
+
+def rounding_draw(k, to=torch.bfloat16):
+    """The k-th REALISATION of storage rounding: round on the grid scaled by 1 + k 2^-12 (k = 0: the plain grid).  One
+    realisation of the rounding noise says little about a mean over pixels (the noise of coarse feature maps is coherent over
+    whole image regions): tests and tools/rounding_draws.py look at several."""
+    s = 1.0 + k * 2.0 ** -12
+    return lambda t: (t * s).to(to).to(torch.float32) / s
 
 
 def fp16_round(t):

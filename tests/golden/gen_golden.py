@@ -20,6 +20,8 @@ What is the reference's own arithmetic here, and what is not:
     them is called.
 """
 import os
+import statistics  # noqa: F401  (the STDLIB module, bound before /root/reference -- which holds a statistics.py of its own, a Blender
+#                                   script -- goes on sys.path: torch.optim pulls torch._inductor in lazily, which imports it)
 import sys
 import types
 
@@ -614,10 +616,11 @@ def gen_bts_resnet(criteria):
     import torchvision.models as tvm
     from network import Bts
     from oracle import trunks
-    saved = {k: tvm.__dict__.get(k) for k in ("resnet50", "resnext50_32x4d")}
+    saved = {k: tvm.__dict__.get(k) for k in ("resnet50", "resnext50_32x4d", "resnet101", "resnext101_32x8d")}
     tvm.resnet50, tvm.resnext50_32x4d = trunks.resnet50_full, trunks.resnext50_32x4d_full
+    tvm.resnet101, tvm.resnext101_32x8d = trunks.resnet101_full, trunks.resnext101_32x8d_full
     try:
-        for version, seed in (("resnet50_bts", 57), ("resnext50_bts", 59)):
+        for version, seed in (("resnet50_bts", 57), ("resnext50_bts", 59), ("resnet101_bts", 63), ("resnext101_bts", 65)):
             torch.manual_seed(0)
             ref = Bts.BtsModel(bts_size=512, max_depth=10, out_channels=1, encoder_version=version)
             W.bts_resnet_fixture_state(ref, seed)
@@ -675,26 +678,58 @@ def gen_bts_image_residuals(criteria):
 def gen_bts_conditioned(criteria, metrics):
     """C2 on a WELL-CONDITIONED state (oracle/weights.bts_conditioned_state: the north-star bound |dAbsRel| <= 1e-4 is only
     meaningful where the fp32 reference itself is stable under bf16 storage): the reference's own network/Bts.py, eval
-    outputs, the metrics of the final depth from the reference's metrics.py, the SILog of one train-mode forward."""
+    outputs and the metrics of the final depth from the reference's metrics.py on the 8-image eval batch
+    (weights.BTS_COND_BATCH; the five outputs are kept for its first two images), and the SILog of one train-mode forward on
+    the 2-image batch the convergence test trains on."""
     from network import Bts
+    H, Wd = BTS_SIZE
     torch.manual_seed(0)
     ref = Bts.BtsModel(bts_size=512, max_depth=10, out_channels=1, encoder_version="densenet161_bts")
     W.bts_conditioned_state(ref, 53)
-    H, Wd = BTS_SIZE
-    rgb, tgt = W.synthetic_batch(53, 2, H, Wd)
+    rgb, tgt = W.synthetic_batch(53, W.BTS_COND_BATCH, H, Wd)
     W.calibrate_running_stats(ref, rgb)
     ref.eval()
     with torch.no_grad():
         ys = ref(rgb)
-    out = {"eval_" + nme: _np(y) for nme, y in zip(("d8", "d4", "d2", "r1", "final"), ys)}
+    out = {"eval_" + nme: _np(y[:2]) for nme, y in zip(("d8", "d4", "d2", "r1", "final"), ys)}
     mc = metrics.MetricComputation(["absrel", "rmse", "delta1", "log10"])
     for n, v in zip(mc.names, mc.compute(ys[4], tgt * 10.0)):
         out["eval_" + n] = _np(v)
+    W.bts_conditioned_state(ref, 53)
+    rgb2, tgt2 = W.synthetic_batch(53, 2, H, Wd)
+    W.calibrate_running_stats(ref, rgb2)
     ref.train()
-    out["train_loss"] = _np(criteria.silog_loss(0.85)(ref(rgb)[4], tgt * 10.0))
+    out["train_loss"] = _np(criteria.silog_loss(0.85)(ref(rgb2)[4], tgt2 * 10.0))
     np.savez_compressed(os.path.join(HERE, "bts_cond.npz"), **out)
     print("bts_cond.npz: eval final range %.4f..%.4f, AbsRel %.6f, train SILog %.5f" % (
-        out["eval_final"].min(), out["eval_final"].max(), float(out["eval_absrel"]), float(out["train_loss"])))
+        float(ys[4].min()), float(ys[4].max()), float(out["eval_absrel"]), float(out["train_loss"])))
+
+
+def gen_bts_curve(criteria):
+    """Convergence parity pinned to the REFERENCE's own training run: network/Bts.py's BtsModel on the conditioned state,
+    20 torch.optim.AdamW steps as modules/bts.py:139-152 configures them (eps 1e-3, weight decay 1e-2 on the encoder / 0 on the
+    decoder, lr 1e-4) on one 2-image batch, criteria.silog_loss(0.85) on the final depth: the loss of every step.  (Round 3's
+    test trained the CPU oracle beside the HIP path at test time: 129 s of the GPU suite.)"""
+    from network import Bts
+    torch.manual_seed(0)
+    ref = Bts.BtsModel(bts_size=512, max_depth=10, out_channels=1, encoder_version="densenet161_bts")
+    W.bts_conditioned_state(ref, 53)
+    rgb, tgt = W.synthetic_batch(53, 2, *BTS_SIZE)
+    W.calibrate_running_stats(ref, rgb)
+    ref.train()
+    enc = [p for n, p in ref.named_parameters() if n.startswith("encoder.") and p.requires_grad]
+    dec = [p for n, p in ref.named_parameters() if not n.startswith("encoder.") and p.requires_grad]
+    opt = torch.optim.AdamW([{"params": enc, "weight_decay": 1e-2}, {"params": dec, "weight_decay": 0.0}], lr=1e-4, eps=1e-3)
+    crit = criteria.silog_loss(0.85)
+    curve = []
+    for _ in range(20):
+        opt.zero_grad()
+        loss = crit(ref(rgb)[4], tgt * 10.0)
+        loss.backward()
+        opt.step()
+        curve.append(float(loss))
+    np.savez_compressed(os.path.join(HERE, "bts_curve.npz"), silog=np.array(curve, dtype=np.float64), lr=1e-4, steps=20)
+    print("bts_curve.npz: SILog %.5f -> %.5f over 20 AdamW steps" % (curve[0], curve[-1]))
 
 
 OFFGRID_FCRN_SEEDS = (7, 21, 22)
@@ -723,20 +758,25 @@ def gen_offgrid(criteria, metrics, FCRN):
     for seed in OFFGRID_FCRN_SEEDS:
         ref = FCRN.ResNet(layers=50, decoder="upproj", output_size=size, in_channels=3, out_channels=1, pretrained=False)
         W.off_grid(ref, W.fcrn_conditioned_state(ref, seed), seed)
-        rgb, tgt = W.synthetic_batch(seed, 2, *size)
+        rgb, tgt = W.synthetic_batch(seed, W.OFFGRID_FCRN_BATCH, *size)
         W.calibrate_running_stats(ref, rgb)
         ref.eval()
         with torch.no_grad():
-            record("fcrn_s%d" % seed, ref(rgb), tgt, seed == OFFGRID_FCRN_SEEDS[0])
+            y = ref(rgb)
+            record("fcrn_s%d" % seed, y, tgt, False)
+            if seed == OFFGRID_FCRN_SEEDS[0]:
+                out["fcrn_s%d_out" % seed] = _np(y[:2])
 
     torch.manual_seed(0)
     ref = Bts.BtsModel(bts_size=512, max_depth=10, out_channels=1, encoder_version="densenet161_bts")
     W.off_grid(ref, W.bts_conditioned_state(ref, 53), 53)
-    rgb, tgt = W.synthetic_batch(53, 2, *BTS_SIZE)
+    rgb, tgt = W.synthetic_batch(53, W.BTS_COND_BATCH, *BTS_SIZE)
     W.calibrate_running_stats(ref, rgb)
     ref.eval()
     with torch.no_grad():
-        record("bts", ref(rgb)[4], tgt * 10.0, True)
+        y = ref(rgb)[4]
+        record("bts", y, tgt * 10.0, False)
+        out["bts_out"] = _np(y[:2])
 
     if not hasattr(np, "int"):
         np.int = int
@@ -744,14 +784,15 @@ def gen_offgrid(criteria, metrics, FCRN):
     torch.manual_seed(0)
     ref = VNL.MetricDepthModel(params)
     W.off_grid(ref, W.vnl_fixture_state(ref, 41), 41)
-    rgb, tgt = W.synthetic_batch(41, 2, *VNL_SIZE)
+    rgb, tgt = W.synthetic_batch(41, W.OFFGRID_BATCH, *VNL_SIZE)
     W.calibrate_running_stats(ref, rgb)
     border = torch.tensor(params.depth_bin_border, dtype=torch.float32)
     ref.eval()
     with torch.no_grad():
         prob = ref(rgb)[1]
         depth = 10 ** (prob.permute(0, 2, 3, 1) * border).sum(3, dtype=torch.float32, keepdim=True).permute(0, 3, 1, 2)
-        record("vnl", depth, tgt, True)
+        record("vnl", depth, tgt, False)
+        out["vnl_out"] = _np(depth[:2])
 
     MiDaS._make_pretrained_resnext101_wsl = lambda use_pretrained: MiDaS._make_resnet_backbone(trunks.resnext101_32x8d())
     for tag, off in (("midas_ongrid", False), ("midas", True)):
@@ -760,11 +801,13 @@ def gen_offgrid(criteria, metrics, FCRN):
         sd = W.midas_conditioned_state(ref, 43)
         if off:
             W.off_grid(ref, sd, 43)
-        rgb, tgt = W.synthetic_batch(43, 2, *MIDAS_SIZE)
+        rgb, tgt = W.synthetic_batch(43, W.OFFGRID_BATCH, *MIDAS_SIZE)
         W.calibrate_running_stats(ref, rgb)
         ref.eval()
         with torch.no_grad():
-            record(tag, ref(rgb)[:, :1], tgt, True)
+            y = ref(rgb)[:, :1]
+            record(tag, y, tgt, False)
+            out[tag + "_out"] = _np(y[:2])
     np.savez_compressed(os.path.join(HERE, "offgrid.npz"), **out)
 
 
@@ -966,6 +1009,8 @@ def main():
         gen_bts_resnet(criteria)
     if want("bts_imgres"):
         gen_bts_image_residuals(criteria)
+    if want("bts_curve"):
+        gen_bts_curve(criteria)
     if want("offgrid"):
         gen_offgrid(criteria, metrics, FCRN)
     if want("eigen"):

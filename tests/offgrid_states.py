@@ -24,7 +24,7 @@ def _round_weights(P, wq):
 def fcrn(seed):
     ora = ofcrn.FCRNOracle(50, FCRN_SIZE, out_channels=1)
     W.off_grid(ora, W.fcrn_conditioned_state(ora, seed), seed)
-    rgb, tgt = W.synthetic_batch(seed, 2, *FCRN_SIZE)
+    rgb, tgt = W.synthetic_batch(seed, W.OFFGRID_FCRN_BATCH, *FCRN_SIZE)
     W.calibrate_running_stats(ora, rgb)
     ora.eval()
     sd = {k: v.clone() for k, v in ora.state_dict().items()}
@@ -40,9 +40,9 @@ def fcrn(seed):
     return sd, oracle, rgb, tgt, (lambda y: y)
 
 
-def _tape(net, state_fn, seed, forward, target_scale=1.0):
+def _tape(net, state_fn, seed, forward, target_scale=1.0, batch=2):
     sd = W.off_grid(None, state_fn(net, seed), seed)
-    rgb, tgt = W.synthetic_batch(seed, 2, *SIZE)
+    rgb, tgt = W.synthetic_batch(seed, batch, *SIZE)
     P = nets.leaf_state(sd)
     with torch.no_grad():
         forward(P, rgb, True, momentum=1.0)          # running statistics = this batch's (weights.calibrate_running_stats)
@@ -53,7 +53,7 @@ def bts():
     from mono_depth_estimation_amd.network import Bts
     torch.manual_seed(0)
     net = Bts.BtsModel(bts_size=512, max_depth=10, out_channels=1, encoder_version="densenet161_bts")
-    P, rgb, tgt = _tape(net, W.bts_conditioned_state, 53, nets.bts_forward, 10.0)
+    P, rgb, tgt = _tape(net, W.bts_conditioned_state, 53, nets.bts_forward, 10.0, batch=W.BTS_COND_BATCH)
 
     def oracle(q=None, wq=None):
         with torch.no_grad():
@@ -66,7 +66,7 @@ def vnl():
     params = nets.vnl_params()
     torch.manual_seed(0)
     net = VNL.MetricDepthModel(params)
-    P, rgb, tgt = _tape(net, W.vnl_fixture_state, 41, nets.vnl_forward)
+    P, rgb, tgt = _tape(net, W.vnl_fixture_state, 41, nets.vnl_forward, batch=W.OFFGRID_BATCH)
     border = torch.tensor(params.depth_bin_border, dtype=torch.float32)
 
     def oracle(q=None, wq=None):
@@ -83,7 +83,7 @@ def midas(offgrid=True):
     sd = state(net, 43)
     if offgrid:
         sd = W.off_grid(None, sd, 43)
-    rgb, tgt = W.synthetic_batch(43, 2, *SIZE)
+    rgb, tgt = W.synthetic_batch(43, W.OFFGRID_BATCH, *SIZE)
     P = nets.leaf_state(sd)
     with torch.no_grad():
         nets.midas_forward(P, rgb, True, momentum=1.0)

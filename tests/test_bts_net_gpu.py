@@ -157,12 +157,12 @@ def test_bts_train_step_against_oracle_and_reference(setup, golden):
     assert _rel(sd["decoder.bn4_2.running_var"].cpu(), torch.from_numpy(g["rv_bn4_2"])) < 5e-2
 
 
-def _conditioned():
+def _conditioned(batch=2):
     from mono_depth_estimation_amd.network import Bts
     torch.manual_seed(0)
     net = Bts.BtsModel(bts_size=512, max_depth=10, out_channels=1, encoder_version="densenet161_bts")
     sd = W.bts_conditioned_state(net, 53)
-    rgb, tgt = W.synthetic_batch(53, 2, *SIZE)
+    rgb, tgt = W.synthetic_batch(53, batch, *SIZE)
     P = nets.leaf_state(sd)
     with torch.no_grad():
         nets.bts_forward(P, rgb, True, momentum=1.0)          # running statistics = this batch's (as the golden's generator)
@@ -172,12 +172,13 @@ def _conditioned():
 def test_bts_conditioned_absrel_within_1e4_of_the_reference(golden):
     """The north-star bound on BTS: on a state where the fp32 reference itself is stable under bf16 storage
     (oracle/weights.bts_conditioned_state: the BatchNorms that read a dense block's concatenation damp the channels the
-    block produced, so rounding noise does not compound over the 78 layers; the oracle's own AbsRel moves by 2.4e-5 when
-    its activations are rounded) the HIP path's AbsRel of the final depth is within 1e-4 of the REFERENCE's
-    (tests/golden/bts_cond.npz, minted from network/Bts.py + metrics.py), 'rmse' / log10 / delta1 likewise, and each of the
-    five outputs within 1.5x the rounding noise."""
+    block produced, so rounding noise does not compound over the 78 layers, and the coarse levels enter the decoder damped;
+    8-image eval batch -- over realisations of the rounding the oracle's own AbsRel moves by +5e-5 +- 1e-5) the HIP path's
+    AbsRel of the final depth is within 1e-4 of the REFERENCE's (tests/golden/bts_cond.npz, minted from network/Bts.py +
+    metrics.py), log10 likewise, 'rmse' within 1e-4 sqrt(10) (it carries the square root of the depth unit; max_depth 10),
+    delta1 within a threshold count's noise, and each of the five outputs within 1.5x the rounding noise."""
     from mono_depth_estimation_amd import metrics
-    net, P, rgb, tgt = _conditioned()
+    net, P, rgb, tgt = _conditioned(W.BTS_COND_BATCH)
     g = golden("bts_cond")
     net.load_state_dict({k: v.clone() for k, v in P.items()})
     net = net.cuda().eval()
@@ -186,34 +187,36 @@ def test_bts_conditioned_absrel_within_1e4_of_the_reference(golden):
         yo = nets.bts_forward(P, rgb, False)
         yq = nets.bts_forward(P, rgb, False, q=nets.bf16_round)
     for nme, y, o, q in zip(NAMES, ys, yo, yq):
-        noise, e_ref = _rel(q, o), _rel(y.cpu(), torch.from_numpy(g["eval_" + nme]))
+        noise, e_ref = _rel(q, o), _rel(y.cpu()[:2], torch.from_numpy(g["eval_" + nme]))
         print("BTS conditioned eval %-5s: HIP vs reference %.3e; the oracle's rounding noise %.3e" % (nme, e_ref, noise))
-        assert _rel(o, torch.from_numpy(g["eval_" + nme])) < 1e-5, nme            # the oracle IS the reference on this state too
+        assert _rel(o[:2], torch.from_numpy(g["eval_" + nme])) < 1e-5, nme            # the oracle IS the reference on this state too
         assert e_ref < 1.5 * noise + 1e-3, nme
     names = ["absrel", "rmse", "delta1", "log10"]
     vals = metrics.MetricComputation(names).compute(ys[4], (tgt * 10.0).cuda())
     for n, v in zip(names, vals):
         print("BTS conditioned %-7s reference %.6f HIP %.6f (delta %.2e)" % (n, float(g["eval_" + n]), float(v), abs(float(v) - float(g["eval_" + n]))))
     assert abs(float(vals[0]) - float(g["eval_absrel"])) <= 1e-4
-    assert abs(float(vals[1]) - float(g["eval_rmse"])) <= 1e-4 and abs(float(vals[3]) - float(g["eval_log10"])) <= 1e-4
-    assert abs(float(vals[2]) - float(g["eval_delta1"])) <= 4e-3           # a threshold count: 12 K pixels, measured 1.9e-3
+    assert abs(float(vals[1]) - float(g["eval_rmse"])) <= 1e-4 * 10 ** 0.5 and abs(float(vals[3]) - float(g["eval_log10"])) <= 1e-4
+    assert abs(float(vals[2]) - float(g["eval_delta1"])) <= 2e-3           # a threshold count over 49 K pixels
 
 
-def test_bts_loss_curves_agree_with_the_oracle(golden):
+def test_bts_loss_curve_agrees_with_the_reference(golden):
     """Convergence parity for the DenseNet network (tests/test_tape_convergence_gpu.py does it for MiDaS,
     tests/test_fcrn_convergence_gpu.py for FCRN): 20 AdamW steps as modules/bts.py:139-152 configures them (eps 1e-3, weight
     decay 1e-2 on the encoder / 0 on the decoder) on one batch from the conditioned state -- the HIP path through its fused
-    flat-range step, the fp32 functional oracle through torch.optim.AdamW.  The SILog curves stay within 1 % of each other
-    at every step, both fall, and on the state the ORACLE reached the two eval paths agree in AbsRel to 2e-4."""
+    flat-range step against the curve the REFERENCE's own network/Bts.py traced under torch.optim.AdamW
+    (tests/golden/bts_curve.npz, minted by gen_golden.py::gen_bts_curve; round 3 trained the CPU oracle at test time: 129 s).
+    The SILog curves stay within 1 % of each other at every step and both fall.  Then the state the HIP path reached -- fp32
+    masters that are NOT on the 16-bit grid -- goes to the fp32 CPU oracle: on identical weights the two eval paths agree in
+    AbsRel to 1e-4 + what storage rounding of the activations alone does to the oracle (three realisations)."""
     from mono_depth_estimation_amd import criteria, metrics
     net, P0, rgb, tgt = _conditioned()
-    g = golden("bts_cond")
-    P = nets.leaf_state(P0, requires_grad=True)
-    net.load_state_dict({k: v.detach().clone() for k, v in P.items()})
+    g, curve = golden("bts_cond"), golden("bts_curve")
+    net.load_state_dict({k: v.detach().clone() for k, v in P0.items()})
     net = net.cuda().train()
     x, t = rgb.cuda(), (tgt * 10.0).cuda()
     crit = criteria.silog_loss(0.85)
-    steps, lr = 20, 1e-4
+    steps, lr = int(curve["steps"]), float(curve["lr"])
     lh = []
     for _ in range(steps):
         net.zero_grad(set_to_none=True)
@@ -221,46 +224,39 @@ def test_bts_loss_curves_agree_with_the_oracle(golden):
         loss.backward()
         net._store.adam_step(lr, lr, eps=1e-3, weight_decay=(1e-2, 0.0), decoupled=True)
         lh.append(float(loss))
-    enc = [v for k, v in P.items() if v.requires_grad and k.startswith("encoder.")]
-    dec = [v for k, v in P.items() if v.requires_grad and not k.startswith("encoder.")]
-    opt = torch.optim.AdamW([{"params": enc, "weight_decay": 1e-2}, {"params": dec, "weight_decay": 0.0}], lr=lr, eps=1e-3)
-    lo = []
-    for _ in range(steps):
-        opt.zero_grad()
-        loss = L.silog(nets.bts_forward(P, rgb, True)[4], tgt * 10.0, 0.85)
-        loss.backward()
-        opt.step()
-        lo.append(float(loss))
-    lh, lo = np.array(lh), np.array(lo)
-    assert abs(lo[0] - float(g["train_loss"])) <= 1e-4 * lo[0]                 # step 0 of the oracle = the reference's own loss
-    print("BTS SILog, HIP   :", np.round(lh[[0, 1, 2, 4, 9, 14, 19]], 4))
-    print("BTS SILog, oracle:", np.round(lo[[0, 1, 2, 4, 9, 14, 19]], 4))
+    lh, lo = np.array(lh), curve["silog"]
+    assert abs(lo[0] - float(g["train_loss"])) <= 1e-4 * lo[0]                 # both goldens start from the same state
+    print("BTS SILog, HIP      :", np.round(lh[[0, 1, 2, 4, 9, 14, 19]], 4))
+    print("BTS SILog, reference:", np.round(lo[[0, 1, 2, 4, 9, 14, 19]], 4))
     band = np.abs(lh - lo) / lo
-    print("relative gap between the curves: max %.4f mean %.4f; fall HIP %.4f oracle %.4f" % (band.max(), band.mean(), lh[-1] / lh[0], lo[-1] / lo[0]))
+    print("relative gap between the curves: max %.4f mean %.4f; fall HIP %.4f reference %.4f" % (band.max(), band.mean(), lh[-1] / lh[0], lo[-1] / lo[0]))
     assert np.isfinite(lh).all() and lh[-1] < 0.97 * lh[0] and lo[-1] < 0.97 * lo[0]
     # (measured 0.62 % / 0.42 %: the gap opens at the FIRST step and then stays -- AdamW's update is g / (|g| + 1e-3) per element,
     #  nearly a sign; the bf16-stored gradients of the DenseNet trunk flip the sign of elements near zero, so a HIP step
-    #  descends a little less than the fp32 oracle's.  VNL under SGD, linear in g, tracks its oracle to 0.09 %.)
+    #  descends a little less than the fp32 reference's.  VNL under SGD, linear in g, tracks its oracle to 0.09 %.)
     assert band.max() < 1e-2 and band.mean() < 6e-3
-    trained = {k: v.detach().clone() for k, v in P.items()}
-    net.load_state_dict(trained)
+    # the trained state, on identical weights: eight images (the conditioned fixtures' eval batch), the HIP path's eval forward
+    # (two-term weight shadow) against the fp32 oracle holding the SAME fp32 masters
+    trained = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+    rgb8, tgt8 = W.synthetic_batch(53, W.BTS_COND_BATCH, *SIZE)
     net.eval()
     with torch.no_grad():
-        yh = net(x)[4]
-        yo = nets.bts_forward(trained, rgb, False)[4]
-        # free-running AdamW leaves weights that are NOT bf16-representable; the HIP path convolves with their bf16 shadow.
-        # That error is the same for every pixel, so it does not average out of AbsRel the way activation rounding does:
-        # the oracle that stands for the HIP path here rounds the conv weights as well as the activations
-        wq = {k: (nets.bf16_round(v) if v.dtype.is_floating_point and v.dim() >= 2 else v) for k, v in trained.items()}
-        yq = nets.bts_forward(wq, rgb, False, q=nets.bf16_round)[4]
+        yh = net(rgb8.cuda())[4]
+        yo = nets.bts_forward(trained, rgb8, False)[4]
+        yqs = [nets.bts_forward(trained, rgb8, False, q=nets.rounding_draw(k))[4] for k in range(3)]
+        net._store.split_eval = False
+        y1 = net(rgb8.cuda())[4]
+        net._store.split_eval = True
     mc = metrics.MetricComputation(["absrel"])
-    a_h, a_o, a_q = (float(mc.compute(y, t)[0]) for y in (yh, yo.cuda(), yq.cuda()))
-    print("trained-like state, eval AbsRel: HIP %.6f oracle %.6f (delta %.2e); oracle with bf16 weights + activations: shift %.2e" % (
-        a_h, a_o, abs(a_h - a_o), abs(a_q - a_o)))
-    assert abs(a_h - a_o) <= 1.5 * abs(a_q - a_o) + 2e-4
+    t8 = (tgt8 * 10.0).cuda()
+    a_h, a_1, a_o = (float(mc.compute(y, t8)[0]) for y in (yh, y1, yo.cuda()))
+    floor = max(abs(float(mc.compute(y.cuda(), t8)[0]) - a_o) for y in yqs)
+    print("trained state, eval AbsRel: HIP %.6f oracle %.6f (delta %.2e; with the one-term weight shadow %.2e); activation rounding alone "
+          "moves the oracle by up to %.2e" % (a_h, a_o, abs(a_h - a_o), abs(a_1 - a_o), floor))
+    assert abs(a_h - a_o) <= 1e-4 + floor
 
 
-@pytest.mark.parametrize("version,seed", [("resnet50_bts", 57), ("resnext50_bts", 59)])
+@pytest.mark.parametrize("version,seed", [("resnet50_bts", 57), ("resnext50_bts", 59), ("resnet101_bts", 63), ("resnext101_bts", 65)])
 def test_bts_resnet_encoders_against_oracle_and_reference(version, seed, golden):
     """Bts.py:293-307: the ResNet-50 and the ResNeXt-50 32x4d encoders (the ResNeXt's 3x3 convs as block-diagonal grouped tiles)
     under the same decoder plan.  Eval: the five outputs within 1.5 x the oracle's own bf16-rounding noise (+ 1e-2) of the
@@ -422,25 +418,39 @@ def test_shallow_densenet_trunk_gradients():
     yo = oracle(P, True)
     (yo * dy).sum().backward()
     net = net.cuda().train()
-    y = net(rgb.cuda())
-    (y * dy.cuda()).sum().backward()
+    net._store.set_deterministic(True)                    # order-independent sums: reproducible figures
+    try:
+        y = net(rgb.cuda())
+        (y * dy.cuda()).sum().backward()
+    finally:
+        net._store.set_deterministic(False)
     assert _rel(y.detach().cpu(), yo.detach()) < 3e-2, _rel(y.detach().cpu(), yo.detach())
+    # The bound on every gradient norm is MEASURED: the fp32 oracle with activations and activation gradients rounded to the
+    # storage type (tests/rounding.py), six realisations of the rounding; the HIP path's ratio to the fp32 oracle must stay
+    # within twice the rounding oracle's largest excursion from 1 (+ 2 %).  (Round 3 gave feats.norm0.bias a flat 15 % after its ratio went
+    # 0.96 -> 0.917 with the convs' K order: the rounding oracle puts that tensor at 0.989 +- 0.034, range 0.94 ... 1.05 --
+    # a shift in front of ReLU -> max-pool -> BatchNorm is a cancellation residue, and both figures are draws from that.)
+    import rounding as R
+
+    def run(k):
+        Pk = nets.leaf_state(sd, requires_grad=True)
+        n = nets.Net(Pk, True, q=R.q_both(k)) if k is not None else nets.Net(Pk, True)
+        f = nets.densenet_features(n, rgb, "feats.", blocks=(3, 2))
+        (torch.nn.functional.conv2d(torch.relu(f[-1]), Pk["head.weight"]) * dy).sum().backward()
+        return {k_: float(v.grad.norm()) for k_, v in Pk.items() if v.grad is not None}
+    base, noise = R.grad_norm_noise(run, draws=6)
     stats = {}
     for k, p in net.named_parameters():
         go, gh = P[k].grad, p.grad.detach().cpu()
         stats[k] = (float(gh.norm() / go.norm()), float((gh * go).sum() / (gh.norm() * go.norm() + 1e-30)))
     print("shallow densenet: output rel %.3e; worst norm ratio %s; worst cosine %s" % (
         _rel(y.detach().cpu(), yo.detach()), max(stats.items(), key=lambda kv: abs(kv[1][0] - 1)), min(stats.items(), key=lambda kv: kv[1][1])))
+    print("the rounding oracle's largest excursions:", sorted(((round(v, 3), k) for k, v in noise.items()), reverse=True)[:4])
     for k, (ratio, cos) in stats.items():
         if k == "feats.norm0.weight":
             continue      # a per-channel scale right in front of another BatchNorm (ReLU and max-pool commute with it): its
-                          # true gradient is a cancellation residue (measured ratio 2.3-3.0 on a |g| 100x below its neighbours')
-        # norm0.bias is that scale's sibling: a shift in front of ReLU -> max-pool -> BatchNorm, most of which the next
-        # BatchNorm's mean subtraction removes again.  Measured 0.96 / cos 0.99 with tap-major K order in the convs, 0.917 /
-        # cos 0.986 with chunk-major (the stem kernels themselves did not change: only the downstream rounding did).  It gets
-        # its own, stated bound; every other tensor keeps 8 %.
-        tol = 0.15 if k == "feats.norm0.bias" else 8e-2
-        assert abs(ratio - 1) < tol and cos >= 0.95, (k, ratio, cos)
+                          # true gradient is a cancellation residue (the rounding oracle itself: ratio 1.6 ... 3.1)
+        assert abs(ratio - 1) <= 2.0 * noise[k] + 2e-2 and cos >= 0.95, (k, ratio, cos, noise[k])
     for k in ("feats.norm5.running_mean", "feats.denseblock1.denselayer3.norm1.running_var", "feats.transition1.norm.running_mean"):
         assert _rel(net.state_dict()[k].cpu(), P[k]) < 1e-2, k
 

@@ -631,17 +631,46 @@ def test_other_decoders_against_the_reference(golden, dec):
                                                                  abs(a - float(g[dec + "_eval_absrel"]))))
     assert abs(a - float(g[dec + "_eval_absrel"])) <= k * 3e-4, (a, float(g[dec + "_eval_absrel"]))
     net.train()
-    loss = criteria.silog_loss(0.85)(net(rgb.cuda()), tgt.cuda())
-    loss.backward()
+    net._store.set_deterministic(True)                   # order-independent sums: the figures below are reproducible
+    try:
+        loss = criteria.silog_loss(0.85)(net(rgb.cuda()), tgt.cuda())
+        loss.backward()
+    finally:
+        net._store.set_deterministic(False)
     ref = float(g[dec + "_train_silog"])
     assert abs(float(loss.detach()) - ref) <= 1e-3 * abs(ref), (float(loss.detach()), ref)
     names = [str(k) for k in g[dec + "_names"]]
     gn = {n: float(p.grad.double().norm()) for n, p in net.named_parameters()}
-    rel = np.array([abs(gn[n] / r - 1.0) for n, r in zip(names, g[dec + "_grad_norm"]) if r > 1e-8])
-    # one train step at random-like weights: single trunk tensors move by up to ~0.18 when the kernels' accumulation order
-    # changes (ReLU masks flip), so the bulk is gated tightly and the tail separately
-    assert np.median(rel) <= 2e-2 and np.quantile(rel, 0.95) <= 0.12 and rel.max() <= 0.30, (
-        float(np.median(rel)), float(np.quantile(rel, 0.95)), float(rel.max()))
+    ref_gn = {n: float(r) for n, r in zip(names, g[dec + "_grad_norm"])}
+    # What may a gradient norm differ by?  One train step at random-like weights: ReLU masks flip under storage rounding and
+    # single trunk tensors move by 10-20 %.  That figure is MEASURED here, per tensor, on the fp32 CPU oracle with its
+    # activations and activation gradients rounded to the storage type (tests/rounding.py), over four realisations of the
+    # rounding; the HIP path (deterministic mode) must stay within twice the oracle's largest excursion (+ 2 %).
+    import rounding as R
+
+    def run(k):
+        hs = R.fcrn_rounding_hooks(ora, k) if k is not None else []
+        ora.train()
+        ora.zero_grad(set_to_none=True)
+        OL.silog(ora(rgb), tgt, 0.85).backward()
+        for h in hs:
+            h.remove()
+        return {n: float(p.grad.double().norm()) for n, p in ora.named_parameters() if p.grad is not None}
+    base, noise = R.grad_norm_noise(run, draws=4)
+    worst = []
+    for n in names:
+        if ref_gn[n] <= 1e-8:
+            continue
+        assert abs(base[n] / ref_gn[n] - 1.0) < 2e-3, (n, base[n], ref_gn[n])          # the oracle IS the reference
+        dev = abs(gn[n] / ref_gn[n] - 1.0)
+        worst.append((dev / (2.0 * noise[n] + 2e-2), n, dev, noise[n]))
+    worst.sort(reverse=True)
+    rel = np.array([w[2] for w in worst])
+    print("decoder %s gradient norms vs the reference: median %.3f q95 %.3f max %.3f; the rounding oracle's own excursions: median %.3f max %.3f; "
+          "worst HIP / bound: %s" % (dec, np.median(rel), np.quantile(rel, 0.95), rel.max(), np.median(list(noise.values())),
+                                     max(noise.values()), [(w[1], round(w[2], 3), round(w[3], 3)) for w in worst[:3]]))
+    assert worst[0][0] <= 1.0, worst[:5]
+    assert np.median(rel) <= 2e-2
     with pytest.raises(RuntimeError):
         net.upSample.layer1(torch.zeros(1, 1024, 2, 3).cuda())        # containers never compute
 

@@ -178,7 +178,7 @@ def test_bts_oracle_matches_the_reference(bts_fixture):
     assert np.allclose(P["decoder.bn4_2.running_var"].numpy(), g["rv_bn4_2"], rtol=1e-4, atol=1e-7)
 
 
-@pytest.mark.parametrize("version,seed", [("resnet50_bts", 57), ("resnext50_bts", 59)])
+@pytest.mark.parametrize("version,seed", [("resnet50_bts", 57), ("resnext50_bts", 59), ("resnet101_bts", 63), ("resnext101_bts", 65)])
 def test_bts_resnet_encoders_match_the_reference(version, seed):
     """Bts.py:293-307: BtsModel over a torchvision ResNet-50 / ResNeXt-50 32x4d kept whole as `encoder.base_model`
     (tests/golden/bts_resnet50.npz, bts_resnext50.npz, minted from the reference): same keys and parameter count in the product
@@ -237,27 +237,38 @@ def test_bts_image_residuals_oracle_matches_the_reference():
 
 def test_bts_oracle_matches_the_reference_on_the_conditioned_state():
     """tests/golden/bts_cond.npz (the reference's network/Bts.py + metrics.py on oracle/weights.bts_conditioned_state): the
-    oracle reproduces its five eval outputs, its AbsRel and its train-mode SILog; and the state is what it is there for --
-    rounding the oracle's own activations to bf16 moves its AbsRel by less than 1e-4."""
+    oracle reproduces its five eval outputs, its AbsRel (8-image eval batch) and its train-mode SILog (the 2-image batch the
+    convergence test trains on); and the state is what it is there for -- rounding the oracle's own activations to bf16
+    moves its AbsRel by less than 1e-4, for each of four realisations of the rounding (oracle/weights.bts_conditioned_state:
+    one realisation proves little)."""
     from mono_depth_estimation_amd.network import Bts
     from oracle import metrics as OM
     g = _golden("bts_cond")
     torch.manual_seed(0)
     net = Bts.BtsModel(bts_size=512, max_depth=10, out_channels=1, encoder_version="densenet161_bts")
     P = nets.leaf_state(W.bts_conditioned_state(net, 53))
-    rgb, tgt = W.synthetic_batch(53, 2, *BTS_SIZE)
+    rgb, tgt = W.synthetic_batch(53, W.BTS_COND_BATCH, *BTS_SIZE)
     with torch.no_grad():
         nets.bts_forward(P, rgb, True, momentum=1.0)
         ys = nets.bts_forward(P, rgb, False)
-        yq = nets.bts_forward(P, rgb, False, q=nets.bf16_round)
-        loss = L.silog(nets.bts_forward(P, rgb, True)[4], tgt * 10.0, 0.85)
     for nme, y in zip(("d8", "d4", "d2", "r1", "final"), ys):
-        assert np.allclose(y.numpy(), g["eval_" + nme], rtol=2e-4, atol=2e-6), nme
+        assert np.allclose(y[:2].numpy(), g["eval_" + nme], rtol=2e-4, atol=2e-6), nme
     m = OM.compute(ys[4], tgt * 10.0)
     for k in ("absrel", "rmse", "delta1", "log10"):
         assert np.allclose(float(m[k]), float(g["eval_" + k]), rtol=2e-5), k
+    shifts = []
+    for k in range(4):
+        with torch.no_grad():
+            yq = nets.bts_forward(P, rgb, False, q=nets.rounding_draw(k))
+        shifts.append(float(OM.compute(yq[4], tgt * 10.0)["absrel"]) - float(m["absrel"]))
+    print("the oracle's AbsRel under four realisations of bf16 storage rounding:", ["%.1e" % v for v in shifts])
+    assert max(abs(v) for v in shifts) < 1e-4
+    P2 = nets.leaf_state(W.bts_conditioned_state(net, 53))
+    rgb2, tgt2 = W.synthetic_batch(53, 2, *BTS_SIZE)
+    with torch.no_grad():
+        nets.bts_forward(P2, rgb2, True, momentum=1.0)
+        loss = L.silog(nets.bts_forward(P2, rgb2, True)[4], tgt2 * 10.0, 0.85)
     assert np.allclose(float(loss), float(g["train_loss"]), rtol=2e-5)
-    assert abs(float(OM.compute(yq[4], tgt * 10.0)["absrel"]) - float(m["absrel"])) < 1e-4
 
 
 # ---------------------------------------------------------------------------------------------- Eigen (SURVEY 8a row C1, BASELINE config 1)

@@ -18,7 +18,7 @@ def _check(tag, oracle, tgt, g, out_rtol=2e-5):
         assert abs(float(m[n]) - float(g["%s_%s" % (tag, n)])) < 3e-6, (tag, n, float(m[n]), float(g["%s_%s" % (tag, n)]))
     if tag + "_out" in g:
         ref = torch.from_numpy(g[tag + "_out"])
-        assert float((y - ref).norm() / ref.norm()) < out_rtol, tag
+        assert float((y[:ref.shape[0]] - ref).norm() / ref.norm()) < out_rtol, tag
     return float(m["absrel"])
 
 

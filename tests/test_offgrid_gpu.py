@@ -44,9 +44,10 @@ def _assert_within(tag, g, two, one, tgt, bound=1e-4, depth_scale=1.0):
     for n, r, a, b in zip(NAMES, ref, m2, m1):
         print("%-12s %-6s reference %.6f | two-term shadow %.6f (delta %.2e) | one-term %.6f (delta %.2e)" % (tag, n, r, a, abs(a - r), b, abs(b - r)))
     if tag + "_out" in g:
-        ref_out = torch.from_numpy(g[tag + "_out"])
+        ref_out = torch.from_numpy(g[tag + "_out"])                      # (BTS: the first two images of its eight)
+        k = ref_out.shape[0]
         print("%-12s output rel. L2 vs reference: two-term %.2e, one-term %.2e" % (
-            tag, float((two.cpu() - ref_out).norm() / ref_out.norm()), float((one.cpu() - ref_out).norm() / ref_out.norm())))
+            tag, float((two.cpu()[:k] - ref_out).norm() / ref_out.norm()), float((one.cpu()[:k] - ref_out).norm() / ref_out.norm())))
     for n, r, a in zip(NAMES, ref, m2):
         assert abs(a - r) <= bound * (depth_scale ** 0.5 if n == "rmse" else 1.0), (tag, n, a, r)
     return abs(m2[0] - ref[0]), abs(m1[0] - ref[0])

@@ -309,3 +309,41 @@ def test_to_nchw_act(C, act, scale):
     torch.cuda.synchronize()
     _close(dx[..., :C].float().cpu().permute(0, 2, 1), pre.grad, "to_nchw dx")
     assert torch.allclose(db[:C].cpu(), pre.grad.sum((0, 2)), rtol=1e-3, atol=1e-3 * pre.grad.abs().sum((0, 2)).max().item())
+
+
+@pytest.mark.parametrize("O,k,s,p,H,Wd", [(96, 7, 2, 3, 48, 64), (64, 3, 2, 1, 33, 47), (64, 9, 2, 0, 40, 56)])
+def test_image_conv_over_the_16_slot_hi_lo_operands(O, k, s, p, H, Wd):
+    """The eval-mode image convolution of graph.ImageStem (densenet161's conv0, DORN's conv1, Eigen's 9x9): image slots
+    [xh | xl | xh], weight slots [wh | wh | wl] (mde_nchw_to_nhwc_split16 / mde_stem_weight_split16), the k x k taps in
+    launches of at most 32 (the later ones accumulating).  Against torch's conv of the FP32 image with the FP32 weights: only
+    the output's own storage rounding is left (and, over several launches, that of the partial sums) -- the one-term path on a
+    16-bit image differs from that reference by the operands' rounding on top."""
+    from mono_depth_estimation_amd import ops
+    N, C, Cp = 2, 3, 8
+    x = W.uniform(9, "img", (N, C, H, Wd))                                        # generic fp32 pixels, as a loader hands them over
+    w = W.normal(9, "w", (O, C, k, k), std=(2.0 / (k * k * C)) ** 0.5)
+    ref = F.conv2d(x, w, stride=s, padding=p)
+    OH, OW = ref.shape[2:]
+    master = torch.zeros(O, k * k, Cp)
+    master[:, :, :C] = w.permute(0, 2, 3, 1).reshape(O, k * k, C)
+    master = master.cuda()
+    x16 = torch.full((N, H, Wd, 16), 7.0, dtype=ACT, device="cuda")
+    w16 = torch.full((O * k * k * 16,), 7.0, dtype=ACT, device="cuda")
+    ops.nchw_to_nhwc_split16(x.cuda(), x16)
+    ops.stem_weight_split16(master, w16, O * k * k, Cp, C)
+    xs = x16.float().cpu()
+    assert torch.equal(xs[..., 0:3], xs[..., 6:9]) and float(xs[..., 9:].abs().max()) == 0.0
+    back = (xs[..., 0:3] + xs[..., 3:6]).permute(0, 3, 1, 2)
+    assert float((back - x).abs().max()) < (2.0 ** -15 if ACT == torch.bfloat16 else 2.0 ** -12)
+    taps = [(i - p, j - p, i * k + j) for i in range(k) for j in range(k)]
+    out = torch.full((N, OH, OW, O), 7.0, dtype=ACT, device="cuda")
+    nl = 0
+    for t0 in range(0, k * k, 32):
+        d = ops.conv_desc(N, H, Wd, 16, 16, x16.numel() * 2, OH, OW, s, s, taps[t0:t0 + 32], k * k, OH, OW, O, ncols=O, accumulate=t0 > 0)
+        ops.conv_gemm(d, x16, w16, out)
+        nl += 1
+    torch.cuda.synchronize()
+    _close(_nchw(out), ref, "image conv over hi / lo slots", tol=2.0 ** -8 if nl == 1 else 2.0 ** -6)
+    e = float((_nchw(out) - ref).mean((0, 2, 3)).abs().mean() / ref.abs().mean())
+    print("mean |per-channel mean error| / mean |value| against the fp32 conv: %.2e" % e)
+    assert e < 2e-4
