@@ -437,6 +437,16 @@ int mde_aug_affine_nearest_u8(const uint8_t* src, int H, int W, int C, const int
  * quotients (computed by the host exactly as numpy does). */
 int mde_aug_crop_flip_to_float(const uint8_t* src, int H, int W, int C, int top, int left, int oh, int ow, int flip, const float* lut,
                                float* dst, void* stream);
+/* The same with one 256-entry table PER CHANNEL (lut[c * lut_stride + v]; lut_stride 0 = one shared table): the last step of
+ * modules/midas.py:107-150 is the hub's `default_transform`, which on an image that already has its 384 x 384 size is
+ * float32((v / 255.0 - mean[c]) / std[c]) evaluated in double -- 3 x 256 values the host computes as numpy does. */
+int mde_aug_crop_flip_to_float_c(const uint8_t* src, int H, int W, int C, int top, int left, int oh, int ow, int flip, const float* lut,
+                                 int lut_stride, float* dst, void* stream);
+/* modules/vnl.py:59-78 (flip_pad_reshape_crop up to its cv2.resize): np.flip(img, axis=1) -> np.pad(img, ((pad_top, 0),
+ * (pad_left, 0)), 'constant', fill) -> img[crop_y : crop_y + oh, crop_x : crop_x + ow] for an H x W x C image of 1-byte
+ * (uint8 RGB) or 4-byte (float32 depth) elements; `fill`: one HOST element.  The crop must lie inside the padded image. */
+int mde_aug_flip_pad_crop(const void* src, int elem_bytes, int H, int W, int C, int flip, int pad_top, int pad_left, int crop_y, int crop_x,
+                          int oh, int ow, const void* fill, void* dst, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Losses and metrics (criteria.py / metrics.py), fp32 in, fp32/fp64 accumulation.

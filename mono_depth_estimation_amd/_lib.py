@@ -139,6 +139,8 @@ SIGNATURES = {
     "mde_aug_resample_u8": (_I, [_P, _I, _I, _I, _P, _P, _I, _I, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
     "mde_aug_affine_nearest_u8": (_I, [_P, _I, _I, _I, _P, _P, _P]),
     "mde_aug_crop_flip_to_float": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
+    "mde_aug_crop_flip_to_float_c": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P]),
+    "mde_aug_flip_pad_crop": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
     "mde_ord_loss_ws_bytes": (_Z, []),
     "mde_ord_loss_fwd": (_I, [_P, _P, _I, _I, _L, _P, _P, _P]),
     "mde_ord_loss_bwd": (_I, [_P, _P, _I, _I, _L, _P, _P, _P]),

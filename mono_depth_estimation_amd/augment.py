@@ -126,9 +126,9 @@ def rotate_u8(img, angle):
     return out
 
 
-def crop_flip_to_float(img, output_size, flip, top=None, left=None):
+def crop_flip_to_float(img, output_size, flip, top=None, left=None, lut=None):
     """CenterCrop(output_size) (or the crop at (top, left)) -> hflip (if flip) -> np.array(img, float32) / 255.0 -> to_tensor:
-    C x oh x ow float32."""
+    C x oh x ow float32.  lut: a [C][256] table of the output values instead of v / 255 (midas_lut)."""
     H, W, Cc = img.shape
     oh, ow = output_size
     if oh > H or ow > W:
@@ -137,6 +137,11 @@ def crop_flip_to_float(img, output_size, flip, top=None, left=None):
     if top is None:
         top, left = int(round((H - oh) / 2.0)), int(round((W - ow) / 2.0))
     out = torch.empty(Cc, oh, ow, device=img.device)
+    if lut is not None:
+        assert lut.shape == (Cc, 256) and lut.dtype == torch.float32 and lut.is_contiguous()
+        check(_lib.load().mde_aug_crop_flip_to_float_c(_p(img), H, W, Cc, top, left, oh, ow, int(bool(flip)), _p(lut), 256, _p(out), _stream()),
+              "mde_aug_crop_flip_to_float_c")
+        return out
     check(_lib.load().mde_aug_crop_flip_to_float(_p(img), H, W, Cc, top, left, oh, ow, int(bool(flip)), _p(_lut(img.device)), _p(out), _stream()),
           "mde_aug_crop_flip_to_float")
     return out
@@ -225,3 +230,118 @@ def bts_train_preprocess(rgb, depth, output_size, params=None):
 
 
 bts_val_preprocess = val_preprocess          # modules/bts.py:202-217: the same operations as the base module's (Resize, CenterCrop, / 255)
+
+
+# ---------------------------------------------------------------------------------------------- modules/midas.py:107-150
+MIDAS_SIZE = 384
+MIDAS_MEAN, MIDAS_STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+_midas_lut_cache = {}
+
+
+def midas_lut(device):
+    """The hub's `default_transform` (modules/midas.py:12: torch.hub 'intel-isl/MiDaS' transforms) on an image that already has
+    its 384 x 384 size -- what train_preprocess / val_preprocess hand it -- as a [3][256] table.  Its published definition:
+    img / 255.0 (float64), Resize(384, 384, keep_aspect_ratio, multiple of 32, cv2.INTER_CUBIC) -- the identity at that size (cv2.resize
+    copies when source and destination sizes agree) --, NormalizeImage(mean, std) in float64, PrepareForNet (HWC -> CHW,
+    float32).  cv2 and the hub repository are absent from the image: the table is this restatement, pinned by definition."""
+    t = _midas_lut_cache.get(str(device))
+    if t is None:
+        v = np.arange(256, dtype=np.uint8)
+        rows = [(((v / 255.0) - m) / s).astype(np.float32) for m, s in zip(MIDAS_MEAN, MIDAS_STD)]
+        t = _midas_lut_cache[str(device)] = torch.from_numpy(np.stack(rows)).to(device).contiguous()
+    return t
+
+
+def midas_draw_train_params(w, h):
+    """The draws of MidasModule.train_preprocess in its order: np.random.randint(384, 720) (the resize target),
+    transforms.RandomCrop.get_params on the RESIZED image (two torch.randint draws, none if it is 384 x 384 already), the flip
+    (np.random.uniform)."""
+    size = int(np.random.randint(384, 720))
+    rw, rh = resized_size(w, h, size)
+    th = tw = MIDAS_SIZE
+    if rh + 1 < th or rw + 1 < tw:
+        raise ValueError("Required crop size %s is larger then input image size %s" % ((th, tw), (rh, rw)))
+    if (rw, rh) == (tw, th):
+        i = j = 0
+    else:
+        i = int(torch.randint(0, rh - th + 1, size=(1,)).item())
+        j = int(torch.randint(0, rw - tw + 1, size=(1,)).item())
+    flip = np.random.uniform(0, 1) > 0.5
+    return size, i, j, flip
+
+
+def midas_train_preprocess(rgb, depth, params=None):
+    """modules/midas.py:107-130 for one sample on the device: random Resize (shorter edge 384 ... 719), RandomCrop(384, 384), flip,
+    then the hub transform on the colour image (midas_lut) and / 255 on the depth layers.  params = (size, top, left, flip)."""
+    _need_gpu(rgb)
+    imgs = [to_u8(rgb), _stack_depth(list(depth), 1.0)]
+    H, W, _ = imgs[0].shape
+    size, i, j, flip = params if params is not None else midas_draw_train_params(W, H)
+    w1, h1 = resized_size(W, H, size)
+    out = (MIDAS_SIZE, MIDAS_SIZE)
+    return (crop_flip_to_float(resize_u8(imgs[0], w1, h1), out, flip, top=i, left=j, lut=midas_lut(rgb.device)),
+            crop_flip_to_float(resize_u8(imgs[1], w1, h1), out, flip, top=i, left=j))
+
+
+def midas_val_preprocess(rgb, depth):
+    """modules/midas.py:132-150: Resize(384), CenterCrop((384, 384)), the hub transform / the division by 255."""
+    _need_gpu(rgb)
+    imgs = [to_u8(rgb), _stack_depth(list(depth), 1.0)]
+    H, W, _ = imgs[0].shape
+    w1, h1 = resized_size(W, H, MIDAS_SIZE)
+    out = (MIDAS_SIZE, MIDAS_SIZE)
+    return (crop_flip_to_float(resize_u8(imgs[0], w1, h1), out, False, lut=midas_lut(rgb.device)),
+            crop_flip_to_float(resize_u8(imgs[1], w1, h1), out, False))
+
+
+def midas_test_preprocess(rgb, depth):
+    """modules/midas.py:152-184 pads with cv2.copyMakeBorder and resizes 640 x 640 -> 384 x 384 with cv2.resize (INTER_LINEAR, OpenCV's
+    own 11-bit fixed-point weights for 8-bit images): cv2 is absent from this image, so there is nothing to pin that arithmetic
+    to, and an unpinned restatement of an integer resampler is not shipped."""
+    raise NotImplementedError("MidasModule.test_preprocess resizes with cv2.resize; OpenCV is not available to pin a device "
+                              "version against (mono_depth_estimation_amd.augment covers train_preprocess / val_preprocess)")
+
+
+# ---------------------------------------------------------------------------------------------- modules/vnl.py:32-138
+VNL_CROP_SIZE = (385, 385)        # modules/vnl.py CROP_SIZE
+
+
+def vnl_draw_params(phase, uniform_size, crop_size=VNL_CROP_SIZE):
+    """set_flip_pad_reshape_crop (modules/vnl.py:32-57), draw for draw: np.random.uniform (flip), np.random.randint (crop size index,
+    'train' only), np.random.randint (start_x), np.random.randint (start_y, only without padding).
+    -> (flip, [start_x, start_y, crop_height, crop_width], [pad_up, 0, 0, 0], resize_ratio)."""
+    flip_prob = np.random.uniform(0.0, 1.0)
+    flip = bool(flip_prob > 0.5 and 'train' in phase)
+    raw_size = np.array([crop_size[1], 416, 448, 480, 512])
+    idx = np.random.randint(0, len(raw_size)) if 'train' in phase else len(raw_size) - 1
+    pad_height = int(raw_size[idx] - uniform_size[0]) if raw_size[idx] > uniform_size[0] else 0
+    ch = cw = int(raw_size[idx])
+    start_x = int(np.random.randint(0, int(uniform_size[1] - cw) + 1))
+    start_y = 0 if pad_height != 0 else int(np.random.randint(0, int(uniform_size[0] - ch) + 1))
+    return flip, [start_x, start_y, ch, cw], [pad_height, 0, 0, 0], float(crop_size[1] / cw)
+
+
+def vnl_flip_pad_crop(img, flip, crop, pad, pad_value=0):
+    """flip_pad_reshape_crop (modules/vnl.py:59-78) UP TO its last line: np.flip(img, axis=1), np.pad(..., 'constant', pad_value),
+    the crop [start_y : start_y + crop[3], start_x : start_x + crop[2]] -- exact data movement, on the device.  img: H x W x C uint8
+    or H x W float32.  The last line, cv2.resize(img_crop, CROP_SIZE, INTER_LINEAR), is NOT here: OpenCV is absent from the image
+    and its 8-bit resampler (11-bit fixed-point weights) has nothing to be pinned to; vnl_preprocess says so when called."""
+    _need_gpu(img)
+    squeeze = img.dim() == 2
+    a = (img.unsqueeze(-1) if squeeze else img).contiguous()
+    H, W, Cc = a.shape
+    assert a.dtype in (torch.uint8, torch.float32), a.dtype
+    oh, ow = int(crop[3]), int(crop[2])
+    out = torch.empty(oh, ow, Cc, dtype=a.dtype, device=a.device)
+    fill = (C.c_uint8(int(pad_value)) if a.dtype == torch.uint8 else C.c_float(float(pad_value)))
+    check(_lib.load().mde_aug_flip_pad_crop(_p(a), a.element_size(), H, W, Cc, int(bool(flip)), int(pad[0]), int(pad[2]), int(crop[1]), int(crop[0]),
+                                            oh, ow, C.cast(C.pointer(fill), C.c_void_p), _p(out), _stream()), "mde_aug_flip_pad_crop")
+    return out.squeeze(-1) if squeeze else out
+
+
+def vnl_preprocess(A, B, phase):
+    """modules/vnl.py:86-111 `preprocess`: every path ends in cv2.resize (INTER_LINEAR to CROP_SIZE; a further cv2.resize to height
+    512 in front when the depth map is not 512 rows tall).  The numpy half is vnl_draw_params + vnl_flip_pad_crop; the resize has
+    no pinnable counterpart here (OpenCV absent), so the composed pipeline is not offered."""
+    raise NotImplementedError("VNL's preprocess resizes with cv2.resize (INTER_LINEAR); OpenCV is not available to pin a device version "
+                              "against -- vnl_draw_params / vnl_flip_pad_crop cover its draws, flip, padding and crop")

@@ -92,7 +92,7 @@ __global__ __launch_bounds__(NT) void aug_affine_nearest_k(const uint8_t* __rest
 // CenterCrop -> hflip -> np.array(img, float32) / 255.0 -> to_tensor: H x W x C uint8 -> C x oh x ow float32 through a
 // 256-entry table of the quotients (computed on the host by numpy itself)
 __global__ __launch_bounds__(NT) void aug_crop_flip_k(const uint8_t* __restrict__ src, int W, int C, int top, int left, int oh, int ow,
-                                                      int flip, const float* __restrict__ lut, float* __restrict__ dst) {
+                                                      int flip, const float* __restrict__ lut, float* __restrict__ dst, int lut_stride = 0) {
     const int64_t total = (int64_t)C * oh * ow;
     for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
         const int x = (int)(i % ow);
@@ -100,7 +100,26 @@ __global__ __launch_bounds__(NT) void aug_crop_flip_k(const uint8_t* __restrict_
         const int y = (int)(q % oh);
         const int c = (int)(q / oh);
         const int sx = left + (flip ? ow - 1 - x : x);
-        dst[i] = lut[src[((int64_t)(top + y) * W + sx) * C + c]];
+        dst[i] = lut[c * lut_stride + src[((int64_t)(top + y) * W + sx) * C + c]];
+    }
+}
+
+// flip (columns) -> constant pad -> crop of an H x W x C image of ELEM-byte elements, as numpy does it (modules/vnl.py:59-78:
+// np.flip(img, axis=1), np.pad(..., 'constant'), the slice): pure data movement.  Output pixel (y, x) is padded-image pixel
+// (cy + y, cx + x); the padded image has `pt` rows / `pl` columns of `fill` in front of the (flipped) image.
+template <typename T>
+__global__ __launch_bounds__(NT) void aug_flip_pad_crop_k(const T* __restrict__ src, int H, int W, int C, int flip, int pt, int pl, int cy, int cx,
+                                                          int oh, int ow, T fill, T* __restrict__ dst) {
+    const int64_t total = (int64_t)oh * ow * C;
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
+        const int c = (int)(i % C);
+        const int64_t q = i / C;
+        const int x = (int)(q % ow), y = (int)(q / ow);
+        const int sy = cy + y - pt;
+        int sx = cx + x - pl;
+        const bool in = sy >= 0 && sy < H && sx >= 0 && sx < W;
+        if (flip) sx = W - 1 - sx;
+        dst[i] = in ? src[((int64_t)sy * W + sx) * C + c] : fill;
     }
 }
 
@@ -144,6 +163,32 @@ extern "C" int mde_aug_affine_nearest_u8(const uint8_t* src, int H, int W, int C
     aug_affine_nearest_k<<<grid_for((int64_t)H * W * C), NT, 0, (hipStream_t)stream>>>(src, H, W, C, coef[0], coef[1], coef[2], coef[3], coef[4],
                                                                                       coef[5], dst);
     MDE_LAUNCH_CHECK("aug_affine_nearest_k");
+    return MDE_OK;
+}
+
+extern "C" int mde_aug_crop_flip_to_float_c(const uint8_t* src, int H, int W, int C, int top, int left, int oh, int ow, int flip,
+                                            const float* lut, int lut_stride, float* dst, void* stream) {
+    MDE_REQUIRE(src && dst && lut && H > 0 && W > 0 && C > 0 && oh > 0 && ow > 0 && top >= 0 && left >= 0 && top + oh <= H && left + ow <= W &&
+                    lut_stride >= 0,
+                "mde_aug_crop_flip_to_float_c: crop %dx%d at (%d, %d) of a %dx%d image", oh, ow, top, left, H, W);
+    aug_crop_flip_k<<<grid_for((int64_t)C * oh * ow), NT, 0, (hipStream_t)stream>>>(src, W, C, top, left, oh, ow, flip, lut, dst, lut_stride);
+    MDE_LAUNCH_CHECK("aug_crop_flip_k");
+    return MDE_OK;
+}
+
+extern "C" int mde_aug_flip_pad_crop(const void* src, int elem_bytes, int H, int W, int C, int flip, int pad_top, int pad_left, int crop_y,
+                                     int crop_x, int oh, int ow, const void* fill, void* dst, void* stream) {
+    MDE_REQUIRE(src && dst && fill && (elem_bytes == 1 || elem_bytes == 4) && H > 0 && W > 0 && C > 0 && oh > 0 && ow > 0 && pad_top >= 0 &&
+                    pad_left >= 0 && crop_y >= 0 && crop_x >= 0 && crop_y + oh <= H + pad_top && crop_x + ow <= W + pad_left,
+                "mde_aug_flip_pad_crop: bad argument (the crop must lie inside the padded image)");
+    const int g = grid_for((int64_t)oh * ow * C);
+    if (elem_bytes == 1)
+        aug_flip_pad_crop_k<uint8_t><<<g, NT, 0, (hipStream_t)stream>>>((const uint8_t*)src, H, W, C, flip, pad_top, pad_left, crop_y, crop_x, oh, ow,
+                                                                         *(const uint8_t*)fill, (uint8_t*)dst);
+    else
+        aug_flip_pad_crop_k<uint32_t><<<g, NT, 0, (hipStream_t)stream>>>((const uint32_t*)src, H, W, C, flip, pad_top, pad_left, crop_y, crop_x, oh, ow,
+                                                                          *(const uint32_t*)fill, (uint32_t*)dst);
+    MDE_LAUNCH_CHECK("aug_flip_pad_crop_k");
     return MDE_OK;
 }
 

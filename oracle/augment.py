@@ -261,3 +261,78 @@ def rotate_u8(a, angle):
     if ang in (90, 270) and W == H:
         return np.rot90(a, 1 if ang == 90 else 3).copy()
     return affine_nearest_u8(a, rotate_matrix(W, H, angle))
+
+
+# ---------------------------------------------------------------------------------------------- modules/midas.py:107-150
+MIDAS_MEAN, MIDAS_STD = np.array([0.485, 0.456, 0.406]), np.array([0.229, 0.224, 0.225])
+
+
+def midas_default_transform(img_u8):
+    """The hub transform MidasModule applies last (modules/midas.py:12,125,145: torch.hub 'intel-isl/MiDaS' transforms
+    .default_transform), restated from its published definition -- the hub repository and cv2 are absent from the image, so this
+    step is pinned by definition only: {"image": img / 255.0} -> Resize(384, 384, keep_aspect_ratio=True, ensure_multiple_of=32,
+    resize_method="upper_bound", cv2.INTER_CUBIC) -> NormalizeImage(mean, std) -> PrepareForNet (transpose to CHW, float32) ->
+    torch.from_numpy(...).unsqueeze(0).  On the 384 x 384 crops train_preprocess / val_preprocess produce, Resize computes a scale
+    of exactly 1 and cv2.resize to the source's own size is a copy; any other size is refused here."""
+    a = np.asarray(img_u8)
+    assert a.dtype == np.uint8 and a.shape[:2] == (384, 384), "this restatement covers the 384 x 384 crops of train / val preprocess"
+    x = a / 255.0
+    x = (x - MIDAS_MEAN) / MIDAS_STD
+    x = np.ascontiguousarray(np.transpose(x, (2, 0, 1))).astype(np.float32)
+    return torch.from_numpy(x).unsqueeze(0)
+
+
+def midas_draw_train_params(w, h):
+    size = int(np.random.randint(384, 720))
+    rw, rh = resized_size(w, h, size)
+    if (rw, rh) == (384, 384):
+        i = j = 0
+    else:
+        i = int(torch.randint(0, rh - 384 + 1, size=(1,)).item())
+        j = int(torch.randint(0, rw - 384 + 1, size=(1,)).item())
+    flip = np.random.uniform(0, 1) > 0.5
+    return size, i, j, flip
+
+
+def midas_train_preprocess(rgb, depth, params=None):
+    """modules/midas.py:107-130 over PIL."""
+    imgs = [to_pil(rgb)] + [to_pil(d) for d in depth]
+    w, h = imgs[0].size
+    size, i, j, flip = params if params is not None else midas_draw_train_params(w, h)
+    imgs = [resize(im, size) for im in imgs]
+    imgs = [im.crop((j, i, j + 384, i + 384)) for im in imgs]
+    if flip:
+        imgs = [hflip(im) for im in imgs]
+    return midas_default_transform(np.array(imgs[0], dtype=np.uint8)).squeeze(0), torch.cat([to_tensor_div255(im) for im in imgs[1:]], dim=0)
+
+
+def midas_val_preprocess(rgb, depth):
+    """modules/midas.py:132-150 over PIL."""
+    imgs = [center_crop(resize(im, 384), (384, 384)) for im in [to_pil(rgb)] + [to_pil(d) for d in depth]]
+    return midas_default_transform(np.array(imgs[0], dtype=np.uint8)).squeeze(0), torch.cat([to_tensor_div255(im) for im in imgs[1:]], dim=0)
+
+
+# ---------------------------------------------------------------------------------------------- modules/vnl.py:32-78 (the numpy half)
+def vnl_draw_params(phase, uniform_size, crop_size=(385, 385)):
+    """set_flip_pad_reshape_crop, modules/vnl.py:32-57."""
+    flip_prob = np.random.uniform(0.0, 1.0)
+    flip_flg = True if flip_prob > 0.5 and 'train' in phase else False
+    raw_size = np.array([crop_size[1], 416, 448, 480, 512])
+    size_index = np.random.randint(0, len(raw_size)) if 'train' in phase else len(raw_size) - 1
+    pad_height = raw_size[size_index] - uniform_size[0] if raw_size[size_index] > uniform_size[0] else 0
+    pad = [int(pad_height), 0, 0, 0]
+    crop_height = crop_width = int(raw_size[size_index])
+    start_x = np.random.randint(0, int(uniform_size[1] - crop_width) + 1)
+    start_y = 0 if pad_height != 0 else np.random.randint(0, int(uniform_size[0] - crop_height) + 1)
+    return flip_flg, [int(start_x), int(start_y), crop_height, crop_width], pad, float(crop_size[1] / crop_width)
+
+
+def vnl_flip_pad_crop(img, flip, crop_size, pad, pad_value=0):
+    """flip_pad_reshape_crop, modules/vnl.py:59-75, up to (not including) its cv2.resize."""
+    if flip:
+        img = np.flip(img, axis=1)
+    if len(img.shape) == 3:
+        img_pad = np.pad(img, ((pad[0], pad[1]), (pad[2], pad[3]), (0, 0)), 'constant', constant_values=(pad_value, pad_value))
+    else:
+        img_pad = np.pad(img, ((pad[0], pad[1]), (pad[2], pad[3])), 'constant', constant_values=(pad_value, pad_value))
+    return img_pad[crop_size[1]:crop_size[1] + crop_size[3], crop_size[0]:crop_size[0] + crop_size[2]]

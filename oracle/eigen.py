@@ -45,8 +45,9 @@ class EigenOracle(nn.Module):
         super().__init__()
         self.scale1, self.scale2, self.scale3 = _VGG(), _Scale2(), _Scale3()
 
-    def forward(self, img):
+    def forward(self, img, q=None):
+        """q: the storage-rounding hook of nets.eigen_forward (nets.bf16_round / nets.rounding_draw(k)); None = plain fp32."""
         P = dict(self.named_parameters())
         P.update(dict(self.named_buffers()))
         # (every BatchNorm here has the default momentum; weights.calibrate_running_stats sets them all to 1.0 for one pass)
-        return nets.eigen_forward(P, img, self.training, momentum=self.scale1.feature_extractor[1].momentum)
+        return nets.eigen_forward(P, img, self.training, momentum=self.scale1.feature_extractor[1].momentum, q=q)

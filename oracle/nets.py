@@ -328,11 +328,13 @@ def bts_forward(P, x, train, max_depth=10.0, momentum=None, q=None, image_residu
 
 
 # ---------------------------------------------------------------------------------------------- Eigen (network/Eigen.py)
-def eigen_forward(P, img, train, momentum=None):
+def eigen_forward(P, img, train, momentum=None, q=None):
     """Eigen.forward (Eigen.py:14-18): VGG-19-BN coarse net -> two Linear layers -> 3x3/4 transposed conv (scale 1, :81-89),
     the 9x9/2 + 5x5 stack of scale 2 (:36-43) and of scale 3 (:62-69).  img: N x 3 x 240 x 320 -> N x 1 x 109 x 149 (the two
-    Linear layers fix the input size: Eigen.py:77-78, 512 * 10 * 7 features)."""
-    n = Net(P, train, momentum=momentum)
+    Linear layers fix the input size: Eigen.py:77-78, 512 * 10 * 7 features).  q: the storage-rounding hook (applied where the
+    HIP plan of network/Eigen.py stores a 16-bit tensor: every conv / Linear / transposed-conv result with its bias and
+    activation, every BatchNorm + ReLU output; the fp32 head output is not rounded)."""
+    n = Net(P, train, q=q, momentum=momentum)
     cfg = [64, 64, "M", 128, 128, "M", 256, 256, 256, 256, "M", 512, 512, 512, 512, "M", 512, 512, 512, 512, "M"]
     x, i = img, 0
     for v in cfg:
@@ -341,23 +343,26 @@ def eigen_forward(P, img, train, momentum=None):
             x = F.max_pool2d(x, 2, 2)
             i += 1
         else:
-            x = F.relu(n.bn(n.conv(x, k + "%d" % i, pad=1), k + "%d" % (i + 1)))
+            x = n.q(F.relu(n.bn(n.conv(x, k + "%d" % i, pad=1), k + "%d" % (i + 1))))
             i += 3
     x = x.flatten(1)
-    x = F.linear(x, P["scale1.mlp1.weight"], P["scale1.mlp1.bias"])
-    x = F.linear(x, P["scale1.mlp2.weight"], P["scale1.mlp2.bias"]).reshape(-1, 64, 14, 19)
-    x0 = F.conv_transpose2d(x, P["scale1.upsample.weight"], P["scale1.upsample.bias"], stride=4)
+    x = n.q(F.linear(x, P["scale1.mlp1.weight"], P["scale1.mlp1.bias"]))
+    x = n.q(F.linear(x, P["scale1.mlp2.weight"], P["scale1.mlp2.bias"])).reshape(-1, 64, 14, 19)
+    x0 = n.q(F.conv_transpose2d(x, P["scale1.upsample.weight"], P["scale1.upsample.bias"], stride=4))
     # Scale2.forward
-    y = F.max_pool2d(F.relu(n.conv(img, "scale2.conv", 2)), 3, 2)[:, :, 1:-1, 1:-1]
+    y = F.max_pool2d(n.q(F.relu(n.conv(img, "scale2.conv", 2))), 3, 2)[:, :, 1:-1, 1:-1]
     y = torch.cat([y, x0], 1)
     for j in (0, 2, 4):
-        y = F.relu(n.conv(y, "scale2.scale2_onestack.%d" % j, pad=2))
-    x1 = F.conv_transpose2d(y, P["scale2.scale2_onestack.6.weight"], P["scale2.scale2_onestack.6.bias"], stride=2, padding=2)
+        y = n.q(F.relu(n.conv(y, "scale2.scale2_onestack.%d" % j, pad=2)))
+    x1 = n.q(F.conv_transpose2d(y, P["scale2.scale2_onestack.6.weight"], P["scale2.scale2_onestack.6.bias"], stride=2, padding=2))
     # Scale3.forward
-    z = F.max_pool2d(F.relu(n.conv(img, "scale3.conv", 2)[:, :, 2:-3, 2:-3]), 3, 1)
+    z = F.max_pool2d(n.q(F.relu(n.conv(img, "scale3.conv", 2)))[:, :, 2:-3, 2:-3], 3, 1)
     z = torch.cat([z, x1], 1)
-    for j in (0, 2, 4, 6):
-        z = F.relu(n.conv(z, "scale3.scale3_onestack.%d" % j, pad=2))
+    for j in (0, 2, 4):
+        z = n.q(F.relu(n.conv(z, "scale3.scale3_onestack.%d" % j, pad=2)))
+    qs, n.q = n.q, (lambda t: t)                               # the head: fp32 N x 1 x H x W output, no storage rounding
+    z = F.relu(n.conv(z, "scale3.scale3_onestack.6", pad=2))
+    n.q = qs
     return z
 
 

@@ -114,11 +114,50 @@ def vnl(out):
     out["vnl_absrel_shift_oracle_bf16"] = abs(absrel(dbf) - absrel(do))
 
 
+def config5(out):
+    """BASELINE configuration 5 at its NAMED precision and full per-GPU size: VNL resnext50 stride 16, 150 bins, 16 x 3 x 480 x 640,
+    ModelLoss = WCEL + 6 VNL, SGD -- on the fp16 storage build, with the static loss scale a precision=16 run needs (the
+    reference: torch's GradScaler, train.py:139-140).  tests/test_full_size_configs_gpu.py runs the same steps on the bf16 build."""
+    from mono_depth_estimation_amd import criteria
+    from mono_depth_estimation_amd.network import VNL
+    params = nets.vnl_params()
+    params.crop_size = (480, 640)
+    torch.manual_seed(1)
+    net = VNL.MetricDepthModel(params).cuda()
+    with torch.no_grad():
+        net.depth_model.decoder_modules.topdown_predict.conv1.weight.mul_(0.1)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(5)
+    x = torch.rand(16, 3, 480, 640, generator=g, device="cuda")
+    gt = 0.05 + 0.95 * torch.rand(16, 1, 480, 640, generator=g, device="cuda")
+    gt = gt.masked_fill(torch.rand(16, 1, 480, 640, generator=g, device="cuda") < 0.1, 0.0)
+    crit = criteria.ModelLoss(params)
+    bins = criteria.depth_to_bins(gt, params.depth_min, 1.1, params.dec_out_c)
+    net.train()
+    scale, losses, finite = 1024.0, [], True
+    for it in range(4):
+        np.random.seed(3)
+        net.zero_grad(set_to_none=True)
+        logit, prob = net(x)
+        loss = crit(criteria.bins_to_depth(prob, params.depth_bin_border), logit, bins, gt)
+        (loss * scale).backward()
+        if it == 0:
+            finite = all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in net.parameters())
+            out["config5_res2_grad_max"] = float(net.depth_model.encoder_modules.bottomup.res2[0].conv2.weight.grad.abs().max()) / scale
+        net._store.sgd_step(2e-3, 2e-3, momentum=0.9, weight_decay=5e-4, grad_scale=1.0 / scale)
+        losses.append(float(loss))
+    out["config5_losses"], out["config5_grads_finite"] = losses, finite
+    out["config5_logit_shape"] = list(logit.shape)
+
+
 if __name__ == "__main__":
     from mono_depth_estimation_amd import _lib, ops
     assert _lib.ACT_NAME == "fp16" and ops.ACT_DTYPE == torch.float16 and _lib.load().mde_act_dtype() == 1
     res = {"lib": _lib.LIB_NAME}
-    fcrn(res)
-    midas(res)
-    vnl(res)
+    if sys.argv[1:] == ["config5"]:
+        config5(res)
+    else:
+        fcrn(res)
+        midas(res)
+        vnl(res)
     sys.stdout.write(json.dumps(res) + "\n")

@@ -89,3 +89,29 @@ def test_bts_pipeline_draws_and_margin_crop():
     torch.manual_seed(1)
     r, d = OA.bts_train_preprocess(rgb, depth, (416, 544))
     assert r.shape == (3, 416, 544) and d.shape == (1, 416, 544)
+
+
+def test_midas_transform_table_and_draws():
+    """The [3][256] table the device pipeline reads for MiDaS' colour image IS the hub transform's published arithmetic (float64:
+    v / 255.0, - mean, / std, then float32) entry by entry, and the product's draw functions consume numpy's / torch's global
+    generators exactly as the oracle's (= the reference's order: midas.py:110,116,120; vnl.py:38-52)."""
+    import torch
+    from mono_depth_estimation_amd import augment
+    lut = augment.midas_lut("cpu")
+    img = np.arange(256, dtype=np.uint8).reshape(16, 16, 1).repeat(3, axis=2)
+    full = np.zeros((384, 384, 3), dtype=np.uint8)
+    full[:16, :16] = img
+    ref = OA.midas_default_transform(full)[0, :, :16, :16].reshape(3, 256)
+    assert lut.shape == (3, 256) and torch.equal(lut, ref)
+    for seed in range(5):
+        np.random.seed(seed)
+        torch.manual_seed(seed)
+        a = OA.midas_draw_train_params(640, 480)
+        np.random.seed(seed)
+        torch.manual_seed(seed)
+        assert augment.midas_draw_train_params(640, 480) == a
+        for phase in ("train", "val"):
+            np.random.seed(seed)
+            b = OA.vnl_draw_params(phase, (512, 683))
+            np.random.seed(seed)
+            assert augment.vnl_draw_params(phase, (512, 683)) == b

@@ -58,8 +58,21 @@ def test_eigen_eval_against_the_reference(setup, golden):
     ref = torch.from_numpy(g["eval_out"])
     assert y.shape == (4, 1, 109, 149) and y.dtype == torch.float32 and torch.isfinite(y).all() and float(y.min()) >= 0.0
     assert _rel(yo, ref) < 2e-4                                              # the oracle is the reference on this state
-    print("Eigen eval: HIP vs reference %.3e (output range %.4f .. %.4f, mean %.4f)" % (_rel(y.cpu(), ref), float(ref.min()), float(ref.max()), float(ref.mean())))
-    assert _rel(y.cpu(), ref) < 3e-2
+    # noise-relative, as for the other networks: what storage rounding alone does to the fp32 ORACLE (oracle/eigen.py's hook,
+    # three realisations of the rounding), on the output and on the AbsRel of the output resized as modules/eigen.py:30 does
+    from oracle import nets
+    up = lambda t: torch.nn.functional.interpolate(t, (240, 320), mode="bilinear") + 0.1
+    absrel = lambda t: float(((up(t) - tgt).abs() / tgt.clamp(min=1e-9))[tgt > 0].mean())
+    with torch.no_grad():
+        yqs = [ora(rgb, q=nets.rounding_draw(k)) for k in range(3)]
+    noise = max(_rel(q, yo) for q in yqs)
+    a_ref, a_hip = absrel(ref), absrel(y.cpu())
+    a_floor = max(abs(absrel(q) - a_ref) for q in yqs)
+    print("Eigen eval: HIP vs reference %.3e, the oracle's rounding noise %.3e (output range %.4f .. %.4f, mean %.4f); AbsRel reference %.5f "
+          "HIP %.5f (delta %.2e), rounding moves the oracle's by up to %.2e" % (_rel(y.cpu(), ref), noise, float(ref.min()), float(ref.max()),
+                                                                              float(ref.mean()), a_ref, a_hip, abs(a_hip - a_ref), a_floor))
+    assert _rel(y.cpu(), ref) < 1.5 * noise + 3e-3
+    assert abs(a_hip - a_ref) <= 2.0 * a_floor + 1e-4
     with pytest.raises(ValueError, match="240 x 320"):
         net(torch.zeros(1, 3, 64, 64, device="cuda"))                        # Eigen.py:77-78
 

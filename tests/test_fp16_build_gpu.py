@@ -55,3 +55,16 @@ def test_training_steps_on_the_fp16_build_need_and_take_a_loss_scale():
     # several times less than bf16 storage would
     assert d["vnl_absrel_shift_hip_fp16"] <= 1.5 * d["vnl_absrel_shift_oracle_fp16"] + 5e-5, d
     assert d["vnl_absrel_shift_hip_fp16"] <= 2.5e-4 and d["vnl_absrel_shift_oracle_bf16"] >= 2.0 * d["vnl_absrel_shift_oracle_fp16"], d
+
+
+def test_config5_vnl_16x3x480x640_at_its_named_precision():
+    """BASELINE configuration 5 ("VNL ... 640x480 fp16 ...") at its full per-GPU size ON THE fp16 BUILD: four SGD steps of
+    ModelLoss with a loss scale; finite gradients everywhere, a falling loss (tests/fp16_checks.py config5)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fp16_checks.py"), "config5"], cwd=ROOT, env=_env(), capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    print(d)
+    L = d["config5_losses"]
+    assert d["lib"] == "libmde_hip_f16.so" and d["config5_logit_shape"] == [16, 150, 480, 640]
+    assert d["config5_grads_finite"] and d["config5_res2_grad_max"] > 0 and all(v == v and abs(v) < 1e6 for v in L) and L[-1] < L[0], L
