@@ -254,6 +254,57 @@ int mde_bn_bwd_apply(const void* dout, int ldd, const void* out, int ldo, const 
                      const float* mask_shift, const uint8_t* relu_bits, const float* coef, int64_t M,
                      int C, int relu, void* dx, int ldxo, int accumulate_dx, void* dres, int ldres,
                      void* stream);
+
+/* ---- finalize work inside the streaming launches.  The one-workgroup finalize kernels above (mde_bn_finalize,
+ * mde_bn_finalize_moments, mde_bn_bwd_finalize) sit between every pair of dependent BatchNorm passes: ~5 us with the chip idle
+ * around each, 128 per FCRN step, ~540 per DenseNet-161 step.  In the *_fin forms every workgroup of the streaming pass derives
+ * the constants of its own channels from the partial sums, workgroup 0 also writes what later passes read (scale / shift /
+ * save_mean / save_rstd and the running statistics; dgamma / dbeta) and zeroes `zero[0 .. zero_n)` -- the partial-sum buffer of
+ * the OTHER direction, which nothing reads while this launch runs.  The sums the launch reads are left as they are: a site
+ * therefore keeps two buffers, forward statistics (zeroed by its backward launch) and backward sums (zeroed by its forward
+ * launch); the caller zeroes them itself where a pass is repeated without its counterpart.  Not in deterministic mode
+ * (integer partial sums): MDE_EINVAL there. */
+typedef struct mde_bn_fin {
+    const float* part;          /* forward sums [mde_stat_slots()][2][part_ld], already offset to the site's first channel, or NULL with */
+    int32_t part_ld;
+    const float* mean_in;       /* ... given batch moments [C] (mde_bn_moments: DenseNet's shared moments) */
+    const float* var_in;
+    int64_t count;              /* elements per channel (M) */
+    const float* gamma;
+    const float* beta;
+    float* rmean;               /* running statistics, updated with `momentum` (both NULL: not tracked) */
+    float* rvar;
+    float momentum, eps;
+    float* scale;               /* written by workgroup 0: gamma / std, beta - mean * scale, batch mean, 1 / std */
+    float* shift;
+    float* smean;
+    float* srstd;
+    float* zero;                /* NULL or a buffer workgroup 0 zeroes (the site's backward sums) */
+    int64_t zero_n;
+} mde_bn_fin;
+typedef struct mde_bn_bfin {
+    const float* part;          /* backward sums [mde_stat_slots()][2][part_ld]: sum(g'), sum(g' xhat) */
+    int32_t part_ld;
+    int64_t count;
+    const float* gamma;
+    const float* srstd;
+    float* dgamma;              /* += by workgroup 0 (NULL: not wanted) */
+    float* dbeta;
+    float* zero;                /* NULL or a buffer workgroup 0 zeroes (the site's forward sums) */
+    int64_t zero_n;
+} mde_bn_bfin;
+/* mde_bn_apply with the statistics' finalize inside: fin_r != NULL = a second BatchNorm on the residual (r must be given). */
+int mde_bn_apply_fin(const void* x, int ldx, const mde_bn_fin* fin, const void* r, int ldr, const mde_bn_fin* fin_r, void* out, int ldo,
+                     uint8_t* relu_bits, int64_t M, int C, int relu, void* stream);
+/* mde_bn_bwd_apply / mde_bn_bwd_apply2 with mde_bn_bwd_finalize inside. */
+int mde_bn_bwd_apply_fin(const void* dout, int ldd, const void* out, int ldo, const void* x, int ldx, const float* save_mean,
+                         const float* save_rstd, const float* mask_scale, const float* mask_shift, const uint8_t* relu_bits,
+                         const mde_bn_bfin* fin, int64_t M, int C, int relu, void* dx, int ldxo, int accumulate_dx, void* dres,
+                         int ldres, void* stream);
+int mde_bn_bwd_apply2_fin(const void* dout, int ldd, const void* xa, int ldxa, const void* xb, int ldxb, const float* save_mean_a,
+                          const float* save_rstd_a, const float* save_mean_b, const float* save_rstd_b, const uint8_t* relu_bits,
+                          const mde_bn_bfin* fin_a, const mde_bn_bfin* fin_b, int64_t M, int C, void* dxa, int ldda, void* dxb,
+                          int lddb, void* stream);
 /* The same two passes for a residual JOIN whose two summands are both BatchNorm outputs
  * (out = relu(bn_a(xa) + bn_b(xb)): the downsample bottlenecks and every up-projection, FCRN.py:170-198):
  * both sites see the same masked gradient g = dout * mask, so dout and the mask are read once per pass

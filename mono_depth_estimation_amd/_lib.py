@@ -34,6 +34,20 @@ class BnRed(C.Structure):
                 ("add", C.c_void_p), ("add_bits", C.c_void_p)]
 
 
+class BnFin(C.Structure):
+    """mde_bn_fin (include/mde_hip.h)."""
+    _fields_ = [("part", C.c_void_p), ("part_ld", C.c_int32), ("mean_in", C.c_void_p), ("var_in", C.c_void_p), ("count", C.c_int64),
+                ("gamma", C.c_void_p), ("beta", C.c_void_p), ("rmean", C.c_void_p), ("rvar", C.c_void_p), ("momentum", C.c_float),
+                ("eps", C.c_float), ("scale", C.c_void_p), ("shift", C.c_void_p), ("smean", C.c_void_p), ("srstd", C.c_void_p),
+                ("zero", C.c_void_p), ("zero_n", C.c_int64)]
+
+
+class BnBfin(C.Structure):
+    """mde_bn_bfin (include/mde_hip.h)."""
+    _fields_ = [("part", C.c_void_p), ("part_ld", C.c_int32), ("count", C.c_int64), ("gamma", C.c_void_p), ("srstd", C.c_void_p),
+                ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("zero", C.c_void_p), ("zero_n", C.c_int64)]
+
+
 class ConvDesc(C.Structure):
     """mde_conv_desc (include/mde_hip.h)."""
     _fields_ = [
@@ -95,6 +109,9 @@ SIGNATURES = {
     "mde_bn_bwd_apply2": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _L, _I, _P, _I, _P, _I, _P]),
     "mde_bn_bwd_finalize": (_I, [_P, _L, _I, _P, _P, _P, _P, _P, _P]),
     "mde_bn_bwd_apply": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P, _I, _I, _P, _I, _P]),
+    "mde_bn_apply_fin": (_I, [_P, _I, C.POINTER(BnFin), _P, _I, C.POINTER(BnFin), _P, _I, _P, _L, _I, _I, _P]),
+    "mde_bn_bwd_apply_fin": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _P, _P, C.POINTER(BnBfin), _L, _I, _I, _P, _I, _I, _P, _I, _P]),
+    "mde_bn_bwd_apply2_fin": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _P, _P, C.POINTER(BnBfin), C.POINTER(BnBfin), _L, _I, _P, _I, _P, _I, _P]),
     "mde_pixel_shuffle2": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
     "mde_maxpool_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "mde_maxpool_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),

@@ -406,6 +406,285 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply2_k(const bf16_t* __restrict__
     }
 }
 
+// ------------------------------------------------------------------ finalize work inside the streaming launches
+// The one-workgroup finalize kernels (scale / shift from the statistics; the backward coefficients from the backward sums) sat
+// between every pair of dependent passes: 128 launches of ~5 us per FCRN step, ~540 per BTS step, each with the whole chip idle
+// around it.  In these forms every workgroup of the streaming pass derives the constants of ITS 8-channel columns from the
+// partial sums itself (32 slots x 2 rows from L2), workgroup 0 also writes what later passes need (scale / shift / saved mean /
+// 1/std, running statistics; dgamma / dbeta) and zeroes the partial-sum buffer of the OTHER direction -- nobody reads that one
+// while this launch runs (the forward sums are dead once backward has started and the other way round), so no workgroup has
+// to wait for another.  The sums this launch reads are left as they are: the other direction's launch zeroes them.
+__device__ __forceinline__ void fin_sum8(const float* part, int ld, int which, int col, double (&s)[8]) {
+    // eight slots in flight at a time: all 32 at once would cost the whole kernel 128 registers more than its streaming loop
+    // needs (256 VGPRs = two waves per SIMD: the loop then ran at half the bandwidth)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s[e] = 0.0;
+    static_assert(MDE_STAT_SLOTS % 8 == 0, "slots are read in chunks of eight");
+#pragma unroll 1
+    for (int k0 = 0; k0 < MDE_STAT_SLOTS; k0 += 8) {
+        f32x4_t a[8], b[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float* p = part + ((size_t)(k0 + k) * 2 + which) * ld + col * 8;
+            a[k] = *reinterpret_cast<const f32x4_t*>(p);
+            b[k] = *reinterpret_cast<const f32x4_t*>(p + 4);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { s[e] += (double)a[k][e]; s[4 + e] += (double)b[k][e]; }
+    }
+}
+
+__device__ __forceinline__ void fin_zero(float* z, int64_t n) {
+    if (z && blockIdx.x == 0)
+        for (int64_t i = threadIdx.x; i < n; i += NT) z[i] = 0.f;
+}
+
+// forward: scale / shift of the thread's 8 channels (bn_finalize_k's arithmetic; or bn_finalize_moments_k's from given moments)
+__device__ __forceinline__ void fin_fwd(const mde_bn_fin& f, int col, bool writer, float (&sc)[8], float (&sh)[8]) {
+    float mean[8], var[8];
+    if (f.part) {
+        double s1[8], s2[8];
+        fin_sum8(f.part, f.part_ld, 0, col, s1);
+        fin_sum8(f.part, f.part_ld, 1, col, s2);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const double m = s1[e] / (double)f.count;
+            double v = s2[e] / (double)f.count - m * m;
+            mean[e] = (float)m;
+            var[e] = (float)(v > 0.0 ? v : 0.0);
+            const float rstd = (float)(1.0 / sqrt((v > 0.0 ? v : 0.0) + (double)f.eps));
+            sc[e] = f.gamma[col * 8 + e] * rstd;
+            sh[e] = f.beta[col * 8 + e] - (float)m * sc[e];
+            if (writer) {
+                f.srstd[col * 8 + e] = rstd;
+                if (f.rmean) {
+                    const double unb = f.count > 1 ? (v > 0.0 ? v : 0.0) * (double)f.count / (double)(f.count - 1) : (v > 0.0 ? v : 0.0);
+                    f.rmean[col * 8 + e] = (1.f - f.momentum) * f.rmean[col * 8 + e] + f.momentum * (float)m;
+                    f.rvar[col * 8 + e] = (1.f - f.momentum) * f.rvar[col * 8 + e] + f.momentum * (float)unb;
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            mean[e] = f.mean_in[col * 8 + e];
+            var[e] = f.var_in[col * 8 + e];
+            const float rstd = (float)(1.0 / sqrt((double)var[e] + (double)f.eps));
+            sc[e] = f.gamma[col * 8 + e] * rstd;
+            sh[e] = f.beta[col * 8 + e] - mean[e] * sc[e];
+            if (writer) {
+                f.srstd[col * 8 + e] = rstd;
+                if (f.rmean) {
+                    const float unb = f.count > 1 ? (float)((double)var[e] * (double)f.count / (double)(f.count - 1)) : var[e];
+                    f.rmean[col * 8 + e] = (1.f - f.momentum) * f.rmean[col * 8 + e] + f.momentum * mean[e];
+                    f.rvar[col * 8 + e] = (1.f - f.momentum) * f.rvar[col * 8 + e] + f.momentum * unb;
+                }
+            }
+        }
+    }
+    if (writer) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            f.scale[col * 8 + e] = sc[e];
+            f.shift[col * 8 + e] = sh[e];
+            f.smean[col * 8 + e] = mean[e];
+        }
+    }
+}
+
+template <int RES>
+__global__ __launch_bounds__(NT) void bn_apply_fin_k(const bf16_t* __restrict__ x, int ldx, const mde_bn_fin f,
+                                                     const bf16_t* __restrict__ r, int ldr, const mde_bn_fin fr,
+                                                     bf16_t* __restrict__ out, int ldo, uint8_t* __restrict__ bits, int64_t M,
+                                                     int C, int relu) {
+    const int cpr = C >> 3, rpb = NT / cpr, col = threadIdx.x % cpr, rl = threadIdx.x / cpr;
+    extern __shared__ float s_fin[];          // [4][C]: the constants, derived ONCE per workgroup by its first row of threads
+    float sc[8], sh[8], rsc[8], rsh[8];
+    if (rl == 0) {
+        fin_fwd(f, col, blockIdx.x == 0, sc, sh);
+        if (RES == 2) fin_fwd(fr, col, blockIdx.x == 0, rsc, rsh);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            s_fin[col * 8 + e] = sc[e];
+            s_fin[C + col * 8 + e] = sh[e];
+            if (RES == 2) {
+                s_fin[2 * C + col * 8 + e] = rsc[e];
+                s_fin[3 * C + col * 8 + e] = rsh[e];
+            }
+        }
+    }
+    fin_zero(f.zero, f.zero_n);
+    if (RES == 2) fin_zero(fr.zero, fr.zero_n);
+    __syncthreads();
+    if (rl != 0 && rl < rpb) {
+        ldf8(s_fin + col * 8, sc);
+        ldf8(s_fin + C + col * 8, sh);
+        if (RES == 2) {
+            ldf8(s_fin + 2 * C + col * 8, rsc);
+            ldf8(s_fin + 3 * C + col * 8, rsh);
+        }
+    }
+#pragma unroll MDE_BN_UNROLL
+    for (int64_t row_ = rl < rpb ? (int64_t)blockIdx.x * rpb + rl : M; row_ < M; row_ += (int64_t)gridDim.x * rpb) {
+        const int64_t row = MDE_BN_SNAKE ? M - 1 - row_ : row_;
+        float v[8], q[8];
+        ld8(x + row * ldx + col * 8, v);
+        if (RES) ld8(r + row * ldr + col * 8, q);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float y = v[e] * sc[e] + sh[e];
+            if (RES == 1) y += q[e];
+            if (RES == 2) y += q[e] * rsc[e] + rsh[e];
+            v[e] = relu ? fmaxf(y, 0.f) : y;
+        }
+        st8(out + row * ldo + col * 8, v);
+        if (bits) {
+            uint32_t m = 0;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) m |= (uint32_t)((float)(bf16_t)v[e] > 0.f) << e;
+            bits[row * cpr + col] = (uint8_t)m;
+        }
+    }
+}
+
+// backward: the three coefficients of the thread's 8 channels (bn_bwd_finalize_k's arithmetic)
+__device__ __forceinline__ void fin_bwd(const mde_bn_bfin& f, int col, bool writer, float (&c0)[8], float (&c1)[8], float (&c2)[8]) {
+    double s1[8], s2[8];
+    fin_sum8(f.part, f.part_ld, 0, col, s1);
+    fin_sum8(f.part, f.part_ld, 1, col, s2);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        c0[e] = f.gamma[col * 8 + e] * f.srstd[col * 8 + e];
+        c1[e] = (float)(s1[e] / (double)f.count);
+        c2[e] = (float)(s2[e] / (double)f.count);
+        if (writer) {
+            if (f.dgamma) f.dgamma[col * 8 + e] += (float)s2[e];
+            if (f.dbeta) f.dbeta[col * 8 + e] += (float)s1[e];
+        }
+    }
+}
+
+template <int MASK>
+__global__ __launch_bounds__(NT) void bn_bwd_apply_fin_k(const bf16_t* __restrict__ dout, int ldd,
+                                                         const bf16_t* __restrict__ out, int ldo,
+                                                         const bf16_t* __restrict__ x, int ldx,
+                                                         const float* __restrict__ smean, const float* __restrict__ srstd,
+                                                         const float* __restrict__ msc, const float* __restrict__ msh,
+                                                         const uint8_t* __restrict__ bits, const mde_bn_bfin f,
+                                                         int64_t M, int C, bf16_t* __restrict__ dx, int ldxo, int accumulate, bf16_t* __restrict__ dres,
+                                                         int ldres) {
+    const int cpr = C >> 3, rpb = NT / cpr, col = threadIdx.x % cpr, rl = threadIdx.x / cpr;
+    float mu[8], rs[8], c0[8], c1[8], c2[8], ms[8], mh[8];
+    extern __shared__ float s_fin[];          // [3][C]
+    if (rl < rpb) {
+        if (MASK == 2) {
+            ldf8(msc + col * 8, ms);
+            ldf8(msh + col * 8, mh);
+        }
+        ldf8(smean + col * 8, mu);
+        ldf8(srstd + col * 8, rs);
+    }
+    if (rl == 0) {
+        fin_bwd(f, col, blockIdx.x == 0, c0, c1, c2);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            s_fin[col * 8 + e] = c0[e];
+            s_fin[C + col * 8 + e] = c1[e];
+            s_fin[2 * C + col * 8 + e] = c2[e];
+        }
+    }
+    fin_zero(f.zero, f.zero_n);
+    __syncthreads();
+    if (rl != 0 && rl < rpb) {
+        ldf8(s_fin + col * 8, c0);
+        ldf8(s_fin + C + col * 8, c1);
+        ldf8(s_fin + 2 * C + col * 8, c2);
+    }
+#pragma unroll MDE_BN_UNROLL
+    for (int64_t row_ = rl < rpb ? (int64_t)blockIdx.x * rpb + rl : M; row_ < M; row_ += (int64_t)gridDim.x * rpb) {
+        const int64_t row = MDE_BN_SNAKE ? M - 1 - row_ : row_;
+        float g[8], v[8], o[8], d[8];
+        ld8(dout + row * ldd + col * 8, g);
+        ld8(x + row * ldx + col * 8, v);
+        if (MASK == 1) ld8(out + row * ldo + col * 8, o);
+        if (accumulate) ld8(dx + row * ldxo + col * 8, d);
+        uint32_t mb = 0;
+        if (MASK == 3) mb = bits[row * cpr + col];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            if (MASK == 2) o[e] = v[e] * ms[e] + mh[e];
+            if (MASK == 3) o[e] = (float)((mb >> e) & 1u);
+            if (MASK && !(o[e] > 0.f)) g[e] = 0.f;
+            const float xh = (v[e] - mu[e]) * rs[e];
+            const float r = c0[e] * (g[e] - c1[e] - xh * c2[e]);
+            d[e] = accumulate ? d[e] + r : r;
+        }
+        st8(dx + row * ldxo + col * 8, d);
+        if (dres) st8(dres + row * ldres + col * 8, g);
+    }
+}
+
+__global__ __launch_bounds__(NT) void bn_bwd_apply2_fin_k(const bf16_t* __restrict__ dout, int ldd,
+                                                          const bf16_t* __restrict__ xa, int ldxa,
+                                                          const bf16_t* __restrict__ xb, int ldxb,
+                                                          const float* __restrict__ mean_a, const float* __restrict__ rstd_a,
+                                                          const float* __restrict__ mean_b, const float* __restrict__ rstd_b,
+                                                          const uint8_t* __restrict__ bits, const mde_bn_bfin fa, const mde_bn_bfin fb,
+                                                          int64_t M, int C, bf16_t* __restrict__ dxa, int ldda, bf16_t* __restrict__ dxb, int lddb) {
+    const int cpr = C >> 3, rpb = NT / cpr, col = threadIdx.x % cpr, rl = threadIdx.x / cpr;
+    float mua[8], rsa[8], a0[8], a1[8], a2[8], mub[8], rsb[8], b0[8], b1[8], b2[8];
+    extern __shared__ float s_fin[];          // [6][C]
+    if (rl < rpb) {
+        ldf8(mean_a + col * 8, mua);
+        ldf8(rstd_a + col * 8, rsa);
+        ldf8(mean_b + col * 8, mub);
+        ldf8(rstd_b + col * 8, rsb);
+    }
+    if (rl == 0) {
+        fin_bwd(fa, col, blockIdx.x == 0, a0, a1, a2);
+        fin_bwd(fb, col, blockIdx.x == 0, b0, b1, b2);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            s_fin[col * 8 + e] = a0[e];
+            s_fin[C + col * 8 + e] = a1[e];
+            s_fin[2 * C + col * 8 + e] = a2[e];
+            s_fin[3 * C + col * 8 + e] = b0[e];
+            s_fin[4 * C + col * 8 + e] = b1[e];
+            s_fin[5 * C + col * 8 + e] = b2[e];
+        }
+    }
+    fin_zero(fa.zero, fa.zero_n);
+    fin_zero(fb.zero, fb.zero_n);
+    __syncthreads();
+    if (rl != 0 && rl < rpb) {
+        ldf8(s_fin + col * 8, a0);
+        ldf8(s_fin + C + col * 8, a1);
+        ldf8(s_fin + 2 * C + col * 8, a2);
+        ldf8(s_fin + 3 * C + col * 8, b0);
+        ldf8(s_fin + 4 * C + col * 8, b1);
+        ldf8(s_fin + 5 * C + col * 8, b2);
+    }
+#pragma unroll MDE_BN_UNROLL
+    for (int64_t row_ = rl < rpb ? (int64_t)blockIdx.x * rpb + rl : M; row_ < M; row_ += (int64_t)gridDim.x * rpb) {
+        const int64_t row = MDE_BN_SNAKE ? M - 1 - row_ : row_;
+        float g[8], va[8], vb[8], da[8], db[8];
+        ld8(dout + row * ldd + col * 8, g);
+        ld8(xa + row * ldxa + col * 8, va);
+        ld8(xb + row * ldxb + col * 8, vb);
+        const uint32_t mb = bits ? bits[row * cpr + col] : 0xFFu;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float ge = ((mb >> e) & 1u) ? g[e] : 0.f;
+            da[e] = a0[e] * (ge - a1[e] - ((va[e] - mua[e]) * rsa[e]) * a2[e]);
+            db[e] = b0[e] * (ge - b1[e] - ((vb[e] - mub[e]) * rsb[e]) * b2[e]);
+        }
+        st8(dxa + row * ldda + col * 8, da);
+        st8(dxb + row * lddb + col * 8, db);
+    }
+}
+
 int check_site(const char* who, int64_t M, int C) {
     MDE_REQUIRE(M > 0 && C > 0, "%s: non-positive size", who);
     // (C / 8 need not divide the 256 threads: the threads past the last whole row group idle -- DenseNet's 48-channel growth)
@@ -603,5 +882,90 @@ extern "C" int mde_bn_bwd_apply(const void* dout, int ldd, const void* out, int 
         bn_bwd_apply_k<1><<<grid, NT, 0, st>>>(d, ldd, o, ldo, xp, ldx, save_mean, save_rstd, nullptr, nullptr, nullptr, coef, M, C,
                                                (bf16_t*)dx, ldxo, accumulate_dx, (bf16_t*)dres, ldres);
     MDE_LAUNCH_CHECK("bn_bwd_apply_k");
+    return MDE_OK;
+}
+
+static int check_fin(const char* who, const mde_bn_fin* f, int C) {
+    MDE_REQUIRE(f && f->gamma && f->beta && f->scale && f->shift && f->smean && f->srstd && f->count > 0, "%s: incomplete mde_bn_fin", who);
+    MDE_REQUIRE((f->part != nullptr) != (f->mean_in != nullptr && f->var_in != nullptr), "%s: partial sums OR given moments", who);
+    MDE_REQUIRE(!f->part || (f->part_ld >= C && f->part_ld % 4 == 0 && ((uintptr_t)f->part % 16) == 0), "%s: partial sums: ld >= C, 16-byte aligned", who);
+    MDE_REQUIRE((f->rmean == nullptr) == (f->rvar == nullptr) && (f->zero == nullptr || f->zero_n > 0), "%s: running statistics come in pairs", who);
+    MDE_REQUIRE(!g_mde_det.on, "%s: the fused finalize reads float partial sums; deterministic mode keeps integer ones (use mde_bn_finalize)", who);
+    return MDE_OK;
+}
+static int check_bfin(const char* who, const mde_bn_bfin* f, int C) {
+    MDE_REQUIRE(f && f->part && f->gamma && f->srstd && f->count > 0 && f->part_ld >= C && f->part_ld % 4 == 0 && ((uintptr_t)f->part % 16) == 0,
+                "%s: incomplete mde_bn_bfin", who);
+    MDE_REQUIRE(!g_mde_det.on, "%s: the fused finalize reads float partial sums; deterministic mode keeps integer ones (use mde_bn_bwd_finalize)", who);
+    return MDE_OK;
+}
+
+extern "C" int mde_bn_apply_fin(const void* x, int ldx, const mde_bn_fin* fin, const void* r, int ldr, const mde_bn_fin* fin_r, void* out, int ldo,
+                                uint8_t* relu_bits, int64_t M, int C, int relu, void* stream) {
+    MDE_REQUIRE(x && out, "mde_bn_apply_fin: null argument");
+    if (int rc = check_site("mde_bn_apply_fin", M, C)) return rc;
+    if (int rc = check_fin("mde_bn_apply_fin", fin, C)) return rc;
+    if (fin_r) {
+        if (int rc = check_fin("mde_bn_apply_fin (residual site)", fin_r, C)) return rc;
+    }
+    MDE_REQUIRE(al16(x, ldx) && al16(out, ldo) && (!r || al16(r, ldr)) && (!fin_r || r), "mde_bn_apply_fin: tensors must be 16-byte aligned, ld %% 8 == 0");
+    const int grid = stream_grid(M, C);
+    hipStream_t st = (hipStream_t)stream;
+    const bf16_t *xp = (const bf16_t*)x, *rp = (const bf16_t*)r;
+    const mde_bn_fin none = {};
+    if (!r)
+        bn_apply_fin_k<0><<<grid, NT, 4 * C * sizeof(float), st>>>(xp, ldx, *fin, nullptr, 0, none, (bf16_t*)out, ldo, relu_bits, M, C, relu);
+    else if (!fin_r)
+        bn_apply_fin_k<1><<<grid, NT, 4 * C * sizeof(float), st>>>(xp, ldx, *fin, rp, ldr, none, (bf16_t*)out, ldo, relu_bits, M, C, relu);
+    else
+        bn_apply_fin_k<2><<<grid, NT, 4 * C * sizeof(float), st>>>(xp, ldx, *fin, rp, ldr, *fin_r, (bf16_t*)out, ldo, relu_bits, M, C, relu);
+    MDE_LAUNCH_CHECK("bn_apply_fin_k");
+    return MDE_OK;
+}
+
+extern "C" int mde_bn_bwd_apply_fin(const void* dout, int ldd, const void* out, int ldo, const void* x, int ldx, const float* save_mean,
+                                    const float* save_rstd, const float* mask_scale, const float* mask_shift, const uint8_t* relu_bits,
+                                    const mde_bn_bfin* fin, int64_t M, int C, int relu, void* dx, int ldxo, int accumulate_dx, void* dres,
+                                    int ldres, void* stream) {
+    const bool recompute = relu && mask_scale && mask_shift;
+    const bool packed = relu && !recompute && relu_bits;
+    MDE_REQUIRE(dout && x && save_mean && save_rstd && dx && (!relu || recompute || packed || out), "mde_bn_bwd_apply_fin: null argument");
+    MDE_REQUIRE((mask_scale == nullptr) == (mask_shift == nullptr), "mde_bn_bwd_apply_fin: mask_scale/mask_shift come in pairs");
+    if (int rc = check_site("mde_bn_bwd_apply_fin", M, C)) return rc;
+    if (int rc = check_bfin("mde_bn_bwd_apply_fin", fin, C)) return rc;
+    MDE_REQUIRE(al16(dout, ldd) && al16(x, ldx) && al16(dx, ldxo) && (!relu || recompute || packed || al16(out, ldo)) &&
+                    (!dres || al16(dres, ldres)), "mde_bn_bwd_apply_fin: alignment");
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = stream_grid(M, C);
+    const bf16_t *d = (const bf16_t*)dout, *o = (const bf16_t*)out, *xp = (const bf16_t*)x;
+    if (!relu)
+        bn_bwd_apply_fin_k<0><<<grid, NT, 3 * C * sizeof(float), st>>>(d, ldd, o, ldo, xp, ldx, save_mean, save_rstd, nullptr, nullptr, nullptr, *fin, M, C,
+                                                   (bf16_t*)dx, ldxo, accumulate_dx, (bf16_t*)dres, ldres);
+    else if (recompute)
+        bn_bwd_apply_fin_k<2><<<grid, NT, 3 * C * sizeof(float), st>>>(d, ldd, o, ldo, xp, ldx, save_mean, save_rstd, mask_scale, mask_shift, nullptr, *fin,
+                                                   M, C, (bf16_t*)dx, ldxo, accumulate_dx, (bf16_t*)dres, ldres);
+    else if (packed)
+        bn_bwd_apply_fin_k<3><<<grid, NT, 3 * C * sizeof(float), st>>>(d, ldd, o, ldo, xp, ldx, save_mean, save_rstd, nullptr, nullptr, relu_bits, *fin, M,
+                                                   C, (bf16_t*)dx, ldxo, accumulate_dx, (bf16_t*)dres, ldres);
+    else
+        bn_bwd_apply_fin_k<1><<<grid, NT, 3 * C * sizeof(float), st>>>(d, ldd, o, ldo, xp, ldx, save_mean, save_rstd, nullptr, nullptr, nullptr, *fin, M, C,
+                                                   (bf16_t*)dx, ldxo, accumulate_dx, (bf16_t*)dres, ldres);
+    MDE_LAUNCH_CHECK("bn_bwd_apply_fin_k");
+    return MDE_OK;
+}
+
+extern "C" int mde_bn_bwd_apply2_fin(const void* dout, int ldd, const void* xa, int ldxa, const void* xb, int ldxb, const float* save_mean_a,
+                                     const float* save_rstd_a, const float* save_mean_b, const float* save_rstd_b, const uint8_t* relu_bits,
+                                     const mde_bn_bfin* fin_a, const mde_bn_bfin* fin_b, int64_t M, int C, void* dxa, int ldda, void* dxb,
+                                     int lddb, void* stream) {
+    MDE_REQUIRE(dout && xa && xb && save_mean_a && save_rstd_a && save_mean_b && save_rstd_b && dxa && dxb, "mde_bn_bwd_apply2_fin: null argument");
+    if (int rc = check_site("mde_bn_bwd_apply2_fin", M, C)) return rc;
+    if (int rc = check_bfin("mde_bn_bwd_apply2_fin (a)", fin_a, C)) return rc;
+    if (int rc = check_bfin("mde_bn_bwd_apply2_fin (b)", fin_b, C)) return rc;
+    MDE_REQUIRE(al16(dout, ldd) && al16(xa, ldxa) && al16(xb, ldxb) && al16(dxa, ldda) && al16(dxb, lddb), "mde_bn_bwd_apply2_fin: alignment");
+    bn_bwd_apply2_fin_k<<<stream_grid(M, C), NT, 6 * C * sizeof(float), (hipStream_t)stream>>>(
+        (const bf16_t*)dout, ldd, (const bf16_t*)xa, ldxa, (const bf16_t*)xb, ldxb, save_mean_a, save_rstd_a, save_mean_b, save_rstd_b,
+        relu_bits, *fin_a, *fin_b, M, C, (bf16_t*)dxa, ldda, (bf16_t*)dxb, lddb);
+    MDE_LAUNCH_CHECK("bn_bwd_apply2_fin_k");
     return MDE_OK;
 }

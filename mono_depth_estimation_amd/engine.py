@@ -20,7 +20,7 @@ import os
 
 import torch
 
-from . import ops
+from . import _lib, ops
 
 _ALIGN = 64
 # BatchNorm-backward sums from the epilogue of the input-gradient launch that writes the site's output gradient
@@ -28,6 +28,13 @@ _ALIGN = 64
 FUSE_BN_RED = os.environ.get("MDE_FUSE_BN_RED", "1") != "0"
 FUSE_DRES = FUSE_BN_RED and os.environ.get("MDE_FUSE_DRES", "1") != "0"      # identity shortcuts: see Bottleneck.bwd
 _CHECK_FUSED_SUMS = os.environ.get("MDE_FUSE_BN_RED_CHECK", "0") == "1"    # (tests switch it on in-process)
+# The one-workgroup BatchNorm finalize kernels folded into the streaming launches that follow them (mde_bn_apply_fin,
+# mde_bn_bwd_apply_fin / _apply2_fin).  MEASURED SLOWER and therefore OFF unless MDE_FUSE_BN_FIN=1 (FCRN
+# 28.3 -> 30.1 ms per step, BTS 51.0 -> 56.1): what the 128 (FCRN) / ~540 (BTS) five-microsecond launches cost is less than what
+# every workgroup of every streaming pass pays for deriving its constants from the 32 partial-sum slots itself -- four dependent
+# L2 round trips in front of its first row, and 50-60 more registers for the whole kernel (114 against 62: half the waves per
+# SIMD for a pass that lives on memory-level parallelism).  Never in deterministic mode.
+FUSE_BN_FIN = os.environ.get("MDE_FUSE_BN_FIN", "0") == "1"
 
 
 def _round_up(n, a=_ALIGN):
@@ -102,8 +109,15 @@ class BNSite:
         self.store, self.g_off, self.b_off = eng.store, g_off, b_off     # gradient slices: offsets into store.Gcur
         self.gamma, self.beta, self.rmean, self.rvar = gamma, beta, rmean, rvar
         self.scale, self.shift, self.smean, self.srstd = (torch.empty(C, device=dev) for _ in range(4))
+        # two partial-sum buffers [slots][2][C]: the forward statistics (conv epilogues / mde_bn_stats add into it) and the backward
+        # sums (mde_bn_bwd_reduce / the input-gradient launches' epilogues).  Separate finalize kernels zero the one they read; in
+        # the fused forms (FUSE_BN_FIN) each direction's launch zeroes the OTHER direction's buffer (EngineCore.begin_* keep watch)
         self.part = ops.new_stat_buffer(C, dev)
+        self.part_b = ops.new_stat_buffer(C, dev)
+        self.fpart, self.fpart_ld, self.fzero = self.part, C, self.part     # where the forward sums of THIS site's channels start
         self.coef = torch.empty(3, C, device=dev)
+        self._fin, self._bfin = {}, {}
+        eng.sites.append(self)
 
     def half(self, eng, i):
         """View of channels [i*C/2, (i+1)*C/2) of a fused site (own partial buffer for backward)."""
@@ -113,8 +127,12 @@ class BNSite:
         s.store, s.g_off, s.b_off = self.store, self.g_off + i * h, self.b_off + i * h
         for k in ("gamma", "beta", "rmean", "rvar", "scale", "shift", "smean", "srstd"):
             setattr(s, k, getattr(self, k)[i * h:(i + 1) * h])
-        s.part = ops.new_stat_buffer(h, eng.dev)
+        s.part = None                                   # (the forward statistics are the parent's: the fused conv writes 2C columns)
+        s.part_b = ops.new_stat_buffer(h, eng.dev)
+        s.fpart, s.fpart_ld, s.fzero = self.part.view(-1)[i * h:], self.C, self.part
         s.coef = torch.empty(3, h, device=eng.dev)
+        s._fin, s._bfin = {}, {}
+        eng.sites.append(s)
         return s
 
     @property
@@ -125,9 +143,59 @@ class BNSite:
     def dbeta(self):
         return self.store.Gcur[self.b_off:self.b_off + self.C]
 
+    def fin(self, M, mean=None, var=None):
+        """mde_bn_fin of this site's training-mode forward: its scale / shift come out of the apply launch itself (from the forward
+        sums, or from given batch moments: DenseNet), which also zeroes the site's backward sums."""
+        key = (M, None if mean is None else mean.data_ptr())
+        f = self._fin.get(key)
+        mom = self.bn.momentum if self.bn.momentum is not None else 0.1
+        if f is None:
+            dp = lambda t: t.data_ptr() if t is not None else None
+            f = _lib.BnFin(dp(self.fpart) if mean is None else None, self.fpart_ld if mean is None else 0, dp(mean), dp(var), M,
+                           dp(self.gamma), dp(self.beta), dp(self.rmean), dp(self.rvar), mom, self.eps, dp(self.scale), dp(self.shift),
+                           dp(self.smean), dp(self.srstd), dp(self.part_b), self.part_b.numel())
+            self._fin[key] = f
+        f.momentum = mom                                   # (read from the module at run time, as finalize does)
+        return f
+
+    def bfin(self, M):
+        """mde_bn_bfin of this site's backward: coefficients, dgamma / dbeta and the zeroing of the forward sums inside the
+        backward apply launch.  (dgamma / dbeta point into the buffer the current backward accumulates into.)"""
+        G = self.store.Gcur
+        key = (M, G.data_ptr())
+        f = self._bfin.get(key)
+        if f is None:
+            dp = lambda t: t.data_ptr() if t is not None else None
+            f = _lib.BnBfin(dp(self.part_b), self.C, M, dp(self.gamma), dp(self.srstd), dp(self.dgamma), dp(self.dbeta), dp(self.fzero),
+                            self.fzero.numel())
+            f._keep = G
+            self._bfin = {key: f}
+        return f
+
+    def apply(self, eng, x, ldx, out, ldo, M, relu, train, r=None, ldr=0, res_site=None, relu_bits=None, finalized=False,
+              mean=None, var=None):
+        """out = [relu](bn(x) [+ r | + bn_res(r)]) with this site's statistics finalized on the way: inside the launch
+        (mde_bn_apply_fin) in a training-mode pass, by the separate kernels otherwise (eval; deterministic mode; MDE_FUSE_BN_FIN=0;
+        `finalized`: the caller has run them already).  mean / var: batch moments already reduced (graph.PrefixBN)."""
+        if train and eng.fin_fused and not finalized:
+            ops.bn_apply_fin(x, ldx, self.fin(M, mean, var), out, ldo, M, self.C, relu, r=r, ldr=ldr,
+                             fin_r=res_site.fin(M) if res_site is not None else None, relu_bits=relu_bits)
+            return
+        if not finalized:
+            if mean is not None:
+                self.finalize_moments(mean, var, M, train)
+            else:
+                self.finalize(M, train)
+            if res_site is not None:
+                res_site.finalize(M, train)
+        ops.bn_apply(x, ldx, self.scale, self.shift, out, ldo, M, self.C, relu, r=r, ldr=ldr,
+                     rscale=res_site.scale if res_site is not None else None, rshift=res_site.shift if res_site is not None else None,
+                     relu_bits=relu_bits)
+
     def finalize(self, M, train):
         if train:
             mom = self.bn.momentum if self.bn.momentum is not None else 0.1
+            assert self.part is not None, "a half site's forward statistics are finalized through its parent (or inside its apply launch)"
             ops.bn_finalize(self.part, M, self.C, self.gamma, self.beta, self.rmean, self.rvar, mom, self.eps,
                             self.scale, self.shift, self.smean, self.srstd)
         else:
@@ -151,15 +219,20 @@ class BNSite:
         ms, mh = (self.scale, self.shift) if (relu and mask_from_x) else (None, None)
         if not reduced:
             ops.bn_bwd_reduce(dout, _ld(dout, out), out.t if out is not None else None, out.ld if out is not None else 0,
-                              x.t, x.ld, self.smean, self.srstd, M, C, relu, self.part, ms, mh, relu_bits)
+                              x.t, x.ld, self.smean, self.srstd, M, C, relu, self.part_b, ms, mh, relu_bits)
         elif _CHECK_FUSED_SUMS:
             # diagnostics (MDE_FUSE_BN_RED_CHECK=1): the sums that came with the conv launch against the reduction pass
-            tmp = torch.zeros_like(self.part)
+            tmp = torch.zeros_like(self.part_b)
             ops.bn_bwd_reduce(dout, _ld(dout, out), out.t if out is not None else None, out.ld if out is not None else 0,
                               x.t, x.ld, self.smean, self.srstd, M, C, relu, tmp, ms, mh, relu_bits)
-            _check_fused_sums(self.part, tmp, "M=%d C=%d x.ld=%d relu=%s mask_from_x=%s bits=%s" % (M, C, x.ld, relu, mask_from_x,
-                                                                                                 relu_bits is not None))
-        ops.bn_bwd_finalize(self.part, M, C, self.gamma, self.srstd, self.dgamma, self.dbeta, self.coef)
+            _check_fused_sums(self.part_b, tmp, "M=%d C=%d x.ld=%d relu=%s mask_from_x=%s bits=%s" % (M, C, x.ld, relu, mask_from_x,
+                                                                                                   relu_bits is not None))
+        if self.store.fin_fused:
+            ops.bn_bwd_apply_fin(dout, _ld(dout, out), out.t if out is not None else None, out.ld if out is not None else 0,
+                                 x.t, x.ld, self.smean, self.srstd, self.bfin(M), M, C, relu, dx, _ld(dx, x), accumulate,
+                                 dres, _ld(dres, x) if dres is not None else 0, ms, mh, relu_bits)
+            return
+        ops.bn_bwd_finalize(self.part_b, M, C, self.gamma, self.srstd, self.dgamma, self.dbeta, self.coef)
         ops.bn_bwd_apply(dout, _ld(dout, out), out.t if out is not None else None, out.ld if out is not None else 0,
                          x.t, x.ld, self.smean, self.srstd, self.coef, M, C, relu, dx, _ld(dx, x), accumulate,
                          dres, _ld(dres, x) if dres is not None else 0, ms, mh, relu_bits)
@@ -171,7 +244,7 @@ class BNSite:
         if not FUSE_BN_RED or self.C % 8 or (relu and not mask_from_x and relu_bits is None):
             return None
         ms, mh = (self.scale, self.shift) if (relu and mask_from_x) else (None, None)
-        return ops.bn_red(x.t, self.smean, self.srstd, self.part, ms, mh, relu_bits if (relu and not mask_from_x) else None, x_ld=x.ld)
+        return ops.bn_red(x.t, self.smean, self.srstd, self.part_b, ms, mh, relu_bits if (relu and not mask_from_x) else None, x_ld=x.ld)
 
 
 FUSED_SUM_CHECKS = []      # diagnostics: (site description, largest relative difference) per checked site and backward
@@ -193,14 +266,18 @@ def bn_join_backward(sa, sb, dout, out, xa, xb, dxa, dxb, relu_bits):
     reduced, out.reduced = out.reduced, False
     if not reduced:
         ops.bn_bwd_reduce2(dout, ldd, xa.t, xa.ld, xb.t, xb.ld, sa.smean, sa.srstd, sb.smean, sb.srstd, relu_bits, M, C,
-                           sa.part, sb.part)
+                           sa.part_b, sb.part_b)
     elif _CHECK_FUSED_SUMS:
-        ta, tb = torch.zeros_like(sa.part), torch.zeros_like(sb.part)
+        ta, tb = torch.zeros_like(sa.part_b), torch.zeros_like(sb.part_b)
         ops.bn_bwd_reduce2(dout, ldd, xa.t, xa.ld, xb.t, xb.ld, sa.smean, sa.srstd, sb.smean, sb.srstd, relu_bits, M, C, ta, tb)
-        _check_fused_sums(sa.part, ta, "join a: M=%d C=%d" % (M, C))
-        _check_fused_sums(sb.part, tb, "join b: M=%d C=%d xb.ld=%d" % (M, C, xb.ld))
-    ops.bn_bwd_finalize(sa.part, M, C, sa.gamma, sa.srstd, sa.dgamma, sa.dbeta, sa.coef)
-    ops.bn_bwd_finalize(sb.part, M, C, sb.gamma, sb.srstd, sb.dgamma, sb.dbeta, sb.coef)
+        _check_fused_sums(sa.part_b, ta, "join a: M=%d C=%d" % (M, C))
+        _check_fused_sums(sb.part_b, tb, "join b: M=%d C=%d xb.ld=%d" % (M, C, xb.ld))
+    if sa.store.fin_fused:
+        ops.bn_bwd_apply2_fin(dout, ldd, xa.t, xa.ld, xb.t, xb.ld, sa.smean, sa.srstd, sb.smean, sb.srstd, relu_bits, sa.bfin(M), sb.bfin(M),
+                              M, C, dxa, _ld(dxa, xa), dxb, _ld(dxb, xb))
+        return
+    ops.bn_bwd_finalize(sa.part_b, M, C, sa.gamma, sa.srstd, sa.dgamma, sa.dbeta, sa.coef)
+    ops.bn_bwd_finalize(sb.part_b, M, C, sb.gamma, sb.srstd, sb.dgamma, sb.dbeta, sb.coef)
     ops.bn_bwd_apply2(dout, ldd, xa.t, xa.ld, xb.t, xb.ld, sa.smean, sa.srstd, sb.smean, sb.srstd, relu_bits, sa.coef,
                       sb.coef, M, C, dxa, _ld(dxa, xa), dxb, _ld(dxb, xb))
 
@@ -308,6 +385,12 @@ class FlatStore:
         self.deterministic = bool(on)
         if not on:
             ops.set_deterministic(False)
+
+    @property
+    def fin_fused(self):
+        """The BatchNorm finalize work runs inside the streaming launches (FUSE_BN_FIN; never in deterministic mode, whose partial
+        sums are integers)."""
+        return FUSE_BN_FIN and not self.deterministic
 
     def det_begin(self):
         """Program the library's (process-wide) accumulation mode for THIS store's forward / backward: the integer gradient
@@ -767,15 +850,59 @@ class EngineCore:
         self.side = torch.cuda.Stream(self.dev) if (on_gpu and os.environ.get("MDE_WGRAD_STREAM", "1") == "1") else None
         self.side_busy = False
         self.split = False            # this forward runs over the two-term eval operands (begin_forward)
+        self.sites = []               # every BNSite of the plan (BNSite.__init__ / half register themselves)
+        # partial sums a pass left behind: the fused-finalize launches read the sums without zeroing them, the OTHER direction's
+        # launch does (BNSite.fin / bfin); a pass that is repeated without its counterpart zeroes them here first
+        self._fwd_sums, self._bwd_sums = False, False
 
     def attach_grads(self):
         return self.store.attach_grads()
+
+    @property
+    def fin_fused(self):
+        return self.store.fin_fused
 
     def begin_forward(self, train, check_data):
         """Weight shadows current for this forward: the one-term shadow always, the two-term eval operands in eval mode."""
         self.store.det_begin()
         self.store.refresh_weights(check_data=check_data)
         self.split = (not train) and self.store.ensure_split(always=check_data)
+        if train:
+            if self._fwd_sums:                 # a training-mode forward without a backward since (or an interrupted pass)
+                for s in self.sites:
+                    if s.part is not None:
+                        s.part.zero_()
+            # fused: this pass leaves its sums for the backward launches to zero, and zeroes the backward sums itself;
+            # separate finalize kernels zero what they read
+            self._fwd_sums = True
+
+    def reset_sums(self):
+        """Zero every BatchNorm partial-sum buffer of the plan.  forward() / backward() keep them consistent by themselves; a driver
+        that runs single layers of the plan (the teacher-forced layer tests) calls this before each training-mode layer pass."""
+        for s in self.sites:
+            if s.part is not None:
+                s.part.zero_()
+            s.part_b.zero_()
+        self._fwd_sums = self._bwd_sums = False
+
+    def end_forward(self, train):
+        if train:
+            if self.fin_fused:
+                self._bwd_sums = False
+            else:
+                self._fwd_sums = False
+
+    def begin_backward(self):
+        if self._bwd_sums:                     # a backward pass repeated without a training-mode forward in between
+            for s in self.sites:
+                s.part_b.zero_()
+        self._bwd_sums = True
+
+    def end_backward(self):
+        if self.fin_fused:
+            self._fwd_sums = False
+        else:
+            self._bwd_sums = False
 
     def fwd_conv(self, desc, x, conv, out, stats=None, transposed=False, bias=None, res=None, act=None):
         """A FORWARD convolution launch.  Training (and MDE_EVAL_SPLIT=0): the one-term bf16 shadow (`conv.wf`, or `conv.wd`
@@ -938,8 +1065,7 @@ class FCRNEngine(EngineCore):
                 self.fwd_conv(d, self.xin.t, self.stem_w, self.stem_c.t)
             if train:
                 ops.bn_stats(self.stem_c.t, self.stem_c.M, 64, 64, s.part)
-        s.finalize(self.stem_c.M, train)
-        ops.bn_apply(self.stem_c.t, 64, s.scale, s.shift, self.stem_a.t, 64, self.stem_c.M, 64, True)
+        s.apply(self, self.stem_c.t, 64, self.stem_a.t, 64, self.stem_c.M, True, train)
         ops.maxpool_fwd(self.stem_a.t, self.pool.t, self.pool_idx, self.N, self.stem_a.H, self.stem_a.W, 64)
         for L in self.layers:
             L.fwd(train)
@@ -948,6 +1074,7 @@ class FCRNEngine(EngineCore):
         ops.upsample_sigmoid_fwd(self.logits, self.y, f.N, f.H, f.W, self.out_channels, self.OH, self.OW)
         if train:
             self.store.nbt += 1
+        self.end_forward(train)
         return self.y
 
     def grad_boundaries(self):
@@ -974,6 +1101,7 @@ class FCRNEngine(EngineCore):
         for L in self.layers:
             L.reset_grad_flags()
         self.pool.gw = self.stem_a.gw = False
+        self.begin_backward()
         ops.upsample_sigmoid_bwd(dy, self.y, self.dlogits, f.N, f.H, f.W, self.out_channels, self.OH, self.OW)
         ops.head_conv_bwd(f.t, self.head_w.w32, self.dlogits, f.g, self.head_w.dw, f.N, f.H, f.W, f.C, self.out_channels)
         f.gw = True
@@ -993,6 +1121,7 @@ class FCRNEngine(EngineCore):
                 self.wgrad(d, self.stem_c.g, self.xin.t, self.stem_w.dw)
         self.join_side()
         self.store.det_end()
+        self.end_backward()
         if det:
             on_progress = progress
         if on_progress is not None:
@@ -1034,20 +1163,22 @@ class ConvBN:
 
     def conv_fwd(self, train):
         self.eng.fwd_conv(self.fdesc, self.x.t, self.conv, self.c.t, self.site.part if train else None)
-        self.site.finalize(self.c.M, train)
+        if not (train and self.eng.fin_fused):
+            self.site.finalize(self.c.M, train)          # (fused: inside the apply launch that reads this site -- fwd below, or the join's)
 
     def fwd(self, train):
         self.conv_fwd(train)
         s, c, o = self.site, self.c, self.out
+        fused = train and self.eng.fin_fused
         if self.res is None:
-            ops.bn_apply(c.t, c.ld, s.scale, s.shift, o.t, o.ld, c.M, c.C, self.relu)
+            s.apply(self.eng, c.t, c.ld, o.t, o.ld, c.M, self.relu, train, finalized=not fused)
         elif self.res_site is None:
-            ops.bn_apply(c.t, c.ld, s.scale, s.shift, o.t, o.ld, c.M, c.C, self.relu, r=self.res.t, ldr=self.res.ld,
-                         relu_bits=self.bits if train else None)
+            s.apply(self.eng, c.t, c.ld, o.t, o.ld, c.M, self.relu, train, r=self.res.t, ldr=self.res.ld,
+                    relu_bits=self.bits if train else None, finalized=not fused)
         else:
-            rs = self.res_site
-            ops.bn_apply(c.t, c.ld, s.scale, s.shift, o.t, o.ld, c.M, c.C, self.relu, r=self.res.t, ldr=self.res.ld,
-                         rscale=rs.scale, rshift=rs.shift, relu_bits=self.bits if train else None)
+            # (the second site was finalized by its own unit's conv_fwd -- a shortcut conv, the up-projection's 5x5 -- unless fused)
+            s.apply(self.eng, c.t, c.ld, o.t, o.ld, c.M, self.relu, train, r=self.res.t, ldr=self.res.ld, res_site=self.res_site,
+                    relu_bits=self.bits if train else None, finalized=not fused)
 
     def red_spec(self):
         """For the launch that completes d(out): this unit's BatchNorm-backward sums (a join: both sites') from that launch's
@@ -1059,8 +1190,8 @@ class ConvBN:
                 self._red = s.red_spec(self.c, self.relu, mask_from_x=self.res is None, relu_bits=self.bits)
             elif self.out is not None and self.out.ld == self.c.ld and FUSE_BN_RED and self.bits is not None and s.C % 8 == 0:
                 # a join: the sums of both sites under the one mask (what bn_join_backward's first pass computes)
-                self._red = ops.bn_red(self.c.t, s.smean, s.srstd, s.part, relu_bits=self.bits, x_ld=self.c.ld,
-                                       second=(self.res.t, rs.smean, rs.srstd, rs.part, self.res.ld))
+                self._red = ops.bn_red(self.c.t, s.smean, s.srstd, s.part_b, relu_bits=self.bits, x_ld=self.c.ld,
+                                       second=(self.res.t, rs.smean, rs.srstd, rs.part_b, self.res.ld))
         return self._red
 
     def bn_bwd(self, dres_to=None):
@@ -1239,9 +1370,13 @@ class UpProjLayer:
         x, y = self.x, self.y55
         for d in self.fdescs:
             self.eng.fwd_conv(d, x.t, self.w55, y.t, self.site55.part if train else None)
-        self.site55.finalize(y.M, train)
         su = self.site_u
-        ops.bn_apply(self.y_u.t, y.ld, su.scale, su.shift, self.a1.t, self.a1.ld, y.M, su.C, True)
+        if train and self.eng.fin_fused:
+            # the upper half's constants come out of its own apply launch; the lower half's out of the join's (c2.fwd: res_site)
+            su.apply(self.eng, self.y_u.t, y.ld, self.a1.t, self.a1.ld, y.M, True, train)
+        else:
+            self.site55.finalize(y.M, train)
+            su.apply(self.eng, self.y_u.t, y.ld, self.a1.t, self.a1.ld, y.M, True, train, finalized=True)
         self.c2.fwd(train)
 
     def bwd(self):
@@ -1290,8 +1425,7 @@ class UpConvLayer:
         x, y, s = self.x, self.y, self.site
         for d in self.fdescs:
             self.eng.fwd_conv(d, x.t, self.w, y.t, s.part if train else None)
-        s.finalize(y.M, train)
-        ops.bn_apply(y.t, y.ld, s.scale, s.shift, self.out.t, self.out.ld, y.M, y.C, True)
+        s.apply(self.eng, y.t, y.ld, self.out.t, self.out.ld, y.M, True, train)
 
     def bwd(self):
         x, y = self.x, self.y
@@ -1342,8 +1476,7 @@ class DeConvLayer:
         for d in self.fdescs:
             d.accumulate = 0
             self.eng.fwd_conv(d, x.t, self.w, y.t, s.part if train else None, transposed=True)
-        s.finalize(y.M, train)
-        ops.bn_apply(y.t, y.ld, s.scale, s.shift, self.out.t, self.out.ld, y.M, y.C, True)
+        s.apply(self.eng, y.t, y.ld, self.out.t, self.out.ld, y.M, True, train)
 
     def bwd(self):
         x, y = self.x, self.y
@@ -1379,14 +1512,16 @@ class _BiasedConvBN:
     def fwd(self, train, relu):
         s, y = self.site, self.y
         self.eng.fwd_conv(self.fdesc, self.x.t, self.conv, y.t, s.part if train else None)
-        s.finalize(y.M, train)
-        with torch.no_grad():
-            if train:
+        if train:
+            s.apply(self.eng, y.t, y.ld, self.yb.t, self.yb.ld, y.M, relu, True)
+            with torch.no_grad():
                 mom = s.bn.momentum if s.bn.momentum is not None else 0.1
-                s.rmean.add_(self.bias, alpha=mom)           # running mean of (conv + bias)
-            else:
+                s.rmean.add_(self.bias, alpha=mom)           # running mean of (conv + bias), after the statistics' own update
+        else:
+            s.finalize(y.M, False)
+            with torch.no_grad():
                 s.shift.addcmul_(s.scale, self.bias)
-        ops.bn_apply(y.t, y.ld, s.scale, s.shift, self.yb.t, self.yb.ld, y.M, y.C, relu)
+            s.apply(self.eng, y.t, y.ld, self.yb.t, self.yb.ld, y.M, relu, False, finalized=True)
 
     def bwd(self, relu):
         x, y, yb = self.x, self.y, self.yb

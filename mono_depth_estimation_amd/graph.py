@@ -117,8 +117,7 @@ class Stem(Op):
     def fwd(self, train):
         s, c, a = self.site, self.c, self.a
         ops.stem_conv_fwd(self.x, self.w.w32, c.t, s.part if train else None)
-        s.finalize(c.M, train)
-        ops.bn_apply(c.t, 64, s.scale, s.shift, a.t, 64, c.M, 64, True)
+        s.apply(self.eng, c.t, 64, a.t, 64, c.M, True, train)
         ops.maxpool_fwd(a.t, self.out.t, self.idx, a.N, a.H, a.W, 64)
 
     def bwd(self):
@@ -280,8 +279,8 @@ class BN(Op):
             return s.red_spec(c, self.relu, relu_bits=self.bits)
         if self.bits is None:
             return None
-        return ops.bn_red(c.t, s.smean, s.srstd, s.part, relu_bits=self.bits, x_ld=c.ld,
-                          second=(self.res.t, rs.smean, rs.srstd, rs.part, self.res.ld))
+        return ops.bn_red(c.t, s.smean, s.srstd, s.part_b, relu_bits=self.bits, x_ld=c.ld,
+                          second=(self.res.t, rs.smean, rs.srstd, rs.part_b, self.res.ld))
 
     def acts(self):
         return (self.out,) if self.own_out else ()
@@ -291,25 +290,24 @@ class BN(Op):
 
     def fwd(self, train):
         s, c, o = self.site, self.c, self.out
-        s.finalize(c.M, train)
-        if self.res_site is not None:
-            self.res_site.finalize(self.res.M, train)
+        rs, r = self.res_site, self.res
+        bits = self.bits if (train and r is not None) else None
+        if train:
+            # (the statistics' finalize runs inside the apply launch unless the store says otherwise: BNSite.apply)
+            s.apply(self.eng, c.t, c.ld, o.t, o.ld, c.M, self.relu, True, r=r.t if r is not None else None, ldr=r.ld if r is not None else 0,
+                    res_site=rs, relu_bits=bits)
+            if self.bias is not None:
+                with torch.no_grad():          # running mean of (conv + bias), after the statistics' own update of it
+                    s.rmean.add_(self.bias, alpha=s.bn.momentum if s.bn.momentum is not None else 0.1)
+            return
+        s.finalize(c.M, False)
+        if rs is not None:
+            rs.finalize(r.M, False)
         if self.bias is not None:
             with torch.no_grad():
-                if train:
-                    mom = s.bn.momentum if s.bn.momentum is not None else 0.1
-                    s.rmean.add_(self.bias, alpha=mom)
-                else:
-                    s.shift.addcmul_(s.scale, self.bias)
-        if self.res is None:
-            ops.bn_apply(c.t, c.ld, s.scale, s.shift, o.t, o.ld, c.M, c.C, self.relu)
-        elif self.res_site is None:
-            ops.bn_apply(c.t, c.ld, s.scale, s.shift, o.t, o.ld, c.M, c.C, self.relu, r=self.res.t, ldr=self.res.ld,
-                         relu_bits=self.bits if train else None)
-        else:
-            rs = self.res_site
-            ops.bn_apply(c.t, c.ld, s.scale, s.shift, o.t, o.ld, c.M, c.C, self.relu, r=self.res.t, ldr=self.res.ld,
-                         rscale=rs.scale, rshift=rs.shift, relu_bits=self.bits if train else None)
+                s.shift.addcmul_(s.scale, self.bias)
+        s.apply(self.eng, c.t, c.ld, o.t, o.ld, c.M, self.relu, False, r=r.t if r is not None else None, ldr=r.ld if r is not None else 0,
+                res_site=rs, relu_bits=bits, finalized=True)
 
     def bwd(self):
         c, o, res = self.c, self.out, self.res
@@ -796,8 +794,7 @@ class PrefixBN(Op):
 
     def fwd(self, train):
         for s, xs, os_, mean, var in self.chunks:
-            s.finalize_moments(mean, var, xs.M, train)
-            ops.bn_apply(xs.t, xs.ld, s.scale, s.shift, os_.t, os_.ld, xs.M, xs.C, self.relu)
+            s.apply(self.eng, xs.t, xs.ld, os_.t, os_.ld, xs.M, self.relu, train, mean=mean, var=var)
 
     def bwd(self):
         acc = _take(self.x)
@@ -1160,6 +1157,7 @@ class TapeEngine(EngineCore):
             op.fwd(train)
         if train:
             self.store.nbt += 1
+        self.end_forward(train)
         return tuple(t for h in self.heads for t in h.outputs)
 
     def progress_thresholds(self):
@@ -1193,6 +1191,7 @@ class TapeEngine(EngineCore):
         consumer orders itself behind the weight-gradient stream (FlatGradReducer(extra_streams=[eng.side])); otherwise that
         stream is joined into the current one before every call."""
         self.store.det_begin()
+        self.begin_backward()
         if self.store.deterministic and on_progress is not None:
             final_cb, on_progress = on_progress, None            # the gradients reach the buffer only with the final flush
         else:
@@ -1235,6 +1234,7 @@ class TapeEngine(EngineCore):
             self._plan_fused_sums(trace)
         self.join_side()
         self.store.det_end()
+        self.end_backward()
         if final_cb is not None:
             final_cb(0)
 

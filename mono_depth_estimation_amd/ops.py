@@ -441,6 +441,25 @@ def bn_bwd_apply(dout, ldd, out, ldo, x, ldx, smean, srstd, coef, M, C_, relu, d
                                        _p(dres), ldres, _stream()), "mde_bn_bwd_apply")
 
 
+def bn_apply_fin(x, ldx, fin, out, ldo, M, C_, relu, r=None, ldr=0, fin_r=None, relu_bits=None):
+    """mde_bn_apply_fin: the statistics' finalize inside the apply launch (fin / fin_r: _lib.BnFin from BNSite.fin())."""
+    check(_lib.load().mde_bn_apply_fin(_p(x), ldx, C.byref(fin), _p(r), ldr, C.byref(fin_r) if fin_r is not None else None, _p(out), ldo,
+                                       _p(relu_bits), M, C_, int(relu), _stream()), "mde_bn_apply_fin")
+
+
+def bn_bwd_apply_fin(dout, ldd, out, ldo, x, ldx, smean, srstd, bfin, M, C_, relu, dx, ldxo, accumulate=False, dres=None, ldres=0,
+                     mask_scale=None, mask_shift=None, relu_bits=None):
+    check(_lib.load().mde_bn_bwd_apply_fin(_p(dout), ldd, _p(out), ldo, _p(x), ldx, _p(smean), _p(srstd), _p(mask_scale), _p(mask_shift),
+                                           _p(relu_bits), C.byref(bfin), M, C_, int(relu), _p(dx), ldxo, int(accumulate), _p(dres), ldres,
+                                           _stream()), "mde_bn_bwd_apply_fin")
+
+
+def bn_bwd_apply2_fin(dout, ldd, xa, ldxa, xb, ldxb, mean_a, rstd_a, mean_b, rstd_b, relu_bits, bfin_a, bfin_b, M, C_, dxa, ldda, dxb, lddb):
+    check(_lib.load().mde_bn_bwd_apply2_fin(_p(dout), ldd, _p(xa), ldxa, _p(xb), ldxb, _p(mean_a), _p(rstd_a), _p(mean_b), _p(rstd_b),
+                                            _p(relu_bits), C.byref(bfin_a), C.byref(bfin_b), M, C_, _p(dxa), ldda, _p(dxb), lddb, _stream()),
+          "mde_bn_bwd_apply2_fin")
+
+
 # ------------------------------------------------------------------------------ pool / resize
 def pixel_shuffle2(src, ld_src, dst, ld_dst, N, h, w, C_, inverse=False):
     check(_lib.load().mde_pixel_shuffle2(_p(src), ld_src, _p(dst), ld_dst, N, h, w, C_, int(inverse), _stream()),

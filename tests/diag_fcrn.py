@@ -100,6 +100,7 @@ def main():
     print("teacher-forced   %-10s %10s %10s %10s" % ("layer", "fwd", "dx", "worst dW"))
     for nm, L in zip(names, eng.layers):
         L.x.t.copy_(to_dev(ins[nm]))
+        eng.reset_sums()               # (a single layer outside forward(): the fused-finalize launches leave their sums to the other pass)
         L.fwd(True)
         e_f = rel(nchw(L.out.t), acts[nm].detach())
         eng.store.G.zero_()

@@ -636,3 +636,136 @@ def test_maxpool_view(N, H, Wd, C, k, s, y0, x0, Hv, Wv):
     ops.maxpool_view_bwd(dyd, C, idx, dx[:, y0:, x0:], C, Wd, H * Wd, Hv, Wv, N, C, k, s, accumulate=True)
     got = dx.float().cpu().permute(0, 3, 1, 2)
     assert torch.allclose(got, xi.grad.to(ACT).float(), rtol=2.0 ** -7, atol=1e-6), float((got - xi.grad).abs().max())
+
+
+# ------------------------------------------------------------------------------------ finalize work inside the streaming launches
+def _fin(part, ld, M, gamma, beta, rmean, rvar, mom, eps, scale, shift, smean, srstd, zero, mean=None, var=None):
+    from mono_depth_estimation_amd import _lib
+    dp = lambda t: t.data_ptr() if t is not None else None
+    f = _lib.BnFin(dp(part), ld, dp(mean), dp(var), M, dp(gamma), dp(beta), dp(rmean), dp(rvar), mom, eps, dp(scale), dp(shift), dp(smean),
+                   dp(srstd), dp(zero), zero.numel() if zero is not None else 0)
+    f._keep = (part, gamma, beta, rmean, rvar, scale, shift, smean, srstd, zero, mean, var)
+    return f
+
+
+@pytest.mark.parametrize("N,H,Wd,C,relu,res", [(2, 9, 11, 64, True, 0), (3, 7, 5, 256, False, 0), (2, 6, 6, 128, True, 1), (2, 5, 9, 64, True, 2),
+                                               (1, 3, 4, 2048, True, 1), (4, 40, 48, 48, True, 0)])
+def test_bn_fused_finalize_equals_the_separate_kernels(N, H, Wd, C, relu, res):
+    """mde_bn_apply_fin / mde_bn_bwd_apply_fin / mde_bn_bwd_apply2_fin against finalize + apply, the same arithmetic in another
+    launch: every output BIT for bit (activation, mask bits, scale / shift / saved statistics, running statistics, dx, dgamma /
+    dbeta), the sums the launch read left untouched, the OTHER direction's buffer zeroed; a site whose forward sums are a column
+    range of a wider buffer (the up-projection's halves) and given batch moments (DenseNet) included."""
+    from mono_depth_estimation_amd import _lib, ops
+    dev, M = "cuda", N * H * Wd
+    x = _bf(W.normal(31, "x", (N, C, H, Wd), 1.5, 0.3))
+    r = _bf(W.normal(31, "r", (N, C, H, Wd)))
+    dy = _bf(W.normal(31, "dy", (N, C, H, Wd)))
+    xd, rd, dyd = _nhwc(x), _nhwc(r), _nhwc(dy)
+    mk = lambda tag: [W.normal(31, tag + "g", (C,), 0.2, 1.0).to(dev), W.normal(31, tag + "b", (C,), 0.2).to(dev),
+                      W.normal(31, tag + "m", (C,), 0.2).to(dev), W.uniform(31, tag + "v", (C,), 0.5, 1.5).to(dev)]
+    wide = 2 * C if C <= 1024 else C                       # forward sums in columns [c0, c0 + C) of a [slots][2][wide] buffer
+    c0 = wide - C
+
+    sums = {}
+    for tag, t in (("a", xd), ("r", rd)):                 # ONE set of sums for both forms (float atomics: a second pass would differ in order)
+        sums[tag] = ops.new_stat_buffer(C)
+        ops.bn_stats(t, M, C, C, sums[tag])                # (the conv epilogue's role)
+
+    def forward(fused):
+        outs = {}
+        sites = []
+        for tag, t in (("a", xd), ("r", rd)):
+            g, b, rm, rv = mk(tag)
+            part = torch.zeros(ops.stat_slots(), 2, wide, device=dev)
+            part[:, :, c0:] = sums[tag]
+            sites.append(dict(g=g, b=b, rm=rm, rv=rv, part=part, sc=torch.empty(C, device=dev), sh=torch.empty(C, device=dev),
+                              sm=torch.empty(C, device=dev), sr=torch.empty(C, device=dev), pb=torch.full((ops.stat_slots(), 2, C), 3.0, device=dev)))
+        a, b2 = sites
+        out = torch.empty_like(xd)
+        bits = torch.zeros(M * C // 8, dtype=torch.uint8, device=dev) if (relu and res) else None
+        if fused:
+            fa = _fin(a["part"].view(-1)[c0:], wide, M, a["g"], a["b"], a["rm"], a["rv"], 0.1, 1e-5, a["sc"], a["sh"], a["sm"], a["sr"], a["pb"])
+            fb = _fin(b2["part"].view(-1)[c0:], wide, M, b2["g"], b2["b"], b2["rm"], b2["rv"], 0.1, 1e-5, b2["sc"], b2["sh"], b2["sm"], b2["sr"], b2["pb"])
+            ops.bn_apply_fin(xd, C, fa, out, C, M, C, relu, r=rd if res else None, ldr=C if res else 0, fin_r=fb if res == 2 else None, relu_bits=bits)
+        else:
+            for s in (a, b2) if res == 2 else (a,):
+                dense = s["part"][:, :, c0:].contiguous()
+                ops.bn_finalize(dense, M, C, s["g"], s["b"], s["rm"], s["rv"], 0.1, 1e-5, s["sc"], s["sh"], s["sm"], s["sr"])
+            ops.bn_apply(xd, C, a["sc"], a["sh"], out, C, M, C, relu, r=rd if res else None, ldr=C if res else 0,
+                         rscale=b2["sc"] if res == 2 else None, rshift=b2["sh"] if res == 2 else None, relu_bits=bits)
+        torch.cuda.synchronize()
+        return out, bits, a, b2
+
+    o1, bits1, a1, r1 = forward(False)
+    part_before = None
+    o2, bits2, a2, r2 = forward(True)
+    assert torch.equal(o1, o2) and (bits1 is None or torch.equal(bits1, bits2))
+    for s1, s2 in ((a1, a2), (r1, r2)) if res == 2 else ((a1, a2),):
+        for k in ("sc", "sh", "sm", "sr", "rm", "rv"):
+            assert torch.equal(s1[k], s2[k]), k
+        assert float(s2["pb"].abs().max()) == 0.0, "the backward sums were to be zeroed"
+        assert float(s2["part"][:, :, c0:].abs().max()) > 0.0 and float(s2["part"][:, :, :c0].abs().max() if c0 else 0.0) == 0.0
+    # given batch moments (DenseNet's shared moments): the same launch against mde_bn_finalize_moments + apply
+    mean, var = a1["sm"].clone(), (1.0 / a1["sr"] ** 2 - 1e-5).clamp(min=0)
+    g, b, rm, rv = mk("a")
+    sc, sh, sm, sr = (torch.empty(C, device=dev) for _ in range(4))
+    ops.bn_finalize_moments(mean, var, M, C, g, b, rm, rv, 0.1, 1e-5, sc, sh, sm, sr)
+    o3 = torch.empty_like(xd)
+    ops.bn_apply(xd, C, sc, sh, o3, C, M, C, relu)
+    g2, b2_, rm2, rv2 = mk("a")
+    sc2, sh2, sm2, sr2 = (torch.empty(C, device=dev) for _ in range(4))
+    o4 = torch.empty_like(xd)
+    ops.bn_apply_fin(xd, C, _fin(None, 0, M, g2, b2_, rm2, rv2, 0.1, 1e-5, sc2, sh2, sm2, sr2, None, mean=mean, var=var), o4, C, M, C, relu)
+    torch.cuda.synchronize()
+    assert torch.equal(o3, o4) and torch.equal(sc, sc2) and torch.equal(sh, sh2) and torch.equal(rm, rm2) and torch.equal(rv, rv2) and torch.equal(sr, sr2)
+
+    # ---- backward
+    def bfin(part_b, gamma, srstd, dg, db, zero):
+        dp = lambda t: t.data_ptr() if t is not None else None
+        f = _lib.BnBfin(dp(part_b), C, M, dp(gamma), dp(srstd), dp(dg), dp(db), dp(zero), zero.numel())
+        f._keep = (part_b, gamma, srstd, dg, db, zero)
+        return f
+    mkw = dict(mask_scale=a1["sc"], mask_shift=a1["sh"]) if (relu and res == 0) else (dict(relu_bits=bits1) if bits1 is not None else {})
+    outs = []
+    pb0 = ops.new_stat_buffer(C)                              # ONE set of sums for both forms (float atomics: a second reduction would differ in order)
+    ops.bn_bwd_reduce(dyd, C, None if (mkw or not relu) else o1, C, xd, C, a1["sm"], a1["sr"], M, C, relu, pb0, **mkw)
+    for fused in (False, True):
+        pb = pb0.clone()
+        dg, db = torch.full((C,), 0.5, device=dev), torch.full((C,), -0.25, device=dev)       # (+=: onto what is there)
+        dx = torch.empty_like(xd)
+        dres = torch.empty_like(xd) if res == 1 else None
+        zero = torch.full((ops.stat_slots(), 2, C), 2.0, device=dev)
+        if fused:
+            ops.bn_bwd_apply_fin(dyd, C, None if (mkw or not relu) else o1, C, xd, C, a1["sm"], a1["sr"], bfin(pb, a1["g"], a1["sr"], dg, db, zero),
+                                 M, C, relu, dx, C, dres=dres, ldres=C, **mkw)
+            torch.cuda.synchronize()
+            assert float(zero.abs().max()) == 0.0 and float(pb.abs().max()) > 0.0
+        else:
+            coef = torch.empty(3, C, device=dev)
+            ops.bn_bwd_finalize(pb, M, C, a1["g"], a1["sr"], dg, db, coef)
+            ops.bn_bwd_apply(dyd, C, None if (mkw or not relu) else o1, C, xd, C, a1["sm"], a1["sr"], coef, M, C, relu, dx, C, dres=dres, ldres=C, **mkw)
+        torch.cuda.synchronize()
+        outs.append((dx, dg, db, dres))
+    for u, v in zip(outs[0], outs[1]):
+        assert (u is None and v is None) or torch.equal(u, v)
+    if res == 2:                                            # the join of two sites
+        joins = []
+        pa0, pb0 = ops.new_stat_buffer(C), ops.new_stat_buffer(C)
+        ops.bn_bwd_reduce2(dyd, C, xd, C, rd, C, a1["sm"], a1["sr"], r1["sm"], r1["sr"], bits1, M, C, pa0, pb0)
+        for fused in (False, True):
+            pa, pb = pa0.clone(), pb0.clone()
+            dga, dba, dgb, dbb = (torch.zeros(C, device=dev) for _ in range(4))
+            dxa, dxb = torch.empty_like(xd), torch.empty_like(xd)
+            za, zb = torch.ones(8, device=dev), torch.ones(8, device=dev)
+            if fused:
+                ops.bn_bwd_apply2_fin(dyd, C, xd, C, rd, C, a1["sm"], a1["sr"], r1["sm"], r1["sr"], bits1, bfin(pa, a1["g"], a1["sr"], dga, dba, za),
+                                      bfin(pb, r1["g"], r1["sr"], dgb, dbb, zb), M, C, dxa, C, dxb, C)
+            else:
+                ca, cb = torch.empty(3, C, device=dev), torch.empty(3, C, device=dev)
+                ops.bn_bwd_finalize(pa, M, C, a1["g"], a1["sr"], dga, dba, ca)
+                ops.bn_bwd_finalize(pb, M, C, r1["g"], r1["sr"], dgb, dbb, cb)
+                ops.bn_bwd_apply2(dyd, C, xd, C, rd, C, a1["sm"], a1["sr"], r1["sm"], r1["sr"], bits1, ca, cb, M, C, dxa, C, dxb, C)
+            torch.cuda.synchronize()
+            joins.append((dxa, dxb, dga, dba, dgb, dbb))
+        for u, v in zip(joins[0], joins[1]):
+            assert torch.equal(u, v)
