@@ -43,7 +43,7 @@ def synthetic(n, seed, device):
     return rgb, depth.masked_fill(hole, 0.0)
 
 
-TRAFFIC_FILE = os.path.join("profiles", "r03_hbm_traffic.json")
+TRAFFIC_FILE = os.path.join("profiles", "r04_hbm_traffic.json")
 TRAFFIC_SOURCES = ("conv_gemm.hip", "conv_wgrad.hip", "mde_common.h")
 
 
