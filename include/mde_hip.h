@@ -598,6 +598,26 @@ int mde_vnl_fwd(const float* gt, const float* pred, const int32_t* p123, int B, 
                 float fy, int select, void* ws, float* loss, void* stream);
 int mde_vnl_bwd(const float* gt, const float* pred, const int32_t* p123, int B, int H, int W, int n, float fx,
                 float fy, const void* ws, const float* gscale, float* grad, void* stream);
+
+/* ---- criterion-fused softmax head (a PRIVATE route between VNL's head and its criterion; the public tensors stay what they are).
+ * network/VNL.py:325-327 returns fp32 NCHW logits and softmax (2 x 2.95 GB at 16 x 150 x 480 x 640) and the reference's criterion
+ * -- ModelLoss(bins_to_depth(softmax), logits, depth_to_bins(gt), gt), modules/vnl.py:255 -- walks them again forwards and
+ * backwards.  When that criterion is handed tensors which come straight from this library's head, it reads the head's INPUT
+ * instead (x: 16-bit [P][ldx], P = N*H*W pixels, the prediction conv's output; logits = x + bias, C <= 192 channels) and the
+ * backward writes d(x) directly: 20 GB less HBM traffic per configuration-5 step.
+ *   mde_vnl_head_depth_fwd: depth[p] = 10 ** sum_c softmax_c border_c (modules/vnl.py:219-230), log10_depth[p], lse[p] = logsumexp.
+ *   mde_vnl_head_wcel_fwd : criteria.WCEL_Loss (criteria.py:839-863) from x and the lse of the call above; ws >= mde_wcel_ws_bytes(C).
+ *   mde_vnl_head_bwd      : dx[p][c] = gscale/valid * -(w[bin][c] - softmax_c rowsum[bin])            (bins / weight / ws given)
+ *                                    + softmax_c * gdepth[p] depth[p] ln10 * (border_c - log10_depth[p])   (gdepth given)
+ *                           as 16-bit [P][lddx] (channels [C, lddx) zero).  (The bias gradient is the column sums of dx: mde_bn_stats.)
+ * x and dx rows are walked in 16-byte chunks: ldx, lddx multiples of 8, 16-byte aligned. */
+int mde_vnl_head_depth_fwd(const void* x, int ldx, const float* bias, const float* border, int64_t P, int C, float* depth,
+                           float* log10_depth, float* lse, void* stream);
+int mde_vnl_head_wcel_fwd(const void* x, int ldx, const float* bias, const int32_t* bins, const float* gt, const float* weight,
+                          const float* lse, int64_t P, int C, void* ws, float* loss, void* stream);
+int mde_vnl_head_bwd(const void* x, int ldx, const float* bias, const int32_t* bins, const float* weight, const void* ws,
+                     const float* gscale, const float* lse, const float* depth, const float* log10_depth, const float* gdepth,
+                     const float* border, int64_t P, int C, void* dx, int lddx, void* stream);
 /* ---- The stdepth composite criterion (reference modules/base_module.py:124-208 `_loss`, stdepth_utils.py) ----
  * pred, targ: [N][C][H][W] fp32, C = 10 or 20; single_layer != 0 is the reference's default layout (front RGBA, back
  * RGBA, depths in channels 8:10, whatever C is: laina's default is 20 output channels with single_layer), 0 the

@@ -186,6 +186,9 @@ SIGNATURES = {
     "mde_vnl_ws_bytes": (_Z, [_I, _I]),
     "mde_vnl_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _F, _F, _I, _P, _P, _P]),
     "mde_vnl_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _F, _F, _P, _P, _P, _P]),
+    "mde_vnl_head_depth_fwd": (_I, [_P, _I, _P, _P, _L, _I, _P, _P, _P, _P]),
+    "mde_vnl_head_wcel_fwd": (_I, [_P, _I, _P, _P, _P, _P, _P, _L, _I, _P, _P, _P]),
+    "mde_vnl_head_bwd": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _P, _I, _P]),
     "mde_stdepth_ws_bytes": (_Z, []),
     "mde_stdepth_scratch_elems": (_Z, [_I, _I, _I, _I, _U]),
     "mde_stdepth_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _U, _F, _F, _F, _F, _F, _P, _P, _P, _P, _P]),

@@ -24,6 +24,8 @@ kernels in csrc/losses.hip; no CPU fallback):
       modules/vnl.py:202-230 (methods of the reference's VNLModule; free functions here, kernels in
       csrc/vnl_losses.hip)
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -370,6 +372,9 @@ class WCEL_Loss(nn.Module):
         if pred_logit.shape[1] != self.args.dec_out_c:
             raise ValueError("WCEL_Loss: %d logit channels, dec_out_c = %d" % (pred_logit.shape[1], self.args.dec_out_c))
         self.weight = self.weight.to(device=pred_logit.device, dtype=torch.float).contiguous()
+        head = _head_of(pred_logit, pred_logit.shape[1])
+        if head is not None:                  # this forward's logits, straight from the HIP head: the private route
+            return _FusedWcelFunction.apply(pred_logit, gt_bins, gt, self.weight, head)
         return _WcelFunction.apply(pred_logit, gt_bins, gt, self.weight)
 
 
@@ -469,6 +474,87 @@ class ModelLoss(nn.Module):
         return loss_metric + self.args.diff_loss_weight * loss_normal
 
 
+# ---------------------------------------------------------------------------------------------- the private route to VNL's head
+_FUSE_HEAD = os.environ.get("MDE_FUSE_VNL_HEAD", "1") != "0"
+
+
+def _head_of(t, C):
+    """The graph.SoftmaxHead whose CURRENT forward produced `t` (graph.SoftmaxHead.tag), or None: the tensor is not one the
+    module handed out, belongs to an earlier forward, or the route does not apply (deterministic mode, > 192 channels)."""
+    ref = getattr(t, "_mde_head", None) if _FUSE_HEAD else None
+    if ref is None:
+        return None
+    h = ref[0]()
+    if h is None or ref[1] != h.serial or h.C != C or C > 192 or h.eng.store.deterministic or not h.fresh:
+        return None
+    return h
+
+
+def _placeholder(t):
+    """A zero gradient of t's shape that owns no memory (stride 0): what the fused route returns for d(logit) / d(softmax); the
+    real gradient travels in SoftmaxHead.stash.  (Should autograd add it to another consumer's gradient, the sum is that
+    consumer's gradient alone -- and the head adds the general pass for it.)"""
+    return torch.zeros((), dtype=t.dtype, device=t.device).expand(t.shape)
+
+
+class _FusedDepthFunction(torch.autograd.Function):
+    """bins_to_depth on the head's own softmax, read from the head's 16-bit input (mde_vnl_head_depth_fwd)."""
+
+    @staticmethod
+    def forward(ctx, prob, border, head):
+        x = head.x
+        P = x.M
+        depth = torch.empty(x.N, 1, x.H, x.W, device=prob.device)
+        l10, lse = torch.empty(P, device=prob.device), torch.empty(P, device=prob.device)
+        ops.vnl_head_depth_fwd(x.t, x.ld, head.bias, border, P, head.C, depth, l10, lse)
+        head.stash = dict(head.stash or {}, serial=head.serial, depth=depth, l10=l10, lse=lse, border=border)
+        ctx.head, ctx.serial, ctx.like = head, head.serial, prob
+        return depth
+
+    @staticmethod
+    def backward(ctx, gdepth):
+        h = ctx.head
+        if h.stash is None or h.stash.get("serial") != ctx.serial:
+            raise RuntimeError("mono_depth_estimation_amd: bins_to_depth's backward after the network ran another forward pass")
+        h.stash["gdepth"] = gdepth.contiguous().float()
+        return _placeholder(ctx.like), None, None
+
+
+class _FusedWcelFunction(torch.autograd.Function):
+    """WCEL_Loss on the head's own logits, read from the head's 16-bit input (mde_vnl_head_wcel_fwd)."""
+
+    @staticmethod
+    def forward(ctx, logit, bins, gt, weight, head):
+        x = head.x
+        P, C = x.M, head.C
+        if bins.numel() != P or gt.numel() != P:
+            raise ValueError("WCEL_Loss: logits %s need %d labels and depths, got %d and %d" % (tuple(logit.shape), P, bins.numel(), gt.numel()))
+        if tuple(weight.shape) != (C, C):
+            raise ValueError("WCEL_Loss: weight %s for %d bins" % (tuple(weight.shape), C))
+        b = bins.to(device=logit.device, dtype=torch.int32).contiguous()
+        g = gt.to(device=logit.device, dtype=torch.float32).contiguous()
+        st = head.stash if (head.stash is not None and head.stash.get("serial") == head.serial) else None
+        if st is None or "lse" not in st:                     # (bins_to_depth was not called on this forward's softmax: the lse alone)
+            lse, scratch = torch.empty(P, device=logit.device), torch.empty(2, P, device=logit.device)
+            ops.vnl_head_depth_fwd(x.t, x.ld, head.bias, torch.zeros(C, device=logit.device), P, C, scratch[0], scratch[1], lse)
+            st = dict(serial=head.serial, lse=lse)
+        ws = ops.wcel_ws(C, logit.device)
+        loss = torch.empty(1, device=logit.device)
+        ops.vnl_head_wcel_fwd(x.t, x.ld, head.bias, b, g, weight, st["lse"], P, C, ws, loss)
+        st["wcel"] = (b, weight, ws)
+        head.stash = st
+        ctx.head, ctx.serial, ctx.like = head, head.serial, logit
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, gout):
+        h = ctx.head
+        if h.stash is None or h.stash.get("serial") != ctx.serial:
+            raise RuntimeError("mono_depth_estimation_amd: WCEL_Loss's backward after the network ran another forward pass")
+        h.stash["gscale"] = gout.contiguous().float().reshape(1)
+        return _placeholder(ctx.like), None, None, None, None
+
+
 class _BinsToDepthFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, prob, border):
@@ -499,6 +585,9 @@ def bins_to_depth(depth_bin, depth_bin_border):
                              dtype=torch.float32).to(depth_bin.device).contiguous()
     if depth_bin.ndim != 4 or border.numel() != depth_bin.shape[1]:
         raise ValueError("bins_to_depth: %s probabilities, %d borders" % (tuple(depth_bin.shape), border.numel()))
+    head = _head_of(depth_bin, depth_bin.shape[1])
+    if head is not None:                      # this forward's softmax, straight from the HIP head: the private route
+        return _FusedDepthFunction.apply(depth_bin, border, head)
     return _BinsToDepthFunction.apply(depth_bin, border)
 
 

@@ -590,7 +590,150 @@ inline int grid_for(int64_t n, int cap = 4096) {
     return (int)(b < 1 ? 1 : (b > cap ? cap : b));
 }
 
+// =================================================================================== criterion-fused softmax head (VNL)
+// VNL's head hands the caller fp32 NCHW logits and softmax (network/VNL.py:325-327; 2 x 2.95 GB at 16 x 150 x 480 x 640), and the
+// reference's criterion -- ModelLoss(bins_to_depth(softmax), logits, bins, gt), modules/vnl.py:255 -- walks them again forwards
+// and backwards.  When the criterion is handed tensors that come straight from this library's head it takes a private route
+// instead: these kernels read the head's INPUT (16-bit NHWC, the 3 x 3 prediction conv's output, 1.5 GB) + its bias and form
+// logits and softmax on the fly; the backward kernel writes d(input) directly.  A WAVE walks pixels, its lanes own the channels
+// (c = lane, lane + 64, lane + 128: C <= 192), so a pixel's row is one coalesced read and a weight-table row one more.
+constexpr int HF_NT = 256;
+
+// A THREAD owns a pixel and walks its row in 16-byte chunks (8 channels; the row stride is a multiple of 8): 19 loads of 16 bytes
+// for 150 channels.  (First version: a wave per pixel, lanes over channels, 2-byte loads and three wave reductions per pixel --
+// 1.5 / 2.4 / 3.2 ms for the three kernels at 16 x 480 x 640, SLOWER than the five passes they replace: ten times the load
+// instructions and a chain of LDS-crossbar shuffles per pixel.)
+__device__ __forceinline__ void hf_chunk(const bf16_t* __restrict__ row, int j, int C, const float* __restrict__ bias, float (&z)[8]) {
+    const bf16x8_t v = *reinterpret_cast<const bf16x8_t*>(row + 8 * j);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) z[e] = 8 * j + e < C ? (float)v[e] + bias[8 * j + e] : -__builtin_inff();
+}
+
+// depth = 10 ** sum_c softmax_c * border_c (modules/vnl.py:219-230 on the head's softmax), log10(depth) and the log-sum-exp:
+// ONE walk with a running maximum (the sums are rescaled when it moves)
+__global__ __launch_bounds__(HF_NT) void head_depth_fwd_k(const bf16_t* __restrict__ x, int ld, const float* __restrict__ bias,
+                                                          const float* __restrict__ border, int64_t P, int C, float* __restrict__ depth,
+                                                          float* __restrict__ l10, float* __restrict__ lse) {
+    const int nch = (C + 7) >> 3;
+    for (int64_t p = (int64_t)blockIdx.x * HF_NT + threadIdx.x; p < P; p += (int64_t)gridDim.x * HF_NT) {
+        const bf16_t* row = x + p * ld;
+        float m = -__builtin_inff(), s = 0.f, t = 0.f;
+        for (int j = 0; j < nch; ++j) {
+            float z[8];
+            hf_chunk(row, j, C, bias, z);
+            float cm = z[0];
+#pragma unroll
+            for (int e = 1; e < 8; ++e) cm = fmaxf(cm, z[e]);
+            if (cm > m) {
+                const float sc = expf(m - cm);          // (exp(-inf) = 0 on the first chunk)
+                s *= sc;
+                t *= sc;
+                m = cm;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float ee = expf(z[e] - m);        // (0 for the slots past C)
+                s += ee;
+                t += 8 * j + e < C ? ee * border[8 * j + e] : 0.f;
+            }
+        }
+        const float l = t / s;
+        l10[p] = l;
+        depth[p] = exp10f(l);
+        lse[p] = m + logf(s);
+    }
+}
+
+// WCEL (criteria.py:839-863) from the head's input: sum_c w[bin][c] * log softmax_c = sum_c w[bin][c] z_c - lse * rowsum[bin];
+// the weight table waits in LDS (C x C floats: 90 KB at 150 bins) as in wcel_fwd_lds_k -- a lane's row lookup is an LDS read
+__global__ __launch_bounds__(WNT) void head_wcel_fwd_k(const bf16_t* __restrict__ x, int ld, const float* __restrict__ bias,
+                                                       const int* __restrict__ bins, const float* __restrict__ gt,
+                                                       const float* __restrict__ weight, const float* __restrict__ rowsum,
+                                                       const float* __restrict__ lse, int64_t P, int C, WcelHead* h) {
+    extern __shared__ float s_w[];
+    __shared__ double s_red[WNT / 64];
+    for (int i = threadIdx.x; i < C * C; i += WNT) s_w[i] = weight[i];
+    __syncthreads();
+    const int nch = (C + 7) >> 3;
+    double part = 0.0, val = 0.0;
+    for (int64_t p = (int64_t)blockIdx.x * WNT + threadIdx.x; p < P; p += (int64_t)gridDim.x * WNT) {
+        const int b = bins[p];
+        val += gt[p] > 0.f ? 1.0 : 0.0;
+        if ((unsigned)b >= (unsigned)C) continue;
+        const bf16_t* row = x + p * ld;
+        const float* wr = s_w + b * C;
+        float a = 0.f;
+        for (int j = 0; j < nch; ++j) {
+            float z[8];
+            hf_chunk(row, j, C, bias, z);
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (8 * j + e < C) a += wr[8 * j + e] * z[e];
+        }
+        part += (double)(a - lse[p] * rowsum[b]);
+    }
+    const double ps = wblock_sum_d(part, s_red);
+    const double vs = wblock_sum_d(val, s_red);
+    if (threadIdx.x == 0) {
+        if (ps != 0.0) atomicAdd(&h->sum, ps);
+        if (vs != 0.0) atomicAdd(&h->valid, vs);
+    }
+}
+
+// d(total) / d(head input): the WCEL term -k (w[bin][c] - softmax_c rowsum[bin]) with k = gscale / valid, plus the depth's,
+// softmax_c * gd * (border_c - log10 depth) with gd = gdepth * depth * ln 10 (bins_to_depth backward through the softmax:
+// sum_k softmax_k border_k IS log10 depth, so no reduction is left): one walk, one 16-byte store per chunk.  (The bias gradient
+// is the column sums of dx: the caller takes them with mde_bn_stats.)
+template <bool TABLE>
+__global__ __launch_bounds__(WNT) void head_fused_bwd_k(const bf16_t* __restrict__ x, int ld, const float* __restrict__ bias,
+                                                        const int* __restrict__ bins, const float* __restrict__ weight,
+                                                        const float* __restrict__ rowsum, const WcelHead* __restrict__ h,
+                                                        const float* __restrict__ gscale, const float* __restrict__ lse,
+                                                        const float* __restrict__ depth, const float* __restrict__ l10,
+                                                        const float* __restrict__ gdepth, const float* __restrict__ border, int64_t P,
+                                                        int C, bf16_t* __restrict__ dx, int lddx) {
+    extern __shared__ float s_w[];
+    if (TABLE) {
+        for (int i = threadIdx.x; i < C * C; i += WNT) s_w[i] = weight[i];
+        __syncthreads();
+    }
+    const int nch = (C + 7) >> 3, nst = lddx >> 3;
+    const float k = TABLE ? (gscale ? *gscale : 1.f) / (float)h->valid : 0.f;
+    for (int64_t p = (int64_t)blockIdx.x * WNT + threadIdx.x; p < P; p += (int64_t)gridDim.x * WNT) {
+        const int bn = TABLE ? bins[p] : -1;
+        const bool inside = (unsigned)bn < (unsigned)C;
+        const float l = lse[p], rs = inside ? rowsum[bn] : 0.f;
+        const float gd = gdepth ? gdepth[p] * depth[p] * 2.302585092994046f : 0.f, ld10 = gdepth ? l10[p] : 0.f;
+        const float* wr = s_w + (inside ? bn : 0) * C;
+        const bf16_t* row = x + p * ld;
+        bf16_t* drow = dx + p * lddx;
+        for (int j = 0; j < nst; ++j) {
+            bf16x8_t o;
+            if (j < nch) {
+                float z[8];
+                hf_chunk(row, j, C, bias, z);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int c = 8 * j + e;
+                    float dz = 0.f;
+                    if (c < C) {
+                        const float pc = expf(z[e] - l);
+                        dz = pc * gd * (border[c] - ld10);
+                        if (TABLE && inside) dz -= k * (wr[c] - pc * rs);
+                    }
+                    o[e] = (bf16_t)dz;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (bf16_t)0.f;
+            }
+            *reinterpret_cast<bf16x8_t*>(drow + 8 * j) = o;
+        }
+    }
+}
+
 }  // namespace
+
 
 extern "C" size_t mde_wcel_ws_bytes(int C) { return sizeof(WcelHead) + (size_t)(C > 0 ? C : 0) * sizeof(float); }
 
@@ -725,5 +868,64 @@ extern "C" int mde_vnl_bwd(const float* gt, const float* pred, const int32_t* p1
     if (int rc = mde_check_hip(hipMemsetAsync(grad, 0, (size_t)B * H * W * sizeof(float), st), "mde_vnl_bwd: memset")) return rc;
     vnl_bwd_k<<<mde_cdiv(total, NT), NT, 0, st>>>(gt, pred, p123, g, total, (const float*)(h + 1), h, gscale, grad);
     MDE_LAUNCH_CHECK("vnl_bwd_k");
+    return MDE_OK;
+}
+
+// ---- criterion-fused softmax head (see the kernels above)
+static int hf_grid(int64_t P, int nt, int per_cu) {
+    int cus = 256;
+    mde_device_cu_count(&cus);
+    const int64_t want = (P + nt - 1) / nt, cap = (int64_t)cus * per_cu;
+    return (int)(want < cap ? (want < 1 ? 1 : want) : cap);
+}
+#define HF_CHECK_X(who) \
+    MDE_REQUIRE(x && bias && P > 0 && C > 0 && C <= WCEL_LDS_MAX_C && ldx >= C && ldx % 8 == 0 && ((uintptr_t)x % 16) == 0, \
+                who ": bad argument (C=%d, ldx=%d: rows of 16-byte chunks, at most %d channels)", C, ldx, WCEL_LDS_MAX_C)
+
+extern "C" int mde_vnl_head_depth_fwd(const void* x, int ldx, const float* bias, const float* border, int64_t P, int C, float* depth,
+                                      float* log10_depth, float* lse, void* stream) {
+    HF_CHECK_X("mde_vnl_head_depth_fwd");
+    MDE_REQUIRE(border && depth && log10_depth && lse, "mde_vnl_head_depth_fwd: null pointer");
+    head_depth_fwd_k<<<hf_grid(P, HF_NT, 16), HF_NT, 0, (hipStream_t)stream>>>((const bf16_t*)x, ldx, bias, border, P, C, depth, log10_depth, lse);
+    MDE_LAUNCH_CHECK("head_depth_fwd_k");
+    return MDE_OK;
+}
+
+extern "C" int mde_vnl_head_wcel_fwd(const void* x, int ldx, const float* bias, const int32_t* bins, const float* gt, const float* weight,
+                                     const float* lse, int64_t P, int C, void* ws, float* loss, void* stream) {
+    HF_CHECK_X("mde_vnl_head_wcel_fwd");
+    MDE_REQUIRE(bins && gt && weight && lse && ws && loss, "mde_vnl_head_wcel_fwd: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    WcelHead* h = (WcelHead*)ws;
+    float* rowsum = reinterpret_cast<float*>(h + 1);
+    wcel_init_k<<<mde_cdiv(C, 64), 64, 0, st>>>(h, weight, C, rowsum);
+    const size_t smem = (size_t)C * C * sizeof(float);
+    if (int rc = wcel_lds_attr(&head_wcel_fwd_k, smem, "hipFuncSetAttribute(head_wcel_fwd_k)")) return rc;
+    head_wcel_fwd_k<<<hf_grid(P, WNT, 1), WNT, smem, st>>>((const bf16_t*)x, ldx, bias, bins, gt, weight, rowsum, lse, P, C, h);
+    wcel_finalize_k<<<1, 1, 0, st>>>(h, loss);
+    MDE_LAUNCH_CHECK("head_wcel_fwd_k");
+    return MDE_OK;
+}
+
+extern "C" int mde_vnl_head_bwd(const void* x, int ldx, const float* bias, const int32_t* bins, const float* weight, const void* ws,
+                                const float* gscale, const float* lse, const float* depth, const float* log10_depth, const float* gdepth,
+                                const float* border, int64_t P, int C, void* dx, int lddx, void* stream) {
+    HF_CHECK_X("mde_vnl_head_bwd");
+    MDE_REQUIRE(lse && dx && lddx >= C && lddx % 8 == 0 && ((uintptr_t)dx % 16) == 0, "mde_vnl_head_bwd: dx rows are 16-byte chunks (lddx=%d)", lddx);
+    MDE_REQUIRE((bins == nullptr) == (weight == nullptr) && (!bins || ws) && (!gdepth || (depth && log10_depth && border)) && (bins || gdepth),
+                "mde_vnl_head_bwd: the WCEL term needs bins + weight + ws, the depth term gdepth + depth + log10_depth + border");
+    const WcelHead* h = (const WcelHead*)ws;
+    const float* rowsum = h ? reinterpret_cast<const float*>(h + 1) : nullptr;
+    hipStream_t st = (hipStream_t)stream;
+    if (bins) {
+        const size_t smem = (size_t)C * C * sizeof(float);
+        if (int rc = wcel_lds_attr(&head_fused_bwd_k<true>, smem, "hipFuncSetAttribute(head_fused_bwd_k)")) return rc;
+        head_fused_bwd_k<true><<<hf_grid(P, WNT, 1), WNT, smem, st>>>((const bf16_t*)x, ldx, bias, bins, weight, rowsum, h, gscale, lse, depth,
+                                                                       log10_depth, gdepth, border, P, C, (bf16_t*)dx, lddx);
+    } else {
+        head_fused_bwd_k<false><<<hf_grid(P, WNT, 2), WNT, 0, st>>>((const bf16_t*)x, ldx, bias, nullptr, nullptr, nullptr, nullptr, nullptr, lse,
+                                                                     depth, log10_depth, gdepth, border, P, C, (bf16_t*)dx, lddx);
+    }
+    MDE_LAUNCH_CHECK("head_fused_bwd_k");
     return MDE_OK;
 }

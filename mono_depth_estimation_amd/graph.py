@@ -460,6 +460,31 @@ class SoftmaxHead(Op):
         self.prob = torch.empty(x.N, C, x.H, x.W, device=eng.dev)
         self.outputs = (self.logit, self.prob)
         self.douts = [None, None]
+        self.fresh = False
+        self.serial = 0          # which forward the current outputs belong to (criteria's private route checks it)
+        self.stash = None        # what the criterion-fused route leaves for bwd (criteria._FusedDepthFunction / _FusedWcelFunction)
+        self._tmp = self._part = None
+
+    def tag(self, logit, prob):
+        """Mark the tensors the module hands out as THIS forward's head outputs: criteria.bins_to_depth / WCEL_Loss then read the
+        head's 16-bit input instead of walking 2 x 2.95 GB of fp32 planes, and their backward leaves its pieces in `stash` for
+        bwd to turn into d(input) in one launch (include/mde_hip.h: mde_vnl_head_*).  A tensor derived from these (a clone, a
+        slice, another dtype) carries no mark and takes the general route."""
+        import weakref
+        ref = (weakref.ref(self), self.serial)
+        logit._mde_head, prob._mde_head = ref, ref
+
+    def new_outputs(self):
+        """The module path hands its outputs to the caller, who may keep them across steps: these two are 2.95 GB each at
+        configuration 5's size, so instead of cloning what a plan-owned buffer holds (2 x 5.9 GB of copy traffic per step, 2.4 ms)
+        every forward of the module path writes into tensors of its own (the caching allocator recycles them) and hands THOSE out."""
+        x = self.x
+        self.logit = torch.empty(x.N, self.C, x.H, x.W, device=self.eng.dev)
+        self.prob = torch.empty(x.N, self.C, x.H, x.W, device=self.eng.dev)
+        self.outputs = (self.logit, self.prob)
+        self.fresh = True
+        self.serial += 1
+        self.stash = None
 
     def grad_ranges(self):
         return [(self.b_off, self.b_off + self.C)]
@@ -474,6 +499,31 @@ class SoftmaxHead(Op):
         x.gw = True
         dl, dp = self.douts
         dbias = self.eng.store.Gcur[self.b_off:self.b_off + self.C]
+        st, self.stash = self.stash, None
+        if st is not None and st.get("serial") == self.serial and (st.get("gdepth") is not None or st.get("gscale") is not None):
+            # the criterion took the private route: its backward left (gdepth, depth, log10 depth, border) and / or (bins, weight,
+            # ws, gscale) here and returned zero-stride placeholders for d(logit) / d(softmax)
+            w = st.get("wcel") if st.get("gscale") is not None else None
+            gd = st.get("gdepth")
+            ops.vnl_head_bwd(x.t, x.ld, self.bias, w[0] if w else None, w[1] if w else None, w[2] if w else None, st.get("gscale"),
+                             st["lse"], st.get("depth") if gd is not None else None, st.get("l10") if gd is not None else None, gd,
+                             st.get("border") if gd is not None else None, x.M, self.C, x.g, _ldg(x))
+            # the bias gradient = the column sums of d(input): one reduction pass over the 16-bit tensor just written
+            if self._part is None:
+                self._part = ops.new_stat_buffer(x.g.shape[-1], self.eng.dev)
+            ops.bn_stats(x.g, x.M, x.g.shape[-1], _ldg(x), self._part)
+            with torch.no_grad():
+                dbias.add_(self._part[:, 0, :self.C].sum(0))
+                self._part.zero_()
+            if dl is not None or dp is not None:           # gradients from OTHER consumers of the public tensors: the general pass, added
+                if self._tmp is None:
+                    self._tmp = torch.empty_like(x.g)
+                ops.softmax_head_bwd(dl, dp, self.prob, self._tmp, _ldg(x), dbias, x.N, x.H * x.W, self.C)
+                ops.pw_fwd(self._tmp, _ldg(x), None, x.g, _ldg(x), x.g, _ldg(x), x.M, x.g.shape[-1], None)
+            return
+        if dl is None and dp is None:
+            x.g.zero_()
+            return
         ops.softmax_head_bwd(dl, dp, self.prob, x.g, _ldg(x), dbias, x.N, x.H * x.W, self.C)
 
 
@@ -1208,6 +1258,8 @@ class TapeEngine(EngineCore):
         for h in self.heads:
             for k in range(len(h.outputs)):
                 d = douts[i]
+                if d is not None and d.dim() > 0 and d.numel() > 1 and all(st_ == 0 for st_ in d.stride()):
+                    d = None               # a zero-stride placeholder of the criterion-fused route (SoftmaxHead.stash has the gradient)
                 h.douts[k] = d.contiguous() if d is not None else None
                 i += 1
         global _TRACE, _CUR_OP
@@ -1296,9 +1348,12 @@ class _TapeFunction(torch.autograd.Function):
     def forward(ctx, x, engine, train, *params):
         ctx.engine, ctx.train = engine, train
         ctx.set_materialize_grads(False)          # an unused output's gradient stays None (no zero tensors of GBs)
-        ys = engine.forward(x, train, check_data=True)
+        for h in engine.heads:               # heads with large outputs write into fresh tensors instead of being cloned
+            if hasattr(h, "new_outputs"):
+                h.new_outputs()
+        engine.forward(x, train, check_data=True)
         engine.forward_serial = ctx.serial = getattr(engine, "forward_serial", 0) + 1
-        return tuple(y.clone() for y in ys)
+        return tuple(y if getattr(h, "fresh", False) else y.clone() for h in engine.heads for y in h.outputs)
 
     @staticmethod
     def backward(ctx, *douts):
@@ -1408,4 +1463,11 @@ class TapeModule(torch.nn.Module):
 
     def _run(self, x):
         eng = self._engine(x)
-        return _TapeFunction.apply(x.contiguous().float(), eng, self.training, *eng.params)
+        outs = _TapeFunction.apply(x.contiguous().float(), eng, self.training, *eng.params)
+        i = 0
+        for h in eng.heads:
+            n = len(h.outputs)
+            if hasattr(h, "tag") and getattr(h, "fresh", False):
+                h.tag(*outs[i:i + n])
+            i += n
+        return outs

@@ -801,6 +801,20 @@ def vnl_bwd(gt, pred, p123, B, H, W, n, fx, fy, ws, gscale, grad):
           "mde_vnl_bwd")
 
 
+def vnl_head_depth_fwd(x, ldx, bias, border, P, C_, depth, l10, lse):
+    check(_lib.load().mde_vnl_head_depth_fwd(_p(x), ldx, _p(bias), _p(border), P, C_, _p(depth), _p(l10), _p(lse), _stream()), "mde_vnl_head_depth_fwd")
+
+
+def vnl_head_wcel_fwd(x, ldx, bias, bins, gt, weight, lse, P, C_, ws, loss):
+    check(_lib.load().mde_vnl_head_wcel_fwd(_p(x), ldx, _p(bias), _p(bins), _p(gt), _p(weight), _p(lse), P, C_, _p(ws), _p(loss), _stream()),
+          "mde_vnl_head_wcel_fwd")
+
+
+def vnl_head_bwd(x, ldx, bias, bins, weight, ws, gscale, lse, depth, l10, gdepth, border, P, C_, dx, lddx):
+    check(_lib.load().mde_vnl_head_bwd(_p(x), ldx, _p(bias), _p(bins), _p(weight), _p(ws), _p(gscale), _p(lse), _p(depth), _p(l10), _p(gdepth),
+                                       _p(border), P, C_, _p(dx), lddx, _stream()), "mde_vnl_head_bwd")
+
+
 # ------------------------------------------------------------------------------ stdepth composite criterion
 def stdepth_ws(device="cuda"):
     return torch.zeros((_lib.load().mde_stdepth_ws_bytes() + 7) // 8, dtype=torch.float64, device=device)

@@ -232,3 +232,63 @@ def test_vnl_device_sampling_opt_in():
     l2 = float(dev(gt, pred))
     assert float(l1) == l2 and torch.isfinite(p.grad).all() and float(p.grad.abs().sum()) > 0
     assert abs(float(l1) - l_host) < 0.2 * l_host          # another sample of the same estimator
+
+
+@pytest.mark.parametrize("N,H,Wd,C", [(2, 24, 32, 150), (1, 9, 11, 64), (3, 16, 20, 152)])
+def test_criterion_fused_head_kernels(N, H, Wd, C):
+    """mde_vnl_head_depth_fwd / _wcel_fwd / _bwd (the private route between VNL's head and its criterion: they read the head's
+    16-bit NHWC input + bias instead of fp32 NCHW logits / softmax) against torch on the logits x + bias: depth = bins_to_depth of
+    the softmax, WCEL as criteria.py:839-863 computes it, and d(total)/dx of  gs * WCEL + sum(gdepth * depth)  from autograd."""
+    from mono_depth_estimation_amd import ops
+    from mono_depth_estimation_amd.ops import ACT_DTYPE as ACT
+    from oracle import weights as Wt
+    dev = "cuda"
+    P, ld = N * H * Wd, (C + 7) // 8 * 8 + 8
+    xs = (Wt.normal(3, "hx", (P, C), 2.0)).to(ACT).float()
+    bias = Wt.normal(3, "hb", (C,), 0.5)
+    border = torch.linspace(-2.0, 0.04, C)
+    bins = (Wt.uniform(3, "hbin", (P,)) * (C + 4)).long() - 2                # a few labels outside [0, C): zero rows
+    gt = Wt.uniform(3, "hgt", (P,)) - 0.1
+    wt = torch.tensor([[np.exp(-0.2 * (i - j) ** 2) for i in range(C)] for j in range(C)], dtype=torch.float64)
+    wt = (wt / wt.sum(1, keepdim=True)).float()
+    gdepth = Wt.normal(3, "hgd", (P,), 1.0)
+    gs = 0.7
+    z = (xs + bias).clone().requires_grad_(True)
+    logp = torch.log_softmax(z, 1)
+    prob = logp.exp()
+    l10 = (prob * border).sum(1)
+    depth = 10.0 ** l10
+    inside = (bins >= 0) & (bins < C)
+    rows = wt[bins.clamp(0, C - 1)] * inside[:, None].float()
+    valid = float((gt > 0).sum())
+    wcel = -(rows * logp).sum() / valid
+    (gs * wcel + (gdepth * depth).sum()).backward()
+
+    x = torch.zeros(P, ld, dtype=ACT, device=dev)
+    x[:, :C] = xs.to(ACT).to(dev)
+    x[:, C:] = 7.0                                                          # padding the kernels must ignore
+    d_b, d_border, d_wt = bias.to(dev), border.to(dev), wt.to(dev).contiguous()
+    o_depth, o_l10, o_lse = (torch.empty(P, device=dev) for _ in range(3))
+    ops.vnl_head_depth_fwd(x, ld, d_b, d_border, P, C, o_depth, o_l10, o_lse)
+    assert torch.allclose(o_depth.cpu(), depth.detach(), rtol=2e-5, atol=1e-7)
+    assert torch.allclose(o_lse.cpu(), torch.logsumexp(z.detach(), 1), rtol=1e-5, atol=1e-5)
+    assert torch.allclose(o_l10.cpu(), l10.detach(), rtol=1e-5, atol=1e-5)
+    ws, loss = ops.wcel_ws(C, dev), torch.empty(1, device=dev)
+    d_bins, d_gt = bins.to(dev).int().contiguous(), gt.to(dev)
+    ops.vnl_head_wcel_fwd(x, ld, d_b, d_bins, d_gt, d_wt, o_lse, P, C, ws, loss)
+    assert abs(float(loss) - float(wcel)) <= 2e-5 * abs(float(wcel)), (float(loss), float(wcel))
+    lddx = (C + 7) // 8 * 8
+    dx = torch.full((P, lddx), 5.0, dtype=ACT, device=dev)
+    ops.vnl_head_bwd(x, ld, d_b, d_bins, d_wt, ws, torch.tensor([gs], device=dev), o_lse, o_depth, o_l10, gdepth.to(dev), d_border, P, C, dx, lddx)
+    torch.cuda.synchronize()
+    got, ref = dx[:, :C].float().cpu(), z.grad
+    err = (got - ref).abs()
+    assert int((~(err <= 2.0 ** -8 * ref.abs() + 1e-6 + 2.0 ** -9 * float(ref.abs().mean()))).sum()) == 0, float(err.max())
+    assert lddx == C or float(dx[:, C:].float().abs().max()) == 0.0
+    # the depth term alone (no WCEL: criteria.VNL_Loss used without ModelLoss)
+    dx2 = torch.empty_like(dx)
+    ops.vnl_head_bwd(x, ld, d_b, None, None, None, None, o_lse, o_depth, o_l10, gdepth.to(dev), d_border, P, C, dx2, lddx)
+    z2 = (xs + bias).clone().requires_grad_(True)
+    ((10.0 ** (torch.softmax(z2, 1) * border).sum(1)) * gdepth).sum().backward()
+    err = (dx2[:, :C].float().cpu() - z2.grad).abs()
+    assert int((~(err <= 2.0 ** -8 * z2.grad.abs() + 1e-6 + 2.0 ** -9 * float(z2.grad.abs().mean()))).sum()) == 0

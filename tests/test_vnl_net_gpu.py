@@ -261,3 +261,57 @@ def test_vnl_loss_curves_agree_with_the_oracle():
     print("gap to the fp32 oracle: HIP max %.3f mean %.3f; rounding oracle max %.3f mean %.3f" % (gap_h.max(), gap_h.mean(), gap_q.max(), gap_q.mean()))
     assert np.isfinite(lh).all() and np.isfinite(lq).all() and lh[-1] < lh[0] and lo[-1] < lo[0] and lq[-1] < lq[0]
     assert gap_h.max() < 0.6 and gap_q.max() < 0.6
+
+
+def test_criterion_fused_head_equals_the_public_route(setup):
+    """The private route between the head and ModelLoss (criteria._FusedDepthFunction / _FusedWcelFunction -> mde_vnl_head_*: the
+    criterion reads the head's 16-bit input instead of the fp32 logits / softmax it was handed, its backward writes d(input) in
+    one launch) against the public route through the same tensors (bins_to_depth, WCEL_Loss, softmax-head backward): the same loss
+    to 1e-5, the same parameter gradients to the rounding of d(input) -- in deterministic order of everything else -- and a
+    derived tensor (a clone) falls back to the public route by itself."""
+    from mono_depth_estimation_amd import criteria
+    net, params, P0, rgb, tgt = setup
+    net.load_state_dict({k: v.clone() for k, v in P0.items()})
+    net.train()
+    x = rgb.cuda()
+    gt = tgt.clone().cuda()
+    gt[:, :, :, :4] = -1.0
+    params.crop_size = SIZE
+    crit = criteria.ModelLoss(params)
+    bins = criteria.depth_to_bins(gt, params.depth_min, 1.1, params.dec_out_c)
+
+    def step(fused, clone=False):
+        criteria._FUSE_HEAD = fused
+        try:
+            np.random.seed(5)
+            net.zero_grad(set_to_none=True)
+            logit, prob = net(x)
+            if clone:
+                logit, prob = logit.clone(), prob.clone()
+            loss = crit(criteria.bins_to_depth(prob, params.depth_bin_border), logit, bins, gt)
+            loss.backward()
+            return float(loss), {k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None}
+        finally:
+            criteria._FUSE_HEAD = True
+    step(True)                                      # (the first backward of a plan traces its fused BatchNorm sums)
+    l_pub, g_pub = step(False)
+    _, g_pub2 = step(False)                         # the public route again: what two passes of identical code differ by (float atomics)
+    l_fus, g_fus = step(True)
+    l_cln, g_cln = step(True, clone=True)
+    print("ModelLoss: public route %.6f, private route %.6f, private route refused for clones %.6f" % (l_pub, l_fus, l_cln))
+    assert abs(l_fus - l_pub) <= 2e-5 * abs(l_pub) and abs(l_cln - l_pub) <= 2e-5 * abs(l_pub)
+    rel = lambda a, b: float((a - b).norm() / (b.norm() + 1e-30))
+    noise = {k: rel(g_pub2[k], g) for k, g in g_pub.items()}
+    diff = {k: rel(g_fus[k], g) for k, g in g_pub.items()}
+    # The kernels' arithmetic is pinned in tests/test_vnl_gpu.py::test_criterion_fused_head_kernels; here the two routes' d(input)
+    # differ by one 16-bit rounding, which the network's backward amplifies tensor by tensor like any other rounding (and the
+    # BatchNorm-bias gradients that are exact zeros in exact arithmetic -- a per-channel constant in front of another train-mode
+    # BatchNorm -- are residues on either route): the bulk is compared, not the tail
+    d = np.array([diff[k] for k in g_pub if float(g_pub[k].norm()) > 1e-9])
+    print("parameter gradients, private vs public route: rel. difference median %.2e, 90 %% %.2e (two public passes: median %.2e)" % (
+        float(np.median(d)), float(np.quantile(d, 0.9)), float(np.median(list(noise.values())))))
+    assert float(np.median(d)) <= 3e-2 and float(np.quantile(d, 0.9)) <= 0.15
+    k = "depth_model.decoder_modules.topdown_predict.conv1.bias"
+    # (the private route takes the bias gradient as the column sums of the 16-bit d(input) it has just written, the public one sums
+    #  the fp32 values before they are rounded: 12 K roundings of up to half an ulp each per channel, 0.6 % of the largest entry here)
+    assert torch.allclose(g_fus[k], g_pub[k], rtol=1e-2, atol=1.5e-2 * float(g_pub[k].abs().max())), "head bias gradient"
