@@ -208,9 +208,9 @@ def test_vnl_loss_curves_agree_with_the_oracle():
     state -- unit normals of point triples on a nearly flat predicted surface, an |.| of their difference, a sort that drops
     the lowest quarter (measured for prediction scales x1 ... x30: cosine 0.87-0.93 throughout).
     (a) WCEL alone (ModelLoss with diff_loss_weight 0: same network, same optimiser, a smooth loss): 20 SGD steps, the HIP
-        and the fp32 oracle's curves within 1 % at every step, both fall; on the state the ORACLE reached, the AbsRel of the
-        decoded depth agrees to 5e-4, and the bf16 storage is held to the bound an fp16-rounding oracle meets (BASELINE
-        configuration 5 names fp16: the reference's precision=16 AMP run).
+        and the fp32 oracle's curves within 1 % at every step, both fall; on the state the ORACLE reached -- weights off the
+        16-bit grid -- the AbsRel of the decoded depth agrees to 1e-4 + the activation-rounding shift of the oracle (the eval
+        forward's two-term weight shadow; the one-term figure is printed beside it).
     (b) the configured loss (WCEL + 6 x VNL): 12 steps, three trajectories (HIP, fp32 oracle, the oracle with its activations
         rounded to bf16).  REPORTED, not bounded by a ratio: two runs of identical code gave a largest HIP gap to the fp32
         oracle of 21 % and of 39 % (float atomics feeding the ill-conditioned loss), the rounding oracle 23 % and 20 % (its
@@ -228,30 +228,33 @@ def test_vnl_loss_curves_agree_with_the_oracle():
     net.eval()
     with torch.no_grad():
         dh = L.bins_to_depth(net(x)[1].cpu(), border)
+        net._store.split_eval = False
+        dh1 = L.bins_to_depth(net(x)[1].cpu(), border)          # the one-term weight shadow the training step uses
+        net._store.split_eval = True
         do = L.bins_to_depth(nets.vnl_forward(trained, rgb, False)[1], border)
-        # free-running SGD leaves weights that are not representable in 16 bits; a 16-bit path convolves with their rounded
-        # copies, and that error -- the same for every pixel -- does not average out of AbsRel the way activation rounding
-        # does.  So the oracles that stand for a 16-bit path round conv weights AND activations.
+        # free-running SGD leaves weights that are not representable in 16 bits; a path that convolves with their rounded copies
+        # carries an error that is the same for every pixel and does not average out of AbsRel the way activation rounding
+        # does -- the oracles that stand for such a path round conv weights AND activations.  The HIP path's EVAL forward
+        # contracts with a two-term shadow (FlatStore.ensure_split), so it answers to the activation-rounding oracles alone.
         rw = lambda f: {k: (f(v) if v.dtype.is_floating_point and v.dim() >= 2 else v) for k, v in trained.items()}
         d16 = L.bins_to_depth(nets.vnl_forward(rw(nets.fp16_round), rgb, False, q=nets.fp16_round)[1], border)
         dbf = L.bins_to_depth(nets.vnl_forward(rw(nets.bf16_round), rgb, False, q=nets.bf16_round)[1], border)
-        dact = L.bins_to_depth(nets.vnl_forward(trained, rgb, False, q=nets.bf16_round)[1], border)
+        from mono_depth_estimation_amd import _lib
+        to = torch.float16 if _lib.ACT_NAME == "fp16" else torch.bfloat16
+        dacts = [L.bins_to_depth(nets.vnl_forward(trained, rgb, False, q=nets.rounding_draw(k, to))[1], border) for k in range(3)]
     t = tgt.clamp(min=0)
     m = t > 0
     absrel = lambda d: float(((d - t).abs() / t.clamp(min=1e-9))[m].mean())
-    s16, sbf, sact, ship = (abs(absrel(d) - absrel(do)) for d in (d16, dbf, dact, dh))
-    print("trained-like state, eval AbsRel: HIP %.6f oracle %.6f" % (absrel(dh), absrel(do)))
-    from mono_depth_estimation_amd import _lib
-    print("AbsRel shift of the ORACLE under 16-bit storage: fp16 weights + activations %.2e, bf16 weights + activations %.2e "
-          "(bf16 activations alone %.2e); the HIP path (%s): %.2e" % (s16, sbf, sact, _lib.ACT_NAME, ship))
-    # BASELINE configuration 5 names fp16 (the reference's precision=16 AMP run).  Both oracles' shifts are on record above.
-    # The default build stores bf16: held to 1.5 x the bf16 oracle's shift, and that shift itself to 2e-3.  The fp16 build
-    # (MDE_ACT_DTYPE=fp16, tests/test_fp16_build_gpu.py runs this test under it) is held to the fp16 oracle's: measured 1.07e-4
-    # against 1.05e-4.
-    if _lib.ACT_NAME == "fp16":
-        assert ship <= 1.5 * s16 + 5e-5 and ship <= 2.5e-4, (ship, s16)
-    else:
-        assert ship <= 1.5 * sbf + 2e-4 and sbf <= 2e-3 and s16 <= sbf + 1e-4
+    s16, sbf, ship, ship1 = (abs(absrel(d) - absrel(do)) for d in (d16, dbf, dh, dh1))
+    sact = max(abs(absrel(d) - absrel(do)) for d in dacts)
+    print("trained state, eval AbsRel: HIP %.6f oracle %.6f" % (absrel(dh), absrel(do)))
+    print("AbsRel shift of the ORACLE under 16-bit storage: fp16 weights + activations %.2e, bf16 weights + activations %.2e; %s "
+          "activations alone (three realisations) up to %.2e.  The HIP path (%s): %.2e with the two-term eval shadow, %.2e with the one-term one"
+          % (s16, sbf, _lib.ACT_NAME, sact, _lib.ACT_NAME, ship, ship1))
+    # identical weights, off the 16-bit grid: within 1e-4 + what activation rounding alone does to the oracle (round 3, one-term
+    # shadow: 7.8e-4 on the bf16 build, 1.07e-4 on the fp16 build)
+    assert ship <= 1e-4 + sact, (ship, sact)
+    assert sbf <= 2e-3 and s16 <= sbf + 1e-4
     # (b)
     _, _, _, _, _, _, lh, lo, lq = _vnl_trajectories(6, 12, True)
     print("WCEL + 6 VNL, HIP            :", np.round(lh[[0, 1, 2, 4, 7, 11]], 4))
