@@ -421,6 +421,20 @@ int mde_pack_grouped(const float* src, void* fwd, void* dgrad, int O, int T, int
 /* The two-term eval shadow (mde_pack_split_batch) of a grouped weight: fwd2 bf16 [O][2T][64]. */
 int mde_pack_grouped_split(const float* src, void* fwd2, int O, int T, int G, void* stream);
 
+/* Depthwise 3x3 convolution, groups == channels (the reference's MobileNetV2 encoder option: VNL.py:427-444, nn.Conv2d(h, h, 3, stride,
+ * groups=h, padding=dilation, dilation=dilation, bias=False)): NHWC 16-bit activations, fp32 weights w [C][9] (the flat master
+ * slice itself) and fp32 weight gradient dw [C][9] (+=).  C % 8 == 0, stride 1 or 2, padding == dilation, so the output is
+ * ((H - 1) / stride + 1) x ((W - 1) / stride + 1).  HBM-bound streaming passes (nine multiply-adds per element): nothing for MFMA.
+ *   fwd  : out[n, oy, ox, c] = sum_ij x[n, oy s + (i - 1) d, ox s + (j - 1) d, c] w[c][3 i + j]
+ *   dgrad: dx over the INPUT's H x W from dy over the output's grid; accumulate != 0: dx += .
+ *   wgrad: dw[c][3 i + j] += sum over output pixels of x[...] dy[...]. */
+int mde_dwconv3x3_fwd(const void* x, int ldx, const float* w, void* out, int ldo, int N, int H, int W, int C, int stride, int dilation,
+                      void* stream);
+int mde_dwconv3x3_dgrad(const void* dy, int ldy, const float* w, void* dx, int lddx, int N, int H, int W, int C, int stride, int dilation,
+                        int accumulate, void* stream);
+int mde_dwconv3x3_wgrad(const void* x, int ldx, const void* dy, int ldy, float* dw, int N, int H, int W, int C, int stride, int dilation,
+                        void* stream);
+
 /* ---- DORN pieces (network/Dorn.py) ---- */
 /* nn.MaxPool2d(3, 2, 1, ceil_mode=True) (Dorn.py:235): as mde_maxpool_fwd / _bwd with the output size of ATen's ceil rule
  * (OH = ceil((H - 1) / 2) + 1, minus one if the last window would start beyond the padded input); out / idx are

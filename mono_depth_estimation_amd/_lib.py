@@ -139,6 +139,9 @@ SIGNATURES = {
     "mde_map_to_slot": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "mde_slot_to_map_add": (_I, [_P, _I, _P, _I, _I, _I, _I, _P]),
     "mde_pack_grouped": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "mde_dwconv3x3_fwd": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "mde_dwconv3x3_dgrad": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "mde_dwconv3x3_wgrad": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
     "mde_maxpool_view_fwd": (_I, [_P, _I, _I, _L, _I, _I, _P, _I, _P, _I, _I, _I, _I, _P]),
     "mde_maxpool_view_bwd": (_I, [_P, _I, _P, _P, _I, _I, _L, _I, _I, _I, _I, _I, _I, _I, _P]),
     "mde_maxpool_fwd2": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),

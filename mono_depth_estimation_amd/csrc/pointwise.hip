@@ -23,6 +23,7 @@ __device__ __forceinline__ float act_fwd(float v, int act) {
         case 1: return fmaxf(v, 0.f);
         case 2: return v > 0.f ? v : expm1f(v);
         case 3: return 1.f / (1.f + expf(-v));
+        case 4: return fminf(fmaxf(v, 0.f), 6.f);          // nn.ReLU6 (MobileNetV2: VNL.py:402,410)
         default: return v;
     }
 }
@@ -32,6 +33,7 @@ __device__ __forceinline__ float act_grad(float y, int act) {
         case 1: return y > 0.f ? 1.f : 0.f;
         case 2: return y > 0.f ? 1.f : y + 1.f;
         case 3: return y * (1.f - y);
+        case 4: return (y > 0.f && y < 6.f) ? 1.f : 0.f;
         default: return 1.f;
     }
 }
@@ -678,7 +680,7 @@ __global__ __launch_bounds__(NT) void pack_grouped_split_k(const float* __restri
 
 extern "C" int mde_pw_fwd(const void* x, int ldx, const float* bias, const void* r, int ldr, void* out, int ldo, int64_t M,
                           int C, int act, void* stream) {
-    MDE_REQUIRE(x && out && M > 0 && C > 0 && C % 8 == 0 && act >= 0 && act <= 3, "mde_pw_fwd: bad argument (C=%d, act=%d)", C, act);
+    MDE_REQUIRE(x && out && M > 0 && C > 0 && C % 8 == 0 && act >= 0 && act <= 4, "mde_pw_fwd: bad argument (C=%d, act=%d)", C, act);
     MDE_REQUIRE(ldx % 8 == 0 && ldo % 8 == 0 && (!r || ldr % 8 == 0) && PW_ALIGNED(x) && PW_ALIGNED(out) && (!r || PW_ALIGNED(r)),
                 "mde_pw_fwd: operands must be 16-byte aligned with ld %% 8 == 0");
     const int tpr = C / 8 < NT ? C / 8 : NT;
@@ -689,7 +691,7 @@ extern "C" int mde_pw_fwd(const void* x, int ldx, const float* bias, const void*
 
 extern "C" int mde_pw_bwd(const void* dout, int ldd, const void* out, int ldo, void* dx, int lddx, int acc_x, void* dr, int lddr,
                           int acc_r, float* dbias, float* bias_part, int64_t M, int C, int act, void* stream) {
-    MDE_REQUIRE(dout && (out || act == 0) && (dx || dr || dbias) && M > 0 && C > 0 && C % 8 == 0 && act >= 0 && act <= 3,
+    MDE_REQUIRE(dout && (out || act == 0) && (dx || dr || dbias) && M > 0 && C > 0 && C % 8 == 0 && act >= 0 && act <= 4,
                 "mde_pw_bwd: bad argument (C=%d, act=%d)", C, act);
     MDE_REQUIRE(ldd % 8 == 0 && (!out || ldo % 8 == 0) && (!dx || lddx % 8 == 0) && (!dr || lddr % 8 == 0) && PW_ALIGNED(dout) &&
                     (!out || PW_ALIGNED(out)) && (!dx || PW_ALIGNED(dx)) && (!dr || PW_ALIGNED(dr)),

@@ -253,6 +253,34 @@ class Conv(Op):
                 ops.conv_gemm(d, og[i:i + n], self.conv.wd, xg[i:i + n], red=self.red)
 
 
+class DwConv(Op):
+    """A depthwise 3x3 convolution (groups == channels, padding == dilation, no bias): MobileNetV2's `dw` layers (VNL.py:427-444).
+    Its weight keeps its exact [C][1][3][3] shape in the flat store (NetStore `raw`): the fp32 master IS the kernels' [C][9]
+    operand and its gradient slice their output; the BatchNorm behind it takes its statistics from a reduction pass."""
+
+    def __init__(self, eng, x, w, stride=1, dil=1):
+        assert tuple(w.shape) == (x.C, 1, 3, 3) and eng.store.sdims[id(w)] == (x.C, 3, 3, 1), (tuple(w.shape), x.C)
+        self.eng, self.x, self.stride, self.dil = eng, x, stride, dil
+        self.off, self.n = eng.store.p_off[id(w)], x.C * 9
+        self.w32 = eng.store.P[self.off:self.off + self.n]
+        self.out = Act(eng.dev, x.N, (x.H - 1) // stride + 1, (x.W - 1) // stride + 1, x.C)
+
+    def acts(self):
+        return (self.out,)
+
+    def grad_ranges(self):
+        return [(self.off, self.off + self.n)]
+
+    def fwd(self, train):
+        x, o = self.x, self.out
+        ops.dwconv3x3_fwd(x.t, x.ld, self.w32, o.t, o.ld, x.N, x.H, x.W, x.C, self.stride, self.dil)
+
+    def bwd(self):
+        x, o = self.x, self.out
+        ops.dwconv3x3_wgrad(x.t, x.ld, o.g, _ldg(o), self.eng.store.Gcur[self.off:self.off + self.n], x.N, x.H, x.W, x.C, self.stride, self.dil)
+        ops.dwconv3x3_dgrad(o.g, _ldg(o), self.w32, x.g, _ldg(x), x.N, x.H, x.W, x.C, self.stride, self.dil, accumulate=_take(x))
+
+
 class BN(Op):
     """out = act(bn(c) [+ res | + bn_r(res)]) with the batch statistics the producing Conv accumulated (training) or the
     running ones (eval).  `bias`: the conv in front had a bias (VNL.py:336 FTB_block.conv2): under batch statistics it

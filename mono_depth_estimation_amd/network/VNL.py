@@ -7,7 +7,8 @@ topdown_predict`), identical state_dict keys, the reference's initialisation rul
 Network (VNL.py:97-387,539-693): ResNeXt-50/101 32x4d body at output stride 16 (grouped 3x3 convs, res5 dilated by 2),
 ASPP on res5 (1x1 + three dilated 3x3 + image pooling), FTB lateral blocks, a top-down decoder of AFA gates + FTB
 blocks with bilinear(align_corners) upsampling, and a dilated 3x3 prediction conv + softmax over 150 depth bins.
-The MobileNetV2 encoder option (VNL.py:389-537, depthwise convolutions) has no kernels here and is refused.
+The MobileNetV2 encoder option (`mobilenetv2_body_stride8`, VNL.py:389-537: inverted residuals around depthwise 3x3
+convolutions, ReLU6, a global-pooling block in the ASPP's place) runs on csrc/dwconv.hip's streaming kernels.
 """
 import math
 from collections import OrderedDict
@@ -153,6 +154,76 @@ def ResNeXt101_32x4d_body_stride16(freeze_backbone):
     return ResNeXt_body((3, 4, 23, 3), 32, 4, 16, freeze_backbone)
 
 
+# ---------------------------------------------------------------------------------------------- MobileNetV2 body (VNL.py:389-537)
+def _mbv2_conv_bn(inp, oup, stride):
+    return _Seq(nn.Conv2d(inp, oup, 3, stride, 1, bias=False), nn.BatchNorm2d(oup), nn.ReLU6(inplace=True))
+
+
+class InvertedResidual(_Container):
+    """VNL.py:416-457: [1x1 expand -> BN -> ReLU6 ->] depthwise 3x3 (stride, dilation) -> BN -> ReLU6 -> 1x1 -> BN [+ x]; `conv`
+    holds the layers under the reference's Sequential indices."""
+
+    def __init__(self, inp, oup, stride, expand_ratio, dilation=1):
+        super().__init__()
+        assert stride in (1, 2)
+        hidden = round(inp * expand_ratio)
+        self.stride, self.dilation, self.expand = stride, dilation, expand_ratio != 1
+        self.use_res_connect = stride == 1 and inp == oup
+        dw = lambda: nn.Conv2d(hidden, hidden, 3, stride, groups=hidden, bias=False, padding=dilation, dilation=dilation)
+        tail = [dw(), nn.BatchNorm2d(hidden), nn.ReLU6(inplace=True), nn.Conv2d(hidden, oup, 1, 1, 0, bias=False), nn.BatchNorm2d(oup)]
+        head = [nn.Conv2d(inp, hidden, 1, 1, 0, bias=False), nn.BatchNorm2d(hidden), nn.ReLU6(inplace=True)] if self.expand else []
+        self.conv = _Seq(*(head + tail))
+
+
+def _mbv2_stage(setting, inp, dilation=1):
+    blocks = []
+    for t, c, n, s in setting:
+        for i in range(n):
+            blocks.append(InvertedResidual(inp, c, s if i == 0 else 1, expand_ratio=t, dilation=dilation))
+            inp = c
+    return _Seq(*blocks), inp
+
+
+class MobileNetV2(_Container):
+    """VNL.py:471-537 (width multiplier 1): res1 = 3x3 / 2 stem, res2 .. res5 = the inverted-residual stages; at output stride 8
+    res4 and res5 keep the 1/8 map and dilate by 2 and 4."""
+
+    def __init__(self, output_stride=32):
+        super().__init__()
+        self.convX, self.last_channel = 5, 320
+        stride1 = 1 if 32 / output_stride == 4 else 2
+        stride2 = 1 if 32 / output_stride > 1 else 2
+        dilation1 = 1 if stride1 == 2 else 2
+        dilation2 = 1 if stride2 == 2 else (2 if stride1 == 2 else 4)
+        self.res1 = _Seq(_mbv2_conv_bn(3, 32, 2))
+        self.res2, c = _mbv2_stage([[1, 16, 1, 1], [6, 24, 2, 2]], 32)
+        self.res3, c = _mbv2_stage([[6, 32, 3, 2]], c)
+        self.res4, c = _mbv2_stage([[6, 64, 4, stride1], [6, 96, 3, 1]], c, dilation1)
+        self.res5, c = _mbv2_stage([[6, 160, 3, stride2], [6, 320, 1, 1]], c, dilation2)
+        for m in self.modules():                          # VNL.py:523-537 _initialize_weights
+            if isinstance(m, nn.Conv2d):
+                m.weight.data.normal_(0, math.sqrt(2. / (m.kernel_size[0] * m.kernel_size[1] * m.out_channels)))
+            elif isinstance(m, nn.BatchNorm2d):
+                m.weight.data.fill_(1)
+                m.bias.data.zero_()
+
+
+def MobileNetV2_body_stride8(freeze_backbone):
+    return MobileNetV2(output_stride=8)
+
+
+class Global_pool_block(_Container):
+    """VNL.py:172-187: 1x1 conv -> BatchNorm (momentum 0.9) -> global average -> `unpool` back to crop_size / output_stride."""
+
+    def __init__(self, dim_in, dim_out, output_stride, crop_size):
+        super().__init__()
+        self.dim_in, self.dim_out = dim_in, dim_out
+        self.globalpool_conv1x1 = nn.Conv2d(dim_in, dim_out, 1, stride=1, padding=0, bias=False)
+        self.globalpool = nn.AdaptiveAvgPool2d((1, 1))
+        self.globalpool_bn = nn.BatchNorm2d(dim_out, momentum=0.9)
+        self.unpool = nn.AdaptiveAvgPool2d((int(crop_size[0] / output_stride), int(crop_size[1] / output_stride)))
+
+
 def _conv_init(m, init_type, kaiming):
     if init_type == 'xavier':
         nn.init.xavier_normal_(m.weight)
@@ -180,7 +251,10 @@ class lateral(_Container):
         self.bottomup = conv_body_func(args.freeze_backbone)
         dilation_rate = [4, 8, 12] if 'stride_8' in self.encoder else [2, 4, 6]
         encoder_stride = 8 if 'stride8' in self.encoder else 16
-        self.bottomup_top = ASPP_block(self.dim_in[0], self.dim_out[0], dilation_rate, encoder_stride)
+        if 'mobilenetv2' in self.encoder:
+            self.bottomup_top = Global_pool_block(self.dim_in[0], self.dim_out[0], encoder_stride, args.crop_size)
+        else:
+            self.bottomup_top = ASPP_block(self.dim_in[0], self.dim_out[0], dilation_rate, encoder_stride)
         if self.pretrained:
             raise NotImplementedError("pretrained=True reads network/pretrained_models/ResNeXt-ImageNet/*.pth (VNL.py:70-95): load such a "
                                       "file through mono_depth_estimation_amd.checkpoint.load_vnl_imagenet_weights instead")
@@ -231,7 +305,7 @@ class fcn_topdown(_Container):
         self.dim_in = args.dec_dim_in
         self.dim_out = args.dec_dim_out + [args.dec_out_c]
         self.num_fcn_topdown = len(self.dim_in)
-        aspp_blocks_num = 5
+        aspp_blocks_num = 1 if 'mobilenetv2' in args.encoder else 5
         self.top = _Seq(
             nn.Conv2d(self.dim_in[0] * aspp_blocks_num, self.dim_in[0], 1, stride=1, padding=0, bias=False),
             nn.BatchNorm2d(self.dim_in[0], 0.5)            # (sic: the second positional argument is eps)
@@ -262,7 +336,7 @@ def get_func(args):
     if args.encoder == 'resnext101_32x4d_body_stride16':
         return lateral(ResNeXt101_32x4d_body_stride16, args)
     if args.encoder == 'mobilenetv2_body_stride8':
-        raise NotImplementedError("the MobileNetV2 encoder (depthwise convolutions, VNL.py:389-537) has no HIP kernels here")
+        return lateral(MobileNetV2_body_stride8, args)
     raise ValueError("Unknown bottom up model")
 
 
@@ -299,16 +373,45 @@ class VNLEngine(G.TapeEngine):
         w = self.pw(w, act="sigmoid")
         return self.add(G.Gate(self, w, lat, top)).out
 
+    def _bn_relu6(self, c, bn, site=None, stats_pass=False):
+        """BatchNorm -> ReLU6 (VNL.py:402,410,433,441): the BatchNorm pass without activation, then the clamp as a pointwise pass."""
+        site = site if site is not None else self._site([bn])
+        if stats_pass:
+            self.add(G.StatsPass(self, c, site))
+        return self.pw(self.add(G.BN(self, c, site, False)).out, act="relu6")
+
+    def _inverted_residual(self, x, blk):
+        L = list(blk.conv)
+        h = x
+        if blk.expand:
+            site = self._site([L[1]])
+            h = self._bn_relu6(self.add(G.Conv(self, h, L[0].weight, 1, site=site)).out, L[1], site=site)
+            L = L[3:]
+        h = self.add(G.DwConv(self, h, L[0].weight, blk.stride, blk.dilation)).out
+        h = self._bn_relu6(h, L[1], stats_pass=True)                          # (no conv epilogue behind a depthwise pass: a reduction)
+        h = self.conv_bn(h, L[3], L[4], False)
+        return self.pw(h, r=x) if blk.use_res_connect else h
+
     def _plan(self):
         m, N, H, W = self.m.depth_model, self.N, self.H, self.W
         enc, dec = m.encoder_modules, m.decoder_modules
         body = enc.bottomup
-        self.stem = self.add(G.Stem(self, body.res1.conv1, body.res1.bn1, N, H, W))
-        x, feats = self.stem.out, []
+        mobile = isinstance(body, MobileNetV2)
+        if mobile:
+            conv, bn = body.res1[0][0], body.res1[0][1]
+            site = self._site([bn])
+            self.stem = self.add(G.ImageStem(self, conv, site, N, H, W))
+            x, feats = self._bn_relu6(self.stem.out, bn, site=site), []
+        else:
+            self.stem = self.add(G.Stem(self, body.res1.conv1, body.res1.bn1, N, H, W))
+            x, feats = self.stem.out, []
         for i in range(2, body.convX + 1):
             for blk in getattr(body, "res%d" % i):
-                x = self._bottleneck(x, blk)
+                x = self._inverted_residual(x, blk) if mobile else self._bottleneck(x, blk)
             feats.append(x)                                                     # res2 .. res5
+        if mobile:
+            self._plan_decoder(feats, self._global_pool_top(feats[-1], enc.bottomup_top))
+            return
         # ASPP (VNL.py:211-228): five branches written side by side into one tensor
         top5, aspp = feats[-1], enc.bottomup_top
         Co = aspp.dim_out
@@ -320,6 +423,20 @@ class VNLEngine(G.TapeEngine):
         v = self.add(G.GlobalAvgPool(self, top5)).out
         u = self.conv_bn(v, aspp.globalpool_conv1x1, aspp.globalpool_bn, False)
         self.add(G.Broadcast(self, u, cat.slice(4 * Co, Co)))
+        self._plan_decoder(feats, cat)
+
+    def _global_pool_top(self, top5, gp):
+        """Global_pool_block.forward (VNL.py:181-186): conv1x1 -> BN -> global average -> `unpool` of the 1 x 1 map = a broadcast."""
+        c = self.conv_bn(top5, gp.globalpool_conv1x1, gp.globalpool_bn, False)
+        v = self.add(G.GlobalAvgPool(self, c)).out
+        h, w = gp.unpool.output_size
+        out = self.buf(top5.N, h, w, gp.dim_out)
+        self.add(G.Broadcast(self, v, out))
+        return out
+
+    def _plan_decoder(self, feats, cat):
+        m, N, H, W = self.m.depth_model, self.N, self.H, self.W
+        enc, dec = m.encoder_modules, m.decoder_modules
         laterals = [cat]
         for i in range(enc.num_lateral_stages):
             laterals.append(self._ftb(feats[-(i + 1)], enc.topdown_lateral_modules[i].lateral))
@@ -352,6 +469,8 @@ class MetricDepthModel(G.TapeModule):
 
     def _make_store(self, device):
         raw = [n for n, p in self.named_parameters() if p.dim() == 4 and (n.endswith("res1.conv1.weight") or ".conv2.weight" in n and "bottomup.res" in n)]
+        # (+ MobileNetV2's depthwise weights [C][1][3][3]: the fp32 master is csrc/dwconv.hip's [C][9] operand as it stands)
+        raw += [n + ".weight" for n, mod in self.named_modules() if isinstance(mod, nn.Conv2d) and mod.groups > 1 and mod.groups == mod.in_channels]
         return G.NetStore(self, device, is_encoder=lambda n: 'res' in n, raw=raw)     # vnl.py:298-305: 'res' in key -> encoder LR
 
     def forward(self, x):

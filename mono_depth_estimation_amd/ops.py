@@ -580,7 +580,19 @@ def nhwc_bf16_to_nchw(src, dst):
 
 
 # ------------------------------------------------------------------------------ pointwise / pooling / resize (VNL, MiDaS, BTS)
-ACT = {None: 0, "none": 0, "relu": 1, "elu": 2, "sigmoid": 3}
+ACT = {None: 0, "none": 0, "relu": 1, "elu": 2, "sigmoid": 3, "relu6": 4}
+
+
+def dwconv3x3_fwd(x, ldx, w, out, ldo, N, H, W, C_, stride, dil):
+    check(_lib.load().mde_dwconv3x3_fwd(_p(x), ldx, _p(w), _p(out), ldo, N, H, W, C_, stride, dil, _stream()), "mde_dwconv3x3_fwd")
+
+
+def dwconv3x3_dgrad(dy, ldy, w, dx, lddx, N, H, W, C_, stride, dil, accumulate=False):
+    check(_lib.load().mde_dwconv3x3_dgrad(_p(dy), ldy, _p(w), _p(dx), lddx, N, H, W, C_, stride, dil, int(accumulate), _stream()), "mde_dwconv3x3_dgrad")
+
+
+def dwconv3x3_wgrad(x, ldx, dy, ldy, dw, N, H, W, C_, stride, dil):
+    check(_lib.load().mde_dwconv3x3_wgrad(_p(x), ldx, _p(dy), ldy, _p(dw), N, H, W, C_, stride, dil, _stream()), "mde_dwconv3x3_wgrad")
 
 
 def pw_fwd(x, ldx, bias, r, ldr, out, ldo, M, C_, act):

@@ -79,14 +79,50 @@ def fp16_round(t):
     return t.to(torch.float16).to(torch.float32)
 
 
-def vnl_forward(P, x, train, block_counts=(3, 4, 6, 3), momentum=None, q=None):
-    """MetricDepthModel.forward (VNL.py:678-693) for the resnext*_32x4d_body_stride16 encoders -> (logits, softmax).
+def _mbv2_features(n, x, b):
+    """MobileNetV2.forward at output stride 8 (VNL.py:471-521; InvertedResidual :416-457): -> [res2 .. res5]."""
+    relu6 = lambda t: n.q(F.relu6(t))
+    y = relu6(n.q(n.bn(n.conv(x, b + "res1.0.0", 2, 1), b + "res1.0.1")))
+    feats = []
+    stages = {2: ([[1, 16, 1, 1], [6, 24, 2, 2]], 1), 3: ([[6, 32, 3, 2]], 1), 4: ([[6, 64, 4, 1], [6, 96, 3, 1]], 2),
+              5: ([[6, 160, 3, 1], [6, 320, 1, 1]], 4)}
+    for stage in (2, 3, 4, 5):
+        setting, dil = stages[stage]
+        idx = 0
+        for t, c, cnt, s in setting:
+            for i in range(cnt):
+                k = b + "res%d.%d.conv." % (stage, idx)
+                stride, inp = (s if i == 0 else 1), y
+                o = 0
+                if t != 1:
+                    y = relu6(n.q(n.bn(n.conv(y, k + "0"), k + "1")))
+                    o = 3
+                ch = y.shape[1]
+                y = relu6(n.q(n.bn(n.conv(y, k + "%d" % o, stride, dil, dil, groups=ch), k + "%d" % (o + 1))))
+                y = n.q(n.bn(n.conv(y, k + "%d" % (o + 3)), k + "%d" % (o + 4)))
+                if stride == 1 and inp.shape[1] == y.shape[1]:
+                    y = n.q(y + inp)
+                idx += 1
+        feats.append(y)
+    return feats
+
+
+def vnl_forward(P, x, train, block_counts=(3, 4, 6, 3), momentum=None, q=None, crop_size=None):
+    """MetricDepthModel.forward (VNL.py:678-693) for the resnext*_32x4d_body_stride16 encoders and for mobilenetv2_body_stride8
+    (told apart by the state dict's keys; crop_size: the size Global_pool_block's `unpool` was built for) -> (logits, softmax).
     momentum: override every BatchNorm's (1.0 = "running statistics := this batch's", weights.calibrate_running_stats).
     q: rounding applied wherever the HIP path stores a bf16 tensor (bf16_round: the bf16-emulating oracle)."""
     n = Net(P, train, q=q, momentum=momentum)
     e, d = "depth_model.encoder_modules.", "depth_model.decoder_modules."
     H, W = x.shape[2:]
     b = e + "bottomup."
+    if b + "res1.0.0.weight" in P:
+        feats = _mbv2_features(n, x, b)
+        a = e + "bottomup_top."
+        g = n.q(n.bn(n.conv(feats[-1], a + "globalpool_conv1x1"), a + "globalpool_bn", 0.9)).mean((2, 3), keepdim=True)
+        cs = crop_size if crop_size is not None else (H, W)
+        lats = [n.q(g).expand(-1, -1, int(cs[0] / 8), int(cs[1] / 8))]
+        return _vnl_decoder(n, feats, lats, e, d, H, W)
     y = n.q(F.relu(n.bn(n.conv(x, b + "res1.conv1", 2, 3), b + "res1.bn1")))
     y = F.max_pool2d(y, 3, 2, 1)
     feats = []
@@ -102,7 +138,11 @@ def vnl_forward(P, x, train, block_counts=(3, 4, 6, 3), momentum=None, q=None):
         xs.append(n.q(n.bn(n.conv(t, a + "aspp_conv3_%d" % (i + 1), pad=r, dil=r), a + "aspp_bn3_%d" % (i + 1), 0.5)))
     g = n.q(n.bn(n.conv(n.q(t.mean((2, 3), keepdim=True)), a + "globalpool_conv1x1"), a + "globalpool_bn", 0.5))
     xs.append(g.expand(-1, -1, t.shape[2], t.shape[3]))          # bilinear(align_corners) of a 1x1 map is a broadcast
-    lats = [torch.cat(xs, 1)]
+    return _vnl_decoder(n, feats, [torch.cat(xs, 1)], e, d, H, W)
+
+
+def _vnl_decoder(n, feats, lats, e, d, H, W):
+    """The lateral FTB blocks (lateral.forward, VNL.py:163-170) and fcn_topdown.forward (VNL.py:286-294)."""
     for i in range(4):
         lats.append(_vnl_ftb(n, feats[-(i + 1)], e + "topdown_lateral_modules.%d.lateral" % i))
     # fcn_topdown.forward (VNL.py:286-294); `top`'s BatchNorm2d(dim, 0.5) has eps = 0.5 (VNL.py:253)
@@ -132,6 +172,17 @@ def vnl_params(depth_max=1.1, depth_min=0.01, dec_out_c=150, encoder="resnext50_
     p.depth_bin_interval = (np.log10(depth_max) - np.log10(depth_min)) / dec_out_c
     p.wce_loss_weight = [[np.exp(-0.2 * (i - j) ** 2) for i in range(dec_out_c)] for j in np.arange(dec_out_c)]
     p.depth_bin_border = np.array([np.log10(depth_min) + p.depth_bin_interval * (i + 0.5) for i in range(dec_out_c)])
+    return p
+
+
+def vnl_mobilenet_params(crop_size, **kw):
+    """vnl_params for `--encoder mobilenetv2_body_stride8`: the channel lists the VNL authors' MobileNetV2 configuration
+    uses (the reference's argparse defaults, VNL.py:702-705, are the ResNeXt ones; its MobileNetV2 widths are
+    VNL.py:489-519's) and the crop size Global_pool_block's `unpool` is built for (VNL.py:180, :707)."""
+    p = vnl_params(encoder="mobilenetv2_body_stride8", **kw)
+    p.enc_dim_in, p.enc_dim_out = [32, 24, 32, 96, 320], [128, 64, 64, 64]
+    p.dec_dim_in, p.dec_dim_out = [128, 64, 64, 64, 64, 64], [64, 64, 64, 64, 64]
+    p.crop_size = tuple(crop_size)
     return p
 
 

@@ -140,6 +140,22 @@ def vnl_fixture_state(model, seed):
     return sd
 
 
+def vnl_mobilenet_fixture_state(model, seed):
+    """vnl_fixture_state for the mobilenetv2_body_stride8 encoder: the projection BatchNorm (`conv.7`, VNL.py:444-445) of the
+    inverted residuals that HAVE a skip connection (input width == output width) takes bn3's place -- a block without one
+    must not be damped: its output would be beta + 0.05 z, stored with beta's rounding error, and the next block's
+    BatchNorm would scale that error up with z (measured: 21 % logit noise from bf16 storage, 3.6 % this way).  Prediction
+    conv x 0.4 (64 input channels, not 256)."""
+    sd = net_conditioned_state(model, seed, damp=("globalpool_bn",), damp_to=0.05)
+    for k in list(sd):
+        if k.endswith(".conv.7.weight") and sd[k[:-8] + "0.weight"].shape[1] == sd[k[:-8] + "6.weight"].shape[0]:
+            sd[k] = sd[k] * 0.05
+    k = "depth_model.decoder_modules.topdown_predict.conv1.weight"
+    sd[k] = (sd[k] * 0.4).to(torch.bfloat16).to(torch.float32)
+    model.load_state_dict(sd)
+    return sd
+
+
 def midas_fixture_state(model, seed):
     """MiDaS parity fixture: net_conditioned_state with the trunk's residual branches damped (bn3 x 0.05) and the 7-channel
     output conv scaled by 0.01 (the BN-free decoder of residual sums grows the activations; He-scale head weights saturate the

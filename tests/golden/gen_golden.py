@@ -536,6 +536,53 @@ def gen_vnl_net(criteria):
         len(out["keys"]), sum(p.numel() for p in ref.parameters()), out["eval_depth"].min(), out["eval_depth"].max(), float(loss)))
 
 
+def gen_vnl_mobilenet(criteria):
+    """C4 with `--encoder mobilenetv2_body_stride8`: the reference's own MobileNetV2 / Global_pool_block (VNL.py:389-537,
+    :172-187) under MetricDepthModel, same protocol as gen_vnl_net."""
+    from network import VNL
+    from oracle import nets
+    if not hasattr(np, "int"):
+        np.int = int
+    H, Wd = VNL_SIZE
+    params = nets.vnl_mobilenet_params((H, Wd))
+    torch.manual_seed(0)
+    ref = VNL.MetricDepthModel(params)
+    W.vnl_mobilenet_fixture_state(ref, 45)
+    rgb, tgt = W.synthetic_batch(45, 2, H, Wd)
+    W.calibrate_running_stats(ref, rgb)
+    border = torch.tensor(params.depth_bin_border, dtype=torch.float32)
+    to_depth = lambda prob: 10 ** (prob.permute(0, 2, 3, 1) * border).sum(3, dtype=torch.float32, keepdim=True).permute(0, 3, 1, 2)
+    out = {"keys": np.array(list(ref.state_dict().keys()))}
+    ref.eval()
+    with torch.no_grad():
+        logit, prob = ref(rgb)
+    out["eval_depth"], out["eval_logit_s"], out["eval_prob_s"] = _np(to_depth(prob)), _np(logit[:, ::5, ::4, ::4]), _np(prob[:, ::5, ::4, ::4])
+    out["eval_logit_csum"] = _np(logit.sum((2, 3)))
+    ref.train()
+    crit = criteria.ModelLoss(params)
+    np.random.seed(77)
+    p123 = crit.virtual_normal_loss.select_index()
+    out["p123"] = np.stack([p123["p%d_y" % i] * Wd + p123["p%d_x" % i] for i in (1, 2, 3)]).astype(np.int32)
+    gt = tgt.clone()
+    gt[:, :, :, :4] = -1.0
+    bins = vnl_bins(gt.clone(), params)
+    gt_loss = gt.clone()
+    gt_loss[gt_loss < params.depth_min] = torch.where(gt_loss[gt_loss < params.depth_min] < 0, torch.tensor(-1.0), torch.tensor(params.depth_min))
+    logit, prob = ref(rgb)
+    np.random.seed(77)
+    loss = crit(to_depth(prob), logit, bins, gt_loss)
+    loss.backward()
+    out["gt"], out["bins"] = _np(gt_loss), _np(bins)
+    out["train_depth"], out["train_logit_s"], out["train_loss"] = _np(to_depth(prob)), _np(logit[:, ::5, ::4, ::4]), _np(loss)
+    out["grad_names"], out["grad_norms"] = _grad_norms(ref)
+    sd = ref.state_dict()
+    out["rm_res5"] = _np(sd["depth_model.encoder_modules.bottomup.res5.3.conv.7.running_mean"])
+    out["rv_top"] = _np(sd["depth_model.encoder_modules.bottomup_top.globalpool_bn.running_var"])
+    np.savez_compressed(os.path.join(HERE, "vnl_mbv2.npz"), **out)
+    print("vnl_mbv2.npz: %d keys, %d params, eval depth range %.4f..%.4f, train loss %.5f" % (
+        len(out["keys"]), sum(p.numel() for p in ref.parameters()), out["eval_depth"].min(), out["eval_depth"].max(), float(loss)))
+
+
 MIDAS_SIZE = (64, 96)
 
 
@@ -999,6 +1046,8 @@ def main():
         gen_fcrn_in_channels(criteria, metrics, FCRN)
     if want("vnl_net"):
         gen_vnl_net(criteria)
+    if want("vnl_mbv2"):
+        gen_vnl_mobilenet(criteria)
     if want("midas_net"):
         gen_midas_net(criteria)
     if want("bts_net"):

