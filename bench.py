@@ -311,13 +311,21 @@ def add_binding_roofline(roof, timer):
 
 
 def print_per_shape(timer, timed_launch_steps):
+    """One line per (kernel, shape, algorithmic bytes): launches per step, time per launch, TFLOP/s, TB/s of the algorithmic
+    bytes (operands, results and whatever the fused epilogue reads, once each), and the time above a PRACTICAL floor --
+    max(flops / 1100 TFLOP/s, bytes / 5.5 TB/s), the rates the best launches of this step reach -- per step."""
     tab = {}
-    for kind, flops, e0, e1, tag in timer.records:
-        n, t = tab.get((kind, tag, flops), (0, 0.0))
-        tab[(kind, tag, flops)] = (n + 1, t + e0.elapsed_time(e1) * 1e-3)
-    for (kind, tag, flops), (n, t) in sorted(tab.items(), key=lambda kv: -kv[1][1]):
-        print("%-14s %-46s x%-3d %8.1f us  %7.1f TF/s  %5.2f ms/step" % (
-            kind, tag, n // timed_launch_steps, 1e6 * t / n, flops / (t / n) / 1e12, 1e3 * t / timed_launch_steps), file=sys.stderr)
+    for (kind, flops, e0, e1, tag), nbytes in zip(timer.records, timer.bytes):
+        n, t = tab.get((kind, tag, flops, nbytes), (0, 0.0))
+        tab[(kind, tag, flops, nbytes)] = (n + 1, t + e0.elapsed_time(e1) * 1e-3)
+    rows = []
+    for (kind, tag, flops, nbytes), (n, t) in tab.items():
+        floor = max(flops / 1.1e15, nbytes / 5.5e12)
+        rows.append((n * max(0.0, t / n - floor), kind, tag, flops, nbytes, n, t, floor))
+    for excess, kind, tag, flops, nbytes, n, t, floor in sorted(rows, key=lambda r: -r[0]):
+        print("%-14s %-46s x%-3d %8.1f us  %7.1f TF/s  %5.2f TB/s  floor %6.1f us (%s)  %5.2f ms/step  above floor %5.2f ms/step" % (
+            kind, tag, n // timed_launch_steps, 1e6 * t / n, flops / (t / n) / 1e12, nbytes / (t / n) / 1e12, 1e6 * floor,
+            "hbm" if nbytes / 5.5e12 > flops / 1.1e15 else "mfma", 1e3 * t / timed_launch_steps, 1e3 * excess / timed_launch_steps), file=sys.stderr)
 
 
 def main():

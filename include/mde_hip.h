@@ -186,6 +186,12 @@ int mde_stem_conv_fwd(const float* x, const float* w, void* out, float* stats, i
                       void* stream);
 /* dw (fp32 [64][7][7][3], caller-zeroed) += wgrad from dout bf16 [N][H/2][W/2][64]. */
 int mde_stem_conv_wgrad(const float* x, const void* dout, float* dw, int N, int H, int W, void* stream);
+/* The same kernels for a stem of Cout = 64 or 96 output channels (densenet161's conv0, reference network/Bts.py:289 through
+ * torchvision's densenet: nn.Conv2d(3, 96, 7, 2, 3)): w fp32 [Cout][7][7][3], out / dout bf16 [N][H/2][W/2][Cout], stats
+ * [mde_stat_slots()][2][Cout], dw fp32 [Cout][7][7][3].  96 channels run as two launches of 48 (the weights of a launch
+ * are register resident); the image is read once per launch. */
+int mde_stem_conv_fwd_c(const float* x, const float* w, void* out, float* stats, int N, int H, int W, int Cout, void* stream);
+int mde_stem_conv_wgrad_c(const float* x, const void* dout, float* dw, int N, int H, int W, int Cout, void* stream);
 
 /* Head conv3 3x3, Cin -> Cout (Cout <= 32), fp32 output (FCRN.py:340,368).
  * x: bf16 [N][H][W][Cin]; w: fp32 [Cout][3][3][Cin]; out: fp32 [N][H][W][Cout]. */

@@ -22,7 +22,7 @@ if ACT_NAME not in ("bf16", "fp16"):
     raise MdeError("MDE_ACT_DTYPE=%s: bf16 (default) or fp16" % ACT_NAME)
 LIB_NAME = "libmde_hip_f16.so" if ACT_NAME == "fp16" else "libmde_hip.so"
 LIB_PATH = os.environ.get("MDE_LIB_PATH") or os.path.join(_HERE, LIB_NAME)   # override: diagnostic builds only
-ABI_VERSION = 11
+ABI_VERSION = 12
 MAX_TAPS = 32
 
 
@@ -95,6 +95,8 @@ SIGNATURES = {
     "mde_conv_wgrad_ws_bytes": (_L, [C.POINTER(WgradDesc)]),
     "mde_stem_conv_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "mde_stem_conv_wgrad": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "mde_stem_conv_fwd_c": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "mde_stem_conv_wgrad_c": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "mde_head_conv_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "mde_head_conv_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "mde_stat_slots": (_I, []),

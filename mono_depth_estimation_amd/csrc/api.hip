@@ -20,7 +20,7 @@ int mde_check_hip(hipError_t e, const char* what) {
 
 extern "C" const char* mde_last_error(void) { return g_err; }
 
-extern "C" int mde_abi_version(void) { return 11; }
+extern "C" int mde_abi_version(void) { return 12; }
 extern "C" int mde_act_dtype(void) { return MDE_ACT_DTYPE_CODE; }       // 0: bf16 storage (libmde_hip.so), 1: fp16 (libmde_hip_f16.so)
 
 extern "C" int mde_device_cu_count(int* out) {

@@ -152,21 +152,25 @@ __device__ __forceinline__ void stem_unpack8(const uint32_t (&wv)[8], bf16x8_t& 
 // profiles/).  8 waves, two per SIMD; wave w owns output row w of the 8 x 64 tile and all 64
 // channels (A operand = weights, register resident for the whole persistent workgroup).
 // stats (optional): BatchNorm partial sums of the fp32 results, kept in registers across tiles.
+// CB: channel blocks of 16 this launch computes (4: torchvision's 64-channel conv1 in one launch; 3: one half of
+// densenet161's 96-channel conv0, Bts.py:289 -- the weights of a launch stay in registers, 6 blocks would not fit);
+// `w` and `out` point at the launch's first channel, ldo is the whole tensor's channel count, c0 the first channel.
 constexpr int NTF = 512;
 constexpr int FTY = 8;             // output rows per forward tile
 constexpr int FKS = 6;             // k-steps of 32 (24 groups of 8)
 #ifndef MDE_STEM_ABLATE
 #define MDE_STEM_ABLATE 0   // diagnostics: 1 no output stores, 2 no MFMAs, 4 no patch loads (bit mask)
 #endif
+template <int CB>
 __global__ __launch_bounds__(NTF, 1) void stem_fwd_k(const float* __restrict__ x, const float* __restrict__ w,
                                                      bf16_t* __restrict__ out, float* stats, int N, int H, int W, int OH,
-                                                     int OW, int det) {
+                                                     int OW, int ldo, int c0, int det) {
     using G = StemGeo<FTY>;
     __shared__ uint32_t patch[2][G::WORDS + G::ZPAD];
-    __shared__ float s_red[NTF / 64][2][64];
+    __shared__ float s_red[NTF / 64][2][CB * 16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lr = lane & 15, lg = lane >> 4;
-    bf16x8_t wa[4][FKS];
+    bf16x8_t wa[CB][FKS];
     int poffb[FKS];                          // byte offset of the lane's group row (even plane, its pixel) in a patch buffer
 #pragma unroll
     for (int ks = 0; ks < FKS; ++ks) {
@@ -175,15 +179,15 @@ __global__ __launch_bounds__(NTF, 1) void stem_fwd_k(const float* __restrict__ x
 #pragma unroll
         for (int e = 0; e < 8; ++e)
 #pragma unroll
-            for (int cb = 0; cb < 4; ++cb)
+            for (int cb = 0; cb < CB; ++cb)
                 wa[cb][ks][e] = (bf16_t)((g < 21 && e < 7) ? w[(cb * 16 + lr) * SK + (kh * 7 + e) * 3 + c] : 0.f);
     }
     for (int i = threadIdx.x; i < G::ZPAD; i += NTF) patch[0][G::WORDS + i] = patch[1][G::WORDS + i] = 0u;
     StemLoader<NTF, FTY>::clear_tails(patch[0]);
     StemLoader<NTF, FTY>::clear_tails(patch[1]);
-    f32x4_t s1[4], s2[4];
+    f32x4_t s1[CB], s2[CB];
 #pragma unroll
-    for (int cb = 0; cb < 4; ++cb) s1[cb] = s2[cb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int cb = 0; cb < CB; ++cb) s1[cb] = s2[cb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     const int tiles_x = (OW + STX - 1) / STX, tiles_y = (OH + FTY - 1) / FTY;
     const int ntiles = N * tiles_y * tiles_x;
@@ -207,9 +211,9 @@ __global__ __launch_bounds__(NTF, 1) void stem_fwd_k(const float* __restrict__ x
 #pragma unroll
         for (int f = 0; f < STX / 16; ++f) {
             if (tl.ox0 + f * 16 >= OW) break;
-            f32x4_t acc[4];
+            f32x4_t acc[CB];
 #pragma unroll
-            for (int cb = 0; cb < 4; ++cb) acc[cb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            for (int cb = 0; cb < CB; ++cb) acc[cb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < FKS; ++ks) {
                 const uint32_t* pe = reinterpret_cast<const uint32_t*>(pb + poffb[ks] + f * 64);
@@ -226,17 +230,17 @@ __global__ __launch_bounds__(NTF, 1) void stem_fwd_k(const float* __restrict__ x
                 acc[1][1] += (float)bh[2] + (float)bl[3] + (float)bh[4] + (float)bl[5] + (float)bh[6] + (float)bl[7];
 #else
 #pragma unroll
-                for (int cb = 0; cb < 4; ++cb) acc[cb] = MDE_MFMA_16x16x32(wa[cb][ks], bh, acc[cb]);
+                for (int cb = 0; cb < CB; ++cb) acc[cb] = MDE_MFMA_16x16x32(wa[cb][ks], bh, acc[cb]);
 #pragma unroll
-                for (int cb = 0; cb < 4; ++cb) acc[cb] = MDE_MFMA_16x16x32(wa[cb][ks], bl, acc[cb]);
+                for (int cb = 0; cb < CB; ++cb) acc[cb] = MDE_MFMA_16x16x32(wa[cb][ks], bl, acc[cb]);
 #endif
             }
             // D: col = pixel (lane&15), rows = channels cb*16 + lg*4 + r
             const int ox = tl.ox0 + f * 16 + lr;
             if (ox < OW) {
-                bf16_t* o = out + ((((int64_t)tl.n * OH + oy) * OW) + ox) * 64 + lg * 4;
+                bf16_t* o = out + ((((int64_t)tl.n * OH + oy) * OW) + ox) * ldo + lg * 4;
 #pragma unroll
-                for (int cb = 0; cb < 4; ++cb) {
+                for (int cb = 0; cb < CB; ++cb) {
                     bf16x4_t v;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = (bf16_t)acc[cb][r];
@@ -262,7 +266,7 @@ __global__ __launch_bounds__(NTF, 1) void stem_fwd_k(const float* __restrict__ x
     }
     if (stats) {
 #pragma unroll
-        for (int cb = 0; cb < 4; ++cb)
+        for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float a1 = mde_row16_sum(s1[cb][r]), a2 = mde_row16_sum(s2[cb][r]);
@@ -272,12 +276,12 @@ __global__ __launch_bounds__(NTF, 1) void stem_fwd_k(const float* __restrict__ x
                 }
             }
         __syncthreads();
-        if (threadIdx.x < 128) {
-            const int which = threadIdx.x >> 6, ch = threadIdx.x & 63;
+        if (threadIdx.x < 2 * CB * 16) {
+            const int which = threadIdx.x / (CB * 16), ch = threadIdx.x % (CB * 16);
             float v = 0.f;
 #pragma unroll
             for (int q = 0; q < NTF / 64; ++q) v += s_red[q][which][ch];
-            mde_stat_add(stats, 64, blockIdx.x, which, ch, v, det);
+            mde_stat_add(stats, ldo, blockIdx.x, which, c0 + ch, v, det);
         }
     }
 }
@@ -297,23 +301,27 @@ __device__ __forceinline__ int stem_patch_off(int k) {   // k -> word offset of 
 __device__ __forceinline__ int stem_dy_off(int row, int ch) {   // [px][64 ch] bf16, 128-B rows, XOR swizzle
     return row * 128 + 16 * (ch ^ ((((row >> 1) & 1) | (((row >> 3) & 1) << 1)) << 1));
 }
-constexpr int SDQ = WTY * STX * 8 / NT;   // 16-byte dY chunks per thread per tile (8)
-
-__device__ __forceinline__ void stem_dy_issue(i32x4_t (&dv)[SDQ], const __amdgpu_buffer_rsrc_t rs, const StemTile tl,
-                                              int OH, int OW) {
+// (CB channel blocks of 16 per launch = 2 CB chunks of 16 bytes per pixel; the LDS rows keep their 128-byte pitch)
+template <int CB>
+__device__ __forceinline__ void stem_dy_issue(i32x4_t (&dv)[WTY * STX * 2 * CB / NT], const __amdgpu_buffer_rsrc_t rs, const StemTile tl,
+                                              int OH, int OW, int ldo) {
 #pragma unroll
-    for (int q = 0; q < SDQ; ++q) {
+    for (int q = 0; q < WTY * STX * 2 * CB / NT; ++q) {
         const int i = threadIdx.x + q * NT;
-        const int p = i >> 3, ch8 = i & 7;
+        const int p = i / (2 * CB), ch8 = i % (2 * CB);
         const int oy = tl.oy0 + p / STX, ox = tl.ox0 + p % STX;       // p < WTY * STX
         const bool ok = (oy < OH) & (ox < OW);                       // pixels outside the image read as zeros
-        const uint32_t off = ok ? (uint32_t)(((tl.n * OH + oy) * OW + ox) * 64 + ch8 * 8) * 2u : MDE_OOB_OFFSET;
+        const uint32_t off = ok ? (uint32_t)(((tl.n * OH + oy) * OW + ox) * ldo + ch8 * 8) * 2u : MDE_OOB_OFFSET;
         dv[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
     }
 }
 
+template <int CB>
 __global__ __launch_bounds__(NT, 2) void stem_wgrad_k(const float* __restrict__ x, const bf16_t* __restrict__ dout,
-                                                      float* __restrict__ dw, int N, int H, int W, int OH, int OW, MdeDetDev det) {
+                                                      float* __restrict__ dw, int N, int H, int W, int OH, int OW, int ldo,
+                                                      MdeDetDev det) {
+    constexpr int SDQ = WTY * STX * 2 * CB / NT;   // 16-byte dY chunks per thread per tile (8 for 64 channels)
+    static_assert(WTY * STX * 2 * CB % NT == 0, "whole chunks per thread");
     using G = StemGeo<WTY>;
     __shared__ uint32_t patch[G::WORDS + G::ZPAD];
     __shared__ __attribute__((aligned(16))) char dyt[WTY * STX * 128];
@@ -328,16 +336,16 @@ __global__ __launch_bounds__(NT, 2) void stem_wgrad_k(const float* __restrict__ 
     }
     for (int i = threadIdx.x; i < G::ZPAD; i += NT) patch[G::WORDS + i] = 0u;
     StemLoader<NT, WTY>::clear_tails(patch);
-    f32x4_t acc[4][NF];
+    f32x4_t acc[CB][NF];
 #pragma unroll
-    for (int cb = 0; cb < 4; ++cb)
+    for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
         for (int f = 0; f < NF; ++f) acc[cb][f] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     const int tiles_x = (OW + STX - 1) / STX, tiles_y = (OH + WTY - 1) / WTY;
     const int ntiles = N * tiles_y * tiles_x;
     typedef __attribute__((address_space(3))) s16x4_t* lds_ptr;
     const __amdgpu_buffer_rsrc_t rs_x = mde_rsrc(x, (uint32_t)((int64_t)N * 3 * H * W * 4));
-    const __amdgpu_buffer_rsrc_t rs_d = mde_rsrc(dout, (uint32_t)((int64_t)N * OH * OW * 64 * 2));
+    const __amdgpu_buffer_rsrc_t rs_d = mde_rsrc(dout, (uint32_t)((((int64_t)N * OH * OW - 1) * ldo + CB * 16) * 2));
     StemLoader<NT, WTY> ld;
     ld.init(H, W);
     StemWalk<WTY> walk;
@@ -346,7 +354,7 @@ __global__ __launch_bounds__(NT, 2) void stem_wgrad_k(const float* __restrict__ 
     i32x4_t dv[SDQ];
     if ((int)blockIdx.x < ntiles) {
         ld.issue(pv, rs_x, walk.tile(), H, W);
-        stem_dy_issue(dv, rs_d, walk.tile(), OH, OW);
+        stem_dy_issue<CB>(dv, rs_d, walk.tile(), OH, OW, ldo);
     }
     for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
         __syncthreads();                               // everyone is done with the previous tile's LDS
@@ -354,18 +362,18 @@ __global__ __launch_bounds__(NT, 2) void stem_wgrad_k(const float* __restrict__ 
 #pragma unroll
         for (int q = 0; q < SDQ; ++q) {
             const int i = threadIdx.x + q * NT;
-            *reinterpret_cast<i32x4_t*>(dyt + stem_dy_off(i >> 3, i & 7)) = dv[q];
+            *reinterpret_cast<i32x4_t*>(dyt + stem_dy_off(i / (2 * CB), i % (2 * CB))) = dv[q];
         }
         __syncthreads();
         if (t + (int)gridDim.x < ntiles) walk.next();
         ld.issue(pv, rs_x, walk.tile(), H, W);
-        stem_dy_issue(dv, rs_d, walk.tile(), OH, OW);
+        stem_dy_issue<CB>(dv, rs_d, walk.tile(), OH, OW, ldo);
 #pragma unroll 2
         for (int kk = 0; kk < WTY * STX; kk += 32) {
             // A fragments (channels cb*16 + lr as rows, pixels kk + 8*lg + j as k): two transposed reads each
-            bf16x8_t fa[4];
+            bf16x8_t fa[CB];
 #pragma unroll
-            for (int cb = 0; cb < 4; ++cb) {
+            for (int cb = 0; cb < CB; ++cb) {
                 const int q = lr >> 2, pp = lr & 3;
                 const int row = kk + 8 * lg + q, ch = cb * 2 + (pp >> 1), sub = (pp & 1) * 8;
                 const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(uintptr_t)(uint32_t)(uintptr_t)(dyt + stem_dy_off(row, ch) + sub));
@@ -386,7 +394,7 @@ __global__ __launch_bounds__(NT, 2) void stem_wgrad_k(const float* __restrict__ 
                 bf16x8_t bh, bl;
                 stem_unpack8(wv, bh, bl);
 #pragma unroll
-                for (int cb = 0; cb < 4; ++cb) {
+                for (int cb = 0; cb < CB; ++cb) {
                     acc[cb][f] = MDE_MFMA_16x16x32(fa[cb], bh, acc[cb][f]);
                     acc[cb][f] = MDE_MFMA_16x16x32(fa[cb], bl, acc[cb][f]);
                 }
@@ -399,7 +407,7 @@ __global__ __launch_bounds__(NT, 2) void stem_wgrad_k(const float* __restrict__ 
         const int k = (wave + 4 * f) * 16 + lr;
         if (wave + 4 * f >= SKP / 16 || k >= SK) continue;
 #pragma unroll
-        for (int cb = 0; cb < 4; ++cb)
+        for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
             for (int r = 0; r < 4; ++r) mde_grad_add(dw + (cb * 16 + lg * 4 + r) * SK + k, acc[cb][f][r], det);
     }
@@ -819,9 +827,11 @@ int head_check(const char* who, int N, int H, int W, int Cin, int Cout) {
 
 }  // namespace
 
-extern "C" int mde_stem_conv_fwd(const float* x, const float* w, void* out, float* stats, int N, int H, int W,
-                                 void* stream) {
+// Cout: 64 (one launch) or 96 (two launches of 48 channels: the weights of a launch are register resident)
+extern "C" int mde_stem_conv_fwd_c(const float* x, const float* w, void* out, float* stats, int N, int H, int W, int Cout,
+                                   void* stream) {
     MDE_REQUIRE(x && w && out && N > 0 && H > 0 && W > 0, "mde_stem_conv_fwd: bad argument");
+    MDE_REQUIRE(Cout == 64 || Cout == 96, "mde_stem_conv_fwd: Cout=%d unsupported (64 or 96)", Cout);
     MDE_REQUIRE(((uintptr_t)out % 16) == 0, "mde_stem_conv_fwd: out must be 16-byte aligned");
     const int OH = (H + 6 - 7) / 2 + 1, OW = (W + 6 - 7) / 2 + 1;
     MDE_REQUIRE((int64_t)N * 3 * H * W * 4 < MDE_OOB_OFFSET && (int64_t)N * OH * OW < (1 << 30),
@@ -830,25 +840,47 @@ extern "C" int mde_stem_conv_fwd(const float* x, const float* w, void* out, floa
     MDE_REQUIRE((int64_t)3 * H * W < (1 << 27), "mde_stem_conv_fwd: image plane too large");
     const int64_t cap = cu_count();                         // persistent: one 8-wave workgroup per CU
     const int grid = (int)(ntiles > cap ? cap : ntiles);
-    stem_fwd_k<<<grid, NTF, 0, (hipStream_t)stream>>>(x, w, (bf16_t*)out, stats, N, H, W, OH, OW, g_mde_det.on);
+    bf16_t* o = (bf16_t*)out;
+    if (Cout == 64) {
+        stem_fwd_k<4><<<grid, NTF, 0, (hipStream_t)stream>>>(x, w, o, stats, N, H, W, OH, OW, 64, 0, g_mde_det.on);
+    } else {
+        stem_fwd_k<3><<<grid, NTF, 0, (hipStream_t)stream>>>(x, w, o, stats, N, H, W, OH, OW, 96, 0, g_mde_det.on);
+        stem_fwd_k<3><<<grid, NTF, 0, (hipStream_t)stream>>>(x, w + 48 * SK, o + 48, stats, N, H, W, OH, OW, 96, 48, g_mde_det.on);
+    }
     MDE_LAUNCH_CHECK("stem_fwd_k");
     return MDE_OK;
 }
 
-extern "C" int mde_stem_conv_wgrad(const float* x, const void* dout, float* dw, int N, int H, int W, void* stream) {
+extern "C" int mde_stem_conv_fwd(const float* x, const float* w, void* out, float* stats, int N, int H, int W,
+                                 void* stream) {
+    return mde_stem_conv_fwd_c(x, w, out, stats, N, H, W, 64, stream);
+}
+
+extern "C" int mde_stem_conv_wgrad_c(const float* x, const void* dout, float* dw, int N, int H, int W, int Cout, void* stream) {
     MDE_REQUIRE(x && dout && dw && N > 0 && H > 0 && W > 0, "mde_stem_conv_wgrad: bad argument");
+    MDE_REQUIRE(Cout == 64 || Cout == 96, "mde_stem_conv_wgrad: Cout=%d unsupported (64 or 96)", Cout);
     MDE_REQUIRE(((uintptr_t)dout % 16) == 0, "mde_stem_conv_wgrad: dout must be 16-byte aligned");
     MDE_REQUIRE((int64_t)3 * H * W < (1 << 27), "mde_stem_conv_wgrad: image plane too large");
-    MDE_REQUIRE((int64_t)N * 3 * H * W * 4 < MDE_OOB_OFFSET && (int64_t)N * (H / 2 + 1) * (W / 2 + 1) * 128 < MDE_OOB_OFFSET,
+    MDE_REQUIRE((int64_t)N * 3 * H * W * 4 < MDE_OOB_OFFSET && (int64_t)N * (H / 2 + 1) * (W / 2 + 1) * 2 * Cout < MDE_OOB_OFFSET,
                 "mde_stem_conv_wgrad: tensors must be < 2 GiB");
     const int OH = (H + 6 - 7) / 2 + 1, OW = (W + 6 - 7) / 2 + 1;
     const int64_t ntiles = (int64_t)N * ((OH + WTY - 1) / WTY) * ((OW + STX - 1) / STX);
     const int64_t cap = 2 * (int64_t)cu_count();
     const int grid = (int)(ntiles > cap ? cap : ntiles);
-    MDE_DET_REQUIRE("mde_stem_conv_wgrad", dw, (int64_t)64 * 7 * 7 * 3);
-    stem_wgrad_k<<<grid, NT, 0, (hipStream_t)stream>>>(x, (const bf16_t*)dout, dw, N, H, W, OH, OW, mde_det_dev());
+    MDE_DET_REQUIRE("mde_stem_conv_wgrad", dw, (int64_t)Cout * 7 * 7 * 3);
+    const bf16_t* d = (const bf16_t*)dout;
+    if (Cout == 64) {
+        stem_wgrad_k<4><<<grid, NT, 0, (hipStream_t)stream>>>(x, d, dw, N, H, W, OH, OW, 64, mde_det_dev());
+    } else {
+        stem_wgrad_k<3><<<grid, NT, 0, (hipStream_t)stream>>>(x, d, dw, N, H, W, OH, OW, 96, mde_det_dev());
+        stem_wgrad_k<3><<<grid, NT, 0, (hipStream_t)stream>>>(x, d + 48, dw + 48 * SK, N, H, W, OH, OW, 96, mde_det_dev());
+    }
     MDE_LAUNCH_CHECK("stem_wgrad_k");
     return MDE_OK;
+}
+
+extern "C" int mde_stem_conv_wgrad(const float* x, const void* dout, float* dw, int N, int H, int W, void* stream) {
+    return mde_stem_conv_wgrad_c(x, dout, dw, N, H, W, 64, stream);
 }
 
 extern "C" int mde_head_conv_fwd(const void* x, const float* w, float* out, int N, int H, int W, int Cin, int Cout,

@@ -669,6 +669,65 @@ class ImageStem(Op):
             self.eng.wgrad(d, self.out.g, self.xin.t, self.w.dw)
 
 
+class Stem7(Op):
+    """A 7x7 / 2 / pad 3 convolution of the fp32 NCHW image to 64 or 96 channels on the stem kernels (csrc/conv_small.hip:
+    the image patch staged once per tile as bf16 hi + lo pairs, BatchNorm sums from the epilogue): densenet161's conv0
+    (Bts.py:289, 96 channels), where the general ImageStem -- 49 taps over 8 zero-padded channel slots through the GEMM
+    kernel, 64-column tiles -- spent 0.8 ms forward and 2.3 ms on the weight gradient of a 16-image step against 0.15 / 0.2 ms
+    here.  The weight keeps its exact [O][7][7][3] shape in the flat store (NetStore `raw`).  Eval with the two-term weight
+    shadow goes through ImageStem's 16-slot hi / lo operands (GEMM kernel).  No input gradient."""
+
+    def __init__(self, eng, conv, site, N, H, W):
+        O = conv.out_channels
+        assert conv.kernel_size == (7, 7) and conv.stride == (2, 2) and conv.padding == (3, 3) and conv.in_channels == 3 and O in (64, 96)
+        assert H % 2 == 0 and W % 2 == 0, "stem kernel: even image sizes"
+        assert eng.store.sdims[id(conv.weight)] == (O, 7, 7, 3), "Stem7: the weight must be stored raw"
+        self.eng, self.site, self.O = eng, site, O
+        self.w = eng._conv([conv.weight], need_dgrad=False)
+        H2, W2 = H // 2, W // 2
+        self.out = Act(eng.dev, N, H2, W2, O)
+        taps = [(i - 3, j - 3, i * 7 + j) for i in range(7) for j in range(7)]
+        self.fd16 = [ops.conv_desc(N, H, W, 16, 16, N * H * W * 16 * 2, H2, W2, 2, 2, taps[t0:t0 + 32], 49, H2, W2, O, ncols=O, accumulate=t0 > 0)
+                     for t0 in (0, 32)]
+        self.split16 = self.w16 = self.x = None
+
+    def acts(self):
+        return (self.out,)
+
+    def grad_ranges(self):
+        return [(self.w.off, self.w.off + self.w.n)]
+
+    def fwd(self, train):
+        o = self.out
+        if self.eng.split:
+            if self.split16 is None:
+                self.split16 = torch.empty(o.N, 2 * o.H, 2 * o.W, 16, dtype=ops.ACT_DTYPE, device=self.eng.dev)
+                self.w16 = torch.empty(self.O * 49 * 16, dtype=ops.ACT_DTYPE, device=self.eng.dev)
+            ops.nchw_to_nhwc_split16(self.x, self.split16)
+            ops.stem_weight_split16(self.w.w32, self.w16, self.O * 49, 3, 3)
+            for d in self.fd16:
+                ops.conv_gemm(d, self.split16, self.w16, o.t)
+            return
+        ops.stem_conv_fwd(self.x, self.w.w32, o.t, self.site.part if (train and self.site is not None) else None, self.O)
+
+    def bwd(self):
+        ops.stem_conv_wgrad(self.x, self.out.g, self.w.dw, self.O)
+
+
+def stem7_weights(module):
+    """Names of the 7x7 / 2 image convs Stem7 can run (3 -> 64 or 96 channels): for a NetStore's `raw` list."""
+    return [n + ".weight" for n, m in module.named_modules()
+            if isinstance(m, torch.nn.Conv2d) and m.in_channels == 3 and m.out_channels in (64, 96) and m.kernel_size == (7, 7)
+            and m.stride == (2, 2) and m.padding == (3, 3) and m.dilation == (1, 1) and m.groups == 1 and m.bias is None]
+
+
+def image_stem(eng, conv, site, N, H, W):
+    """Stem7 where the conv's weight is stored raw (see stem7_weights) and the image size is even, ImageStem otherwise."""
+    if eng.store.sdims[id(conv.weight)] == (conv.out_channels, 7, 7, 3):
+        return Stem7(eng, conv, site, N, H, W)
+    return ImageStem(eng, conv, site, N, H, W)
+
+
 class MaxPool(Op):
     """nn.MaxPool2d(3, 2, 1[, ceil_mode=True]) on a contiguous NHWC tensor."""
 

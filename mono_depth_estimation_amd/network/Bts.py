@@ -307,7 +307,7 @@ class BtsEngine(G.TapeEngine):
     def _dense_trunk(self, feats, N, H, W):
         dev = self.dev
         s0 = self._site([feats.norm0])
-        self.stem = self.add(G.ImageStem(self, feats.conv0, s0, N, H, W))
+        self.stem = self.add(G.image_stem(self, feats.conv0, s0, N, H, W))     # (96 channels for densenet161, 64 for densenet121)
         relu0 = self.add(G.BN(self, self.stem.out, s0, True)).out
         pool0 = self.add(G.MaxPool(self, relu0)).out
         skips, x, c = [relu0, pool0], pool0, pool0.C
@@ -350,7 +350,7 @@ class BtsEngine(G.TapeEngine):
         """encoder.forward (Bts.py:309-321) over a whole torchvision ResNet / ResNeXt: 'relu' (after conv1 / bn1), then
         layer1 .. layer4 are the five features; the 3x3 convs of the ResNeXt variants run as block-diagonal grouped tiles."""
         s0 = self._site([rn.bn1])
-        self.stem = self.add(G.ImageStem(self, rn.conv1, s0, N, H, W))
+        self.stem = self.add(G.image_stem(self, rn.conv1, s0, N, H, W))
         relu = self.add(G.BN(self, self.stem.out, s0, True)).out
         x = self.add(G.MaxPool(self, relu)).out
         skips = [relu]
@@ -438,6 +438,7 @@ class BtsModel(G.TapeModule):
         # (the grouped 3x3 weights of the ResNeXt encoders, [O][G][3][3] with G = 4 or 8, keep their exact shape: their
         #  block-diagonal packings are built from it)
         raw = [n + ".weight" for n, m in self.named_modules() if isinstance(m, nn.Conv2d) and m.groups > 1]
+        raw += G.stem7_weights(self)               # (the 7x7 / 2 image conv: [O][7][7][3], the stem kernels' operand)
         return G.NetStore(self, device, is_encoder=lambda n: n.startswith("encoder."), raw=raw)      # bts.py:140-141
 
     def forward(self, x, focal=518.8579):

@@ -201,7 +201,7 @@ class MyModel(G.TapeModule):
         self._init_runtime()
 
     def _make_store(self, device):
-        return G.NetStore(self, device, is_encoder=lambda n: n.startswith("encoder."))      # my.py:67-69
+        return G.NetStore(self, device, is_encoder=lambda n: n.startswith("encoder."), raw=G.stem7_weights(self))      # my.py:67-69
 
     def forward(self, x):
         return self._run(x)[0]

@@ -361,14 +361,14 @@ def choose_ksplit(pixels, row_tiles, col_tiles, ntaps, cus=256, min_steps=8, wg_
 
 
 # ------------------------------------------------------------------------------ small convs
-def stem_conv_fwd(x, w, out, stats=None):
+def stem_conv_fwd(x, w, out, stats=None, cout=64):
     N, _, H, W = x.shape
-    check(_lib.load().mde_stem_conv_fwd(_p(x), _p(w), _p(out), _p(stats), N, H, W, _stream()), "mde_stem_conv_fwd")
+    check(_lib.load().mde_stem_conv_fwd_c(_p(x), _p(w), _p(out), _p(stats), N, H, W, cout, _stream()), "mde_stem_conv_fwd_c")
 
 
-def stem_conv_wgrad(x, dout, dw):
+def stem_conv_wgrad(x, dout, dw, cout=64):
     N, _, H, W = x.shape
-    check(_lib.load().mde_stem_conv_wgrad(_p(x), _p(dout), _p(dw), N, H, W, _stream()), "mde_stem_conv_wgrad")
+    check(_lib.load().mde_stem_conv_wgrad_c(_p(x), _p(dout), _p(dw), N, H, W, cout, _stream()), "mde_stem_conv_wgrad_c")
 
 
 def head_conv_fwd(x, w, out, N, H, W, Cin, Cout):

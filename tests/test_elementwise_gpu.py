@@ -538,23 +538,25 @@ def test_bn_join_backward_two_sites(N, H, Wd, C):
 
 
 # ------------------------------------------------------------------------------------ stem / head convs
-@pytest.mark.parametrize("N,H,Wd", [(2, 32, 48), (1, 30, 200), (3, 62, 260), (40, 64, 256)])
-def test_stem_conv(N, H, Wd):
+@pytest.mark.parametrize("N,H,Wd,CO", [(2, 32, 48, 64), (1, 30, 200, 64), (3, 62, 260, 64), (40, 64, 256, 64),
+                                        (2, 32, 48, 96), (3, 62, 260, 96), (1, 30, 200, 96)])
+def test_stem_conv(N, H, Wd, CO):
+    """CO = 96: densenet161's conv0 (two launches of 48 channels into one 96-channel tensor, one statistics buffer)."""
     from mono_depth_estimation_amd import ops
     x = W.uniform(14, "x", (N, 3, H, Wd))
     # the kernel multiplies bf16 weights (as every MFMA conv here) with the image split into
     # bf16 hi+lo parts (~fp32): the reference uses bf16-representable weights and the fp32 image
-    w = _bf(W.normal(14, "w", (64, 3, 7, 7), (2.0 / (49 * 64)) ** 0.5)).requires_grad_(True)
+    w = _bf(W.normal(14, "w", (CO, 3, 7, 7), (2.0 / (49 * 64)) ** 0.5)).requires_grad_(True)
     y = F.conv2d(x, w, stride=2, padding=3)
     dy = _bf(W.normal(14, "dy", tuple(y.shape)))
     y.backward(dy)
     w_ohwi = w.detach().permute(0, 2, 3, 1).contiguous().cuda()
     OH, OW = y.shape[2:]
-    out = torch.empty(N, OH, OW, 64, dtype=ACT, device="cuda")
-    dw = torch.zeros(64, 7, 7, 3, device="cuda")
-    part = ops.new_stat_buffer(64)
-    ops.stem_conv_fwd(x.cuda(), w_ohwi, out, part)
-    ops.stem_conv_wgrad(x.cuda(), _nhwc(dy), dw)
+    out = torch.empty(N, OH, OW, CO, dtype=ACT, device="cuda")
+    dw = torch.zeros(CO, 7, 7, 3, device="cuda")
+    part = ops.new_stat_buffer(CO)
+    ops.stem_conv_fwd(x.cuda(), w_ohwi, out, part, CO)
+    ops.stem_conv_wgrad(x.cuda(), _nhwc(dy), dw, CO)
     torch.cuda.synchronize()
     _close_bf16(_nchw(out), y.detach(), "stem fwd")
     # BatchNorm partial sums from the epilogue (fp32 results): sum and sum of squares per channel
