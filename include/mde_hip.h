@@ -396,6 +396,13 @@ int mde_softmax_head_fwd(const void* x, int ldx, const float* bias, float* logit
                          void* stream);
 int mde_softmax_head_bwd(const float* dlogit, const float* dprob, const float* prob, void* dx, int lddx, float* dbias, int N,
                          int64_t HW, int C, void* stream);
+/* y = scale * act(p) on an fp32 map of n elements (n % 4 == 0), and its backward through the kept output:
+ * dp = dy * scale * act'(.) with act' expressed through y / scale.  The activation behind a one-channel head convolution that
+ * already produced fp32 (mde_head_conv_fwd) -- BTS' get_depth + nn.Sigmoid x max_depth (reference network/Bts.py:168,262).
+ * act: 0 none, 1 ReLU, 2 ELU, 3 sigmoid, 4 ReLU6. */
+int mde_map_act_fwd(const float* p, float* y, int64_t n, int act, float scale, void* stream);
+int mde_map_act_bwd(const float* dy, const float* y, float* dp, int64_t n, int act, float scale, void* stream);
+
 /* out[n][c][p] = scale * act(x[n][p][c] + bias[c]), fp32 NCHW: the small-C output heads (MiDaS.py:54-56: 7 channels +
  * sigmoid; Bts.py:202-203,273: sigmoid * max_depth).  bwd: dx bf16 [N*HW][lddx] (pad channels zero), dbias += (C <= 64). */
 int mde_to_nchw_act_fwd(const void* x, int ldx, const float* bias, float* out, int N, int64_t HW, int C, int act, float scale,

@@ -132,6 +132,8 @@ SIGNATURES = {
     "mde_spread2x2": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _F, _I, _P]),
     "mde_softmax_head_fwd": (_I, [_P, _I, _P, _P, _P, _I, _L, _I, _P]),
     "mde_softmax_head_bwd": (_I, [_P, _P, _P, _P, _I, _P, _I, _L, _I, _P]),
+    "mde_map_act_fwd": (_I, [_P, _P, _L, _I, _F, _P]),
+    "mde_map_act_bwd": (_I, [_P, _P, _P, _L, _I, _F, _P]),
     "mde_to_nchw_act_fwd": (_I, [_P, _I, _P, _P, _I, _L, _I, _I, _F, _P]),
     "mde_to_nchw_act_bwd": (_I, [_P, _P, _P, _I, _P, _I, _L, _I, _I, _F, _P]),
     "mde_image_residual_fwd": (_I, [_P, _P, _P, _I, _L, _I, _P]),

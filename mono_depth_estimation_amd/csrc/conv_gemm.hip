@@ -161,6 +161,10 @@ __device__ __forceinline__ int chunk_off(int row, int kslot8) {
 #ifndef MDE_DEEP_RING
 #define MDE_DEEP_RING 4
 #endif
+// waves along the columns of a tile: two for 128+ columns, and for the 8-wave form of the 128 x 64 tile (each wave needs two
+// 16-pixel fragments at least)
+template <int BP, int BC, int NT>
+constexpr int waves_c() { return (BC >= 128 || NT / 64 > BP / 32) ? 2 : 1; }
 constexpr int HALO_MAX_Q = 8;    // halo DMA instructions per wave and chunk (4 waves x 8 x 8 rows = 256 halo rows)
 // RED = 1 / 2: the instances behind mde_conv_gemm_bnred (the epilogue also reduces the backward sums of a BatchNorm site / of the
 // two sites of a residual join); kept apart so that the registers that epilogue needs do not cost the other launches their occupancy
@@ -171,7 +175,7 @@ __global__ __launch_bounds__(NT, HALO ? (NT == 512 ? 4 : BC <= 64 ? 5 : 4)
     constexpr int RPL = NT / 8;          // tile rows covered by one load pass (8 chunks per row)
     constexpr int XP = BP / RPL;         // X chunks per thread per K-step
     constexpr int WP = BC / RPL;         // W chunks per thread per K-step
-    constexpr int WAVES_C = BC >= 128 ? 2 : 1;   // waves along columns
+    constexpr int WAVES_C = waves_c<BP, BC, NT>();   // waves along columns
     constexpr int WAVES_P = NW / WAVES_C;        // waves along pixels
     constexpr int PF = BP / WAVES_P / 16;        // 16-pixel fragments per wave
     constexpr int CF = BC / WAVES_C / 16;        // 16-column fragments per wave
@@ -1268,10 +1272,17 @@ __global__ __launch_bounds__(NT, HALO ? (NT == 512 ? 4 : BC <= 64 ? 5 : 4)
 #endif
 }
 
+// waves of the deep-ring tiles (grids of at most one tile per CU): a K-step there costs what its DMA instructions take to
+// ISSUE (~190 cycles each, item 27 of DESIGN section 3) -- eight waves issue a step's pieces in half the time of four
+inline int deep_waves() {
+    const char* e = getenv("MDE_CONV_DEEP_WAVES");             // (read per call: the tests switch it between launches)
+    return (e && !strcmp(e, "4")) ? 4 : 8;
+}
+
 template <int BP, int BC, int NT, int NBUF>
 constexpr size_t smem_bytes() {
     return NBUF * (size_t)(BP + BC) * BK * 2 + 3 * BP * sizeof(int) +
-           ((NT / 64) / (BC >= 128 ? 2 : 1)) * 2 * BC * sizeof(float) + 3 * MDE_MAX_TAPS * sizeof(int);
+           ((NT / 64) / waves_c<BP, BC, NT>()) * 2 * BC * sizeof(float) + 3 * MDE_MAX_TAPS * sizeof(int);
 }
 
 template <int BP, int BC, int NT, bool DMA, int NBUF, bool PP = false>
@@ -1472,7 +1483,7 @@ int pick_and_launch(KArgs& ka, int64_t M, hipStream_t st) {
         const char* de = getenv("MDE_CONV_DEEP");
         const int deep64 = !(de && !strcmp(de, "0"));
         if (ring64 == 4 || (ring64 == -2 && deep64 && forced == 0 && tiles64 <= MDE_RING3_MAX_TILES_PER_CU * cus_() && ka.d.ntaps * ((ka.d.C + BK - 1) / BK) >= 4))
-            return launch<128, 64, 256, true, MDE_DEEP_RING>(ka, M, st);
+            return deep_waves() == 8 ? launch<128, 64, 512, true, MDE_DEEP_RING>(ka, M, st) : launch<128, 64, 256, true, MDE_DEEP_RING>(ka, M, st);
         return (ring64 == 1 || forced == 6) ? launch<128, 64, 256, true, 2>(ka, M, st) : launch<128, 64, 256, true, 1>(ka, M, st);
     }
     const int cus = cus_();
@@ -1507,7 +1518,7 @@ int pick_and_launch(KArgs& ka, int64_t M, hipStream_t st) {
         const int deep = !(de && !strcmp(de, "0"));
         const int nst = ka.d.ntaps * ((ka.d.C + BK - 1) / BK);
         if (deep && forced == 0 && !reg && nst >= 4 && (int64_t)mde_cdiv(M, 128) * nc128 <= MDE_RING3_MAX_TILES_PER_CU * cus)
-            return launch<128, 128, 256, true, MDE_DEEP_RING>(ka, M, st);
+            return deep_waves() == 8 ? launch<128, 128, 512, true, MDE_DEEP_RING>(ka, M, st) : launch<128, 128, 256, true, MDE_DEEP_RING>(ka, M, st);
     }
     const int64_t p256 = mde_cdiv(M, 256), t256 = p256 * nc256;
     auto rounds = [](int64_t tiles, int64_t slots) { return (tiles + slots - 1) / slots; };

@@ -553,27 +553,33 @@ __global__ __launch_bounds__(NT) void head_wgrad_k(const bf16_t* __restrict__ x,
     }
 }
 
-// ------------------------------------------------------------------- head, Cin = 64 -> Cout = 1 (the FCRN case)
-// Eight lanes per pixel (lane c8 owns channels [c8*8, c8*8+8)); a lane group walks runs of HR
+// ------------------------------------------------------------------- head, Cin = 64 or 32 -> Cout = 1 (FCRN conv3; BTS get_depth)
+// LPP = Cin / 8 lanes per pixel: eight or four (lane c8 owns channels [c8*8, c8*8+8)); a lane group walks runs of HR
 // consecutive pixels of one row, so the 3x3 windows of neighbouring outputs share their loads
 // (18 instead of 36 per run).  All weights sit in registers; out-of-image taps are buffer loads
 // with an out-of-range offset (read as 0).
 constexpr int HR = 4;
 typedef bf16x2_t bf16pair_t;
 
-__device__ __forceinline__ float head_sum8(float v) {     // sum over the 8 lanes of a pixel, result in all of them
+template <int LPP>
+__device__ __forceinline__ float head_sum(float v) {     // sum over the LPP (8 or 4) lanes of a pixel, result in all of them
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
     asm("" : "+v"(v));
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));   // quad_perm [2,3,0,1]
-    asm("" : "+v"(v));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, false));  // row_half_mirror
+    if constexpr (LPP == 8) {
+        asm("" : "+v"(v));
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, false));  // row_half_mirror
+    }
     return v;
 }
 
 // forward: weights as bf16 hi + lo pairs, v_dot2c_f32_bf16 against the bf16 activations (no conversions)
+template <int LPP>
 __global__ __launch_bounds__(NT) void head1_fwd_k(const bf16_t* __restrict__ x, const float* __restrict__ w,
                                                   float* __restrict__ out, int N, int H, int W) {
-    const int c8 = threadIdx.x & 7, grp = threadIdx.x >> 3;
+    constexpr int CIN = 8 * LPP;
+    static_assert((LPP == 8 || LPP == 4) && LPP >= HR, "a pixel owns 8 or 4 lanes, one per output of a run");
+    const int c8 = threadIdx.x & (LPP - 1), grp = threadIdx.x / LPP;
     bf16pair_t wh[9][4], wl[9][4];
 #pragma unroll
     for (int t = 0; t < 9; ++t)
@@ -581,15 +587,15 @@ __global__ __launch_bounds__(NT) void head1_fwd_k(const bf16_t* __restrict__ x, 
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const float v = w[t * 64 + c8 * 8 + 2 * i + h];
+                const float v = w[t * CIN + c8 * 8 + 2 * i + h];
                 const bf16_t hi = (bf16_t)v;
                 wh[t][i][h] = hi;
                 wl[t][i][h] = (bf16_t)(v - (float)hi);
             }
-    const __amdgpu_buffer_rsrc_t rs = mde_rsrc(x, (uint32_t)((int64_t)N * H * W * 128));
+    const __amdgpu_buffer_rsrc_t rs = mde_rsrc(x, (uint32_t)((int64_t)N * H * W * CIN * 2));
     const int runs_x = (W + HR - 1) / HR;
     const int nruns = N * H * runs_x;
-    for (int it = blockIdx.x * (NT / 8) + grp; it < nruns; it += gridDim.x * (NT / 8)) {
+    for (int it = blockIdx.x * (NT / LPP) + grp; it < nruns; it += gridDim.x * (NT / LPP)) {
         const int xb = it % runs_x, ny = it / runs_x, y = ny % H;
         const int x0 = xb * HR;
         float acc[HR];
@@ -599,13 +605,13 @@ __global__ __launch_bounds__(NT) void head1_fwd_k(const bf16_t* __restrict__ x, 
         for (int ky = 0; ky < 3; ++ky) {
             const int yy = y + ky - 1;
             const bool rok = (unsigned)yy < (unsigned)H;
-            const int rowbase = ((ny - y + yy) * W) * 64 + c8 * 8;      // (n*H + yy) * W pixels
+            const int rowbase = ((ny - y + yy) * W) * CIN + c8 * 8;      // (n*H + yy) * W pixels
             i32x4_t v[HR + 2];
 #pragma unroll
             for (int j = 0; j < HR + 2; ++j) {
                 const int col = x0 - 1 + j;
                 const bool ok = rok & ((unsigned)col < (unsigned)W);
-                v[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? (uint32_t)(rowbase + col * 64) * 2u : MDE_OOB_OFFSET, 0, 0);
+                v[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? (uint32_t)(rowbase + col * CIN) * 2u : MDE_OOB_OFFSET, 0, 0);
             }
 #pragma unroll
             for (int p = 0; p < HR; ++p)
@@ -622,7 +628,7 @@ __global__ __launch_bounds__(NT) void head1_fwd_k(const bf16_t* __restrict__ x, 
         float mine = 0.f;
 #pragma unroll
         for (int p = 0; p < HR; ++p) {
-            const float sp = head_sum8(acc[p]);
+            const float sp = head_sum<LPP>(acc[p]);
             mine = c8 == p ? sp : mine;
         }
         if (c8 < HR && x0 + c8 < W) out[(int64_t)ny * W + x0 + c8] = mine;
@@ -630,18 +636,21 @@ __global__ __launch_bounds__(NT) void head1_fwd_k(const bf16_t* __restrict__ x, 
 }
 
 // input gradient: dx[p][c] = sum_tap dout[p - off(tap)] * w[tap][c]   (fp32 weights in registers)
+template <int LPP>
 __global__ __launch_bounds__(NT) void head1_dgrad_k(const float* __restrict__ w, const float* __restrict__ dout,
                                                     bf16_t* __restrict__ dx, int N, int H, int W) {
-    const int c8 = threadIdx.x & 7, grp = threadIdx.x >> 3;
+    constexpr int CIN = 8 * LPP;
+    static_assert((LPP == 8 || LPP == 4) && LPP >= HR, "a pixel owns 8 or 4 lanes, one per output of a run");
+    const int c8 = threadIdx.x & (LPP - 1), grp = threadIdx.x / LPP;
     f32x2_t wr[9][4];
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) wr[t][i] = f32x2_t{w[t * 64 + c8 * 8 + 2 * i], w[t * 64 + c8 * 8 + 2 * i + 1]};
+        for (int i = 0; i < 4; ++i) wr[t][i] = f32x2_t{w[t * CIN + c8 * 8 + 2 * i], w[t * CIN + c8 * 8 + 2 * i + 1]};
     const __amdgpu_buffer_rsrc_t rs = mde_rsrc(dout, (uint32_t)((int64_t)N * H * W * 4));
     const int runs_x = (W + HR - 1) / HR;
     const int nruns = N * H * runs_x;
-    for (int it = blockIdx.x * (NT / 8) + grp; it < nruns; it += gridDim.x * (NT / 8)) {
+    for (int it = blockIdx.x * (NT / LPP) + grp; it < nruns; it += gridDim.x * (NT / LPP)) {
         const int xb = it % runs_x, ny = it / runs_x, y = ny % H;
         const int x0 = xb * HR;
         f32x2_t acc[HR][4];
@@ -681,33 +690,36 @@ __global__ __launch_bounds__(NT) void head1_dgrad_k(const float* __restrict__ w,
                 o[2 * i] = (bf16_t)acc[p][i][0];
                 o[2 * i + 1] = (bf16_t)acc[p][i][1];
             }
-            *reinterpret_cast<bf16x8_t*>(dx + ((int64_t)ny * W + x0 + p) * 64 + c8 * 8) = o;
+            *reinterpret_cast<bf16x8_t*>(dx + ((int64_t)ny * W + x0 + p) * CIN + c8 * 8) = o;
         }
     }
 }
 
 // weight gradient, input-stationary: every activation is converted once and meets the nine dout
 // values around it:  dw[(ky,kx)][c] += dout[p - (ky-1, kx-1)] * x[p][c]
+template <int LPP>
 __global__ __launch_bounds__(NT) void head1_wgrad_k(const bf16_t* __restrict__ x, const float* __restrict__ dout,
                                                     float* __restrict__ dw, int N, int H, int W, MdeDetDev det) {
-    __shared__ float red[NT / 64][9 * 64];
-    const int c8 = threadIdx.x & 7, grp = threadIdx.x >> 3;
+    __shared__ float red[NT / 64][9 * 8 * LPP];
+    constexpr int CIN = 8 * LPP;
+    static_assert((LPP == 8 || LPP == 4) && LPP >= HR, "a pixel owns 8 or 4 lanes, one per output of a run");
+    const int c8 = threadIdx.x & (LPP - 1), grp = threadIdx.x / LPP;
     f32x2_t acc[9][4];
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[t][i] = f32x2_t{0.f, 0.f};
     const __amdgpu_buffer_rsrc_t rs_d = mde_rsrc(dout, (uint32_t)((int64_t)N * H * W * 4));
-    const __amdgpu_buffer_rsrc_t rs_x = mde_rsrc(x, (uint32_t)((int64_t)N * H * W * 128));
+    const __amdgpu_buffer_rsrc_t rs_x = mde_rsrc(x, (uint32_t)((int64_t)N * H * W * CIN * 2));
     const int runs_x = (W + HR - 1) / HR;
     const int nruns = N * H * runs_x;
-    for (int it = blockIdx.x * (NT / 8) + grp; it < nruns; it += gridDim.x * (NT / 8)) {
+    for (int it = blockIdx.x * (NT / LPP) + grp; it < nruns; it += gridDim.x * (NT / LPP)) {
         const int xb = it % runs_x, ny = it / runs_x, y = ny % H;
         const int x0 = xb * HR;
         i32x4_t xv[HR];
 #pragma unroll
         for (int p = 0; p < HR; ++p)
-            xv[p] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, x0 + p < W ? (uint32_t)((ny * W + x0 + p) * 64 + c8 * 8) * 2u : MDE_OOB_OFFSET, 0, 0);
+            xv[p] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, x0 + p < W ? (uint32_t)((ny * W + x0 + p) * CIN + c8 * 8) * 2u : MDE_OOB_OFFSET, 0, 0);
         float d[3][HR + 2];
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
@@ -755,12 +767,16 @@ __global__ __launch_bounds__(NT) void head1_wgrad_k(const bf16_t* __restrict__ x
             for (int h = 0; h < 2; ++h) {
                 float s = acc[t][i][h];
                 s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x128, 0xF, 0xF, false));   // row_ror:8
+                if constexpr (LPP == 4) {
+                    asm("" : "+v"(s));
+                    s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x124, 0xF, 0xF, false));   // row_ror:4
+                }
                 s += __shfl_xor(s, 16, 64);
                 s += __shfl_xor(s, 32, 64);
-                if (lane < 8) red[wv][t * 64 + lane * 8 + 2 * i + h] = s;
+                if (lane < LPP) red[wv][t * CIN + lane * 8 + 2 * i + h] = s;
             }
     __syncthreads();
-    for (int i = threadIdx.x; i < 9 * 64; i += NT) {
+    for (int i = threadIdx.x; i < 9 * CIN; i += NT) {
         float s = 0.f;
 #pragma unroll
         for (int q = 0; q < NT / 64; ++q) s += red[q][i];
@@ -778,9 +794,9 @@ int cu_count() {
     return cus;
 }
 
-int head1_grid(int N, int H, int W) {          // persistent-ish: up to 8 workgroups per CU over the pixel runs
+int head1_grid(int N, int H, int W, int lpp = 8) {          // persistent-ish: up to 8 workgroups per CU over the pixel runs
     const int64_t nruns = (int64_t)N * H * ((W + HR - 1) / HR);
-    const int64_t nb = (nruns + NT / 8 - 1) / (NT / 8), cap = 8 * (int64_t)cu_count();
+    const int64_t nb = (nruns + NT / lpp - 1) / (NT / lpp), cap = 8 * (int64_t)cu_count();
     return (int)(nb > cap ? cap : (nb < 1 ? 1 : nb));
 }
 
@@ -889,8 +905,9 @@ extern "C" int mde_head_conv_fwd(const void* x, const float* w, float* out, int 
     if (int rc = head_check("mde_head_conv_fwd", N, H, W, Cin, Cout)) return rc;
     MDE_REQUIRE(((uintptr_t)x % 16) == 0, "mde_head_conv_fwd: x must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
-    if (Cout == 1 && Cin == 64 && (int64_t)N * H * W * 128 < MDE_OOB_OFFSET) {
-        head1_fwd_k<<<head1_grid(N, H, W), NT, 0, st>>>((const bf16_t*)x, w, out, N, H, W);
+    if (Cout == 1 && (Cin == 64 || Cin == 32) && (int64_t)N * H * W * Cin * 2 < MDE_OOB_OFFSET) {
+        if (Cin == 64) head1_fwd_k<8><<<head1_grid(N, H, W), NT, 0, st>>>((const bf16_t*)x, w, out, N, H, W);
+        else head1_fwd_k<4><<<head1_grid(N, H, W, 4), NT, 0, st>>>((const bf16_t*)x, w, out, N, H, W);
         MDE_LAUNCH_CHECK("head1_fwd_k");
         return MDE_OK;
     }
@@ -904,14 +921,17 @@ extern "C" int mde_head_conv_bwd(const void* x, const float* w, const float* dou
     MDE_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)dx % 16) == 0, "mde_head_conv_bwd: x/dx must be 16-byte aligned");
     MDE_DET_REQUIRE("mde_head_conv_bwd", dw, (int64_t)Cout * 9 * Cin);
     hipStream_t st = (hipStream_t)stream;
-    if (Cout == 1 && Cin == 64 && (int64_t)N * H * W * 128 < MDE_OOB_OFFSET) {
+    if (Cout == 1 && (Cin == 64 || Cin == 32) && (int64_t)N * H * W * Cin * 2 < MDE_OOB_OFFSET) {
+        const int lpp = Cin / 8;
         if (dx) {
-            head1_dgrad_k<<<head1_grid(N, H, W), NT, 0, st>>>(w, dout, (bf16_t*)dx, N, H, W);
+            if (lpp == 8) head1_dgrad_k<8><<<head1_grid(N, H, W), NT, 0, st>>>(w, dout, (bf16_t*)dx, N, H, W);
+            else head1_dgrad_k<4><<<head1_grid(N, H, W, 4), NT, 0, st>>>(w, dout, (bf16_t*)dx, N, H, W);
             MDE_LAUNCH_CHECK("head1_dgrad_k");
         }
         if (dw) {
-            const int g = head1_grid(N, H, W);
-            head1_wgrad_k<<<g > 1024 ? 1024 : g, NT, 0, st>>>((const bf16_t*)x, dout, dw, N, H, W, mde_det_dev());
+            const int g = head1_grid(N, H, W, lpp), gc = g > 1024 ? 1024 : g;
+            if (lpp == 8) head1_wgrad_k<8><<<gc, NT, 0, st>>>((const bf16_t*)x, dout, dw, N, H, W, mde_det_dev());
+            else head1_wgrad_k<4><<<gc, NT, 0, st>>>((const bf16_t*)x, dout, dw, N, H, W, mde_det_dev());
             MDE_LAUNCH_CHECK("head1_wgrad_k");
         }
         return MDE_OK;

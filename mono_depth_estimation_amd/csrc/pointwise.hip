@@ -577,6 +577,28 @@ __global__ __launch_bounds__(NT) void softmax_head_bwd_k(const float* __restrict
     if (dbias && (int)threadIdx.x < C) mde_grad_add(dbias + threadIdx.x, bacc, det);
 }
 
+// y = scale act(p) on an fp32 map, and its backward through the kept output: the activation behind a one-channel head conv that
+// already produced fp32 (mde_head_conv_fwd), e.g. BTS' get_depth + Sigmoid x max_depth (Bts.py:168,262).
+__global__ __launch_bounds__(NT) void map_act_fwd_k(const float* __restrict__ p, float* __restrict__ y, int64_t n4, int act, float scale) {
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n4; i += (int64_t)gridDim.x * NT) {
+        f32x4_t v = reinterpret_cast<const f32x4_t*>(p)[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = scale * act_fwd(v[e], act);
+        reinterpret_cast<f32x4_t*>(y)[i] = v;
+    }
+}
+__global__ __launch_bounds__(NT) void map_act_bwd_k(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ dp,
+                                                    int64_t n4, int act, float scale) {
+    const float inv = 1.f / scale;
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n4; i += (int64_t)gridDim.x * NT) {
+        const f32x4_t g = reinterpret_cast<const f32x4_t*>(dy)[i], o = reinterpret_cast<const f32x4_t*>(y)[i];
+        f32x4_t v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = g[e] * scale * act_grad(o[e] * inv, act);
+        reinterpret_cast<f32x4_t*>(dp)[i] = v;
+    }
+}
+
 // ------------------------------------------------------------------ out[n][c][p] = scale * act(x[n][p][c] + bias[c])   (small C heads)
 __global__ __launch_bounds__(NT) void to_nchw_act_fwd_k(const bf16_t* __restrict__ x, int ldx, const float* __restrict__ bias,
                                                         float* __restrict__ out, int N, int64_t HW, int C, int act, float scale) {
@@ -854,6 +876,23 @@ extern "C" int mde_softmax_head_bwd(const float* dlogit, const float* dprob, con
     else
         softmax_head_bwd_k<SM_MAXC><<<grid, NT, smem, (hipStream_t)stream>>>(dlogit, dprob, prob, (bf16_t*)dx, lddx, dbias, N, HW, C, mde_det_dev());
     MDE_LAUNCH_CHECK("softmax_head_bwd_k");
+    return MDE_OK;
+}
+
+extern "C" int mde_map_act_fwd(const float* p, float* y, int64_t n, int act, float scale, void* stream) {
+    MDE_REQUIRE(p && y && n > 0 && n % 4 == 0 && act >= 0 && act <= 4 && ((uintptr_t)p % 16) == 0 && ((uintptr_t)y % 16) == 0,
+                "mde_map_act_fwd: bad argument (n=%lld must be a multiple of 4, 16-byte aligned maps)", (long long)n);
+    map_act_fwd_k<<<grid_flat(n / 4), NT, 0, (hipStream_t)stream>>>(p, y, n / 4, act, scale);
+    MDE_LAUNCH_CHECK("map_act_fwd_k");
+    return MDE_OK;
+}
+
+extern "C" int mde_map_act_bwd(const float* dy, const float* y, float* dp, int64_t n, int act, float scale, void* stream) {
+    MDE_REQUIRE(dy && y && dp && n > 0 && n % 4 == 0 && act >= 0 && act <= 4 && scale != 0.f && ((uintptr_t)dy % 16) == 0 &&
+                    ((uintptr_t)y % 16) == 0 && ((uintptr_t)dp % 16) == 0,
+                "mde_map_act_bwd: bad argument (n=%lld must be a multiple of 4, 16-byte aligned maps, scale != 0)", (long long)n);
+    map_act_bwd_k<<<grid_flat(n / 4), NT, 0, (hipStream_t)stream>>>(dy, y, dp, n / 4, act, scale);
+    MDE_LAUNCH_CHECK("map_act_bwd_k");
     return MDE_OK;
 }
 

@@ -580,6 +580,37 @@ class ToNCHW(Op):
         ops.to_nchw_act_bwd(self.douts[0], self.y, x.g, _ldg(x), dbias, x.N, x.H * x.W, self.C, self.act, self.scale)
 
 
+class HeadConvMap(Op):
+    """A 3x3 / pad 1 convolution to ONE channel with an activation and a scale, as an fp32 map (NCHW == NHWC for one channel):
+    BTS' get_depth -> Sigmoid -> x max_depth (Bts.py:168,262) on the head kernels of csrc/conv_small.hip -- fp32 accumulation
+    straight to the fp32 result -- instead of a 64-column GEMM tile for 1 useful column (16 x 480 x 640 pixels, 32 channels:
+    390 + 389 + 731 us forward / input gradient / weight gradient on the GEMM kernels)."""
+
+    def __init__(self, eng, x, weight, act, scale=1.0):
+        assert weight.shape[0] == 1 and tuple(weight.shape[2:]) == (3, 3) and x.C in (8, 16, 32, 64) and x.ld == x.C and weight.shape[1] == x.C
+        self.eng, self.x, self.act, self.scale = eng, x, act, float(scale)
+        self.off, self.n = eng.store.p_off[id(weight)], 9 * x.C           # (fp32 master [O padded][3][3][C]: row 0 is the filter)
+        self.w32 = eng.store.P[self.off:self.off + self.n]
+        self.pre = torch.empty(x.N, 1, x.H, x.W, device=eng.dev)
+        self.y = torch.empty(x.N, 1, x.H, x.W, device=eng.dev)
+        self.outputs, self.douts = (self.y,), [None]
+
+    def grad_ranges(self):
+        return [(self.off, self.off + self.n)]
+
+    def fwd(self, train):
+        x = self.x
+        ops.head_conv_fwd(x.t, self.w32, self.pre, x.N, x.H, x.W, x.C, 1)
+        ops.map_act_fwd(self.pre, self.y, self.act, self.scale)
+
+    def bwd(self):
+        x = self.x
+        assert not x.gw
+        x.gw = True
+        ops.map_act_bwd(self.douts[0], self.y, self.pre, self.act, self.scale)           # (pre: its own gradient from here on)
+        ops.head_conv_bwd(x.t, self.w32, self.pre, x.g, self.eng.store.Gcur[self.off:self.off + self.n], x.N, x.H, x.W, x.C, 1)
+
+
 class ImageResidualHead(ToNCHW):
     """BTS' final_depth with image_residuals (Bts.py:264-271): the sigmoid head's ten channels, the colour ones as residuals on
     the input image.  The image is the plan's input (`eng.stem.x`), read as it is (fp32 NCHW)."""

@@ -413,12 +413,15 @@ class BtsEngine(G.TapeEngine):
         for j, mp in enumerate((r1.map, d2.map, d4.map, d8.map)):
             self.add(G.MapSlot(self, mp, cat1, s + j, 1))
         i1 = self._conv_elu(cat1, d.conv1[0])
-        c = self.add(G.Conv(self, i1, d.get_depth[0].weight, 3, 1, 1)).out
         oc = d.get_depth[0].out_channels
-        if d.out_channels == 10 and d.image_residuals:          # Bts.py:264-271 (no max_depth factor on this branch)
-            final = self.add(G.ImageResidualHead(self, c, oc))
+        if oc == 1 and i1.C in (8, 16, 32, 64) and i1.ld == i1.C and (H * W) % 4 == 0:
+            final = self.add(G.HeadConvMap(self, i1, d.get_depth[0].weight, "sigmoid", md))       # one output channel: the head kernels
         else:
-            final = self.add(G.ToNCHW(self, c, None, oc, "sigmoid", md))
+            c = self.add(G.Conv(self, i1, d.get_depth[0].weight, 3, 1, 1)).out
+            if d.out_channels == 10 and d.image_residuals:          # Bts.py:264-271 (no max_depth factor on this branch)
+                final = self.add(G.ImageResidualHead(self, c, oc))
+            else:
+                final = self.add(G.ToNCHW(self, c, None, oc, "sigmoid", md))
         self.heads = [d8, d4, d2, r1, final]
 
 

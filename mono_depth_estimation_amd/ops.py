@@ -653,6 +653,14 @@ def softmax_head_bwd(dlogit, dprob, prob, dx, lddx, dbias, N, HW, C_):
           "mde_softmax_head_bwd")
 
 
+def map_act_fwd(p, y, act, scale=1.0):
+    check(_lib.load().mde_map_act_fwd(_p(p), _p(y), p.numel(), ACT[act], scale, _stream()), "mde_map_act_fwd")
+
+
+def map_act_bwd(dy, y, dp, act, scale=1.0):
+    check(_lib.load().mde_map_act_bwd(_p(dy), _p(y), _p(dp), y.numel(), ACT[act], scale, _stream()), "mde_map_act_bwd")
+
+
 def to_nchw_act_fwd(x, ldx, bias, out, N, HW, C_, act, scale=1.0):
     check(_lib.load().mde_to_nchw_act_fwd(_p(x), ldx, _p(bias), _p(out), N, HW, C_, ACT[act], scale, _stream()), "mde_to_nchw_act_fwd")
 
