@@ -232,7 +232,9 @@ int mde_bn_finalize_moments(const float* mean, const float* var, int64_t M, int 
 int mde_bn_eval_scale_shift(const float* gamma, const float* beta, const float* running_mean,
                             const float* running_var, float eps, int C, float* scale, float* shift,
                             void* stream);
-/* out = act( x*scale + shift  [+ r  |  + r*rscale + rshift] );  relu != 0 applies ReLU.
+/* out = act( x*scale + shift  [+ r  |  + r*rscale + rshift] );  relu == 1 applies ReLU.
+ * relu == 2: out = ELU(x)*scale + shift [+ ...] -- x is the pre-activation of an ELU in front of the BatchNorm (the eval form
+ * of BTS' upconv -> ELU -> bn, reference network/Bts.py:76-80,216-229): the ELU value is never stored in 16 bits.
  * r may be NULL; rscale/rshift may be NULL (plain residual add).  All bf16, own ld each.
  * relu_bits (optional, uint8 [M][C/8]): bit e of byte (row, c/8) = (out[row][c/8*8+e] > 0), the
  * packed ReLU mask the backward passes can read instead of `out` (16x fewer bytes). */

@@ -181,10 +181,14 @@ __global__ __launch_bounds__(NT) void bn_apply_k(const bf16_t* __restrict__ x, i
         if (RES) ld8(r + row * ldr + col * 8, q);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            float y = v[e] * sc[e] + sh[e];
+            // relu == 2: x is the PRE-activation of an ELU (the eval form of conv -> ELU -> BatchNorm, Bts.py:216-217): ELU here,
+            // in fp32 -- a stored ELU output piles up on -1 (every value in (-1, -1 + 2^-10) rounds to -1), a bias per element
+            // that the BatchNorm's 1 / sigma then scales
+            const float xe = (relu == 2 && v[e] < 0.f) ? expm1f(v[e]) : v[e];
+            float y = xe * sc[e] + sh[e];
             if (RES == 1) y += q[e];
             if (RES == 2) y += q[e] * rsc[e] + rsh[e];
-            v[e] = relu ? fmaxf(y, 0.f) : y;
+            v[e] = relu == 1 ? fmaxf(y, 0.f) : y;
         }
         st8(out + row * ldo + col * 8, v);
         if (bits) {
@@ -773,6 +777,7 @@ extern "C" int mde_bn_apply(const void* x, int ldx, const float* scale, const fl
     if (int rc = check_site("mde_bn_apply", M, C)) return rc;
     MDE_REQUIRE(al16(x, ldx) && al16(out, ldo) && (!r || al16(r, ldr)), "mde_bn_apply: tensors must be 16-byte aligned, ld %% 8 == 0");
     MDE_REQUIRE((rscale == nullptr) == (rshift == nullptr) && (!rscale || r), "mde_bn_apply: rscale/rshift need r and each other");
+    MDE_REQUIRE(relu >= 0 && relu <= 2 && !(relu == 2 && relu_bits), "mde_bn_apply: relu=%d (0 none, 1 ReLU behind, 2 ELU in front; no mask bits with 2)", relu);
     const int grid = stream_grid(M, C);
     hipStream_t st = (hipStream_t)stream;
     const bf16_t *xp = (const bf16_t*)x, *rp = (const bf16_t*)r;

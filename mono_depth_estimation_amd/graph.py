@@ -184,6 +184,7 @@ class Conv(Op):
         # fused epilogue (TapeEngine.pw): out = act(conv + bias + res) written by the conv launch itself
         self.f_bias = self.f_boff = self.f_res = self.f_act = self.f_part = self.pre_g = None
         self.fused = False
+        self.eval_raw = False
         self.red = None        # ops.bn_red of the BatchNorm op that wrote x, when this conv completes d(x) (see _TRACE)
         self.first_writer = False   # ... and is its only writer: the identity shortcut's share comes in through red.add
 
@@ -220,9 +221,11 @@ class Conv(Op):
         n = self.chunk
         if self.fused:
             r = self.f_res
+            # (eval_raw: an ELU whose only reader is a BatchNorm -- in eval mode that BatchNorm's pass applies it, BN.pre_elu)
+            act = None if (self.eval_raw and not train) else self.f_act
             for i in self._chunks():
                 self.eng.fwd_conv(self.fdesc, self.x.t[i:i + n], self.conv, self.out.t[i:i + n], bias=self.f_bias,
-                                  res=r.t[i:i + n] if r is not None else None, act=self.f_act)
+                                  res=r.t[i:i + n] if r is not None else None, act=act)
             return
         for i in self._chunks():
             self.eng.fwd_conv(self.fdesc, self.x.t[i:i + n], self.conv, self.out.t[i:i + n], stats)
@@ -296,6 +299,7 @@ class BN(Op):
             raise NotImplementedError("BN + identity residual without ReLU")
         self.reduced = False   # the backward sums come with the launch that completes d(out) (see _TRACE)
         self.skip_dres = False
+        self.pre_elu = False   # eval mode: c holds the pre-activation of an ELU (Conv.eval_raw); this pass applies it in fp32
 
     def red_spec(self):
         s, c, rs = self.site, self.c, self.res_site
@@ -334,8 +338,8 @@ class BN(Op):
         if self.bias is not None:
             with torch.no_grad():
                 s.shift.addcmul_(s.scale, self.bias)
-        s.apply(self.eng, c.t, c.ld, o.t, o.ld, c.M, self.relu, False, r=r.t if r is not None else None, ldr=r.ld if r is not None else 0,
-                res_site=rs, relu_bits=bits, finalized=True)
+        s.apply(self.eng, c.t, c.ld, o.t, o.ld, c.M, 2 if self.pre_elu else self.relu, False, r=r.t if r is not None else None,
+                ldr=r.ld if r is not None else 0, res_site=rs, relu_bits=bits, finalized=True)
 
     def bwd(self):
         c, o, res = self.c, self.out, self.res

@@ -238,9 +238,14 @@ def midas_forward(P, x, train, blocks=(3, 4, 23, 3), groups=32, momentum=None, q
 
 
 # ---------------------------------------------------------------------------------------------- BTS (network/Bts.py)
-def _bts_upconv(n, x, k):
-    """upconv.forward (Bts.py:76-80): nearest x2 -> 3x3 -> ELU."""
-    return n.q(F.elu(n.conv(n.q(F.interpolate(x, scale_factor=2, mode="nearest")), k + ".conv", pad=1)))
+def _bts_upconv(n, x, k, bn=None):
+    """upconv.forward (Bts.py:76-80): nearest x2 -> 3x3 -> ELU [-> the BatchNorm `bn(t)` behind it, Bts.py:216-229].
+    16-bit emulation: in eval mode the HIP path stores the conv's PRE-activation and applies ELU and the BatchNorm's affine in one
+    fp32 pass (mde_bn_apply, relu = 2); in training mode the ELU output is stored (the statistics pass reads it)."""
+    z = n.conv(n.q(F.interpolate(x, scale_factor=2, mode="nearest")), k + ".conv", pad=1)
+    if bn is None:
+        return n.q(F.elu(z))
+    return n.q(bn(F.elu(z) if not n.train else n.q(F.elu(z))))
 
 
 def _bts_atrous(n, x, k, dil, bn_first=True):
@@ -339,11 +344,12 @@ def bts_forward(P, x, train, max_depth=10.0, momentum=None, q=None, image_residu
     d = "decoder."
     bnk = lambda t, k: n.bn(t, d + k, 0.01, 1.1e-5)
     dense = n.q(F.relu(dense))
-    up5 = n.q(bnk(_bts_upconv(n, dense, d + "upconv5"), "bn5"))
+    up5 = _bts_upconv(n, dense, d + "upconv5", lambda t: bnk(t, "bn5"))
     i5 = n.q(F.elu(n.conv(torch.cat([up5, s3], 1), d + "conv5.0", pad=1)))
-    up4 = n.q(bnk(_bts_upconv(n, i5, d + "upconv4"), "bn4"))
+    up4 = _bts_upconv(n, i5, d + "upconv4", lambda t: bnk(t, "bn4"))
     cat4 = torch.cat([up4, s2], 1)
-    i4 = n.q(bnk(n.q(F.elu(n.conv(cat4, d + "conv4.0", pad=1))), "bn4_2"))
+    z4 = F.elu(n.conv(cat4, d + "conv4.0", pad=1))
+    i4 = n.q(bnk(z4 if not train else n.q(z4), "bn4_2"))
     d3 = _bts_atrous(n, i4, d + "daspp_3", 3, bn_first=False)
     c = torch.cat([cat4, d3], 1)
     d6 = _bts_atrous(n, c, d + "daspp_6", 6)
@@ -355,10 +361,10 @@ def bts_forward(P, x, train, max_depth=10.0, momentum=None, q=None, image_residu
     d24 = _bts_atrous(n, c, d + "daspp_24", 24)
     feat = n.q(F.elu(n.conv(torch.cat([i4, d3, d6, d12, d18, d24], 1), d + "daspp_conv.0", pad=1)))
     d8 = _bts_plane_depth(n, feat, d + "reduc8x8", 8, max_depth)
-    up3 = n.q(bnk(_bts_upconv(n, feat, d + "upconv3"), "bn3"))
+    up3 = _bts_upconv(n, feat, d + "upconv3", lambda t: bnk(t, "bn3"))
     i3 = n.q(F.elu(n.conv(torch.cat([up3, s1, F.interpolate(d8, scale_factor=0.25, mode="nearest")], 1), d + "conv3.0", pad=1)))
     d4 = _bts_plane_depth(n, i3, d + "reduc4x4", 4, max_depth)
-    up2 = n.q(bnk(_bts_upconv(n, i3, d + "upconv2"), "bn2"))
+    up2 = _bts_upconv(n, i3, d + "upconv2", lambda t: bnk(t, "bn2"))
     i2 = n.q(F.elu(n.conv(torch.cat([up2, s0, F.interpolate(d4, scale_factor=0.5, mode="nearest")], 1), d + "conv2.0", pad=1)))
     d2 = _bts_plane_depth(n, i2, d + "reduc2x2", 2, max_depth)
     up1 = _bts_upconv(n, i2, d + "upconv1")
