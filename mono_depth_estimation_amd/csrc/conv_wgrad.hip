@@ -559,10 +559,37 @@ extern "C" int mde_conv_wgrad_ws(const mde_wgrad_desc* d, const void* direct, co
         const char* e = getenv("MDE_WGRAD_MIXED");
         mixed = !(e && !strcmp(e, "0"));
     }
-    if (mixed && ba == 64 && !ka.gsize && ka.Crows > 128 && ka.Crows % 128 > 32) {
+    static int mixed_min = -1;
+    if (mixed_min < 0) {
+        const char* e = getenv("MDE_WGRAD_MIXED_MIN");          // (diagnostics: the smallest remainder that still takes a 64-row tile of its own)
+        mixed_min = e ? atoi(e) : 16;
+    }
+    if (mixed && ba == 64 && !ka.gsize && ka.Crows > 128 && ka.Crows % 128 > mixed_min) {
         const int head = ka.Crows / 128 * 128;
-        if (int rc = go(128, 0, head)) return rc;
-        if (int rc = go(64, head, ka.Crows - head)) return rc;
+        // The split factor was chosen for a grid of 64-row tiles; each of the two launches here has a fraction of those
+        // workgroups (152 rows: 1 of 3 row tiles each) and would leave CUs empty: with atomics (no shared workspace layout)
+        // both take twice the slices.  VNL's 256 -> 152 prediction conv, 2 x 2 457 600 pixels: step 68.9 -> 67.4 ms.
+        static int mks = -1;
+        if (mks < 0) {
+            const char* e = getenv("MDE_WGRAD_MIXED_KS");
+            mks = e ? atoi(e) : 2;
+        }
+        int ks2 = kslices;
+        if (!ka.ws && mks > 1 && head == 128) {
+            int64_t c2 = (M + (int64_t)d->ksplit * mks - 1) / ((int64_t)d->ksplit * mks);
+            c2 = (c2 + BKP - 1) / BKP * BKP;
+            ka.kchunk = (int32_t)c2;
+            ks2 = mde_cdiv(M, c2);
+        }
+        auto go2 = [&](int tile_a, int row_off, int rows) -> int {
+            ka.row_off = row_off;
+            ka.nA = mde_cdiv(rows, tile_a);
+            const int64_t nblk = (int64_t)d->ntaps * ka.nA * ka.nB * ks2;
+            MDE_REQUIRE(nblk < (1ll << 31), "mde_conv_wgrad: grid too large");
+            return ga ? dispatch<true>(ka, tile_a, bb, (int)nblk, st) : dispatch<false>(ka, tile_a, bb, (int)nblk, st);
+        };
+        if (int rc = go2(128, 0, head)) return rc;
+        if (int rc = go2(64, head, ka.Crows - head)) return rc;
         return reduce();
     }
     if (int rc = go(ba, 0, ka.Crows)) return rc;
