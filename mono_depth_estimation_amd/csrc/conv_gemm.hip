@@ -1455,6 +1455,16 @@ int pick_and_launch(KArgs& ka, int64_t M, hipStream_t st) {
                 const double fill = (double)M / ((double)ka.d.N * hp.dil * hp.dil * hp.nty * hp.ntx * bp);
                 take = ka.d.ntaps >= 4 && hp.tiles >= 2 * cus_() && fill >= 0.75;
             }
+            // <= 32 columns on a map of at least a million pixels (BTS' and MiDaS' full-resolution decoder layers): the 128-pixel
+            // form with a 32-column tile -- half the MFMAs and weight reads of the 64-column tile, which is mostly padding there
+            {
+                const char* ne = getenv("MDE_CONV_NARROW");        // (read per call; "0": off, "2": wherever eligible -- tests)
+                const int nar = !ne ? 1 : atoi(ne);
+                if (n <= 32 && nar && ((halo < 0 && ka.d.ntaps >= 4 && M >= (1 << 20)) || nar == 2)) {
+                    const HaloPlan h32 = halo_plan(ka.d, 128, 32);
+                    if (h32.ok) return launch_halo<128, 32>(ka, h32, st);
+                }
+            }
             if (take) {
                 if (bp == 128) return bc == 64 ? launch_halo<128, 64>(ka, hp, st) : launch_halo<128, 128>(ka, hp, st);
                 return bc == 64 ? launch_halo<256, 64>(ka, hp, st) : launch_halo<256, 128>(ka, hp, st);
@@ -1463,6 +1473,14 @@ int pick_and_launch(KArgs& ka, int64_t M, hipStream_t st) {
     }
     const bool pp = gpp == 1 || (gpp == 2 && ka.d.ntaps * ((ka.d.C + BK - 1) / BK) >= 18);
     if (forced == 10 && !ka.d.grouped) return launch<128, 64, 256, true, 1>(ka, M, st);      // diagnostics: 64-column single-buffer tile everywhere
+    {
+        // <= 32 columns, one tap, a map of a million pixels or more (BTS' reduc1x1 chain at full resolution): the single-buffer
+        // tile with 32 columns (20 KB of LDS: more workgroups per CU, half the padding)
+        const char* ne = getenv("MDE_CONV_NARROW");
+        const int nar = !ne ? 1 : atoi(ne);
+        if (n <= 32 && !ka.d.grouped && !reg && forced == 0 && nar && (M >= (1 << 20) || nar == 2) && ka.d.ntaps * ((ka.d.C + BK - 1) / BK) <= 2)
+            return launch<128, 32, 256, true, 1>(ka, M, st);
+    }
     if (n <= 64 || ka.d.grouped) {
         // 2-deep ring = 48 KB LDS = three workgroups per CU.  Measured alternatives, all slower on M = 2 457 600 / 614 400,
         // 64->64 3x3: 256x64 with 8 waves (423 / 423 TFLOP/s), 256x64 with 4 waves (365 / 343), 3-deep ring at two

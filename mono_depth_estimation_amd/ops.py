@@ -4,6 +4,7 @@ Tensors are torch CUDA tensors used purely as device-memory handles (data_ptr + 
 stream); all arithmetic happens in libmde_hip.so.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -357,7 +358,8 @@ def choose_ksplit(pixels, row_tiles, col_tiles, ntaps, cus=256, min_steps=8, wg_
         t = wgrad_time_model(pixels, row_tiles, col_tiles, ntaps, ks, cus, wg_per_cu, tile_elems)
         if best_t is None or t < best_t * (1.0 - 1e-9):
             best, best_t = ks, t
-    return best
+    scale = float(os.environ.get("MDE_WGRAD_KS_SCALE", "1"))       # (diagnostics: the model is fitted to launches running alone)
+    return best if scale == 1.0 else max(1, min(cap, int(round(best * scale))))
 
 
 # ------------------------------------------------------------------------------ small convs

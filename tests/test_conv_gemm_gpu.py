@@ -531,3 +531,55 @@ def test_transposed_conv_forward_two_term_weight_shadow(N, h, w, Cin, Cout, k, s
         ops.conv_gemm_eval(d, xd, w2d, out)
     torch.cuda.synchronize()
     _assert_close(_nchw(out), ref, "two-term transposed conv")
+
+
+@pytest.mark.parametrize("N,H,Wd,Cin,Cout,k,dil", [(2, 37, 53, 64, 32, 3, 1), (1, 40, 64, 40, 32, 3, 1), (2, 33, 47, 128, 24, 3, 1),
+                                                  (1, 29, 31, 64, 8, 3, 2), (2, 21, 40, 32, 32, 5, 1), (1, 16, 16, 64, 16, 3, 1),
+                                                  (2, 37, 53, 32, 16, 1, 1), (1, 40, 64, 16, 8, 1, 1), (3, 19, 23, 128, 32, 1, 1)])
+def test_narrow_halo_tile_for_32_columns(N, H, Wd, Cin, Cout, k, dil, conv_form):
+    """The 128-pixel halo form with a 32-COLUMN tile (conv_gemm_nt<128, 32, 256, ..., HALO>: the full-resolution decoder layers of
+    BTS and MiDaS, <= 32 output channels over millions of pixels -- the library takes it there by itself; MDE_CONV_NARROW=2 forces
+    it at test sizes; k = 1: the plain single-buffer 128 x 32 tile of the full-resolution 1x1 chains): forward with BatchNorm
+    statistics, the fused bias + ELU epilogue, and an accumulating launch."""
+    import os
+    from mono_depth_estimation_amd import ops
+    if conv_form != "auto":
+        pytest.skip("one form is under test here")
+    old = os.environ.get("MDE_CONV_NARROW")
+    os.environ["MDE_CONV_NARROW"] = "2"
+    try:
+        g = torch.Generator().manual_seed(Cin + Cout + k)
+        p = dil * (k // 2)
+        x = _bf(torch.randn(N, Cin, H, Wd, generator=g))
+        w = _bf(torch.randn(Cout, Cin, k, k, generator=g) * (2.0 / (k * k * Cin)) ** 0.5)
+        b = torch.randn(Cout, generator=g) * 0.5
+        ref = F.conv2d(x, w, padding=p, dilation=dil)
+        xd, wd = _nhwc(x), _pack_fwd(w)
+        d = ops.fwd_desc(N, H, Wd, Cin, Cin, xd.numel() * 2, k, 1, p, Cout, Cout, dil=dil)
+        out = torch.full((N, H, Wd, Cout), 7.0, dtype=ACT, device="cuda")
+        stats = ops.new_stat_buffer(Cout)
+        ops.conv_gemm(d, xd, wd, out, stats)
+        _assert_close(_nchw(out), ref, "narrow fwd")
+        st = stats.sum(0).cpu()
+        r1, r2 = ref.sum((0, 2, 3)), (ref ** 2).sum((0, 2, 3))
+        assert torch.allclose(st[0], r1, rtol=2e-3, atol=2e-2 * r2.max().sqrt().item()) and torch.allclose(st[1], r2, rtol=2e-3, atol=2e-3 * r2.max().item())
+        out2 = torch.empty_like(out)
+        ops.conv_gemm(d, xd, wd, out2, bias=b.cuda(), act="elu")
+        _assert_close(_nchw(out2), F.elu(ref + b.view(1, -1, 1, 1)), "narrow fwd + bias + ELU")
+        d.accumulate = 1
+        base = _bf(torch.randn(N, Cout, H, Wd, generator=g))
+        out3 = _nhwc(base)
+        ops.conv_gemm(d, xd, wd, out3)
+        _assert_close(_nchw(out3), ref + base, "narrow accumulate", tol=2.0 ** -7)
+        # into a channel slice of a wider tensor (the decoders' concatenation buffers)
+        d.accumulate = 0
+        wide = torch.zeros(N, H, Wd, Cout + 16, dtype=ACT, device="cuda")
+        d2 = ops.fwd_desc(N, H, Wd, Cin, Cin, xd.numel() * 2, k, 1, p, Cout, Cout + 16, dil=dil)
+        ops.conv_gemm(d2, xd, wd, wide[..., 8:])
+        _assert_close(_nchw(wide[..., 8:8 + Cout]), ref, "narrow fwd into a slice")
+        assert float(wide[..., :8].float().abs().max()) == 0 and float(wide[..., 8 + Cout:].float().abs().max()) == 0
+    finally:
+        if old is None:
+            os.environ.pop("MDE_CONV_NARROW", None)
+        else:
+            os.environ["MDE_CONV_NARROW"] = old
