@@ -1537,6 +1537,13 @@ int pick_and_launch(KArgs& ka, int64_t M, hipStream_t st) {
         const int nst = ka.d.ntaps * ((ka.d.C + BK - 1) / BK);
         if (deep && forced == 0 && !reg && nst >= 4 && (int64_t)mde_cdiv(M, 128) * nc128 <= MDE_RING3_MAX_TILES_PER_CU * cus)
             return deep_waves() == 8 ? launch<128, 128, 512, true, MDE_DEEP_RING>(ka, M, st) : launch<128, 128, 256, true, MDE_DEEP_RING>(ka, M, st);
+        // ... and a grid that is a little more than one 128-column tile per CU but at most two 64-column tiles (DenseNet's 3x3
+        // input gradients on 19 200 pixels, 48 -> 192 channels: 300 / 450 tiles): the 8-wave 64-column tile with a 3-deep ring
+        // (72 KB: two per CU), everything resident in one round.  MDE_CONV_DEEP64=0: off.
+        const char* d6 = getenv("MDE_CONV_DEEP64");
+        if (deep && !(d6 && !strcmp(d6, "0")) && forced == 0 && !reg && nst >= 4 && nst <= 32 && (int64_t)mde_cdiv(M, 128) * nc128 <= 2 * cus &&
+            (int64_t)mde_cdiv(M, 128) * mde_cdiv(n, 64) <= 2 * cus && deep_waves() == 8)
+            return launch<128, 64, 512, true, 3>(ka, M, st);
     }
     const int64_t p256 = mde_cdiv(M, 256), t256 = p256 * nc256;
     auto rounds = [](int64_t tiles, int64_t slots) { return (tiles + slots - 1) / slots; };
