@@ -44,11 +44,15 @@ struct KArgs {
     float* ws;
 };
 
-// byte offset of 16-byte chunk `ch` of row `row` in a [64][CH] bf16 tile, CH = 128 or 64
+// byte offset of 16-byte chunk `ch` of row `row` in a [64][CH] bf16 tile, CH = 128, 64 or 32 (32: row tiles only)
 template <int CH>
 __device__ __forceinline__ int tile_off(int row, int ch) {
     if constexpr (CH == 128) {
         return row * 256 + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
+    } else if constexpr (CH == 32) {
+        // 64-byte rows: four of them span the banks once, so the four pixel groups of a transposed read (rows 8 apart) would
+        // meet on the same banks; bit 3 of the row swaps the two 32-byte halves
+        return row * 64 + 16 * (ch ^ (((row >> 3) & 1) << 1));
     } else {
         return row * 128 + 16 * (ch ^ ((((row >> 1) & 1) | (((row >> 3) & 1) << 1)) << 1));
     }
@@ -195,7 +199,9 @@ __global__ __launch_bounds__(NT, NBUF == 1 ? 4 : 2) void conv_wgrad_tn(const KAr
         // this lane's tile-row inside a piece and the source chunk that lands at its lane-linear slot
         const int a_lr = lane / CPR_A, b_lr = lane / CPR_B;
         int a_sw, b_sw;
-        if constexpr (BA == 128) a_sw = (a_lr << 2) | (wv & 3); else a_sw = (((a_lr >> 1) & 1) | ((wv & 1) << 1)) << 1;
+        if constexpr (BA == 128) a_sw = (a_lr << 2) | (wv & 3);
+        else if constexpr (BA == 32) a_sw = ((a_lr >> 3) & 1) << 1;            // (16 rows per piece: row = 16 wv + a_lr)
+        else a_sw = (((a_lr >> 1) & 1) | ((wv & 1) << 1)) << 1;
         if constexpr (BB == 128) b_sw = (b_lr << 2) | (wv & 3); else b_sw = (((b_lr >> 1) & 1) | ((wv & 1) << 1)) << 1;
         const int a_cs = row0 + ((lane % CPR_A) ^ a_sw) * 8, b_cs = col0 + ((lane % CPR_B) ^ b_sw) * 8;
         typedef __attribute__((address_space(3))) void* lds_ptr;
@@ -350,6 +356,7 @@ int launch(const KArgs& ka, int nblk, hipStream_t st) {
 
 template <bool GA>
 int dispatch(const KArgs& ka, int ba, int bb, int nblk, hipStream_t st) {
+    if (ba == 32) return bb == 128 ? launch<32, 128, GA>(ka, nblk, st) : launch<32, 64, GA>(ka, nblk, st);
     if (ba == 128 && bb == 128) return launch<128, 128, GA>(ka, nblk, st);
     if (ba == 128 && bb == 64) return launch<128, 64, GA>(ka, nblk, st);
     if (ba == 64 && bb == 128) return launch<64, 128, GA>(ka, nblk, st);
@@ -485,7 +492,14 @@ extern "C" int mde_conv_wgrad_ws(const mde_wgrad_desc* d, const void* direct, co
         MDE_REQUIRE(dw >= g_mde_det.gbase && dw + nw <= g_mde_det.gbase + g_mde_det.n,
                     "mde_conv_wgrad: deterministic mode is on and dw lies outside the registered gradient buffer");
     }
-    const int ba = (ka.Crows % 128 == 0 && !ka.gsize) ? 128 : 64;
+    // (<= 32 rows -- the full-resolution decoder layers of BTS and MiDaS, 32 output channels over millions of pixels -- take the
+    //  32-row tile: half the padding of the 64-row one.  MDE_WGRAD_ROWS32=0: off)
+    static int rows32 = -1;
+    if (rows32 < 0) {
+        const char* e = getenv("MDE_WGRAD_ROWS32");
+        rows32 = !(e && !strcmp(e, "0"));
+    }
+    const int ba = (ka.Crows % 128 == 0 && !ka.gsize) ? 128 : (rows32 && !ka.gsize && ka.Crows <= 32) ? 32 : 64;
     const int bb = (ka.Ccols % 128 == 0 && !ka.gsize) ? 128 : 64;
     ka.nB = ka.gsize ? 1 : mde_cdiv(ka.Ccols, bb);
     int64_t chunk = (M + d->ksplit - 1) / d->ksplit;
@@ -589,7 +603,7 @@ extern "C" int mde_conv_wgrad_ws(const mde_wgrad_desc* d, const void* direct, co
             return ga ? dispatch<true>(ka, tile_a, bb, (int)nblk, st) : dispatch<false>(ka, tile_a, bb, (int)nblk, st);
         };
         if (int rc = go2(128, 0, head)) return rc;
-        if (int rc = go2(64, head, ka.Crows - head)) return rc;
+        if (int rc = go2((rows32 && ka.Crows - head <= 32) ? 32 : 64, head, ka.Crows - head)) return rc;
         return reduce();
     }
     if (int rc = go(ba, 0, ka.Crows)) return rc;

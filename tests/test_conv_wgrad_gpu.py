@@ -78,6 +78,11 @@ def _assert_close(got, ref, what, tol=1e-3):
     (2, 33, 50, 192, 136, 3, 1, 1, 2),    # blocks that hang over the grid (33 x 50), channel tails on both operands
     (1, 20, 37, 72, 64, 5, 1, 2, 1),      # 5 taps per kernel row: groups of 3 + 2
     (2, 17, 23, 64, 128, 3, 1, 2, 2),     # padding 2 (the window starts two pixels outside)
+    (2, 21, 30, 64, 32, 3, 1, 1, 3),      # 32 rows: the 32-row tile (BTS / MiDaS full-resolution decoder layers), 64 columns
+    (1, 18, 26, 128, 32, 3, 1, 1, 2),     # ... 128-column tiles
+    (2, 15, 17, 40, 24, 3, 1, 1, 1),      # ... 24 rows, 40 columns (channel tails on both operands)
+    (1, 22, 31, 256, 152, 3, 1, 1, 2),    # 152 rows = 128 + 24: a launch of 128-row tiles and one of 32-row tiles (VNL's prediction conv)
+    (2, 9, 13, 64, 8, 1, 1, 0, 1),        # 8 rows, 1x1
 ])
 def test_conv_wgrad(N, H, Wd, Cin, Cout, k, s, p, ksplit, wgrad_form):
     from mono_depth_estimation_amd import ops
