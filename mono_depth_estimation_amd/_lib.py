@@ -18,6 +18,22 @@ class MdeError(RuntimeError):
 ACT_NAME = os.environ.get("MDE_ACT_DTYPE", "bf16").lower()
 if ACT_NAME in ("float16", "half", "f16"):
     ACT_NAME = "fp16"
+_FP16_NOTED = False
+
+
+def note_fp16_backward():
+    """The fp16 storage build flushes activation gradients below 6e-8 to zero: a backward pass through it needs the caller's
+    loss scale (the reference's precision=16 run brings a GradScaler; bench.py applies a static one).  Said once per process,
+    on the first backward -- the library cannot see whether the gradient it is handed was scaled."""
+    global _FP16_NOTED
+    if ACT_NAME == "fp16" and not _FP16_NOTED and os.environ.get("MDE_FP16_QUIET", "0") != "1":
+        _FP16_NOTED = True
+        import warnings
+        warnings.warn("mono_depth_estimation_amd: fp16 storage build (MDE_ACT_DTYPE=fp16) -- backward expects a SCALED loss "
+                      "(torch.cuda.amp.GradScaler, or a static loss scale as bench.py's); unscaled fp16 activation gradients "
+                      "underflow (INTEGRATION.md, section 1).  MDE_FP16_QUIET=1 silences this note.", stacklevel=3)
+
+
 if ACT_NAME not in ("bf16", "fp16"):
     raise MdeError("MDE_ACT_DTYPE=%s: bf16 (default) or fp16" % ACT_NAME)
 LIB_NAME = "libmde_hip_f16.so" if ACT_NAME == "fp16" else "libmde_hip.so"

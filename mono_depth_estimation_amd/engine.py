@@ -893,9 +893,12 @@ class EngineCore:
                 self._fwd_sums = False
 
     def begin_backward(self):
-        if self._bwd_sums:                     # a backward pass repeated without a training-mode forward in between
+        if self._bwd_sums:                     # a backward pass repeated, or interrupted, without a training-mode forward in between
             for s in self.sites:
                 s.part_b.zero_()
+            for op in getattr(self, "tape", ()):       # ... whose launches may have left "sums already added" marks behind
+                for a in op.acts():
+                    a.reduced = False
         self._bwd_sums = True
 
     def end_backward(self):

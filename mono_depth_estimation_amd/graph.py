@@ -13,7 +13,7 @@ import os
 
 import torch
 
-from . import ops
+from . import _lib, ops
 from .engine import FUSE_BN_RED, FUSE_DRES, Act, BNSite, EngineCore, FlatStore, bn_join_backward
 
 
@@ -1479,6 +1479,7 @@ class _TapeFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *douts):
+        _lib.note_fp16_backward()
         eng = ctx.engine
         if not ctx.train:
             raise RuntimeError("mono_depth_estimation_amd: backward() through a forward pass run in eval() mode is not supported "

@@ -17,6 +17,7 @@ import warnings
 import torch
 import torch.nn as nn
 
+from .. import _lib
 from ..engine import FCRNEngine, ParamStore
 
 
@@ -287,6 +288,7 @@ class _FCRNFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        _lib.note_fp16_backward()
         eng = ctx.engine
         if not ctx.train:
             # the backward plan is the TRAINING-mode one (batch statistics, the ReLU masks a train-mode forward wrote);
