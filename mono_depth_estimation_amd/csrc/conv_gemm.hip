@@ -161,6 +161,9 @@ __device__ __forceinline__ int chunk_off(int row, int kslot8) {
 #ifndef MDE_DEEP_RING
 #define MDE_DEEP_RING 4
 #endif
+#ifndef MDE_PAD_LDS
+#define MDE_PAD_LDS 0
+#endif
 // waves along the columns of a tile: two for 128+ columns, and for the 8-wave form of the 128 x 64 tile (each wave needs two
 // 16-pixel fragments at least)
 template <int BP, int BC, int NT>
@@ -1273,10 +1276,25 @@ __global__ __launch_bounds__(NT, HALO ? (NT == 512 ? 4 : BC <= 64 ? 5 : 4)
 }
 
 // waves of the deep-ring tiles (grids of at most one tile per CU): a K-step there costs what its DMA instructions take to
-// ISSUE (~190 cycles each, item 27 of DESIGN section 3) -- eight waves issue a step's pieces in half the time of four
-inline int deep_waves() {
+// ISSUE (~190 cycles each, item 27 of DESIGN section 3) -- eight waves issue a step's pieces in half the time of four.
+// bc: 128 = the 4-deep 128-column tile, 64 = the 4-deep 64-column tile, 1 = the 3-deep 64-column tile of grids between one and
+// two rounds.  Only the 128-column tile runs with eight waves by default.  The 8-wave 64-COLUMN forms are correct alone (all
+// kernel tests pass with them forced) and 0.7 ms per BTS step faster, but the fused BatchNorm-backward sums of such a launch
+// came out wrong now and then (one site 42 % off in one step of four) whenever a weight-gradient workgroup of the other stream
+// was RESIDENT ON THE SAME CU: tests/test_fcrn_convergence_gpu.py's bit-identity check in deterministic mode caught it;
+// tools/probes/det_repeat.py (joining the streams behind that one weight-gradient launch removes it), fused_sum_check.py,
+// det_repeat_bts.py; with the tile's LDS request padded to 132 KB -- nothing else fits the CU -- it is gone; the 128-column tile
+// (137 KB) cannot share a CU in the first place.  Neither kernel touches LDS outside its allocation by my reading; not
+// understood, so not used.  MDE_CONV_DEEP_WAVES: 4 = four waves everywhere, 8 = eight everywhere, 64 / 128 / d64 = eight for
+// that one form (diagnostics).
+inline int deep_waves(int bc = 0) {
     const char* e = getenv("MDE_CONV_DEEP_WAVES");             // (read per call: the tests switch it between launches)
-    return (e && !strcmp(e, "4")) ? 4 : 8;
+    if (e && !strcmp(e, "4")) return 4;
+    if (e && !strcmp(e, "8")) return 8;
+    if (e && !strcmp(e, "64")) return bc == 64 ? 8 : 4;
+    if (e && !strcmp(e, "128")) return bc == 128 ? 8 : 4;
+    if (e && !strcmp(e, "d64")) return bc == 1 ? 8 : 4;
+    return bc == 128 ? 8 : 4;
 }
 
 template <int BP, int BC, int NT, int NBUF>
@@ -1288,7 +1306,10 @@ constexpr size_t smem_bytes() {
 template <int BP, int BC, int NT, bool DMA, int NBUF, bool PP = false>
 int launch(KArgs& ka, int64_t M, hipStream_t st) {
     static bool attr_done = false;
-    constexpr size_t smem = smem_bytes<BP, BC, NT, NBUF>();
+    // (diagnostics, MDE_CONV_PAD_LDS=1: the 8-wave 64-column deep tiles ask for 132 KB so that no other kernel's workgroup
+    //  fits a CU beside them)
+    constexpr size_t smem0 = smem_bytes<BP, BC, NT, NBUF>();
+    constexpr size_t smem = (NT == 512 && BC == 64 && NBUF == 4 && smem0 < 132 * 1024) ? (MDE_PAD_LDS ? 132 * 1024 : smem0) : smem0;
     static_assert(smem <= 160 * 1024, "LDS budget");
     if (!attr_done) {
         int rc = mde_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_nt<BP, BC, NT, DMA, NBUF, PP>),
@@ -1501,7 +1522,7 @@ int pick_and_launch(KArgs& ka, int64_t M, hipStream_t st) {
         const char* de = getenv("MDE_CONV_DEEP");
         const int deep64 = !(de && !strcmp(de, "0"));
         if (ring64 == 4 || (ring64 == -2 && deep64 && forced == 0 && tiles64 <= MDE_RING3_MAX_TILES_PER_CU * cus_() && ka.d.ntaps * ((ka.d.C + BK - 1) / BK) >= 4))
-            return deep_waves() == 8 ? launch<128, 64, 512, true, MDE_DEEP_RING>(ka, M, st) : launch<128, 64, 256, true, MDE_DEEP_RING>(ka, M, st);
+            return deep_waves(64) == 8 ? launch<128, 64, 512, true, MDE_DEEP_RING>(ka, M, st) : launch<128, 64, 256, true, MDE_DEEP_RING>(ka, M, st);
         return (ring64 == 1 || forced == 6) ? launch<128, 64, 256, true, 2>(ka, M, st) : launch<128, 64, 256, true, 1>(ka, M, st);
     }
     const int cus = cus_();
@@ -1536,13 +1557,13 @@ int pick_and_launch(KArgs& ka, int64_t M, hipStream_t st) {
         const int deep = !(de && !strcmp(de, "0"));
         const int nst = ka.d.ntaps * ((ka.d.C + BK - 1) / BK);
         if (deep && forced == 0 && !reg && nst >= 4 && (int64_t)mde_cdiv(M, 128) * nc128 <= MDE_RING3_MAX_TILES_PER_CU * cus)
-            return deep_waves() == 8 ? launch<128, 128, 512, true, MDE_DEEP_RING>(ka, M, st) : launch<128, 128, 256, true, MDE_DEEP_RING>(ka, M, st);
+            return deep_waves(128) == 8 ? launch<128, 128, 512, true, MDE_DEEP_RING>(ka, M, st) : launch<128, 128, 256, true, MDE_DEEP_RING>(ka, M, st);
         // ... and a grid that is a little more than one 128-column tile per CU but at most two 64-column tiles (DenseNet's 3x3
         // input gradients on 19 200 pixels, 48 -> 192 channels: 300 / 450 tiles): the 8-wave 64-column tile with a 3-deep ring
         // (72 KB: two per CU), everything resident in one round.  MDE_CONV_DEEP64=0: off.
         const char* d6 = getenv("MDE_CONV_DEEP64");
         if (deep && !(d6 && !strcmp(d6, "0")) && forced == 0 && !reg && nst >= 4 && nst <= 32 && (int64_t)mde_cdiv(M, 128) * nc128 <= 2 * cus &&
-            (int64_t)mde_cdiv(M, 128) * mde_cdiv(n, 64) <= 2 * cus && deep_waves() == 8)
+            (int64_t)mde_cdiv(M, 128) * mde_cdiv(n, 64) <= 2 * cus && deep_waves(1) == 8)
             return launch<128, 64, 512, true, 3>(ka, M, st);
     }
     const int64_t p256 = mde_cdiv(M, 256), t256 = p256 * nc256;

@@ -35,6 +35,7 @@ _CHECK_FUSED_SUMS = os.environ.get("MDE_FUSE_BN_RED_CHECK", "0") == "1"    # (te
 # L2 round trips in front of its first row, and 50-60 more registers for the whole kernel (114 against 62: half the waves per
 # SIMD for a pass that lives on memory-level parallelism).  Never in deterministic mode.
 FUSE_BN_FIN = os.environ.get("MDE_FUSE_BN_FIN", "0") == "1"
+_JOIN_RANGE = tuple(int(v) for v in os.environ["MDE_WGRAD_JOIN"].split(":")) if os.environ.get("MDE_WGRAD_JOIN") else None
 
 
 def _round_up(n, a=_ALIGN):
@@ -849,6 +850,9 @@ class EngineCore:
         # while ops.TIMER is recording (bench.py's roofline leg: one instrumented step) everything runs on ONE stream.
         self.side = torch.cuda.Stream(self.dev) if (on_gpu and os.environ.get("MDE_WGRAD_STREAM", "1") == "1") else None
         self.side_busy = False
+        # (diagnostics: MDE_WGRAD_STREAMS=2 deals the weight-gradient launches over two side streams, each with a workspace of its own)
+        self.side2 = torch.cuda.Stream(self.dev) if (self.side is not None and os.environ.get("MDE_WGRAD_STREAMS", "1") == "2") else None
+        self._wturn = 0
         self.split = False            # this forward runs over the two-term eval operands (begin_forward)
         self.sites = []               # every BNSite of the plan (BNSite.__init__ / half register themselves)
         # partial sums a pass left behind: the fused-finalize launches read the sums without zeroing them, the OTHER direction's
@@ -893,6 +897,7 @@ class EngineCore:
                 self._fwd_sums = False
 
     def begin_backward(self):
+        self._wcount = 0
         if self._bwd_sums:                     # a backward pass repeated, or interrupted, without a training-mode forward in between
             for s in self.sites:
                 s.part_b.zero_()
@@ -949,6 +954,15 @@ class EngineCore:
         input-gradient GEMM of the same layer: on a second stream its workgroups fill the CUs that the other
         kernel leaves idle and its MFMAs overlap the HBM-bound BatchNorm passes (MDE_WGRAD_STREAM=0 turns it off; a step that
         is being timed per launch — ops.TIMER — stays on one stream so that each duration describes one kernel)."""
+        if self.side2 is not None and ops.TIMER is None:
+            self._wturn ^= 1
+            st = self.side2 if self._wturn else self.side
+            ws = self._wgrad_ws(desc, "_ws2" if self._wturn else "_ws")
+            st.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(st):
+                ops.conv_wgrad(desc, a, b, dw, ws)
+            self.side_busy = True
+            return
         ws = self._wgrad_ws(desc)
         if self.side is None or ops.TIMER is not None:
             ops.conv_wgrad(desc, a, b, dw, ws)
@@ -958,10 +972,14 @@ class EngineCore:
         with torch.cuda.stream(self.side):
             ops.conv_wgrad(desc, a, b, dw, ws)
         self.side_busy = True
+        if _JOIN_RANGE is not None:                 # diagnostics: MDE_WGRAD_JOIN=lo:hi joins the side stream right behind launches lo..hi-1 of a pass
+            self._wcount = getattr(self, "_wcount", 0) + 1
+            if _JOIN_RANGE[0] <= self._wcount - 1 < _JOIN_RANGE[1]:
+                cur.wait_stream(self.side)
 
     _WS_MIN, _WS_MAX = 256 << 20, 2 << 30
 
-    def _wgrad_ws(self, desc):
+    def _wgrad_ws(self, desc, slot="_ws"):
         """The workspace of the two-stage split-K reduction (ops.conv_wgrad): ONE buffer per engine, shared by all of its
         weight-gradient launches -- they are ordered on one stream (the side stream, or the main one without it).  Grown on
         demand after a device synchronisation; launches that would need more than 2 GiB keep the atomic path."""
@@ -970,15 +988,18 @@ class EngineCore:
             need = desc._ws_need = ops.wgrad_ws_bytes(desc)
         if need == 0 or need > self._WS_MAX:
             return None
-        ws = getattr(self, "_ws", None)
+        ws = getattr(self, slot, None)
         if ws is None or ws.numel() < need:
             torch.cuda.synchronize(self.dev)
-            self._ws = ws = torch.empty(max(need, self._WS_MIN), dtype=torch.uint8, device=self.dev)
+            ws = torch.empty(max(need, self._WS_MIN), dtype=torch.uint8, device=self.dev)
+            setattr(self, slot, ws)
         return ws
 
     def join_side(self):
         if self.side is not None and self.side_busy:
             torch.cuda.current_stream().wait_stream(self.side)
+            if self.side2 is not None:
+                torch.cuda.current_stream().wait_stream(self.side2)
             self.side_busy = False
 
 

@@ -1,0 +1,33 @@
+"""Diagnostic: repeated deterministic-mode FCRN steps must give bit-identical gradients; prints the parameters that differ."""
+import os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from oracle import weights as W  # noqa: E402
+from mono_depth_estimation_amd import criteria  # noqa: E402
+from mono_depth_estimation_amd.network import FCRN  # noqa: E402
+
+torch.manual_seed(0)
+net = FCRN.ResNet(layers=50, output_size=(128, 160), out_channels=1, pretrained=False).cuda().train()
+net._store.set_deterministic(True)
+rgb, tgt = W.synthetic_batch(5, 4, 128, 160)
+x, t = rgb.cuda(), tgt.cuda()
+crit = criteria.silog_loss(0.85)
+
+
+def grads():
+    net.zero_grad(set_to_none=True)
+    crit(net(x), t).backward()
+    torch.cuda.synchronize()
+    return {n: p.grad.clone() for n, p in net.named_parameters()}
+
+
+runs = [grads() for _ in range(4)]
+for i in range(1, 4):
+    bad = [n for n in runs[0] if not torch.equal(runs[0][n], runs[i][n])]
+    print("run %d vs run 0: %d tensors differ: %s" % (i, len(bad), bad[:8]))
+    names = list(runs[0])
+    if bad:
+        last = max(names.index(n) for n in bad)
+        print("   last differing (first in backward order): %s; equal after it: %s" % (names[last], names[last + 1:last + 4]))
+        big = sorted(bad, key=lambda n: -float((runs[0][n] - runs[i][n]).abs().max() / (runs[0][n].abs().max() + 1e-30)))[:4]
+        print("   largest relative differences:", [(n, float((runs[0][n] - runs[i][n]).abs().max() / (runs[0][n].abs().max() + 1e-30))) for n in big])
