@@ -772,3 +772,48 @@ def test_bn_fused_finalize_equals_the_separate_kernels(N, H, Wd, C, relu, res):
             joins.append((dxa, dxb, dga, dba, dgb, dbb))
         for u, v in zip(joins[0], joins[1]):
             assert torch.equal(u, v)
+
+
+def test_bn_apply_with_the_elu_in_front():
+    """mde_bn_apply relu = 2: out = ELU(x) * scale + shift -- the eval form of conv -> ELU -> BatchNorm (Bts.py:216-229): the conv
+    stores its pre-activation and the ELU value never exists in 16 bits.  Against torch on the same bf16 input; and the point of
+    it: values saturated towards -1 keep their distance from -1 (a stored ELU output would round every one of them to -1)."""
+    from mono_depth_estimation_amd import ops
+    M, C = 4096, 72
+    x = _bf(W.normal(61, "x", (M, C)) * 4.0)
+    x[:64] = _bf(torch.linspace(-12.0, -7.0, 64 * C).view(64, C))            # ELU within 1e-3 .. 6e-6 of -1
+    sc, sh = 0.5 + W.uniform(61, "sc", (C,)), W.normal(61, "sh", (C,))
+    out = torch.empty(M, C, dtype=ACT, device="cuda")
+    ops.bn_apply(x.to(ACT).cuda(), C, sc.cuda(), sh.cuda(), out, C, M, C, 2)
+    ref = F.elu(x) * sc + sh
+    _close_bf16(out.float().cpu(), ref, "bn_apply relu=2")
+    with pytest.raises(RuntimeError):
+        ops.bn_apply(x.to(ACT).cuda(), C, sc.cuda(), sh.cuda(), out, C, M, C, 3)
+    # what it is for: a BatchNorm that amplifies (scale 1e3, shift chosen so that ELU = -1 maps to 0) resolves the saturated values
+    big, off = torch.full((C,), 1e3), torch.full((C,), 1e3)
+    ops.bn_apply(x.to(ACT).cuda(), C, big.cuda(), off.cuda(), out, C, M, C, 2)
+    fused = out[:64].float().cpu()
+    stored = (_bf(F.elu(x[:64])) * 1e3 + 1e3)                                # the same through a stored 16-bit ELU output
+    exact = torch.expm1(x[:64].double()).add(1.0).mul(1e3).float()
+    assert float((fused - exact).abs().max()) < 2.0 ** -7 * float(exact.abs().max()) + 1e-3
+    assert float((stored - exact).abs().max()) > 20 * float((fused - exact).abs().max())
+
+
+@pytest.mark.parametrize("act,scale", [("sigmoid", 10.0), ("relu", 1.0), ("elu", 0.5), (None, 2.0)])
+def test_map_act_on_fp32_maps(act, scale):
+    """mde_map_act_fwd / _bwd: y = scale act(p) on an fp32 map and dp = dy scale act'(.) through the kept output (BTS' get_depth ->
+    Sigmoid -> x max_depth behind the one-channel head kernels)."""
+    from mono_depth_estimation_amd import ops
+    p = W.normal(62, "p", (2, 1, 30, 42)) * 2.0
+    dy = W.normal(62, "dy", (2, 1, 30, 42))
+    pr = p.clone().requires_grad_(True)
+    f = {"sigmoid": torch.sigmoid, "relu": F.relu, "elu": F.elu, None: (lambda t: t)}[act]
+    (scale * f(pr)).backward(dy)
+    y = torch.empty_like(p).cuda()
+    ops.map_act_fwd(p.cuda(), y, act, scale)
+    assert torch.allclose(y.cpu(), (scale * f(p)), rtol=1e-5, atol=1e-6)
+    dp = torch.empty_like(p).cuda()
+    ops.map_act_bwd(dy.cuda(), y, dp, act, scale)
+    assert torch.allclose(dp.cpu(), pr.grad, rtol=2e-4, atol=1e-5)
+    with pytest.raises(RuntimeError):
+        ops.map_act_fwd(p.cuda().flatten()[:7], y.flatten()[:7], act, scale)          # n % 4 != 0
