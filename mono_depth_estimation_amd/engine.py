@@ -850,9 +850,6 @@ class EngineCore:
         # while ops.TIMER is recording (bench.py's roofline leg: one instrumented step) everything runs on ONE stream.
         self.side = torch.cuda.Stream(self.dev) if (on_gpu and os.environ.get("MDE_WGRAD_STREAM", "1") == "1") else None
         self.side_busy = False
-        # (diagnostics: MDE_WGRAD_STREAMS=2 deals the weight-gradient launches over two side streams, each with a workspace of its own)
-        self.side2 = torch.cuda.Stream(self.dev) if (self.side is not None and os.environ.get("MDE_WGRAD_STREAMS", "1") == "2") else None
-        self._wturn = 0
         self.split = False            # this forward runs over the two-term eval operands (begin_forward)
         self.sites = []               # every BNSite of the plan (BNSite.__init__ / half register themselves)
         # partial sums a pass left behind: the fused-finalize launches read the sums without zeroing them, the OTHER direction's
@@ -953,16 +950,9 @@ class EngineCore:
         """Weight-gradient GEMM of one conv.  It only reads dY and the activation, so it can run beside the
         input-gradient GEMM of the same layer: on a second stream its workgroups fill the CUs that the other
         kernel leaves idle and its MFMAs overlap the HBM-bound BatchNorm passes (MDE_WGRAD_STREAM=0 turns it off; a step that
-        is being timed per launch — ops.TIMER — stays on one stream so that each duration describes one kernel)."""
-        if self.side2 is not None and ops.TIMER is None:
-            self._wturn ^= 1
-            st = self.side2 if self._wturn else self.side
-            ws = self._wgrad_ws(desc, "_ws2" if self._wturn else "_ws")
-            st.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(st):
-                ops.conv_wgrad(desc, a, b, dw, ws)
-            self.side_busy = True
-            return
+        is being timed per launch — ops.TIMER — stays on one stream so that each duration describes one kernel).  (Round 4: the
+        launches dealt over TWO side streams measured slower -- FCRN 28.0 -> 28.4 ms, BTS 44.8 -> 45.4: the weight-gradient
+        kernels then compete with each other, not only with the main stream.)"""
         ws = self._wgrad_ws(desc)
         if self.side is None or ops.TIMER is not None:
             ops.conv_wgrad(desc, a, b, dw, ws)
@@ -998,8 +988,6 @@ class EngineCore:
     def join_side(self):
         if self.side is not None and self.side_busy:
             torch.cuda.current_stream().wait_stream(self.side)
-            if self.side2 is not None:
-                torch.cuda.current_stream().wait_stream(self.side2)
             self.side_busy = False
 
 
