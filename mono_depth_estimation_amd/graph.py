@@ -611,6 +611,9 @@ class HeadConvMap(Op):
         x = self.x
         assert not x.gw
         x.gw = True
+        if self.douts[0] is None:              # this output took no part in the loss: no gradient flows through the head
+            x.g.zero_()
+            return
         ops.map_act_bwd(self.douts[0], self.y, self.pre, self.act, self.scale)           # (pre: its own gradient from here on)
         ops.head_conv_bwd(x.t, self.w32, self.pre, x.g, self.eng.store.Gcur[self.off:self.off + self.n], x.N, x.H, x.W, x.C, 1)
 
