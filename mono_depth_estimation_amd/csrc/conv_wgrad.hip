@@ -84,14 +84,15 @@ __device__ __forceinline__ bf16x8_t read_frag_tr(const char* tile, int k0, int c
 // chunk swizzle of tile_off<> is applied to the SOURCE chunk each lane fetches.
 // NBUF = 1: ONE staging buffer (fetch -> wait -> MFMA per K-step), so twice as many workgroups fit a CU and overlap each
 // other's fetches and MFMAs (conv_gemm.hip's single-buffer tiles: occupancy beat the ring there on nearly every shape).
-// BA2 = 32: the tile carries 32 MORE rows behind its 128 (a second, 64-byte-row operand tile next to the first: one more
-// fragment per wave against the same column fragments) -- a row count of 128 + a remainder <= 32 (VNL's 152-row prediction
-// conv) in ONE launch instead of a 128-row launch and a 32-row launch that stages the whole column operand again for a
-// quarter of the MFMAs.
+// BA2 = 32 / 64: the tile carries 32 / 64 MORE rows behind its 128 (a second operand tile next to the first: one / two more
+// fragments per wave against the same column fragments) -- a row count of 128 + a remainder <= 64 (VNL's 152-row prediction
+// conv; DenseNet's 192-channel bottlenecks) in ONE launch instead of a 128-row launch and a second launch that stages the whole
+// column operand again for a quarter / a half of the MFMAs.
 template <int BA, int BB, bool GA, bool DMA, int NBUF = 2, int BA2 = 0>
 __global__ __launch_bounds__(NT, NBUF == 1 ? 4 : 2) void conv_wgrad_tn(const KArgs a) {
     static_assert(NBUF == 2 || (NBUF == 1 && DMA), "single-buffer form: LDS-DMA loop only");
-    static_assert(BA2 == 0 || (BA2 == 32 && BA == 128 && DMA && NBUF == 2), "the extra rows ride on the 128-row ring tile");
+    static_assert(BA2 == 0 || ((BA2 == 32 || BA2 == 64) && BA == 128 && DMA && NBUF == 2), "the extra rows ride on the 128-row ring tile");
+    constexpr int FA2 = BA2 / 32;                  // extra 16-row fragments per wave
     constexpr int FA = BA / 32, FB = BB / 32;      // 16-wide fragments per wave along rows / cols
     constexpr int AT_BYTES = BKP * BA * 2, BT_BYTES = BKP * BB * 2;
     constexpr int AT2_BYTES = BKP * BA2 * 2;       // the extra rows' tile, behind the first operand tile
@@ -176,13 +177,15 @@ __global__ __launch_bounds__(NT, NBUF == 1 ? 4 : 2) void conv_wgrad_tn(const KAr
     };
 
     f32x4_t acc[FA][FB];
-    f32x4_t acc2[BA2 ? FB : 1];                    // rows row0 + BA + wa * 16 .. + 16 (BA2)
+    f32x4_t acc2[BA2 ? FA2 : 1][BA2 ? FB : 1];     // rows row0 + BA + wa * (BA2 / 2) + i * 16 .. + 16 (BA2)
 #pragma unroll
     for (int i = 0; i < FA; ++i)
 #pragma unroll
         for (int j = 0; j < FB; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int j = 0; j < (BA2 ? FB : 1); ++j) acc2[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < (BA2 ? FA2 : 1); ++i)
+#pragma unroll
+        for (int j = 0; j < (BA2 ? FB : 1); ++j) acc2[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     auto compute = [&](int buf) {
         const char* at = smem + buf * BUF_BYTES;
@@ -200,9 +203,12 @@ __global__ __launch_bounds__(NT, NBUF == 1 ? 4 : 2) void conv_wgrad_tn(const KAr
                 for (int j = 0; j < FB; ++j)
                     acc[i][j] = MDE_MFMA_16x16x32(fa[i], fb[j], acc[i][j]);
             if constexpr (BA2 != 0) {
-                const bf16x8_t f2 = read_frag_tr<32>(at + AT_BYTES, kk, wa * 16, lane);
 #pragma unroll
-                for (int j = 0; j < FB; ++j) acc2[j] = MDE_MFMA_16x16x32(f2, fb[j], acc2[j]);
+                for (int i = 0; i < FA2; ++i) {
+                    const bf16x8_t f2 = read_frag_tr<BA2 ? BA2 : 32>(at + AT_BYTES, kk, wa * (BA2 / 2) + i * 16, lane);
+#pragma unroll
+                    for (int j = 0; j < FB; ++j) acc2[i][j] = MDE_MFMA_16x16x32(f2, fb[j], acc2[i][j]);
+                }
             }
         }
     };
@@ -219,9 +225,12 @@ __global__ __launch_bounds__(NT, NBUF == 1 ? 4 : 2) void conv_wgrad_tn(const KAr
         else a_sw = (((a_lr >> 1) & 1) | ((wv & 1) << 1)) << 1;
         if constexpr (BB == 128) b_sw = (b_lr << 2) | (wv & 3); else b_sw = (((b_lr >> 1) & 1) | ((wv & 1) << 1)) << 1;
         const int a_cs = row0 + ((lane % CPR_A) ^ a_sw) * 8, b_cs = col0 + ((lane % CPR_B) ^ b_sw) * 8;
-        // (BA2: 16 rows of 64 bytes per piece, one piece per wave; tile_off<32>'s swizzle on the source chunk)
-        const int a2_lr = lane >> 2;
-        const int a2_cs = row0 + BA + ((lane & 3) ^ (((a2_lr >> 3) & 1) << 1)) * 8;
+        // (BA2 = 32: 16 rows of 64 bytes per piece, one piece per wave; 64: 8 rows of 128 bytes, two pieces; the swizzle of
+        //  tile_off<BA2> on the source chunk, as for the first operand tile)
+        constexpr int CPR_A2 = BA2 ? BA2 / 8 : 4, RPI_A2 = 1024 / (CPR_A2 * 16), QA2 = BKP / RPI_A2 / 4;
+        const int a2_lr = lane / CPR_A2;
+        const int a2_sw = BA2 == 64 ? (((a2_lr >> 1) & 1) | ((wv & 1) << 1)) << 1 : ((a2_lr >> 3) & 1) << 1;
+        const int a2_cs = row0 + BA + ((lane % CPR_A2) ^ a2_sw) * 8;
         typedef __attribute__((address_space(3))) void* lds_ptr;
         // Gathered-operand addressing: the 64 pixels of a K-step are decoded ONCE per workgroup (one
         // wave, one pixel per lane, two steps ahead, waves taking turns) into s_goff[step&1][64] =
@@ -245,10 +254,13 @@ __global__ __launch_bounds__(NT, NBUF == 1 ? 4 : 2) void conv_wgrad_tn(const KAr
                 else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_d, (lds_ptr)(at + q * 4096), 16, off, 0, 0, 0);
             }
             if constexpr (BA2 != 0) {
-                const int r = wv * 16 + a2_lr;
-                const uint32_t off = GA ? (a2_cs < d.Cg ? go[r] + (uint32_t)a2_cs * 2u : MDE_OOB_OFFSET) : direct_off(mb + r, a2_cs);
-                if (GA) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_g, (lds_ptr)(at + AT_BYTES), 16, off, 0, 0, 0);
-                else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_d, (lds_ptr)(at + AT_BYTES), 16, off, 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < QA2; ++q) {
+                    const int r = (wv + 4 * q) * RPI_A2 + a2_lr;
+                    const uint32_t off = GA ? (a2_cs < d.Cg ? go[r] + (uint32_t)a2_cs * 2u : MDE_OOB_OFFSET) : direct_off(mb + r, a2_cs);
+                    if (GA) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_g, (lds_ptr)(at + AT_BYTES + q * 4096), 16, off, 0, 0, 0);
+                    else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_d, (lds_ptr)(at + AT_BYTES + q * 4096), 16, off, 0, 0, 0);
+                }
             }
 #pragma unroll
             for (int q = 0; q < QB; ++q) {
@@ -302,7 +314,7 @@ __global__ __launch_bounds__(NT, NBUF == 1 ? 4 : 2) void conv_wgrad_tn(const KAr
         for (int i = 0; i < FA; ++i)
 #pragma unroll
             for (int j = 0; j < FB; ++j) keep += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
-        if constexpr (BA2 != 0) keep += acc2[0][0];
+        if constexpr (BA2 != 0) keep += acc2[0][0][0];
         if (keep == 123456.789f) a.dw[0] = keep;      // (keeps the accumulators alive)
         return;
     }
@@ -325,15 +337,17 @@ __global__ __launch_bounds__(NT, NBUF == 1 ? 4 : 2) void conv_wgrad_tn(const KAr
             }
         if constexpr (BA2 != 0) {
 #pragma unroll
-            for (int j = 0; j < FB; ++j) {
-                const int col = col0 + wb * (BB / 2) + j * 16 + (lane & 15);
-                const int rbase = row0 + BA + wa * 16 + (lane >> 4) * 4;
-                if (col < a.Ccols) {
+            for (int i = 0; i < FA2; ++i)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (rbase + r < a.Crows) wsl[(size_t)(rbase + r) * wstride + col] = acc2[j][r];
+                for (int j = 0; j < FB; ++j) {
+                    const int col = col0 + wb * (BB / 2) + j * 16 + (lane & 15);
+                    const int rbase = row0 + BA + wa * (BA2 / 2) + i * 16 + (lane >> 4) * 4;
+                    if (col < a.Ccols) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (rbase + r < a.Crows) wsl[(size_t)(rbase + r) * wstride + col] = acc2[i][j][r];
+                    }
                 }
-            }
         }
         return;
     }
@@ -365,18 +379,20 @@ __global__ __launch_bounds__(NT, NBUF == 1 ? 4 : 2) void conv_wgrad_tn(const KAr
         }
     if constexpr (BA2 != 0) {
 #pragma unroll
-        for (int j = 0; j < FB; ++j) {
-            const int col = col0 + wb * (BB / 2) + j * 16 + (lane & 15);
-            const int rbase = row0 + BA + wa * 16 + (lane >> 4) * 4;
-            if (col < a.Ccols) {
+        for (int i = 0; i < FA2; ++i)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = rbase + r;
-                    if (row < a.Crows)
-                        mde_grad_add(a.dw + (size_t)row * rstride + (size_t)otap * a.Ccols + col, acc2[j][r], a.det);
+            for (int j = 0; j < FB; ++j) {
+                const int col = col0 + wb * (BB / 2) + j * 16 + (lane & 15);
+                const int rbase = row0 + BA + wa * (BA2 / 2) + i * 16 + (lane >> 4) * 4;
+                if (col < a.Ccols) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = rbase + r;
+                        if (row < a.Crows)
+                            mde_grad_add(a.dw + (size_t)row * rstride + (size_t)otap * a.Ccols + col, acc2[i][j][r], a.det);
+                    }
                 }
             }
-        }
     }
 }
 
@@ -420,25 +436,26 @@ int dispatch(const KArgs& ka, int ba, int bb, int nblk, hipStream_t st) {
     return launch<64, 64, GA>(ka, nblk, st);
 }
 
-// the 128 + 32-row tile (conv_wgrad_tn<128, BB, GA, true, 2, 32>): one row tile, the ring form
-template <bool GA>
-int launch160(const KArgs& ka, int bb, int nblk, hipStream_t st) {
-    if (bb == 128) {
-        constexpr size_t smem = 2 * (size_t)BKP * (128 + 32 + 128) * 2 + 2 * BKP * sizeof(uint32_t);
-        static bool done = false;
-        if (!done) {
-            int rc = mde_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_tn<128, 128, GA, true, 2, 32>),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem), "hipFuncSetAttribute(conv_wgrad_tn 160)");
-            if (rc) return rc;
-            done = true;
-        }
-        conv_wgrad_tn<128, 128, GA, true, 2, 32><<<dim3(nblk), dim3(NT), smem, st>>>(ka);
-    } else {
-        constexpr size_t smem = 2 * (size_t)BKP * (128 + 32 + 64) * 2 + 2 * BKP * sizeof(uint32_t);
-        conv_wgrad_tn<128, 64, GA, true, 2, 32><<<dim3(nblk), dim3(NT), smem, st>>>(ka);
+// the 128 + 32 / 64-row tiles (conv_wgrad_tn<128, BB, GA, true, 2, 32 | 64>): one row tile, the ring form.  The 64-row extension
+// runs with 64-column tiles only (128 + 64 rows against 128 columns would be 80 KB of staging: one workgroup per CU)
+template <bool GA, int BB, int BA2>
+int launch_ext1(const KArgs& ka, int nblk, hipStream_t st) {
+    constexpr size_t smem = 2 * (size_t)BKP * (128 + BA2 + BB) * 2 + 2 * BKP * sizeof(uint32_t);
+    static bool done = false;
+    if (!done && smem > 64 * 1024) {
+        int rc = mde_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_tn<128, BB, GA, true, 2, BA2>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem), "hipFuncSetAttribute(conv_wgrad_tn 128 + extra rows)");
+        if (rc) return rc;
+        done = true;
     }
-    MDE_LAUNCH_CHECK("conv_wgrad_tn (128 + 32 rows)");
+    conv_wgrad_tn<128, BB, GA, true, 2, BA2><<<dim3(nblk), dim3(NT), smem, st>>>(ka);
+    MDE_LAUNCH_CHECK("conv_wgrad_tn (128 + extra rows)");
     return MDE_OK;
+}
+template <bool GA>
+int launch_ext(const KArgs& ka, int bb, int extra, int nblk, hipStream_t st) {
+    if (extra == 64) return launch_ext1<GA, 64, 64>(ka, nblk, st);
+    return bb == 128 ? launch_ext1<GA, 128, 32>(ka, nblk, st) : launch_ext1<GA, 64, 32>(ka, nblk, st);
 }
 
 inline uint32_t inv32(uint32_t dv) { return dv <= 1 ? 0xFFFFFFFFu : (uint32_t)((1ull << 32) / dv); }
@@ -680,18 +697,23 @@ extern "C" int mde_conv_wgrad_ws(const mde_wgrad_desc* d, const void* direct, co
             MDE_REQUIRE(nblk < (1ll << 31), "mde_conv_wgrad: grid too large");
             return ga ? dispatch<true>(ka, tile_a, bb, (int)nblk, st) : dispatch<false>(ka, tile_a, bb, (int)nblk, st);
         };
-        // 128 + a remainder <= 32: ONE launch of the 128 + 32-row tile (MDE_WGRAD_ROWS160=0: two launches, as before)
+        // 128 + a remainder <= 64: ONE launch of the 128 + 32 / 64-row tile (MDE_WGRAD_ROWS160=0: two launches, as before; =32: only
+        // the 32-row extension)
         static int rows160 = -1;
         if (rows160 < 0) {
             const char* e = getenv("MDE_WGRAD_ROWS160");
-            rows160 = !(e && !strcmp(e, "0"));
+            rows160 = !e ? 64 : atoi(e);
         }
-        if (rows160 && rows32 && head == 128 && ka.Crows - head <= 32 && !reg_path()) {
+        const int rem = ka.Crows - head;
+        if (rows160 && rows32 && head == 128 && rem <= rows160 && !reg_path()) {
+            const int extra = rem <= 32 ? 32 : 64;
+            const int bbx = extra == 64 ? 64 : bb;                 // (see launch_ext1)
             ka.row_off = 0;
             ka.nA = 1;
+            ka.nB = mde_cdiv(ka.Ccols, bbx);
             const int64_t nblk = (int64_t)d->ntaps * ka.nB * ks2;
             MDE_REQUIRE(nblk < (1ll << 31), "mde_conv_wgrad: grid too large");
-            if (int rc = ga ? launch160<true>(ka, bb, (int)nblk, st) : launch160<false>(ka, bb, (int)nblk, st)) return rc;
+            if (int rc = ga ? launch_ext<true>(ka, bbx, extra, (int)nblk, st) : launch_ext<false>(ka, bbx, extra, (int)nblk, st)) return rc;
             return reduce();
         }
         if (int rc = go2(128, 0, head)) return rc;
