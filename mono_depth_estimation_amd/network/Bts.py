@@ -14,6 +14,7 @@ densenet121 / 161 and the whole-model ResNet-50 / -101, ResNeXt-50 32x4d / -101 
 block-diagonal tiles); ResNet-50 and ResNeXt-50 are pinned by goldens, the 101-layer variants by their parameter tree only.
 """
 import math
+import os
 from collections import OrderedDict
 
 import torch
@@ -423,7 +424,7 @@ class BtsEngine(G.TapeEngine):
             self.add(G.MapSlot(self, mp, cat1, s + j, 1))
         i1 = self._conv_elu(cat1, d.conv1[0])
         oc = d.get_depth[0].out_channels
-        if oc == 1 and i1.C in (8, 16, 32, 64) and i1.ld == i1.C and (H * W) % 4 == 0:
+        if oc == 1 and i1.C in (8, 16, 32, 64) and i1.ld == i1.C and (H * W) % 4 == 0 and os.environ.get("MDE_BTS_HEADMAP", "1") != "0":   # ("0": the GEMM path, diagnostics)
             final = self.add(G.HeadConvMap(self, i1, d.get_depth[0].weight, "sigmoid", md))       # one output channel: the head kernels
         else:
             c = self.add(G.Conv(self, i1, d.get_depth[0].weight, 3, 1, 1)).out
