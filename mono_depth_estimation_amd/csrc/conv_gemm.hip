@@ -676,10 +676,13 @@ __global__ __launch_bounds__(NT, HALO ? (NT == 512 ? 4 : BC <= 64 ? 5 : 4)
                     ha[j] = h * 128 + ((ks4 ^ (h & 7)) << 4);
                 }
             };
-            auto compute_step = [&](int buf, const int (&ha)[PF]) {
+            // half: the chunk has at most 32 channels (a 32-channel layer; the tail of 152 = 64 + 64 + 24): the upper half of the
+            // K-step is zero fill on both operands, its MFMAs and fragment reads are skipped (wave-uniform)
+            auto compute_step = [&](int buf, const int (&ha)[PF], bool half) {
                 const char* wbuf = smem + halo_bytes + buf * WT_BYTES + wc * (CF * 2048);
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb) {
+                    if (kb == 1 && half) break;
                     bf16x8_t fa[CF], fb[PF];
 #pragma unroll
                     for (int i = 0; i < CF; ++i) fa[i] = *reinterpret_cast<const bf16x8_t*>(wbuf + i * 2048 + rd_off[kb]);
@@ -706,7 +709,7 @@ __global__ __launch_bounds__(NT, HALO ? (NT == 512 ? 4 : BC <= 64 ? 5 : 4)
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     __builtin_amdgcn_s_barrier();
                     __builtin_amdgcn_sched_barrier(0);
-                    compute_step(0, ha);
+                    compute_step(0, ha, d.C - cc * BK <= 32);
                     if (++t == d.ntaps) { t = 0; ++cc; }
                 }
             } else {
@@ -728,7 +731,7 @@ __global__ __launch_bounds__(NT, HALO ? (NT == 512 ? 4 : BC <= 64 ? 5 : 4)
                     __builtin_amdgcn_s_barrier();                         // everyone's are in; everyone left step s-1
                     __builtin_amdgcn_sched_barrier(0);
                     if (s + 1 < nsteps) issue_weights(cur ^ 1, cn, tn);
-                    compute_step(cur, ha);
+                    compute_step(cur, ha, d.C - cc * BK <= 32);
                     if (tn == 0 && s + 1 < nsteps) {
                         __builtin_amdgcn_s_barrier();                     // the old window is dead
                         issue_window(cn);
@@ -775,7 +778,8 @@ __global__ __launch_bounds__(NT, HALO ? (NT == 512 ? 4 : BC <= 64 ? 5 : 4)
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
                 SB_ADD(4, t0); t0 = SB_T();
-                compute(0);
+                compute_half(0, 0);
+                if (d.C - (s / d.ntaps) * BK > 32) compute_half(0, 1);      // (a chunk of <= 32 channels: the upper half is zero fill)
                 SB_ADD(5, t0);
             }
 #ifdef MDE_SB_STAMP
