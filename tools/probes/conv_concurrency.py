@@ -20,14 +20,36 @@ mean, rstd = torch.randn(O, device="cuda") * 0.1, torch.rand(O, device="cuda") +
 msc, msh = torch.rand(O, device="cuda") + 0.5, torch.randn(O, device="cuda") * 0.1
 
 
+# co-runners for the other stream: a library GEMM, the weight-gradient kernel (64 x 64 tiles, as a 64 -> 64 3x3 layer's), a 4-wave conv
+CO = os.environ.get("CO", "mm")
+wx = torch.randn(8, 128, 160, 64, device="cuda").to(ACT)
+wdy = torch.randn(8, 128, 160, 64, device="cuda").to(ACT)
+wdw = torch.zeros(64, 9, 64, device="cuda")
+wd = ops.conv_wgrad_desc(8, 128, 160, 64, 64, wx.numel() * 2, 128, 160, 64, 64, wdy.numel() * 2, 3, 1, 1, 14)
+cx = torch.randn(8, 128, 160, 64, device="cuda").to(ACT)
+cout = torch.empty(8, 128, 160, 64, dtype=ACT, device="cuda")
+cd = ops.fwd_desc(8, 128, 160, 64, 64, cx.numel() * 2, 3, 1, 1, 64, 64)
+
+
+def corun():
+    if CO == "mm":
+        for _ in range(3):
+            torch.mm(big_a, big_b)
+    elif CO == "wgrad":
+        for _ in range(6):
+            ops.conv_wgrad(wd, wdy, wx, wdw)
+    else:
+        for _ in range(6):
+            ops.conv_gemm(cd, cx, w, cout)
+
+
 def run(mode, busy):
     out = torch.empty(N, H, W, O, dtype=ACT, device="cuda")
     part = ops.new_stat_buffer(O)
     if busy:
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            for _ in range(3):
-                torch.mm(big_a, big_b)
+            corun()
     if mode == "plain":
         ops.conv_gemm(d, x, w, out)
     elif mode == "stats":
@@ -50,4 +72,4 @@ for mode in ("plain", "stats", "red"):
         if not torch.allclose(p, ref_p, rtol=1e-4, atol=1e-3):
             bad_p += 1
             worst = max(worst, float(((p - ref_p).abs() / (ref_p.abs() + 1e-3)).max()))
-    print("%-6s: outputs differing from the quiet run in %d of 30 busy runs; sums differing (> 1e-4) in %d, worst relative %.3g" % (mode, bad_o, bad_p, worst))
+    print("[co-runner %s] %-6s: outputs differing from the quiet run in %d of 30 busy runs; sums differing (> 1e-4) in %d, worst relative %.3g" % (CO, mode, bad_o, bad_p, worst))
