@@ -1282,23 +1282,20 @@ __global__ __launch_bounds__(NT, HALO ? (NT == 512 ? 4 : BC <= 64 ? 5 : 4)
 // waves of the deep-ring tiles (grids of at most one tile per CU): a K-step there costs what its DMA instructions take to
 // ISSUE (~190 cycles each, item 27 of DESIGN section 3) -- eight waves issue a step's pieces in half the time of four.
 // bc: 128 = the 4-deep 128-column tile, 64 = the 4-deep 64-column tile, 1 = the 3-deep 64-column tile of grids between one and
-// two rounds.  Only the 128-column tile runs with eight waves by default.  The 8-wave 64-COLUMN forms are correct alone (all
-// kernel tests pass with them forced) and 0.7 ms per BTS step faster, but the fused BatchNorm-backward sums of such a launch
-// came out wrong now and then (one site 42 % off in one step of four) whenever a weight-gradient workgroup of the other stream
-// was RESIDENT ON THE SAME CU: tests/test_fcrn_convergence_gpu.py's bit-identity check in deterministic mode caught it;
-// tools/probes/det_repeat.py (joining the streams behind that one weight-gradient launch removes it), fused_sum_check.py,
-// det_repeat_bts.py; with the tile's LDS request padded to 132 KB -- nothing else fits the CU -- it is gone; the 128-column tile
-// (137 KB) cannot share a CU in the first place.  Neither kernel touches LDS outside its allocation by my reading; not
-// understood, so not used.  MDE_CONV_DEEP_WAVES: 4 = four waves everywhere, 8 = eight everywhere, 64 / 128 / d64 = eight for
-// that one form (diagnostics).
+// two rounds.  All three run with eight waves.  (The 64-column forms were held back for most of round 4: their fused
+// BatchNorm-backward sums came out wrong whenever a weight-gradient workgroup of the other stream shared the CU.  Cause, found
+// with tools/probes/conv_concurrency3.py: hipcc's SLP vectoriser had paired the sums' accumulations crosswise in exactly these
+// two instances -- v_pk_add_f32 / v_pk_mul_f32 with op_sel:[0,1] -- and on gfx950 the low lane of such an instruction is
+// unreliable while a wave of another kernel shares the SIMD.  build.sh now compiles this file without the SLP pass and
+// check_isa.py rejects a library that holds such an instruction: DESIGN section 3, item 44.)
+// MDE_CONV_DEEP_WAVES: 4 = four waves everywhere, 64 / 128 / d64 = eight for that one form only (diagnostics).
 inline int deep_waves(int bc = 0) {
     const char* e = getenv("MDE_CONV_DEEP_WAVES");             // (read per call: the tests switch it between launches)
     if (e && !strcmp(e, "4")) return 4;
-    if (e && !strcmp(e, "8")) return 8;
     if (e && !strcmp(e, "64")) return bc == 64 ? 8 : 4;
     if (e && !strcmp(e, "128")) return bc == 128 ? 8 : 4;
     if (e && !strcmp(e, "d64")) return bc == 1 ? 8 : 4;
-    return bc == 128 ? 8 : 4;
+    return 8;
 }
 
 template <int BP, int BC, int NT, int NBUF>

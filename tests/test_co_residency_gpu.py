@@ -1,0 +1,85 @@
+"""A launch's results must not depend on what runs beside it.
+
+Round 4 found the one case where they did: the fused BatchNorm-backward sums of the 8-wave 64-column conv tiles came out wrong
+(up to 90 % on a channel, in 30 of 30 runs) whenever a workgroup of ANOTHER kernel -- the weight gradient of the second stream, a
+4-wave conv -- shared the CU; the output tile itself stayed bit-identical.  Cause: packed-fp32 instructions with a lane-crossing
+op_sel (v_pk_add_f32 ... op_sel:[0,1]), which hipcc's SLP vectoriser had emitted for exactly those instances, return a wrong
+low lane on gfx950 while a wave of another kernel shares the SIMD.  The library is built without
+such instructions now (csrc/build.sh, csrc/check_isa.py; tests/test_abi_cpu.py checks the built files).  This test keeps the
+symptom itself under watch: one conv launch repeated on the main stream while a second stream runs a co-runner whose workgroups
+fit the same CUs -- output, forward statistics and fused backward sums against the quiet run, for every deep-ring form."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+N, H, W, C, O = 4, 64, 80, 64, 64
+
+
+@pytest.fixture(scope="module")
+def setup():
+    from mono_depth_estimation_amd import ops
+    torch.manual_seed(0)
+    act = ops.ACT_DTYPE
+    s = {"ops": ops}
+    s["x"] = torch.randn(N, H, W, C, device="cuda").to(act)
+    s["w"] = (torch.randn(O, 9, C, device="cuda") * 0.05).to(act)
+    s["d"] = ops.fwd_desc(N, H, W, C, C, s["x"].numel() * 2, 3, 1, 1, O, O)
+    s["side"] = torch.cuda.Stream()
+    # a BatchNorm site for the fused backward sums: its input, statistics and mask constants
+    s["sx"] = torch.randn(N, H, W, O, device="cuda").to(act)
+    s["mean"], s["rstd"] = torch.randn(O, device="cuda") * 0.1, torch.rand(O, device="cuda") + 0.5
+    s["msc"], s["msh"] = torch.rand(O, device="cuda") + 0.5, torch.randn(O, device="cuda") * 0.1
+    # co-runners: the weight-gradient kernel (64 x 64 tiles, as a 64 -> 64 3x3 layer's) and a 4-wave conv
+    s["wx"] = torch.randn(8, 128, 160, 64, device="cuda").to(act)
+    s["wdy"] = torch.randn(8, 128, 160, 64, device="cuda").to(act)
+    s["wdw"] = torch.zeros(64, 9, 64, device="cuda")
+    s["wd"] = ops.conv_wgrad_desc(8, 128, 160, 64, 64, s["wx"].numel() * 2, 128, 160, 64, 64, s["wdy"].numel() * 2, 3, 1, 1, 14)
+    s["cout"] = torch.empty(8, 128, 160, 64, dtype=act, device="cuda")
+    s["cd"] = ops.fwd_desc(8, 128, 160, 64, 64, s["wx"].numel() * 2, 3, 1, 1, 64, 64)
+    return s
+
+
+def _run(s, mode, co):
+    ops = s["ops"]
+    out = torch.empty(N, H, W, O, dtype=ops.ACT_DTYPE, device="cuda")
+    part = ops.new_stat_buffer(O)
+    if co:
+        s["side"].wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s["side"]):
+            for _ in range(6):
+                if co == "wgrad":
+                    ops.conv_wgrad(s["wd"], s["wdy"], s["wx"], s["wdw"])
+                else:
+                    ops.conv_gemm(s["cd"], s["wx"], s["w"], s["cout"])
+    if mode == "stats":
+        ops.conv_gemm(s["d"], s["x"], s["w"], out, part)
+    else:
+        red = ops.bn_red(s["sx"], s["mean"], s["rstd"], part, mask_scale=s["msc"], mask_shift=s["msh"]) if mode == "red_mask" \
+            else ops.bn_red(s["sx"], s["mean"], s["rstd"], part)
+        ops.conv_gemm(s["d"], s["x"], s["w"], out, red=red)
+    torch.cuda.current_stream().wait_stream(s["side"])
+    torch.cuda.synchronize()
+    return out, part.sum(0)
+
+
+@pytest.mark.parametrize("form", ["default", "64", "d64", "4"])
+@pytest.mark.parametrize("co", ["wgrad", "conv"])
+def test_sums_do_not_depend_on_the_neighbour(setup, form, co, monkeypatch):
+    if form != "default":
+        monkeypatch.setenv("MDE_CONV_DEEP_WAVES", form)       # (read per launch)
+    for mode in ("stats", "red_mask", "red"):
+        ref_o, ref_p = _run(setup, mode, None)
+        # the quiet run against the sums recomputed from its own output
+        if mode != "stats":
+            g = ref_o.float()
+            on = (setup["sx"].float() * setup["msc"] + setup["msh"]) > 0 if mode == "red_mask" else torch.ones_like(g, dtype=torch.bool)
+            ge = torch.where(on, g, torch.zeros_like(g))
+            s1 = ge.sum((0, 1, 2))
+            s2 = (ge * ((setup["sx"].float() - setup["mean"]) * setup["rstd"])).sum((0, 1, 2))
+            torch.testing.assert_close(ref_p[0], s1, rtol=1e-4, atol=2e-2)
+            torch.testing.assert_close(ref_p[1], s2, rtol=1e-4, atol=2e-2)
+        for it in range(8):
+            o, p = _run(setup, mode, co)
+            assert torch.equal(o, ref_o), (form, co, mode, it)
+            # (float atomics over 32 slots: the order of the addends differs from run to run, nothing else may)
+            torch.testing.assert_close(p, ref_p, rtol=1e-4, atol=1e-3, msg=lambda m: "%s beside %s, %s, run %d: %s" % (form, co, mode, it, m))
