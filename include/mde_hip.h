@@ -170,7 +170,9 @@ int mde_conv_wgrad(const mde_wgrad_desc* d, const void* direct, const void* gath
 /* The same with a workspace for a two-stage split-K reduction: every workgroup stores its partial tile (fp32
  * [slices][rows][ntaps][cols]) and a second kernel adds the slices into dw -- plain stores and one streaming pass instead of
  * slices x |dw| fp32 atomics (the L2 atomic units add one dword per clock and channel).  ws: fp32, 16-byte aligned, ws_bytes
- * >= mde_conv_wgrad_ws_bytes(d), otherwise (or ws == NULL, a grouped weight, deterministic mode) the atomic path runs.  The
+ * >= mde_conv_wgrad_ws_bytes(d), otherwise (or ws == NULL, a grouped weight, deterministic mode) the atomic path runs;
+ * mde_conv_wgrad_ws_bytes returns 0 for a launch that would keep the atomic path anyway (the measured rule in
+ * conv_wgrad.hip: ws_choice), so a caller sizing its workspace from it reserves nothing for those.  The
  * second kernel updates dw with plain read-modify-writes: launches into the same dw, and launches that share a workspace,
  * must be ordered on one stream. */
 int64_t mde_conv_wgrad_ws_bytes(const mde_wgrad_desc* d);

@@ -522,13 +522,51 @@ extern "C" int mde_conv_wgrad(const mde_wgrad_desc* d, const void* direct, const
     return mde_conv_wgrad_ws(d, direct, gathered, dw, nullptr, 0, stream);
 }
 
-extern "C" int64_t mde_conv_wgrad_ws_bytes(const mde_wgrad_desc* d) {
-    if (!d || d->group_size || d->Cd <= 0 || d->Cg <= 0 || d->ntaps < 1 || d->ksplit < 1) return 0;
+// The two-stage split-K reduction of a launch: bytes of partial tiles it needs, and whether the launch would take that form
+// given a workspace (MDE_WGRAD_TWOSTAGE: 0 never, 2 wherever possible, otherwise the measured rule).  ONE place for
+// mde_conv_wgrad_ws (which decides) and mde_conv_wgrad_ws_bytes (which tells the caller what to allocate): a caller that sizes
+// its workspace from the latter no longer reserves memory for launches that keep the atomic path.
+static bool ws_choice(const mde_wgrad_desc* d, int64_t* need_out) {
     const int64_t M = (int64_t)d->N * d->GH * d->GW;
+    const bool ga = d->rows_from_gathered != 0;
+    const int crows = ga ? d->Cg : d->Cd, ccols = ga ? d->Cd : d->Cg;
     int64_t chunk = (M + d->ksplit - 1) / d->ksplit;
     chunk = (chunk + BKP - 1) / BKP * BKP;
     const int64_t kslices = (M + chunk - 1) / chunk;
-    return kslices * d->Cd * d->Cg * d->ntaps * 4;
+    const int64_t need = kslices * crows * ccols * d->ntaps * 4;
+    *need_out = need;
+    if (d->group_size) return false;
+    const char* e = getenv("MDE_WGRAD_TWOSTAGE");           // (read per call: the tests switch it between launches)
+    const int two = !e ? 1 : atoi(e);
+    if (!two) return false;
+    if (two == 2) return true;
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+    }
+    static int rows32 = -1;
+    if (rows32 < 0) {
+        const char* r = getenv("MDE_WGRAD_ROWS32");
+        rows32 = !(r && !strcmp(r, "0"));
+    }
+    const int ba = crows % 128 == 0 ? 128 : (rows32 && crows <= 32) ? 32 : 64;
+    const int bb = ccols % 128 == 0 ? 128 : 64;
+    // Where it pays (in-network, tools/per_shape_diff.py over `bench.py --per-shape` with MDE_WGRAD_TWOSTAGE=0 / 2): what the
+    // atomics cost is the burst at the END of a launch whose workgroups all finish together -- one round of short workgroups
+    // (512 x 128 weights split 128 ways: 92 -> 67 us; 1024 x 256 split 32: 63 -> 50; 256 x 256 x 9 split 14: 87 -> 77).  A grid
+    // of several rounds, or workgroups of hundreds of K-steps, hides its atomics under the other workgroups' MFMAs and
+    // only pays for the extra pass (1024 x 1024 x 25 split 2: +3 %; 128 x 128 x 9 over 614 400 pixels: +5 %); below ~20 MB
+    // of partial tiles the second launch costs more than the burst (64 x 64 x 9 split 113: +6 %).
+    const int64_t blocks = (int64_t)d->ntaps * mde_cdiv(crows, ba) * mde_cdiv(ccols, bb) * kslices;
+    return need >= (20ll << 20) && blocks <= 5 * (int64_t)ncu && chunk / BKP <= 96;
+}
+
+extern "C" int64_t mde_conv_wgrad_ws_bytes(const mde_wgrad_desc* d) {
+    if (!d || d->group_size || d->Cd <= 0 || d->Cg <= 0 || d->ntaps < 1 || d->ksplit < 1) return 0;
+    int64_t need = 0;
+    return ws_choice(d, &need) ? need : 0;
 }
 
 extern "C" int mde_conv_wgrad_ws(const mde_wgrad_desc* d, const void* direct, const void* gathered,
@@ -608,25 +646,9 @@ extern "C" int mde_conv_wgrad_ws(const mde_wgrad_desc* d, const void* direct, co
     // deterministic mode (its integer atomics are order-free already), not for grouped weights (block-diagonal dw).
     ka.ws = nullptr;
     {
-        const char* e = getenv("MDE_WGRAD_TWOSTAGE");           // (read per call: the tests switch it between launches)
-        const int two = !e ? 1 : atoi(e);
-        static int ncu = 0;
-        if (!ncu) {
-            int dev = 0;
-            hipDeviceProp_t prop;
-            ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
-        }
-        const int64_t need = (int64_t)kslices * ka.Crows * ka.Ccols * d->ntaps * 4;
-        // Where it pays (in-network, tools/per_shape_diff.py over `bench.py --per-shape` with MDE_WGRAD_TWOSTAGE=0 / 2): what the
-        // atomics cost is the burst at the END of a launch whose workgroups all finish together -- one round of short workgroups
-        // (512 x 128 weights split 128 ways: 92 -> 67 us; 1024 x 256 split 32: 63 -> 50; 256 x 256 x 9 split 14: 87 -> 77).  A grid
-        // of several rounds, or workgroups of hundreds of K-steps, hides its atomics under the other workgroups' MFMAs and
-        // only pays for the extra pass (1024 x 1024 x 25 split 2: +3 %; 128 x 128 x 9 over 614 400 pixels: +5 %); below ~20 MB
-        // of partial tiles the second launch costs more than the burst (64 x 64 x 9 split 113: +6 %).
-        // MDE_WGRAD_TWOSTAGE=2: wherever possible (tests, measurements).
-        const int64_t blocks = (int64_t)d->ntaps * mde_cdiv(ka.Crows, ba) * ka.nB * kslices;
-        const bool pays = two == 2 || (need >= (20ll << 20) && blocks <= 5 * (int64_t)ncu && chunk / BKP <= 96);
-        if (two && pays && ws && !ka.gsize && !ka.det.scratch && !ka.skip_store && need <= ws_bytes && ka.Ccols % 4 == 0 &&
+        int64_t need = 0;
+        const bool pays = ws_choice(d, &need);          // (MDE_WGRAD_TWOSTAGE and the measured rule: above)
+        if (pays && ws && !ka.gsize && !ka.det.scratch && !ka.skip_store && need <= ws_bytes && ka.Ccols % 4 == 0 &&
             ((uintptr_t)ws % 16) == 0 && ((uintptr_t)dw % 16) == 0)
             ka.ws = ws;
     }
