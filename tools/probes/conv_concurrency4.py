@@ -26,7 +26,13 @@ msc, msh = torch.rand(O, device="cuda") + 0.5, torch.randn(O, device="cuda") * 0
 out = torch.empty(N, H, W, O, dtype=ACT, device="cuda")          # ONE output buffer, poisoned before every launch
 
 
+FRESH = os.environ.get("FRESH", "0") == "1"            # a new output tensor per launch, as tests/test_co_residency_gpu.py has
+
+
 def run(mode, busy):
+    global out
+    if FRESH:
+        out = torch.empty(N, H, W, O, dtype=ACT, device="cuda")
     out.fill_(float("nan"))
     part = ops.new_stat_buffer(O)
     if busy:
