@@ -5,8 +5,10 @@
 Why: with such an instruction the LOW lane's result (the one op_sel feeds from the HIGH register of
 a source pair) came out wrong in a few lanes whenever a wave of ANOTHER kernel shared the SIMD -- the fused BatchNorm-backward
 sums of the 8-wave 64-column conv tiles beside a weight-gradient workgroup of the second stream (30 of 30 runs), a sparse
-one-ulp variation in BTS' planar-guidance backward.  The same instructions in natural lane order are fine (every BatchNorm
-kernel is full of them).  hipcc's SLP vectoriser is what emits the op_sel forms (it pairs the odd / even halves of an unpacked
+one-ulp variation in BTS' planar-guidance backward.  tools/probes/pk_opsel_probe.hip shows it on the bare instruction: beside an
+MFMA loop of another kernel the low lane of v_pk_add / mul / fma_f32 op_sel:[0,1] (source 1 taken from the high register) is
+wrong in up to 10 % of the results, and never alone or beside a VALU loop.  The same instructions in natural lane order are fine
+(every BatchNorm kernel is full of them), so is op_sel on source 0 and on v_pk_mov_b32; the pattern below is a superset.  hipcc's SLP vectoriser is what emits the op_sel forms (it pairs the odd / even halves of an unpacked
 16-bit pair crosswise); build.sh compiles the affected files with -fno-slp-vectorize, and this check keeps a later change
 from bringing them back.
 
