@@ -31,7 +31,8 @@ def _env():
 def test_kernel_parity_tests_pass_on_the_fp16_build():
     cmd = [sys.executable, "-m", "pytest", "-x", "-q", "-p", "no:cacheprovider",
            os.path.join(ROOT, "tests", "test_conv_gemm_gpu.py"), os.path.join(ROOT, "tests", "test_conv_wgrad_gpu.py"),
-           os.path.join(ROOT, "tests", "test_tape_ops_gpu.py"), "-k", "not shallow and not halo128 and not plain"]
+           os.path.join(ROOT, "tests", "test_tape_ops_gpu.py"), os.path.join(ROOT, "tests", "test_co_residency_gpu.py"),
+           "-k", "not shallow and not halo128 and not plain"]
     r = subprocess.run(cmd, cwd=ROOT, env=_env(), capture_output=True, text=True, timeout=900)
     tail = r.stdout[-1500:]
     assert r.returncode == 0 and " passed" in tail and "failed" not in tail, tail + r.stderr[-1500:]
