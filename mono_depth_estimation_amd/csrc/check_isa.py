@@ -21,6 +21,7 @@ import sys
 import tempfile
 
 OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+BUNDLER = "/opt/rocm/lib/llvm/bin/clang-offload-bundler"
 READELF = "/opt/rocm/lib/llvm/bin/llvm-readelf"
 MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
 BAD = re.compile(r"v_pk_(?:add|mul|fma)_f32\b.*\bop_sel:")
@@ -40,7 +41,20 @@ def fatbin(path):
 
 
 def code_objects(blob):
-    """Every gfx950 code object of every offload bundle in the section (one bundle per translation unit)."""
+    """Every gfx950 code object of every offload bundle in the section (one bundle per translation unit).  A section that
+    holds a COMPRESSED bundle instead (magic CCOB: librccl.so, for one) goes through clang-offload-bundler."""
+    if MAGIC not in blob and blob[:4] == b"CCOB":
+        with tempfile.TemporaryDirectory() as d:
+            src = d + "/fat.bin"
+            with open(src, "wb") as f:
+                f.write(blob)
+            listed = subprocess.run([BUNDLER, "--list", "--type=o", "--input=" + src], capture_output=True, text=True, check=True).stdout
+            for i, triple in enumerate(t for t in listed.split() if "gfx950" in t):
+                out = "%s/%d.co" % (d, i)
+                subprocess.run([BUNDLER, "--unbundle", "--type=o", "--targets=" + triple, "--input=" + src, "--output=" + out], check=True)
+                with open(out, "rb") as f:
+                    yield f.read()
+        return
     pos = 0
     while True:
         pos = blob.find(MAGIC, pos)
